@@ -1,0 +1,755 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY (see ulc_oracle.h for the pinning status).
+ *
+ * orc_encoder.c — CPU restatement of the ulc-codec encoder hot path.  Compiled
+ * like the reference (gcc -O2, no -mfma, no fast-math: /root/reference/Makefile:33)
+ * plus -ffp-contract=off, so every float operation below is an individually
+ * rounded IEEE binary32/binary64 operation in the order written.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "ulc_oracle.h"
+
+#define SQRF(x) ((x) * (x))
+static inline float absf(float x) { return x < 0 ? -x : x; }
+
+/* ========================================================================== */
+/* Shared inline math: /root/reference/libulc/ulcHelper.h                      */
+/* ========================================================================== */
+
+/* ulcHelper.h:24-46 — one nybble per subblock, LSB first: bits0-2 = size shift,
+ * bit3 = overlap-scaled ("transient") subblock. Indexed by WindowCtrl >> 4. */
+uint16_t orc_decimation_pattern(int WindowCtrl) {
+    static const uint16_t tbl[16] = {
+        0x0000, 0x0008, 0x0019, 0x0091, 0x012A, 0x01A2, 0x02A1, 0x0A21,
+        0x123B, 0x12B3, 0x13B2, 0x1B32, 0x23B1, 0x2B31, 0x3B21, 0xB321,
+    };
+    return tbl[(WindowCtrl >> 4) & 15];
+}
+
+/* ulcHelper.h:127-136 */
+float orc_fastlog(float x) {
+    uint32_t b; memcpy(&b, &x, 4);
+    int32_t e = (int32_t)(b >> 23) - 127;
+    b = (127u << 23) | (b & 0x7FFFFFu);
+    float m; memcpy(&m, &b, 4);
+    return -1.7417939f + (2.8212026f + (-1.4699568f + (0.44717955f - 0.056570851f * m) * m) * m) * m + 0.6931471806f * e;
+}
+
+/* ulcHelper.h:51-72 */
+int orc_companded_quantize_unsigned(float v) {
+    return (v >= 0.5f) ? (int)(0.5f + sqrtf(v - 0.25f)) : 0;
+}
+/* ulcHelper.h:77-91 */
+static int quant_coef_unsigned(float v, int limit) {
+    int q = orc_companded_quantize_unsigned(v);
+    return q < limit ? q : limit;
+}
+static int quant_coef(float v, int limit) {
+    int q = quant_coef_unsigned(absf(v), limit);
+    return v < 0.0f ? -q : q;
+}
+
+/* ulcHelper.h:96-120 */
+static float freq_to_line(float hz, float nyq, uint32_t n) { return (hz * (float)n / nyq) - 0.5f; }
+static float line_to_freq(uint32_t line, float nyq, uint32_t n) { return ((float)line + 0.5f) * nyq / (float)n; }
+static float freq_to_bark(float hz) { return 6.0f * asinhf(hz * (1.0f / 600.0f)); }
+static float bark_to_freq(float bark) { return 600.0f * sinhf(bark * (1.0f / 6.0f)); }
+
+/* ========================================================================== */
+/* Window control: /root/reference/libulc/ulcEncoder_WindowControl.c           */
+/* ========================================================================== */
+
+/* WindowControl.c:31-40 — 3-tap FIR energies, accumulated into {hp,bp} pairs */
+static void fir_energy(float *dst, const float *src, float *taps, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) {
+        taps[0] = taps[1];
+        taps[1] = taps[2];
+        taps[2] = src[i];
+        float hp = -taps[0] + 2 * taps[1] - taps[2];
+        float bp = -taps[0] + taps[2];
+        dst[2*i+0] += SQRF(hp);
+        dst[2*i+1] += SQRF(bp);
+    }
+}
+
+/* WindowControl.c:41-135 */
+static void transient_filtering(const float *blk, orc_transient_t *tb, float *tf, float *tmp,
+                                int BS, int nChan, int RateHz) {
+    float *E = tmp;
+    for (int n = 0; n < 2 * BS; n++) E[n] = 0.0f;
+    for (int ch = 0; ch < nChan; ch++) {                       /* :58-70 */
+        int lag = BS / 2;
+        const float *so = blk + ch * BS + BS - lag;
+        const float *sn = blk + ch * BS + nChan * BS;
+        float taps[3];
+        taps[1] = so[-1];
+        taps[2] = so[0];
+        uint32_t nOld = (uint32_t)(BS - lag - 1);
+        uint32_t nNew = (uint32_t)(lag + 1);
+        fir_energy(E, so + 1, taps, nOld);
+        fir_energy(E + nOld * 2, sn, taps, nNew);
+    }
+    /* :72-88 forward (post-masking) one-pole smear in the amplitude domain */
+    float envHP = tf[0], envBP = tf[1];
+    float rHP = expf(-0x1.CC845Cp6f / RateHz);
+    float rBP = expf(-0x1.596344p8f / RateHz);
+    for (int n = 0; n < BS; n++) {
+        float vHP = sqrtf(E[2*n+0]), dHP = vHP - envHP;
+        float vBP = sqrtf(E[2*n+1]), dBP = vBP - envBP;
+        envHP += dHP * (1.0f - rHP);
+        envBP += dBP * (1.0f - rBP);
+        E[2*n+0] = envHP;
+        E[2*n+1] = envBP;
+    }
+    tf[0] = envHP;
+    tf[1] = envBP;
+    /* :90-104 backward (pre-masking) sweep, cross-normalised error */
+    float preHP = envHP, preBP = envBP;
+    float qHP = expf(-0x1.CC845Cp7f / RateHz);
+    float qBP = expf(-0x1.596344p8f / RateHz);
+    for (int n = BS - 1; n >= 0; n--) {
+        float vHP = E[2*n+0], dHP = vHP - preHP;
+        float vBP = E[2*n+1], dBP = vBP - preBP;
+        preHP += dHP * (1.0f - qHP);
+        preBP += dBP * (1.0f - qBP);
+        E[2*n+0] = SQRF(dHP * preBP) + SQRF(dBP * preHP);
+    }
+    /* :106-134 integrate into 8 bins; L <- old R */
+    int bin = BS / ORC_MAX_DECIMATION;
+    orc_transient_t *dst = tb + ORC_MAX_DECIMATION;
+    for (int i = 0; i < ORC_MAX_DECIMATION; i++, dst++) {
+        dst[-ORC_MAX_DECIMATION] = *dst;
+        dst->Sum = 0.0f; dst->SumW = 0.0f;
+        float env = tf[2];
+        float rate = expf(-0x1.1AF110p-6f * BS / RateHz);
+        for (int n = 0; n < bin; n++) {
+            float v = E[2*n+0], d = v - env;
+            env += d * (1.0f - rate);
+            dst->Sum += env; dst->SumW += 1;
+        }
+        tf[2] = env;
+        E += bin * 2;
+    }
+}
+
+/* WindowControl.c:140-239 */
+int orc_get_window_ctrl(const float *BlockData, orc_transient_t *TransientBuffer, float *TransientFilter,
+                        float *TmpBuffer, int BlockSize, int nChan, int RateHz) {
+    transient_filtering(BlockData, TransientBuffer, TransientFilter, TmpBuffer, BlockSize, nChan, RateHz);
+    const orc_transient_t *R = TransientBuffer + ORC_MAX_DECIMATION;
+
+    int log2sub = 31 - __builtin_clz((unsigned)(BlockSize / ORC_MAX_DECIMATION));
+    int decimation = 1;
+    float ratio = 0.0f;
+    int nSeg = ORC_MAX_DECIMATION, segSize = 1;
+    if (log2sub < 6) {                                        /* :165-170 */
+        int sh = 6 - log2sub;
+        nSeg >>= sh; segSize <<= sh; log2sub = 6;
+    }
+    for (;;) {
+        log2sub++;                                            /* :176 */
+        int maxSeg = 0;
+        float maxRatio = -1000.0f;
+        for (int seg = 0; seg < nSeg; seg++) {                /* :184-201 */
+            float Ls = 0.0f, Lw = 0.0f, Rs = 0.0f, Rw = 0.0f;
+            const orc_transient_t *src = R + seg * segSize;
+            for (int n = 0; n < segSize; n++) {
+                Ls += src[n - segSize].Sum; Lw += src[n - segSize].SumW;
+                Rs += src[n].Sum;           Rw += src[n].SumW;
+            }
+            Ls = Ls ? logf(Ls / Lw) : -100.0f;
+            Rs = Rs ? logf(Rs / Rw) : -100.0f;
+            float r = absf(Rs - Ls);
+            if (r > maxRatio) { maxSeg = seg; maxRatio = r; }
+        }
+        if (maxRatio - ratio < 0x1.62E430p-1f) break;         /* :213 */
+        decimation = nSeg + maxSeg;                           /* :218-224 */
+        ratio = maxRatio;
+        if (nSeg > 1 && ratio < 0x1.62E430p-1f) { nSeg /= 2; segSize *= 2; }
+        else break;
+    }
+    if (ratio < 0x1.62E430p-2f) return 0x10;                  /* :229 */
+    ratio *= 0x1.715476p0f;                                   /* :233 */
+    int scale = (ratio < 0.5f) ? 0 : (ratio >= 6.5f) ? 7 : (int)lrintf(ratio);
+    if (log2sub - scale < 5 + 1) scale = log2sub - (5 + 1);   /* :235 */
+    return scale + 0x8 * (decimation != 1) + 0x10 * decimation;
+}
+
+/* ========================================================================== */
+/* Psychoacoustics + noise spectrum: /root/reference/libulc/ulcEncoder_Psyopt.c */
+/* ========================================================================== */
+
+typedef struct { int end; double floor_, peak, peakw; } linesum_t;   /* Psyopt.c:16-21 */
+
+/* Psyopt.c:30-51 */
+static void linesum_advance(const float *src, const float *srcLog, linesum_t *ls, int end) {
+    double f = ls->floor_, p = ls->peak, w = ls->peakw;
+    for (int line = ls->end; line < end; line++) {
+        double v = (double)src[line];
+        double vl = (double)srcLog[line];
+        f += vl;
+        p += vl * v;
+        w += v;
+    }
+    ls->end = end; ls->floor_ = f; ls->peak = p; ls->peakw = w;
+}
+
+/* Psyopt.c:60-155 */
+void orc_calc_psychoacoustics(float *MaskingNp, float *BufferAmp2, void *BufferTemp, int BlockSize, int RateHz, uint32_t WindowCtrl) {
+    float nyq = (float)RateHz * 0.5f;
+    BlockSize /= 2;
+    for (int line = 0; line < BlockSize; line++)
+        MaskingNp[line] = orc_fastlog(0x1.0p-126f + BufferAmp2[line]);      /* :77-79 */
+    uint16_t pat = orc_decimation_pattern((int)WindowCtrl);
+    do {
+        int S = BlockSize >> (pat & 7);
+        float unmask = 0.0f;
+        float *bark = (float *)BufferTemp;
+        linesum_t lo = {0, 0.0, 0.0, 0.0}, hi = {0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < ORC_N_BARK_BANDS; b++) {                         /* :103-137 */
+            float f0 = bark_to_freq((float)b - 0.75f);
+            float f1 = bark_to_freq((float)b + 0.25f);
+            int l0 = (int)floorf(freq_to_line(f0, nyq, (uint32_t)S));
+            int l1 = (int)ceilf(freq_to_line(f1, nyq, (uint32_t)S));
+            if (l0 < 0) l0 = 0;
+            if (l1 < 0) l1 = 0;
+            if (l0 > S - 1) l0 = S - 1;
+            if (l1 > S) l1 = S;
+            linesum_advance(BufferAmp2, MaskingNp, &lo, l0);
+            linesum_advance(BufferAmp2, MaskingNp, &hi, l1);
+            double sf = hi.floor_ - lo.floor_;
+            double sp = hi.peak - lo.peak;
+            double sw = hi.peakw - lo.peakw;
+            if (sw > 0.0) {
+                sp = sp / sw;
+                sf = sf / (double)(l1 - l0);
+                unmask = (float)(sp - sf - log(sw));
+            }
+            bark[b] = unmask;
+        }
+        for (int line = 0; line < S; line++) {                               /* :140-150 */
+            float bb = freq_to_bark(line_to_freq((uint32_t)line, nyq, (uint32_t)S));
+            int bi = (int)bb;
+            float fr = bb - (float)bi;
+            float L = (bi < ORC_N_BARK_BANDS) ? bark[bi] : bark[ORC_N_BARK_BANDS - 1];
+            float Rv = (bi + 1 < ORC_N_BARK_BANDS) ? bark[bi + 1] : L;
+            MaskingNp[line] = L * (1.0f - fr) + Rv * fr;
+        }
+        MaskingNp += S;
+        BufferAmp2 += S;
+    } while (pat >>= 4);
+}
+
+/* Psyopt.c:168-250 */
+void orc_calc_noise_log_spectrum(float *Data, void *Temp, int N, int RateHz) {
+    float nyq = (float)RateHz * 0.5f;
+    N /= 2;
+    float *logd = (float *)Temp;
+    for (int line = 0; line < N; line++) logd[line] = orc_fastlog(0x1.0p-126f + Data[line]);
+    float level = -100.0f;
+    float *bark = logd + N;
+    linesum_t lo = {0, 0.0, 0.0, 0.0}, hi = {0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < ORC_N_BARK_BANDS; b++) {                             /* :191-224 */
+        float f0 = bark_to_freq((float)b);
+        float f1 = bark_to_freq((float)b + 2.0f);
+        int l0 = (int)floorf(freq_to_line(f0, nyq, (uint32_t)N));
+        int l1 = (int)ceilf(freq_to_line(f1, nyq, (uint32_t)N));
+        if (l0 < 0) l0 = 0;
+        if (l1 < 0) l1 = 0;
+        if (l0 > N - 1) l0 = N - 1;
+        if (l1 > N) l1 = N;
+        linesum_advance(Data, logd, &lo, l0);
+        linesum_advance(Data, logd, &hi, l1);
+        double sf = hi.floor_ - lo.floor_;
+        double sp = hi.peak - lo.peak;
+        double sw = hi.peakw - lo.peakw;
+        if (sw > 0.0) {
+            double scale = 1.0 / (double)(l1 - l0);
+            sp = sp / sw;
+            sf = sf * scale;
+            level = 0.5f * (float)(log(sw * scale) + sf - sp);
+        }
+        bark[b] = level;
+    }
+    for (int line = 0; line < N; line++) {                                   /* :236-248 */
+        float bb = freq_to_bark(line_to_freq((uint32_t)line, nyq, (uint32_t)N));
+        int bi = (int)bb;
+        float fr = bb - (float)bi;
+        float L = (bi < ORC_N_BARK_BANDS) ? bark[bi] : bark[ORC_N_BARK_BANDS - 1];
+        float Rv = (bi + 1 < ORC_N_BARK_BANDS) ? bark[bi + 1] : L;
+        float noise = L * (1.0f - fr) + Rv * fr;
+        float w = expf(0.5f * noise);
+        Data[2*line+0] = w;
+        Data[2*line+1] = w * (noise + 0x1.62E430p-1f);
+    }
+}
+
+/* ========================================================================== */
+/* Noise fill: /root/reference/libulc/ulcEncoder_NoiseFill.c                   */
+/* ========================================================================== */
+
+/* NoiseFill.c:15-36 */
+int orc_get_noise_q(const float *Data, int Band, int N, float q) {
+    Data += Band / 2 * 2;
+    N = (N + (Band & 1) + 1) / 2;
+    float sum = 0.0f, sumw = 0.0f;
+    for (int n = 0; n < N; n++) {
+        float w = Data[2*n+0], wy = Data[2*n+1];
+        sum += wy; sumw += w;
+    }
+    if (sum == 0.0f) return 0;
+    float amp = expf(sum / sumw);
+    return quant_coef_unsigned(amp * q, 1 + 0x7);
+}
+
+/* NoiseFill.c:41-94 */
+void orc_get_hfext_params(const float *Data, int Band, int N, float q, int *NoiseQ, int *NoiseDecay) {
+    Data += Band / 2 * 2;
+    N = (N + (Band & 1) + 1) / 2;
+    float sx = 0.0f, sx2 = 0.0f, sxy = 0.0f, sy = 0.0f, sw = 0.0f;
+    for (int n = 0; n < N; n++) {                                            /* :49-58 */
+        float x = n * 2.0f;
+        float w = Data[2*n+0], wy = Data[2*n+1];
+        sx  += w * x;
+        sx2 += w * x * x;
+        sxy += x * wy;
+        sy  += wy;
+        sw  += w;
+    }
+    float det = sw * sx2 - SQRF(sx);
+    if (det == 0.0f) { *NoiseQ = *NoiseDecay = 0; return; }
+    float amp = (sx2 * sy - sx * sxy) / det;
+    float dec = (sw * sxy - sx * sy) / det;
+    amp = expf(amp);
+    dec = (dec < 0.0f) ? expf(dec) : 1.0f;
+    int nq = quant_coef_unsigned(amp * q * 4.0f, 1 + 0xF);
+    int nd = orc_companded_quantize_unsigned((dec - 1.0f) * -0x1.0p19f);
+    if (!nd) return;                       /* :90 — leaves the caller's zeros in place */
+    if (nd > 0xFF) nd = 0xFF;
+    *NoiseQ = nq;
+    *NoiseDecay = nd;
+}
+
+/* ========================================================================== */
+/* Bitstream writer: /root/reference/libulc/ulcEncoder_Encode.c                */
+/* ========================================================================== */
+
+/* Encode.c:23-29 — low nybble of each byte first */
+static void put_nybble(unsigned x, uint8_t *dst, int *size) {
+    uint8_t *p = &dst[*size / 8];
+    *p = (uint8_t)((*p >> 4) | ((x & 0xF) << 4));
+    *size += 4;
+}
+
+/* Encode.c:32-45 */
+static void put_quantizer(int qi, uint8_t *dst, int *size, int lead) {
+    int s = qi - 5;
+    if (lead) put_nybble(0xF, dst, size);
+    if (s < 0xE) put_nybble((unsigned)s, dst, size);
+    else { put_nybble(0xE, dst, size); put_nybble((unsigned)(s - 0xE), dst, size); }
+}
+
+/* Encode.c:50-87 */
+int orc_build_quantizer(float MaxVal) {
+    int q = (int)(0x1.657006p2f + -0x1.715476p0f * logf(MaxVal));
+    if (q < 5) q = 5;
+    if (q > 5 + 0xE + 0xC) q = 5 + 0xE + 0xC;
+    return q;
+}
+
+/* Encode.c:92-197 */
+static int write_zone(int cur, int end, float quant, const float *coef, const float *noise, const int *rank,
+                      int nextCoded, int nOut, uint8_t *dst, int *size) {
+    for (;;) {
+        while (cur < end && rank[cur] >= nOut) cur++;                        /* :108 */
+        if (cur >= end) break;
+        if (absf(coef[cur] * quant) < 2.5f) { cur++; continue; }             /* :114 */
+        int n = 0, v = 0;
+        int zr = cur - nextCoded;
+        while (zr) {
+            if (zr <= 2) {                                                   /* :122-132 */
+                int q1 = quant_coef(coef[nextCoded] * quant, 7);
+                int q2 = 0;
+                if (zr >= 2) q2 = quant_coef(coef[nextCoded + 1] * quant, 7);
+                if (abs(q1) > 1 && (zr < 2 || abs(q2) > 1)) {
+                    put_nybble((unsigned)q1, dst, size);
+                    if (zr >= 2) put_nybble((unsigned)q2, dst, size);
+                    nextCoded += zr;
+                    break;
+                }
+            }
+            int nq = 0;                                                      /* :149-154 */
+            if (zr >= 16) {
+                v = zr - 16; if (v > 0x1FF) v = 0x1FF;
+                n = v + 16;
+                nq = orc_get_noise_q(noise, nextCoded, n, quant);
+            }
+            if (nq) {                                                        /* :155-160 */
+                put_nybble(0x8, dst, size);
+                put_nybble((unsigned)(v >> 5), dst, size);
+                put_nybble((unsigned)(v >> 1), dst, size);
+                put_nybble((unsigned)((v & 1) | ((nq - 1) << 1)), dst, size);
+            } else if (zr < 33) {                                            /* :168-173 */
+                v = zr - 1; if (v > 0xF) v = 0xF;
+                n = v + 1;
+                put_nybble(0x0, dst, size);
+                put_nybble((unsigned)v, dst, size);
+            } else {                                                         /* :174-181 */
+                v = zr - 33; if (v > 0xFF) v = 0xFF;
+                n = v + 33;
+                put_nybble(0x1, dst, size);
+                put_nybble((unsigned)(v >> 4), dst, size);
+                put_nybble((unsigned)v, dst, size);
+            }
+            nextCoded += n;
+            zr -= n;
+        }
+        int qn = quant_coef(coef[cur] * quant, 7);                           /* :191-194 */
+        put_nybble((unsigned)qn, dst, size);
+        nextCoded++;
+        cur++;
+    }
+    return nextCoded;
+}
+
+/* Encode.c:200-313 */
+static void write_subblock(int idx, int S, const float *coef, const float *noise, const int *rank,
+                           int nOut, uint8_t *dst, int *size) {
+    int end = idx + S;
+    int nextCoded = idx;
+    int prevQ = -1, zoneStart = -1;
+    float qmin = 1000.0f, qmax = -1000.0f;
+    do {
+        while (idx < end && rank[idx] >= nOut) idx++;                        /* :220 */
+        float nmin = 0.0f, nmax = qmax, lvl = 0.0f;
+        if (idx < end) {
+            lvl = absf(coef[idx]);
+            nmin = (lvl < qmin) ? lvl : qmin;
+            nmax = (lvl > qmax) ? lvl : qmax;
+            if (zoneStart == -1) zoneStart = idx;
+        }
+        if (nmax > nmin * 4.0f) {                                            /* :238 */
+            int qi = orc_build_quantizer(qmax);
+            if (qi != prevQ) { put_quantizer(qi, dst, size, prevQ != -1); prevQ = qi; }
+            nextCoded = write_zone(zoneStart, idx, (float)(1u << qi), coef, noise, rank, nextCoded, nOut, dst, size);
+            zoneStart = idx;
+            qmin = qmax = lvl;
+        } else { qmin = nmin; qmax = nmax; }
+    } while (++idx <= end);
+
+    int n = end - nextCoded;                                                 /* :273-312 */
+    if (n > 4) {
+        if (prevQ != -1) put_nybble(0xF, dst, size);
+        int nq = 0, nd = 0;
+        if (prevQ != -1 && n >= 16)
+            orc_get_hfext_params(noise, nextCoded, n, (float)(1u << prevQ), &nq, &nd);
+        if (nq) {
+            put_nybble(0xF, dst, size);
+            put_nybble((unsigned)(nq - 1), dst, size);
+            put_nybble((unsigned)(nd >> 4), dst, size);
+            put_nybble((unsigned)nd, dst, size);
+        } else {
+            put_nybble(0xE, dst, size);
+            put_nybble(0xF, dst, size);
+        }
+    } else if (n > 0) {
+        put_nybble(0x0, dst, size);
+        put_nybble((unsigned)(n - 1), dst, size);
+    }
+}
+
+/* Encode.c:319-360 */
+int orc_encode_pass(const orc_encoder *st, void *Dst, int nOutCoef) {
+    uint8_t *dst = (uint8_t *)Dst;
+    int BS = st->BlockSize;
+    int idx = 0, size = 0;
+    int wc = st->WindowCtrl;
+    put_nybble((unsigned)wc, dst, &size);
+    if (wc & 0x8) put_nybble((unsigned)(wc >> 4), dst, &size);
+    for (int ch = 0; ch < st->nChan; ch++) {
+        uint16_t pat = orc_decimation_pattern(wc);
+        do {
+            int S = BS >> (pat & 7);
+            write_subblock(idx, S, st->TransformBuffer, st->TransformNoise, st->TransformIndex, nOutCoef, dst, &size);
+            idx += S;
+        } while (pat >>= 4);
+    }
+    dst[size / 8] = (uint8_t)(dst[size / 8] >> ((unsigned)(-size) % 8u));    /* :357 */
+    size = (size + 7) & ~7;
+    return size;
+}
+
+/* ========================================================================== */
+/* Block transform: /root/reference/libulc/ulcEncoder_BlockTransform.c         */
+/* ========================================================================== */
+
+/* BlockTransform.c:20-51 — min-heap sift-down on Order[] keyed by SortValues[] */
+static void sift_down(const float *val, int *order, int root, int n) {
+    int child = 2 * root + 1;
+    if (child >= n) return;
+    for (;;) {
+        int ri = order[root];
+        int ci = order[child];
+        if (child + 1 < n && val[order[child + 1]] < val[ci]) { child++; ci = order[child]; }
+        if (val[ci] > val[ri]) return;
+        order[root] = ci;
+        order[child] = ri;
+        root = child; child = 2 * root + 1;
+        if (child >= n) return;
+    }
+}
+
+/* BlockTransform.c:52-77.  SortedIndices may alias SortValues (as at :353): a
+ * slot is overwritten with its rank only after its element left the heap. */
+void orc_sort_indices(int *SortedIndices, const float *SortValues, int *Temp, int N) {
+    int *order = Temp;
+    for (int n = 0; n < N; n++) order[n] = n;
+    for (int n = N / 2 - 1; n >= 0; n--) sift_down(SortValues, order, n, N);
+    for (int n = N - 1; n > 0; n--) {
+        SortedIndices[order[0]] = n;
+        order[0] = order[n];
+        sift_down(SortValues, order, 0, n);
+    }
+    SortedIndices[order[0]] = 0;
+}
+
+/* ulcEncoder.c:25-80 */
+int orc_encoder_init(orc_encoder *st) {
+    int C = st->nChan, BS = st->BlockSize;
+    st->SampleBuffer = NULL;
+    if (C < 1 || C > 255) return -1;
+    if (BS < 256 || BS > 32768) return -1;
+    if ((BS & (-BS)) != BS) return -1;
+    size_t cb = (size_t)C * BS;
+    st->SampleBuffer    = (float *)calloc(cb * 2, sizeof(float));
+    st->TransformBuffer = (float *)calloc(cb, sizeof(float));
+    st->TransformNoise  = (float *)calloc(cb, sizeof(float));
+    st->TransformFwdLap = (float *)calloc(cb, sizeof(float));
+    st->TransformTemp   = (float *)calloc((size_t)(C < 2 ? 2 : C) * BS, sizeof(float));
+    st->TransformIndex  = (int *)calloc(cb, sizeof(int));
+    st->Keys            = (float *)calloc(cb, sizeof(float));
+    st->Masking         = (float *)calloc((size_t)BS / 2, sizeof(float));
+    st->MDSTdbg         = (float *)calloc(cb, sizeof(float));
+    st->NextWindowCtrl = 0x10;
+    st->WindowCtrl = 0;
+    st->BlockComplexity = 0.0f;
+    for (int i = 0; i < 3; i++) st->TransientFilter[i] = 0.0f;
+    for (int i = 0; i < ORC_MAX_DECIMATION * 2; i++) { st->TransientBuffer[i].Sum = 0.0f; st->TransientBuffer[i].SumW = 0.0f; }
+    st->nNzCoef = 0;
+    st->lastNOutCoef = 0;
+    return 1;
+}
+
+void orc_encoder_destroy(orc_encoder *st) {
+    free(st->SampleBuffer); free(st->TransformBuffer); free(st->TransformNoise);
+    free(st->TransformFwdLap); free(st->TransformTemp); free(st->TransformIndex);
+    free(st->Keys); free(st->Masking); free(st->MDSTdbg);
+    memset(st, 0, sizeof(*st));
+}
+
+/* BlockTransform.c:82-356 */
+int orc_transform_block(orc_encoder *st, const float *Data) {
+    int C = st->nChan, BS = st->BlockSize;
+    float *Old = st->SampleBuffer, *New = st->SampleBuffer + (size_t)BS * C;
+
+    for (int n = 0; n < BS * C; n++) Old[n] = New[n];                         /* :93 */
+    for (int ch = 0; ch < C; ch++)                                            /* :96-98 */
+        for (int n = 0; n < BS; n++) New[ch * BS + n] = Data[n * C + ch];
+    for (int ch = 1; ch < C; ch += 2) {                                       /* :102-110 */
+        float *b = New + ch * BS;
+        for (int n = 0; n < BS; n++) {
+            float l = b[n - BS], r = b[n];
+            b[n - BS] = (l + r) * 0.5f;
+            b[n]      = (l - r) * 0.5f;
+        }
+    }
+
+    int wc = st->WindowCtrl = st->NextWindowCtrl;                             /* :114-123 */
+    int nwc = st->NextWindowCtrl = orc_get_window_ctrl(st->SampleBuffer, st->TransientBuffer, st->TransientFilter,
+                                                       st->TransformTemp, BS, C, st->RateHz);
+    int nextOverlap;                                                          /* :124-128 */
+    {
+        int p = orc_decimation_pattern(nwc);
+        nextOverlap = BS >> (p & 7);
+        if (p & 8) nextOverlap >>= (nwc & 7);
+    }
+
+    int nNz = 0;
+    float *smp   = st->SampleBuffer;
+    float *mdct  = st->TransformBuffer;
+    float *key   = (float *)st->TransformIndex;
+    float *lap   = st->TransformFwdLap;
+    float *noise = st->TransformNoise;
+    float *tmp   = st->TransformTemp;
+    float *amp2  = tmp + BS;
+    float *mdstOut = st->MDSTdbg;
+    for (int n = 0; n < C * BS; n++) noise[n] = 0.0f;                         /* :144 */
+    for (int n = 0; n < BS / 2; n++) amp2[n] = 0.0f;                          /* :152 */
+
+    float cplx = 0.0f, cplxW = 0.0f;
+    for (int ch = 0; ch < C; ch++) {
+        uint16_t pat = orc_decimation_pattern(wc);
+        do {
+            int S = BS >> (pat & 7);                                          /* :160-172 */
+            int ov;
+            pat >>= 4;
+            if (pat) {
+                ov = BS >> (pat & 7);
+                if (pat & 8) ov >>= (wc & 7);
+            } else ov = nextOverlap;
+            if (ov > S) ov = S;
+
+            /* :175-224 lapping FIFO: [L zeros | M lap (S) | R pending raw] */
+            float *buf = tmp;
+            int avail = (BS - S) / 2;
+            float *sd = buf;
+            const float *ss = smp;
+            float *ld = lap + (BS + S) / 2;
+            const float *lsrc = ld;
+            int n;
+            if (avail < S) {
+                for (n = 0; n < avail; n++) *sd++ = *lsrc++;
+                for (; n < S; n++)          *sd++ = *ss++;
+                for (n = 0; n < avail; n++) *ld++ = *ss++;
+            } else {
+                for (n = 0; n < S; n++)     *sd++ = *lsrc++;
+                for (; n < avail; n++)      *ld++ = *lsrc++;
+                for (n = 0; n < S; n++)     *ld++ = *ss++;
+            }
+
+            /* :229-237 (MDST goes where the consumed samples were) */
+            orc_mdct_mdst(mdct, smp, buf, lap + (BS - S) / 2, tmp, S, ov);
+            memcpy(mdstOut, smp, sizeof(float) * S);
+
+            /* :243-281 */
+            float norm = 2.0f / S;
+            for (n = 0; n < S; n++) {
+                float re = (mdct[n] *= norm), re2 = SQRF(re);
+                float im = (smp[n] * norm),   im2 = SQRF(im);
+                float are = absf(re);
+                float a2 = re2 + im2;
+                if (are < 0.5f * ORC_COEF_EPS) key[n] = -INFINITY;
+                else { key[n] = orc_fastlog(re2); nNz++; }
+                noise[n / 2] += a2;
+                amp2[n / 2]  += a2;
+                cplx  += re2;
+                cplxW += are;
+            }
+            orc_calc_noise_log_spectrum(noise, tmp, S, st->RateHz);           /* :286 */
+
+            smp += S; mdct += S; key += S; amp2 += S / 2; noise += S; mdstOut += S;
+        } while (pat);
+        lap += BS;
+        amp2 -= BS / 2;                                                       /* :303 */
+    }
+    key -= (size_t)BS * C;
+
+    if (cplx) {                                                               /* :310-324 */
+        float scale = 0x1.62E430p-1f * (31 - __builtin_clz((unsigned)BS));
+        cplx = logf(SQRF(cplxW) / cplx) / scale;
+        if (cplx < 0.0f) cplx = 0.0f;
+        if (cplx > 1.0f) cplx = 1.0f;
+    }
+    st->BlockComplexity = cplx;
+
+    float *mask = st->SampleBuffer;                                           /* :148, :329 */
+    orc_calc_psychoacoustics(mask, amp2, tmp, BS, st->RateHz, (uint32_t)wc);
+    memcpy(st->Masking, mask, sizeof(float) * (BS / 2));
+    for (int ch = 0; ch < C; ch++) {                                          /* :337-345 */
+        for (int n = 0; n < BS; n++) {
+            float v = key[n];
+            key[n] = 2 * v + mask[n / 2] + -0x1.62E430p0f * (ch & 1);
+        }
+        key += BS;
+    }
+    key -= (size_t)BS * C;
+    memcpy(st->Keys, key, sizeof(float) * (size_t)BS * C);
+
+    orc_sort_indices(st->TransformIndex, (const float *)st->TransformIndex, (int *)st->TransformTemp, C * BS);  /* :350-354 */
+    st->nNzCoef = nNz;
+    return nNz;
+}
+
+/* ========================================================================== */
+/* Rate control: /root/reference/libulc/ulcEncoder.c                           */
+/* ========================================================================== */
+
+/* ulcEncoder.c:93-116 */
+static int cbr_core(orc_encoder *st, uint8_t *dst, float RateKbps, int MaxCoef) {
+    int size = 0, nOut = -1;
+    int budget = (int)((st->BlockSize * RateKbps) * 1000.0f / st->RateHz);
+    int lo = 0, hi = MaxCoef;
+    if (lo < hi) do {
+        nOut = (int)((unsigned)(lo + hi) / 2u);
+        size = orc_encode_pass(st, dst, nOut);
+        if (size < budget) lo = nOut;
+        else if (size > budget) hi = nOut - 1;
+        else { lo = nOut; break; }
+    } while (lo < hi - 1);
+    int fin = lo;
+    if (fin != nOut) size = orc_encode_pass(st, dst, nOut = fin);
+    st->lastNOutCoef = nOut;
+    return size;
+}
+
+/* ulcEncoder.c:117-123 */
+int orc_encode_block_cbr(orc_encoder *st, uint8_t *Dst, const float *Src, float RateKbps) {
+    int maxCoef = orc_transform_block(st, Src);
+    return cbr_core(st, Dst, RateKbps, maxCoef);
+}
+
+/* ulcEncoder.c:128-135 */
+int orc_encode_block_abr(orc_encoder *st, uint8_t *Dst, const float *Src, float RateKbps, float AvgComplexity) {
+    int maxCoef = orc_transform_block(st, Src);
+    float target = RateKbps * st->BlockComplexity / AvgComplexity;
+    return cbr_core(st, Dst, target, maxCoef);
+}
+
+/* ulcEncoder.c:140-158 */
+int orc_encode_block_vbr(orc_encoder *st, uint8_t *Dst, const float *Src, float Quality) {
+    float targetComplexity = 0x1.E4EFB7p3f * logf(100.0f / Quality);
+    int maxCoef = orc_transform_block(st, Src);
+    int nTarget = maxCoef;
+    if (targetComplexity > 0.0f) {
+        float f = (st->nChan * st->BlockSize) * st->BlockComplexity / targetComplexity;
+        if (f < maxCoef) nTarget = (int)f;
+    }
+    st->lastNOutCoef = nTarget;
+    return orc_encode_pass(st, Dst, nTarget);
+}
+
+/* ========================================================================== */
+/* whole-stream helpers (tests / cpu_baseline)                                 */
+/* ========================================================================== */
+static int encode_stream(int mode, int RateHz, int nChan, int BlockSize, const float *pcm, int nBlocks, float p0,
+                         uint8_t *out, int slotBytes, int32_t *bits, int32_t *wc, float *cplx) {
+    orc_encoder st; memset(&st, 0, sizeof(st));
+    st.RateHz = RateHz; st.nChan = nChan; st.BlockSize = BlockSize;
+    if (orc_encoder_init(&st) < 0) return -1;
+    size_t blk = (size_t)nChan * BlockSize;
+    uint8_t *tmp = (uint8_t *)malloc(blk * 4 + 64);
+    int rc = 0;
+    for (int k = 0; k < nBlocks; k++) {
+        int sz = (mode == 0) ? orc_encode_block_vbr(&st, tmp, pcm + k * blk, p0)
+                             : orc_encode_block_cbr(&st, tmp, pcm + k * blk, p0);
+        if (sz / 8 > slotBytes) { rc = -2; break; }
+        memcpy(out + (size_t)k * slotBytes, tmp, (size_t)sz / 8);
+        if (bits) bits[k] = sz;
+        if (wc)   wc[k] = st.WindowCtrl;
+        if (cplx) cplx[k] = st.BlockComplexity;
+    }
+    free(tmp);
+    orc_encoder_destroy(&st);
+    return rc;
+}
+int orc_encode_stream_vbr(int RateHz, int nChan, int BlockSize, const float *pcm, int nBlocks, float Quality,
+                          uint8_t *out, int slotBytes, int32_t *bits, int32_t *wc, float *cplx) {
+    return encode_stream(0, RateHz, nChan, BlockSize, pcm, nBlocks, Quality, out, slotBytes, bits, wc, cplx);
+}
+int orc_encode_stream_cbr(int RateHz, int nChan, int BlockSize, const float *pcm, int nBlocks, float RateKbps,
+                          uint8_t *out, int slotBytes, int32_t *bits, int32_t *wc, float *cplx) {
+    return encode_stream(1, RateHz, nChan, BlockSize, pcm, nBlocks, RateKbps, out, slotBytes, bits, wc, cplx);
+}

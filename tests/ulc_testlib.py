@@ -1,0 +1,139 @@
+"""Shared test plumbing: ctypes handles for the oracle (checker only), the partial
+real-reference build (oracle/_ref, when prebuilt) and a seeded synthetic PCM
+generator."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+i32p = C.POINTER(C.c_int32)
+u8p = C.POINTER(C.c_uint8)
+
+
+def ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+def build_oracle():
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("orc_fourier.c", "orc_encoder.c", "orc_decoder.c", "ulc_oracle.h")]
+    if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        lib = C.CDLL(build_oracle())
+        lib.orc_fastlog.restype = C.c_float
+        lib.orc_fastlog.argtypes = [C.c_float]
+        lib.orc_companded_quantize_unsigned.argtypes = [C.c_float]
+        lib.orc_build_quantizer.argtypes = [C.c_float]
+        lib.orc_get_noise_q.argtypes = [f32p, C.c_int, C.c_int, C.c_float]
+        lib.orc_get_hfext_params.argtypes = [f32p, C.c_int, C.c_int, C.c_float, i32p, i32p]
+        lib.orc_get_window_ctrl.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int]
+        lib.orc_calc_psychoacoustics.argtypes = [f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_uint32]
+        lib.orc_calc_noise_log_spectrum.argtypes = [f32p, C.c_void_p, C.c_int, C.c_int]
+        lib.orc_mdct_mdst.argtypes = [f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int]
+        lib.orc_imdct.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int]
+        lib.orc_dct4.argtypes = [f32p, f32p, f32p, C.c_int]
+        lib.orc_ref64_mdct_mdst.argtypes = [f64p, f64p, f32p, f64p, f64p, C.c_int, C.c_int]
+        lib.orc_ref64_imdct_raw.argtypes = [f64p, f32p, C.c_int]
+        lib.orc_window_tables.argtypes = [C.c_int, f32p, f32p]
+        lib.orc_sort_indices.argtypes = [i32p, f32p, i32p, C.c_int]
+        lib.orc_xorshift32.restype = C.c_uint32
+        lib.orc_xorshift32.argtypes = [C.c_uint32]
+        lib.orc_decimation_pattern.restype = C.c_uint16
+        lib.orc_encode_stream_vbr.argtypes = [C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_float, u8p, C.c_int, i32p, i32p, f32p]
+        lib.orc_encode_stream_cbr.argtypes = lib.orc_encode_stream_vbr.argtypes
+        lib.orc_decode_stream.argtypes = [C.c_int, C.c_int, u8p, C.c_int, C.c_int, f32p, i32p]
+        _oracle = lib
+    return _oracle
+
+
+def ref_partial():
+    """The real reference's WindowControl/Psyopt/NoiseFill objects (oracle/_ref), or None."""
+    so = os.path.join(ORACLE_DIR, "_ref", "libulc_ref_partial.so")
+    if not os.path.exists(so):
+        if os.path.isdir("/root/reference/libulc"):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
+        else:
+            return None
+    lib = C.CDLL(so)
+    lib.ULCi_GetNoiseQ.argtypes = [f32p, C.c_int, C.c_int, C.c_float]
+    lib.ULCi_GetHFExtParams.argtypes = [f32p, C.c_int, C.c_int, C.c_float, i32p, i32p]
+    lib.ULCi_GetWindowCtrl.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int]
+    lib.ULCi_CalculatePsychoacoustics.argtypes = [f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_uint32]
+    lib.ULCi_CalculateNoiseLogSpectrum.argtypes = [f32p, C.c_void_p, C.c_int, C.c_int]
+    return lib
+
+
+# ---------------------------------------------------------------------------
+# synthetic PCM: tones + noise (+ decaying bursts), quantised to the
+# PCM16 grid and scaled by 2^-15 exactly as a WAV reader would.
+# ---------------------------------------------------------------------------
+def synth_pcm(stream_id, n_samples, n_chan=2, rate=44100, transient=False, seed=0):
+    rng = np.random.default_rng([0x9E3779B9, seed, stream_id])
+    t = np.arange(n_samples, dtype=np.float64) / rate
+    x = np.zeros(n_samples)
+    for _ in range(3):
+        f = np.exp(rng.uniform(np.log(80.0), np.log(12000.0)))
+        a = rng.uniform(0.05, 0.3)
+        x += a * np.sin(2 * np.pi * f * t + rng.uniform(0, 2 * np.pi))
+    x += rng.normal(0, 0.02, n_samples)
+    if transient:
+        pos = 0
+        while True:
+            pos += int(rng.uniform(0.1, 0.3) * rate) if rate else 0
+            if pos >= n_samples:
+                break
+            ln = min(n_samples - pos, 3000)
+            amp = 10 ** rng.uniform(-2.5, -0.3)
+            x[pos:pos + ln] += rng.normal(0, amp, ln) * np.exp(-np.arange(ln) / 300.0)
+    chans = [x]
+    for c in range(1, n_chan):
+        d = 7 * c
+        y = 0.8 * np.concatenate([np.zeros(d), x[:-d]]) + rng.normal(0, 0.01, n_samples)
+        chans.append(y)
+    pcm = np.stack(chans, axis=1)
+    q = np.clip(np.rint(pcm * 32768.0), -32768, 32767)
+    return (q * (1.0 / 32768.0)).astype(np.float32)  # [n_samples][n_chan] interleaved
+
+
+def oracle_encode_stream(pcm, block_size, rate, quality=None, kbps=None):
+    """pcm: [n][C] float32 (n multiple of block_size). Returns (bytes[nBlk][slot], bits, wc, cplx)."""
+    lib = oracle()
+    n, ch = pcm.shape
+    nblk = n // block_size
+    slot = 4 * ch * block_size
+    out = np.zeros((nblk, slot), np.uint8)
+    bits = np.zeros(nblk, np.int32)
+    wc = np.zeros(nblk, np.int32)
+    cplx = np.zeros(nblk, np.float32)
+    flat = np.ascontiguousarray(pcm.reshape(-1))
+    if quality is not None:
+        rc = lib.orc_encode_stream_vbr(rate, ch, block_size, ptr(flat, f32p), nblk, quality, ptr(out, u8p), slot,
+                                       ptr(bits, i32p), ptr(wc, i32p), ptr(cplx, f32p))
+    else:
+        rc = lib.orc_encode_stream_cbr(rate, ch, block_size, ptr(flat, f32p), nblk, kbps, ptr(out, u8p), slot,
+                                       ptr(bits, i32p), ptr(wc, i32p), ptr(cplx, f32p))
+    assert rc == 0
+    return out, bits, wc, cplx
+
+
+def oracle_decode_stream(blocks, n_chan, block_size):
+    lib = oracle()
+    nblk, slot = blocks.shape
+    pcm = np.zeros((nblk * block_size, n_chan), np.float32)
+    bits = np.zeros(nblk, np.int32)
+    rc = lib.orc_decode_stream(n_chan, block_size, ptr(np.ascontiguousarray(blocks), u8p), slot, nblk,
+                               ptr(pcm, f32p), ptr(bits, i32p))
+    return rc, pcm, bits
