@@ -1,0 +1,174 @@
+/*
+ * ulc_amd.h — C ABI of libulc_amd.so, the MI355X (gfx950) implementation of the
+ * ulc-codec per-block hot path.  Plain C, plain pointers and sizes; no torch, no
+ * C++ types.  Two layers:
+ *
+ *  1. DROP-IN layer: the reference's own public API, same symbols, same struct
+ *     layout (size/offsets are ABI: ULC_EncoderState_t = 104 bytes,
+ *     ULC_DecoderState_t = 48 bytes on x86-64), same return conventions, so
+ *     /root/reference/tools/ulcEncodeTool.c and ulcDecodeTool.c compile against the
+ *     reference's own headers and link against this library unchanged.
+ *     Replaces: /root/reference/include/ulcEncoder.h:47-78,85-88,135-137 and
+ *               /root/reference/include/ulcDecoder.h:13-32,39-42,56
+ *     (implemented by /root/reference/libulc/ulcEncoder.c:25-158 and ulcDecoder.c:26-302).
+ *     Each call is a batch of one stream x one block through the batched path below.
+ *
+ *  2. BATCHED layer (ulcx_*): B independent streams x K consecutive blocks per
+ *     call, state resident in HBM between calls.  This is what bench.py measures.
+ *     It is what a maintainer would bind from ulcEncodeTool.c's block loop
+ *     (tools/ulcEncodeTool.c:133-169) when encoding many files at once
+ *     (INTEGRATION.md).
+ *
+ * Every entry point fails loudly (negative return + ulcx_last_error()) when no
+ * gfx950 device / HIP runtime is usable — there is no CPU fallback in this library.
+ */
+#ifndef ULC_AMD_H
+#define ULC_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* 1. Drop-in layer (reference ABI)                                           */
+/* ------------------------------------------------------------------------- */
+#ifndef ULC_AMD_NO_DROPIN_TYPES
+struct ULC_TransientData_t { float Sum, SumW; };           /* ulcEncoder.h:44-46 */
+
+/* ulcEncoder.h:47-78.  Caller sets RateHz/nChan/BlockSize, then Init.  The
+ * pointer fields are private to the library: BufferData owns the (host) block,
+ * TransformTemp receives each encoded block (the pointer the EncodeBlock calls
+ * return), BlockComplexity is readable after each call (ulcEncodeTool.c:164). */
+struct ULC_EncoderState_t {
+    int    RateHz;
+    int    nChan;
+    int    BlockSize;
+    int    WindowCtrl;
+    int    NextWindowCtrl;
+    float  BlockComplexity;
+    float  TransientFilter[3];
+    void  *BufferData;
+    float *SampleBuffer;
+    float *TransformBuffer;
+    float *TransformNoise;
+    float *TransformFwdLap;
+    float *TransformTemp;
+    int   *TransformIndex;
+    struct ULC_TransientData_t *TransientBuffer;
+};
+
+/* ulcDecoder.h:13-32 */
+struct ULC_DecoderState_t {
+    int    nChan;
+    int    BlockSize;
+    int    LastSubBlockSize;
+    void  *BufferData;
+    float *TransformBuffer;
+    float *TransformTemp;
+    float *TransformInvLap;
+};
+#endif
+
+/* ulcEncoder.h:85-88 / ulcEncoder.c:25-88.  Returns 1 on success, -1 on failure
+ * (bad nChan/BlockSize, out of memory, or no usable GPU). */
+int  ULC_EncoderState_Init(struct ULC_EncoderState_t *State);
+void ULC_EncoderState_Destroy(struct ULC_EncoderState_t *State);
+
+/* ulcEncoder.h:135-137 / ulcEncoder.c:93-158.  SrcData: BlockSize*nChan
+ * interleaved floats.  Returns a pointer valid until the next call on State;
+ * *Size (may be NULL) = bits, multiple of 8. */
+const void *ULC_EncodeBlock_CBR(struct ULC_EncoderState_t *State, const float *SrcData, int *Size, float RateKbps);
+const void *ULC_EncodeBlock_ABR(struct ULC_EncoderState_t *State, const float *SrcData, int *Size, float RateKbps, float AvgComplexity);
+const void *ULC_EncodeBlock_VBR(struct ULC_EncoderState_t *State, const float *SrcData, int *Size, float Quality);
+
+/* ulcDecoder.h:39-42,56 / ulcDecoder.c:26-302.  DecodeBlock returns bits
+ * consumed (nybble granular), 0 = corrupt block. */
+int  ULC_DecoderState_Init(struct ULC_DecoderState_t *State);
+void ULC_DecoderState_Destroy(struct ULC_DecoderState_t *State);
+int  ULC_DecodeBlock(struct ULC_DecoderState_t *State, float *DstData, const void *SrcBuffer);
+
+/* ------------------------------------------------------------------------- */
+/* 2. Batched layer                                                           */
+/* ------------------------------------------------------------------------- */
+typedef struct ulcx_encoder ulcx_encoder;
+typedef struct ulcx_decoder ulcx_decoder;
+
+enum {
+    ULCX_OK            =  0,
+    ULCX_ERR_ARG       = -1,   /* same validation as ulcEncoder.c:32-34 + batch limits */
+    ULCX_ERR_NO_DEVICE = -2,   /* HIP runtime / gfx950 device not usable */
+    ULCX_ERR_HIP       = -3,   /* a HIP call failed (message in ulcx_last_error) */
+    ULCX_ERR_NOMEM     = -4,
+    ULCX_ERR_UNSUPPORTED = -5  /* valid for the reference, not built for the device yet (BlockSize > 8192) */
+};
+
+enum { ULCX_MODE_VBR = 0, ULCX_MODE_CBR = 1, ULCX_MODE_ABR = 2 };
+
+const char *ulcx_last_error(void);
+int  ulcx_device_count(void);                 /* <= 0 when no usable device */
+
+/* Encoder for nStreams independent streams (all same RateHz/nChan/BlockSize);
+ * at most maxBlocksPerCall blocks per stream per call.  device = HIP ordinal. */
+int  ulcx_encoder_create(ulcx_encoder **enc, int device, int nStreams, int nChan, int BlockSize, int RateHz, int maxBlocksPerCall);
+void ulcx_encoder_destroy(ulcx_encoder *enc);
+int  ulcx_encoder_reset(ulcx_encoder *enc);   /* back to the state right after create */
+int  ulcx_encoder_slot_bytes(const ulcx_encoder *enc);   /* bytes reserved per encoded block */
+
+/* Encode nBlocks consecutive blocks of every stream.  All pointers are DEVICE
+ * pointers; work is enqueued on hipStream (a hipStream_t, NULL = default stream)
+ * and is asynchronous with respect to the host.
+ *   d_pcm  [nStreams][nBlocks][BlockSize][nChan] f32 interleaved (the layout the
+ *          reference's EncodeBlock reads: ulcEncoder_BlockTransform.c:96-98)
+ *   d_out  [nStreams][nBlocks][slot_bytes] encoded blocks, byte aligned, each
+ *          identical to what ULC_EncodeBlock_* returns for that call
+ *   d_bits [nStreams][nBlocks] int32 block size in bits (multiple of 8)
+ *   d_wc   optional [nStreams][nBlocks] int32 State->WindowCtrl of that call
+ *   d_cplx optional [nStreams][nBlocks] f32 State->BlockComplexity of that call
+ * mode/param0/param1: VBR(Quality) | CBR(RateKbps) | ABR(RateKbps, AvgComplexity). */
+int  ulcx_encode_dev(ulcx_encoder *enc, int mode, float param0, float param1,
+                     const float *d_pcm, int nBlocks,
+                     uint8_t *d_out, int32_t *d_bits, int32_t *d_wc, float *d_cplx, void *hipStream);
+
+/* Host-pointer convenience (H2D, encode, D2H, synchronous). */
+int  ulcx_encode_host(ulcx_encoder *enc, int mode, float param0, float param1,
+                      const float *h_pcm, int nBlocks,
+                      uint8_t *h_out, int32_t *h_bits, int32_t *h_wc, float *h_cplx);
+
+/* Debug/parity taps (device->host copies of the intermediates of the LAST call;
+ * what the reference keeps in State->TransformBuffer / TransformNoise / the final
+ * importance keys).  Each array is [nStreams][nBlocks][nChan*BlockSize] f32; pass
+ * NULL to skip.  keep: [nStreams][nBlocks][nChan*BlockSize] uint8 (1 = coefficient
+ * rank < nOutCoef of the final pass). nout: [nStreams][nBlocks] int32. */
+int  ulcx_encoder_debug_fetch(ulcx_encoder *enc, int nBlocks, float *h_coef, float *h_noise, float *h_keys,
+                              uint8_t *h_keep, int32_t *h_nout);
+
+int  ulcx_decoder_create(ulcx_decoder **dec, int device, int nStreams, int nChan, int BlockSize, int maxBlocksPerCall);
+void ulcx_decoder_destroy(ulcx_decoder *dec);
+int  ulcx_decoder_reset(ulcx_decoder *dec);
+
+/* Decode nBlocks consecutive blocks of every stream (device pointers).
+ *   d_in   [nStreams][nBlocks][slotBytes] encoded blocks (each starts at its slot)
+ *   d_pcm  [nStreams][nBlocks][BlockSize][nChan] f32 interleaved
+ *          (ulcDecoder.c:291-297)
+ *   d_bits [nStreams][nBlocks] int32 bits consumed per block; 0 = corrupt: that
+ *          stream stops there (later blocks also report 0), like the tool aborting
+ *          (tools/ulcDecodeTool.c:154-157). */
+int  ulcx_decode_dev(ulcx_decoder *dec, const uint8_t *d_in, int slotBytes, int nBlocks,
+                     float *d_pcm, int32_t *d_bits, void *hipStream);
+int  ulcx_decode_host(ulcx_decoder *dec, const uint8_t *h_in, int slotBytes, int nBlocks,
+                      float *h_pcm, int32_t *h_bits);
+
+/* Timing helper for bench.py: device time (ms, hipEvent) of the kernels the last
+ * ulcx_*_dev call enqueued, per pipeline stage; returns number of stages written.
+ * Only valid after the stream has been synchronised. */
+int  ulcx_encoder_stage_ms(ulcx_encoder *enc, float *ms, int maxStages);
+const char *ulcx_encoder_stage_name(int stage);
+int  ulcx_decoder_stage_ms(ulcx_decoder *dec, float *ms, int maxStages);
+const char *ulcx_decoder_stage_name(int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

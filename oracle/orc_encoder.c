@@ -753,3 +753,36 @@ int orc_encode_stream_cbr(int RateHz, int nChan, int BlockSize, const float *pcm
                           uint8_t *out, int slotBytes, int32_t *bits, int32_t *wc, float *cplx) {
     return encode_stream(1, RateHz, nChan, BlockSize, pcm, nBlocks, RateKbps, out, slotBytes, bits, wc, cplx);
 }
+
+/* Same as orc_encode_stream_vbr/cbr but also dumps the per-block intermediates the
+ * parity tests compare stage by stage (any pointer may be NULL):
+ * coef/noise/keys: [nBlocks][nChan*BlockSize] f32, ranks: int32, nout: [nBlocks]. */
+int orc_encode_stream_debug(int mode, int RateHz, int nChan, int BlockSize, const float *pcm, int nBlocks, float p0, float p1,
+                            uint8_t *out, int slotBytes, int32_t *bits, int32_t *wc, float *cplx,
+                            float *coef, float *noise, float *keys, int32_t *ranks, int32_t *nout) {
+    orc_encoder st; memset(&st, 0, sizeof(st));
+    st.RateHz = RateHz; st.nChan = nChan; st.BlockSize = BlockSize;
+    if (orc_encoder_init(&st) < 0) return -1;
+    size_t blk = (size_t)nChan * BlockSize;
+    uint8_t *tmp = (uint8_t *)malloc(blk * 4 + 64);
+    int rc = 0;
+    for (int k = 0; k < nBlocks; k++) {
+        int sz;
+        if (mode == 0) sz = orc_encode_block_vbr(&st, tmp, pcm + k * blk, p0);
+        else if (mode == 1) sz = orc_encode_block_cbr(&st, tmp, pcm + k * blk, p0);
+        else sz = orc_encode_block_abr(&st, tmp, pcm + k * blk, p0, p1);
+        if (sz / 8 > slotBytes) { rc = -2; break; }
+        memcpy(out + (size_t)k * slotBytes, tmp, (size_t)sz / 8);
+        if (bits) bits[k] = sz;
+        if (wc)   wc[k] = st.WindowCtrl;
+        if (cplx) cplx[k] = st.BlockComplexity;
+        if (coef)  memcpy(coef + k * blk, st.TransformBuffer, sizeof(float) * blk);
+        if (noise) memcpy(noise + k * blk, st.TransformNoise, sizeof(float) * blk);
+        if (keys)  memcpy(keys + k * blk, st.Keys, sizeof(float) * blk);
+        if (ranks) memcpy(ranks + k * blk, st.TransformIndex, sizeof(int) * blk);
+        if (nout)  nout[k] = st.lastNOutCoef;
+    }
+    free(tmp);
+    orc_encoder_destroy(&st);
+    return rc;
+}

@@ -110,6 +110,9 @@ int orc_encode_stream_vbr(int RateHz, int nChan, int BlockSize, const float *pcm
                           uint8_t *out, int slotBytes, int32_t *bits, int32_t *wc, float *cplx);
 int orc_encode_stream_cbr(int RateHz, int nChan, int BlockSize, const float *pcm, int nBlocks, float RateKbps,
                           uint8_t *out, int slotBytes, int32_t *bits, int32_t *wc, float *cplx);
+int orc_encode_stream_debug(int mode, int RateHz, int nChan, int BlockSize, const float *pcm, int nBlocks, float p0, float p1,
+                            uint8_t *out, int slotBytes, int32_t *bits, int32_t *wc, float *cplx,
+                            float *coef, float *noise, float *keys, int32_t *ranks, int32_t *nout);
 /* Decodes nBlocks from per-block slots (fresh state, fresh RNG seed). Returns 0 on success, blockIndex+1 of the first corrupt block otherwise. */
 int orc_decode_stream(int nChan, int BlockSize, const uint8_t *in, int slotBytes, int nBlocks, float *pcm, int32_t *bitsRead);
 

@@ -1,0 +1,123 @@
+"""GPU parity tests proper: the HIP path (through the C ABI of libulc_amd.so) against the
+oracle on the same seeded inputs.  Bit-exact on the packed stream, WindowCtrl and
+BlockComplexity; MDCT coefficients additionally within 1e-5 (relative to the block
+peak) of the binary64 referee via the oracle's own referee test."""
+import os
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ulc-codec_amd"))
+from ulc_testlib import synth_pcm, oracle_encode_debug, oracle_decode_stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _amd():
+    import ulc_amd
+    return ulc_amd
+
+
+def _streams(B, nblk, bs, ch, rate, transient, seed):
+    return np.stack([synth_pcm(s, nblk * bs, ch, rate, transient=transient, seed=seed) for s in range(B)])
+
+
+def _compare_encode(enc_out, ref, s, k0, K, dbg=None, what=""):
+    out, bits, wc, cplx = enc_out
+    for k in range(K):
+        kk = k0 + k
+        tag = f"{what} stream {s} block {kk}"
+        assert wc[s, k] == ref["wc"][kk], f"{tag}: WindowCtrl {wc[s, k]:#x} != {ref['wc'][kk]:#x}"
+        if dbg is not None:
+            assert np.array_equal(dbg["coef"][s, k], ref["coef"][kk]), f"{tag}: MDCT coefficients differ"
+            assert np.array_equal(dbg["noise"][s, k], ref["noise"][kk]), f"{tag}: noise spectrum differs"
+            assert np.array_equal(dbg["keys"][s, k], ref["keys"][kk]), f"{tag}: importance keys differ"
+            assert dbg["nout"][s, k] == ref["nout"][kk], f"{tag}: nOutCoef {dbg['nout'][s, k]} != {ref['nout'][kk]}"
+            keep_ref = (ref["ranks"][kk] < ref["nout"][kk]).astype(np.uint8)
+            assert np.array_equal(dbg["keep"][s, k], keep_ref), f"{tag}: kept-coefficient set differs"
+        assert cplx[s, k].tobytes() == ref["cplx"][kk].tobytes(), f"{tag}: BlockComplexity {cplx[s, k]} != {ref['cplx'][kk]}"
+        assert bits[s, k] == ref["bits"][kk], f"{tag}: size {bits[s, k]} != {ref['bits'][kk]}"
+        nb = bits[s, k] // 8
+        assert np.array_equal(out[s, k, :nb], ref["out"][kk, :nb]), f"{tag}: stream bytes differ"
+
+
+@pytest.mark.parametrize("bs,ch,rate,transient,q", [
+    (2048, 2, 44100, True, 50.0),      # the bench shape
+    (2048, 1, 44100, True, 50.0),      # BASELINE config 1 shape
+    (4096, 2, 48000, True, 70.0),      # config 5 shape
+    (256, 1, 44100, True, 90.0),       # smallest block: D=4..7 window codes
+    (512, 3, 32000, True, 30.0),       # odd channel count (unpaired last channel)
+    (2048, 2, 44100, False, 10.0),
+])
+def test_encode_vbr_bit_exact(bs, ch, rate, transient, q):
+    amd = _amd()
+    B, calls, K = 6, 3, 5
+    pcm = _streams(B, calls * K, bs, ch, rate, transient, seed=bs + ch)
+    enc = amd.BatchEncoder(B, ch, bs, rate, K)
+    refs = [oracle_encode_debug(pcm[s], bs, rate, 0, q, slot=enc.slot) for s in range(B)]
+    for c in range(calls):                      # state must carry across calls
+        res = enc.encode(pcm[:, c * K * bs:(c + 1) * K * bs], amd.MODE_VBR, q)
+        dbg = enc.debug_fetch()
+        for s in range(B):
+            _compare_encode(res, refs[s], s, c * K, K, dbg, f"bs={bs} ch={ch}")
+    enc.close()
+
+
+@pytest.mark.parametrize("bs,ch,rate,mode,p0,p1", [
+    (2048, 2, 48000, 1, 64.0, 0.0),     # BASELINE config 4 shape: CBR 64 kbps 48 kHz stereo
+    (2048, 1, 44100, 1, 32.0, 0.0),
+    (1024, 2, 44100, 2, 96.0, 0.45),    # ABR
+])
+def test_encode_cbr_abr_bit_exact(bs, ch, rate, mode, p0, p1):
+    amd = _amd()
+    B, K = 4, 6
+    pcm = _streams(B, K, bs, ch, rate, True, seed=17)
+    enc = amd.BatchEncoder(B, ch, bs, rate, K)
+    res = enc.encode(pcm, mode, p0, p1)
+    dbg = enc.debug_fetch()
+    for s in range(B):
+        ref = oracle_encode_debug(pcm[s], bs, rate, mode, p0, p1, slot=enc.slot)
+        _compare_encode(res, ref, s, 0, K, dbg, f"mode={mode}")
+    enc.close()
+
+
+@pytest.mark.parametrize("bs,ch,rate,q", [(2048, 2, 44100, 50.0), (2048, 1, 44100, 80.0), (4096, 2, 48000, 60.0), (256, 2, 44100, 90.0)])
+def test_decode_bit_exact(bs, ch, rate, q):
+    amd = _amd()
+    B, calls, K = 5, 2, 6
+    pcm = _streams(B, calls * K, bs, ch, rate, True, seed=3)
+    slot = 2 * ch * bs + 16
+    refs = [oracle_encode_debug(pcm[s], bs, rate, 0, q, slot=slot) for s in range(B)]
+    blocks = np.stack([r["out"] for r in refs])                  # [B][nblk][slot]
+    dec = amd.BatchDecoder(B, ch, bs, K)
+    got = []
+    gbits = []
+    for c in range(calls):
+        p, b = dec.decode(blocks[:, c * K:(c + 1) * K])
+        got.append(p); gbits.append(b)
+    got = np.concatenate(got, axis=1); gbits = np.concatenate(gbits, axis=1)
+    for s in range(B):
+        rc, ref_pcm, ref_bits = oracle_decode_stream(refs[s]["out"], ch, bs)
+        assert rc == 0
+        assert np.array_equal(gbits[s], ref_bits), f"stream {s}: bits consumed differ"
+        assert np.array_equal(got[s], ref_pcm), f"stream {s}: decoded PCM differs (max {np.abs(got[s]-ref_pcm).max()})"
+    dec.close()
+
+
+def test_roundtrip_delay_and_snr_at_bench_shape():
+    """Size-independent property: encode -> decode reproduces the input delayed by exactly
+    2*BlockSize samples with codec-level SNR."""
+    amd = _amd()
+    bs, ch, rate, B, K = 2048, 2, 44100, 64, 16
+    pcm = _streams(B, K, bs, ch, rate, True, seed=99)
+    enc = amd.BatchEncoder(B, ch, bs, rate, K)
+    out, bits, wc, cplx = enc.encode(pcm, amd.MODE_VBR, 60.0)
+    dec = amd.BatchDecoder(B, ch, bs, K)
+    got, gbits = dec.decode(out)
+    assert (gbits > 0).all() and (gbits <= bits).all() and (bits - gbits < 8).all()
+    d = 2 * bs
+    x, y = pcm[:, :-d], got[:, d:]
+    snr = 10 * np.log10((x ** 2).sum() / ((x - y) ** 2).sum())
+    assert snr > 12.0, snr
+    enc.close(); dec.close()

@@ -54,6 +54,8 @@ def oracle():
         lib.orc_decimation_pattern.restype = C.c_uint16
         lib.orc_encode_stream_vbr.argtypes = [C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_float, u8p, C.c_int, i32p, i32p, f32p]
         lib.orc_encode_stream_cbr.argtypes = lib.orc_encode_stream_vbr.argtypes
+        lib.orc_encode_stream_debug.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_float, C.c_float,
+                                                u8p, C.c_int, i32p, i32p, f32p, f32p, f32p, f32p, i32p, i32p]
         lib.orc_decode_stream.argtypes = [C.c_int, C.c_int, u8p, C.c_int, C.c_int, f32p, i32p]
         _oracle = lib
     return _oracle
@@ -137,3 +139,21 @@ def oracle_decode_stream(blocks, n_chan, block_size):
     rc = lib.orc_decode_stream(n_chan, block_size, ptr(np.ascontiguousarray(blocks), u8p), slot, nblk,
                                ptr(pcm, f32p), ptr(bits, i32p))
     return rc, pcm, bits
+
+
+def oracle_encode_debug(pcm, block_size, rate, mode=0, p0=50.0, p1=0.0, slot=None):
+    """Full oracle encode of one stream with intermediates. pcm [n][C]."""
+    lib = oracle()
+    n, ch = pcm.shape
+    nblk = n // block_size
+    slot = slot or (2 * ch * block_size + 16)
+    cb = ch * block_size
+    r = dict(out=np.zeros((nblk, slot), np.uint8), bits=np.zeros(nblk, np.int32), wc=np.zeros(nblk, np.int32),
+             cplx=np.zeros(nblk, np.float32), coef=np.zeros((nblk, cb), np.float32), noise=np.zeros((nblk, cb), np.float32),
+             keys=np.zeros((nblk, cb), np.float32), ranks=np.zeros((nblk, cb), np.int32), nout=np.zeros(nblk, np.int32))
+    flat = np.ascontiguousarray(pcm.reshape(-1))
+    rc = lib.orc_encode_stream_debug(mode, rate, ch, block_size, ptr(flat, f32p), nblk, p0, p1, ptr(r["out"], u8p), slot,
+                                     ptr(r["bits"], i32p), ptr(r["wc"], i32p), ptr(r["cplx"], f32p), ptr(r["coef"], f32p),
+                                     ptr(r["noise"], f32p), ptr(r["keys"], f32p), ptr(r["ranks"], i32p), ptr(r["nout"], i32p))
+    assert rc == 0, rc
+    return r

@@ -1,0 +1,337 @@
+// ulcx_api.cpp — C ABI of the batched layer (include/ulc_amd.h §2): object lifetime,
+// HBM layout, host-side constants, launches.  Host code only; every kernel lives in
+// ulcx_enc.hip / ulcx_dec.hip.  There is no CPU fallback: if HIP cannot give us a
+// device, every entry point returns ULCX_ERR_NO_DEVICE.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "ulcx_internal.h"
+
+size_t ulcx_dec_lds_bytes(int BS, int C);
+
+#define CKR(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)
+
+struct ulcx_encoder {
+    int device, B, C, BS, rate, maxK;
+    UlcxEncCtx ctx;
+    void *tables;
+    std::vector<void *> allocs;
+    hipEvent_t ev[ULCX_ENC_STAGES + 1];
+    bool evOk, evRecorded;
+    int lastK;
+    // staging for the host-pointer API
+    float *d_pcm; uint8_t *d_out; int32_t *d_bits, *d_wc; float *d_cplx;
+};
+struct ulcx_decoder {
+    int device, B, C, BS, maxK;
+    UlcxDecCtx ctx;
+    void *tables;
+    std::vector<void *> allocs;
+    hipEvent_t ev[ULCX_DEC_STAGES + 1];
+    bool evOk, evRecorded;
+    uint8_t *d_in; int d_in_bytes; float *d_pcm; int32_t *d_bits;
+};
+
+extern "C" int ulcx_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { ulcx_set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return 0; }
+    return n;
+}
+
+static int validate(int C, int BS) {                 // ulcEncoder.c:32-34 / ulcDecoder.c:33-35
+    if (C < 1 || C > 255) return 0;
+    if (BS < 256 || BS > 32768) return 0;
+    if ((BS & (-BS)) != BS) return 0;
+    return 1;
+}
+static int ilog2i(int x) { int r = 0; while ((1 << r) < x) r++; return r; }
+
+template <typename T>
+static int dalloc(std::vector<void *> &v, T **p, size_t count, bool zero) {
+    void *q = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) { ulcx_set_error("hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e)); return ULCX_ERR_NOMEM; }
+    if (zero) { e = hipMemset(q, 0, bytes); if (e != hipSuccess) { ulcx_set_error("hipMemset: %s", hipGetErrorString(e)); hipFree(q); return ULCX_ERR_HIP; } }
+    v.push_back(q);
+    *p = (T *)q;
+    return ULCX_OK;
+}
+#define DA(ptr, count, zero) do { int rc_ = dalloc(e->allocs, &(ptr), (size_t)(count), zero); if (rc_) { cleanup(e); return rc_; } } while (0)
+
+static int select_device(int device) {
+    int n = ulcx_device_count();
+    if (n <= 0) { if (!ulcx_last_error()[0]) ulcx_set_error("no HIP device visible"); return ULCX_ERR_NO_DEVICE; }
+    if (device < 0 || device >= n) { ulcx_set_error("device %d out of range (have %d)", device, n); return ULCX_ERR_ARG; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { ulcx_set_error("hipSetDevice: %s", hipGetErrorString(e)); return ULCX_ERR_NO_DEVICE; }
+    return ULCX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// encoder
+// ---------------------------------------------------------------------------
+static void cleanup(ulcx_encoder *e) {
+    if (!e) return;
+    for (void *p : e->allocs) hipFree(p);
+    if (e->tables) hipFree(e->tables);
+    if (e->evOk) for (auto &v : e->ev) hipEventDestroy(v);
+    delete e;
+}
+
+static int enc_reset_state(ulcx_encoder *e) {
+    UlcxEncCtx &c = e->ctx;
+    CKR(hipMemset(c.hist, 0, sizeof(float) * (size_t)e->B * 2 * e->BS * e->C));
+    std::vector<UlcxWcState> w((size_t)e->B);
+    for (auto &x : w) {
+        memset(&x, 0, sizeof(x));
+        x.wcPrev = 0x10;              // virtual block -1: full-size, full-overlap
+        x.wcCur  = 0x10;              // State->NextWindowCtrl = 0x10 (ulcEncoder.c:70)
+    }
+    CKR(hipMemcpy(c.wcs, w.data(), sizeof(UlcxWcState) * w.size(), hipMemcpyHostToDevice));
+    return ULCX_OK;
+}
+
+extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams, int nChan, int BlockSize, int RateHz, int maxBlocksPerCall) {
+    if (!out) return ULCX_ERR_ARG;
+    *out = nullptr;
+    if (!validate(nChan, BlockSize) || nStreams < 1 || maxBlocksPerCall < 1 || RateHz < 1) {
+        ulcx_set_error("invalid encoder geometry (nStreams=%d nChan=%d BlockSize=%d RateHz=%d maxBlocks=%d)", nStreams, nChan, BlockSize, RateHz, maxBlocksPerCall);
+        return ULCX_ERR_ARG;
+    }
+    if (BlockSize > ULCX_MAX_BS_DEVICE) { ulcx_set_error("BlockSize %d > %d not built for the device yet", BlockSize, ULCX_MAX_BS_DEVICE); return ULCX_ERR_UNSUPPORTED; }
+    int rc = select_device(device);
+    if (rc) return rc;
+    ulcx_encoder *e = new ulcx_encoder();
+    e->device = device; e->B = nStreams; e->C = nChan; e->BS = BlockSize; e->rate = RateHz; e->maxK = maxBlocksPerCall;
+    e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->lastK = 0;
+    e->d_pcm = nullptr; e->d_out = nullptr; e->d_bits = nullptr; e->d_wc = nullptr; e->d_cplx = nullptr;
+    UlcxEncCtx &c = e->ctx;
+    memset(&c, 0, sizeof(c));
+    c.B = nStreams; c.C = nChan; c.BS = BlockSize; c.lgBS = ilog2i(BlockSize); c.maxK = maxBlocksPerCall; c.K = 0;
+    c.rateHz = RateHz;
+    c.slot = 2 * nChan * BlockSize + 16;          // >= worst case 4 nybbles/coefficient + header
+    c.unitCap = 2 * BlockSize + 32;
+    // data-independent libm calls of the reference, evaluated on the host like the reference does
+    c.cHP  = 1.0f - expf(-0x1.CC845Cp6f / RateHz);            // WindowControl.c:75,82
+    c.cBP  = 1.0f - expf(-0x1.596344p8f / RateHz);            // :76,83
+    c.qHP  = 1.0f - expf(-0x1.CC845Cp7f / RateHz);            // :94,101
+    c.qBP  = 1.0f - expf(-0x1.596344p8f / RateHz);            // :95,102
+    c.cBlk = 1.0f - expf(-0x1.1AF110p-6f * BlockSize / RateHz); // :120,126
+    c.cplxScale = 0x1.62E430p-1f * (31 - __builtin_clz((unsigned)BlockSize));   // BlockTransform.c:320
+    rc = ulcx_tables_build(&c.T, &e->tables, BlockSize, RateHz, true);
+    if (rc) { cleanup(e); return rc; }
+    size_t B = nStreams, K = maxBlocksPerCall, NB = B * K, cb = (size_t)nChan * BlockSize;
+    DA(c.hist, B * 2 * BlockSize * nChan, true);
+    DA(c.wcs, B, true);
+    DA(c.env, B * K * BlockSize, false);
+    DA(c.bins, B * (K + 1) * 16, true);
+    DA(c.wcArr, B * (K + 2), true);
+    DA(c.coef, NB * cb, false);
+    DA(c.key, NB * cb, false);
+    DA(c.nsum, NB * cb / 2, false);
+    DA(c.npair, NB * cb, false);
+    DA(c.amp2, NB * BlockSize / 2, false);
+    DA(c.mask, NB * BlockSize / 2, false);
+    DA(c.barkN, NB * nChan * 4 * ULCX_NBARK, true);
+    DA(c.barkP, NB * 4 * ULCX_NBARK, true);
+    DA(c.nnz, NB, true);
+    DA(c.cplx, NB, true);
+    DA(c.nout, NB, true);
+    DA(c.cbrLo, NB, true); DA(c.cbrHi, NB, true); DA(c.cbrDone, NB, true); DA(c.cbrBudget, NB, true);
+    DA(c.keep, NB * cb / 32, true);
+    DA(c.fbList, NB, true);
+    DA(c.fbCount, 4, true);
+    DA(c.unitBuf, NB * nChan * (size_t)c.unitCap, true);
+    DA(c.unitNyb, NB * nChan * 4, true);
+    {
+        size_t heapBytes = (cb * 8 > ULCX_HEAP_LDS_BYTES) ? (size_t)ULCX_HEAP_GRID * cb * 8 : 16;
+        uint8_t *hp = nullptr;
+        DA(hp, heapBytes, false);
+        c.heapScratch = hp;
+    }
+    for (auto &v : e->ev) { if (hipEventCreate(&v) != hipSuccess) { ulcx_set_error("hipEventCreate failed"); cleanup(e); return ULCX_ERR_HIP; } }
+    e->evOk = true;
+    rc = enc_reset_state(e);
+    if (rc) { cleanup(e); return rc; }
+    *out = e;
+    return ULCX_OK;
+}
+
+extern "C" void ulcx_encoder_destroy(ulcx_encoder *e) { if (e) { hipSetDevice(e->device); cleanup(e); } }
+extern "C" int ulcx_encoder_reset(ulcx_encoder *e) { if (!e) return ULCX_ERR_ARG; CKR(hipSetDevice(e->device)); return enc_reset_state(e); }
+extern "C" int ulcx_encoder_slot_bytes(const ulcx_encoder *e) { return e ? e->ctx.slot : 0; }
+
+extern "C" int ulcx_encode_dev(ulcx_encoder *e, int mode, float p0, float p1, const float *d_pcm, int nBlocks,
+                               uint8_t *d_out, int32_t *d_bits, int32_t *d_wc, float *d_cplx, void *hipStream) {
+    if (!e || !d_pcm || !d_out || !d_bits || nBlocks < 1 || nBlocks > e->maxK) { ulcx_set_error("ulcx_encode_dev: bad argument"); return ULCX_ERR_ARG; }
+    if (mode != ULCX_MODE_VBR && mode != ULCX_MODE_CBR && mode != ULCX_MODE_ABR) { ulcx_set_error("bad mode"); return ULCX_ERR_ARG; }
+    CKR(hipSetDevice(e->device));
+    UlcxEncCtx c = e->ctx;
+    c.K = nBlocks; c.mode = mode; c.p0 = p0; c.p1 = p1;
+    c.vbrTarget = (mode == ULCX_MODE_VBR) ? 0x1.E4EFB7p3f * logf(100.0f / p0) : 0.0f;     // ulcEncoder.c:144 (host libm, data independent)
+    c.pcm = d_pcm; c.out = d_out; c.bits = d_bits; c.wcOut = d_wc; c.cplxOut = d_cplx;
+    int rc = ulcx_enc_launch(c, (hipStream_t)hipStream, e->ev);
+    e->evRecorded = (rc == ULCX_OK);
+    e->lastK = nBlocks;
+    return rc;
+}
+
+extern "C" int ulcx_encode_host(ulcx_encoder *e, int mode, float p0, float p1, const float *h_pcm, int nBlocks,
+                                uint8_t *h_out, int32_t *h_bits, int32_t *h_wc, float *h_cplx) {
+    if (!e || !h_pcm || !h_out || !h_bits) return ULCX_ERR_ARG;
+    CKR(hipSetDevice(e->device));
+    size_t NBmax = (size_t)e->B * e->maxK, cb = (size_t)e->C * e->BS;
+    if (!e->d_pcm) {
+        int rc;
+        if ((rc = dalloc(e->allocs, &e->d_pcm, NBmax * cb, false))) return rc;
+        if ((rc = dalloc(e->allocs, &e->d_out, NBmax * e->ctx.slot, false))) return rc;
+        if ((rc = dalloc(e->allocs, &e->d_bits, NBmax, false))) return rc;
+        if ((rc = dalloc(e->allocs, &e->d_wc, NBmax, false))) return rc;
+        if ((rc = dalloc(e->allocs, &e->d_cplx, NBmax, false))) return rc;
+    }
+    if (nBlocks < 1 || nBlocks > e->maxK) { ulcx_set_error("nBlocks out of range"); return ULCX_ERR_ARG; }
+    size_t NB = (size_t)e->B * nBlocks;
+    CKR(hipMemcpy(e->d_pcm, h_pcm, sizeof(float) * NB * cb, hipMemcpyHostToDevice));
+    int rc = ulcx_encode_dev(e, mode, p0, p1, e->d_pcm, nBlocks, e->d_out, e->d_bits, e->d_wc, e->d_cplx, nullptr);
+    if (rc) return rc;
+    CKR(hipDeviceSynchronize());
+    CKR(hipMemcpy(h_out, e->d_out, NB * e->ctx.slot, hipMemcpyDeviceToHost));
+    CKR(hipMemcpy(h_bits, e->d_bits, sizeof(int32_t) * NB, hipMemcpyDeviceToHost));
+    if (h_wc) CKR(hipMemcpy(h_wc, e->d_wc, sizeof(int32_t) * NB, hipMemcpyDeviceToHost));
+    if (h_cplx) CKR(hipMemcpy(h_cplx, e->d_cplx, sizeof(float) * NB, hipMemcpyDeviceToHost));
+    return ULCX_OK;
+}
+
+extern "C" int ulcx_encoder_debug_fetch(ulcx_encoder *e, int nBlocks, float *h_coef, float *h_noise, float *h_keys, uint8_t *h_keep, int32_t *h_nout) {
+    if (!e || nBlocks < 1 || nBlocks > e->maxK) return ULCX_ERR_ARG;
+    CKR(hipSetDevice(e->device));
+    CKR(hipDeviceSynchronize());
+    size_t NB = (size_t)e->B * nBlocks, cb = (size_t)e->C * e->BS;
+    if (h_coef)  CKR(hipMemcpy(h_coef, e->ctx.coef, sizeof(float) * NB * cb, hipMemcpyDeviceToHost));
+    if (h_noise) CKR(hipMemcpy(h_noise, e->ctx.npair, sizeof(float) * NB * cb, hipMemcpyDeviceToHost));
+    if (h_keys)  CKR(hipMemcpy(h_keys, e->ctx.key, sizeof(float) * NB * cb, hipMemcpyDeviceToHost));
+    if (h_nout)  CKR(hipMemcpy(h_nout, e->ctx.nout, sizeof(int32_t) * NB, hipMemcpyDeviceToHost));
+    if (h_keep) {
+        std::vector<uint32_t> bits(NB * cb / 32);
+        CKR(hipMemcpy(bits.data(), e->ctx.keep, sizeof(uint32_t) * bits.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < NB * cb; i++) h_keep[i] = (bits[i >> 5] >> (i & 31)) & 1;
+    }
+    return ULCX_OK;
+}
+
+static const char *kEncStage[ULCX_ENC_STAGES] = { "window_ctrl", "transform", "complexity", "noise_spectrum", "psycho_keys", "select", "encode_pack", "state_update" };
+extern "C" const char *ulcx_encoder_stage_name(int i) { return (i >= 0 && i < ULCX_ENC_STAGES) ? kEncStage[i] : ""; }
+extern "C" int ulcx_encoder_stage_ms(ulcx_encoder *e, float *ms, int maxStages) {
+    if (!e || !e->evRecorded) return 0;
+    int n = 0;
+    for (int i = 0; i < ULCX_ENC_STAGES && i < maxStages; i++) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, e->ev[i], e->ev[i + 1]) != hipSuccess) break;
+        ms[n++] = t;
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------
+// decoder
+// ---------------------------------------------------------------------------
+static void cleanup(ulcx_decoder *e) {
+    if (!e) return;
+    for (void *p : e->allocs) hipFree(p);
+    if (e->tables) hipFree(e->tables);
+    if (e->evOk) for (auto &v : e->ev) hipEventDestroy(v);
+    delete e;
+}
+static int dec_reset_state(ulcx_decoder *e) {
+    UlcxDecCtx &c = e->ctx;
+    CKR(hipMemset(c.lap, 0, sizeof(float) * (size_t)e->B * e->C * (e->BS / 2)));     // ulcDecoder.c:56
+    CKR(hipMemset(c.lastSub, 0, sizeof(int) * (size_t)e->B));                          // ulcDecoder.c:52
+    CKR(hipMemset(c.dead, 0, sizeof(int) * (size_t)e->B));
+    std::vector<uint32_t> seed((size_t)e->B, 1234567u);                                // ulcDecoder.c:76, one RNG per stream
+    CKR(hipMemcpy(c.seed, seed.data(), sizeof(uint32_t) * seed.size(), hipMemcpyHostToDevice));
+    return ULCX_OK;
+}
+
+extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams, int nChan, int BlockSize, int maxBlocksPerCall) {
+    if (!out) return ULCX_ERR_ARG;
+    *out = nullptr;
+    if (!validate(nChan, BlockSize) || nStreams < 1 || maxBlocksPerCall < 1) { ulcx_set_error("invalid decoder geometry"); return ULCX_ERR_ARG; }
+    if (BlockSize > ULCX_MAX_BS_DEVICE) { ulcx_set_error("BlockSize %d > %d not built for the device yet", BlockSize, ULCX_MAX_BS_DEVICE); return ULCX_ERR_UNSUPPORTED; }
+    if (ulcx_dec_lds_bytes(BlockSize, nChan) > 160 * 1024) { ulcx_set_error("nChan*BlockSize too large for the LDS-resident lapping state"); return ULCX_ERR_UNSUPPORTED; }
+    int rc = select_device(device);
+    if (rc) return rc;
+    ulcx_decoder *e = new ulcx_decoder();
+    e->device = device; e->B = nStreams; e->C = nChan; e->BS = BlockSize; e->maxK = maxBlocksPerCall;
+    e->tables = nullptr; e->evOk = false; e->evRecorded = false;
+    e->d_in = nullptr; e->d_in_bytes = 0; e->d_pcm = nullptr; e->d_bits = nullptr;
+    UlcxDecCtx &c = e->ctx;
+    memset(&c, 0, sizeof(c));
+    c.B = nStreams; c.C = nChan; c.BS = BlockSize; c.lgBS = ilog2i(BlockSize); c.maxK = maxBlocksPerCall;
+    rc = ulcx_tables_build(&c.T, &e->tables, BlockSize, 44100, false);
+    if (rc) { cleanup(e); return rc; }
+    size_t B = nStreams, NB = B * maxBlocksPerCall, cb = (size_t)nChan * BlockSize;
+    DA(c.lap, B * nChan * (BlockSize / 2), true);
+    DA(c.lastSub, B, true);
+    DA(c.seed, B, true);
+    DA(c.dead, B, true);
+    DA(c.coef, NB * cb, false);
+    DA(c.wc, NB, true);
+    for (auto &v : e->ev) { if (hipEventCreate(&v) != hipSuccess) { ulcx_set_error("hipEventCreate failed"); cleanup(e); return ULCX_ERR_HIP; } }
+    e->evOk = true;
+    rc = dec_reset_state(e);
+    if (rc) { cleanup(e); return rc; }
+    *out = e;
+    return ULCX_OK;
+}
+extern "C" void ulcx_decoder_destroy(ulcx_decoder *e) { if (e) { hipSetDevice(e->device); cleanup(e); } }
+extern "C" int ulcx_decoder_reset(ulcx_decoder *e) { if (!e) return ULCX_ERR_ARG; CKR(hipSetDevice(e->device)); return dec_reset_state(e); }
+
+extern "C" int ulcx_decode_dev(ulcx_decoder *e, const uint8_t *d_in, int slotBytes, int nBlocks, float *d_pcm, int32_t *d_bits, void *hipStream) {
+    if (!e || !d_in || !d_pcm || !d_bits || slotBytes < 1 || nBlocks < 1 || nBlocks > e->maxK) { ulcx_set_error("ulcx_decode_dev: bad argument"); return ULCX_ERR_ARG; }
+    CKR(hipSetDevice(e->device));
+    UlcxDecCtx c = e->ctx;
+    c.K = nBlocks; c.slot = slotBytes; c.in = d_in; c.pcm = d_pcm; c.bits = d_bits;
+    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->ev);
+    e->evRecorded = (rc == ULCX_OK);
+    return rc;
+}
+extern "C" int ulcx_decode_host(ulcx_decoder *e, const uint8_t *h_in, int slotBytes, int nBlocks, float *h_pcm, int32_t *h_bits) {
+    if (!e || !h_in || !h_pcm || !h_bits || nBlocks < 1 || nBlocks > e->maxK || slotBytes < 1) return ULCX_ERR_ARG;
+    CKR(hipSetDevice(e->device));
+    size_t NBmax = (size_t)e->B * e->maxK, cb = (size_t)e->C * e->BS, NB = (size_t)e->B * nBlocks;
+    size_t inBytes = NBmax * (size_t)slotBytes + 16;
+    if (!e->d_in || (size_t)e->d_in_bytes < inBytes) {
+        int rc;
+        if ((rc = dalloc(e->allocs, &e->d_in, inBytes, true))) return rc;
+        e->d_in_bytes = (int)inBytes;
+    }
+    if (!e->d_pcm) {
+        int rc;
+        if ((rc = dalloc(e->allocs, &e->d_pcm, NBmax * cb, false))) return rc;
+        if ((rc = dalloc(e->allocs, &e->d_bits, NBmax, false))) return rc;
+    }
+    CKR(hipMemcpy(e->d_in, h_in, NB * slotBytes, hipMemcpyHostToDevice));
+    int rc = ulcx_decode_dev(e, e->d_in, slotBytes, nBlocks, e->d_pcm, e->d_bits, nullptr);
+    if (rc) return rc;
+    CKR(hipDeviceSynchronize());
+    CKR(hipMemcpy(h_pcm, e->d_pcm, sizeof(float) * NB * cb, hipMemcpyDeviceToHost));
+    CKR(hipMemcpy(h_bits, e->d_bits, sizeof(int32_t) * NB, hipMemcpyDeviceToHost));
+    return ULCX_OK;
+}
+static const char *kDecStage[ULCX_DEC_STAGES] = { "parse_dequant", "imdct_ola" };
+extern "C" const char *ulcx_decoder_stage_name(int i) { return (i >= 0 && i < ULCX_DEC_STAGES) ? kDecStage[i] : ""; }
+extern "C" int ulcx_decoder_stage_ms(ulcx_decoder *e, float *ms, int maxStages) {
+    if (!e || !e->evRecorded) return 0;
+    int n = 0;
+    for (int i = 0; i < ULCX_DEC_STAGES && i < maxStages; i++) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, e->ev[i], e->ev[i + 1]) != hipSuccess) break;
+        ms[n++] = t;
+    }
+    return n;
+}

@@ -1,0 +1,289 @@
+// ulcx_dec.hip — batched ulc-codec decoder for gfx950 (MI355X), hand-written HIP.
+//
+//   k_dparse  nybble parser + dequantiser + noise synthesis
+//             (libulc/ulcDecoder.c:75-197; syntax FormatSpecs.md:57-141).  The syntax is
+//             a sequential state machine and the noise RNG is one chain per stream, so
+//             this runs one lane per stream, blocks in order.
+//   k_dimdct  one workgroup per stream, blocks in order, lapping state resident in LDS:
+//             IMDCT (one DCT-IV = complex FFT in LDS), sine-window overlap-add, the
+//             reversed-time centring FIFO, inverse M/S, interleave
+//             (libulc/ulcDecoder.c:198-302; IMDCT per FormatSpecs.md:150-157).
+// Compiled with -ffp-contract=off (see ulcx_enc.hip).
+#include "ulcx_internal.h"
+
+#define WG 256
+#include "ulcx_fft.h"
+
+// ---------------------------------------------------------------------------
+struct NybReader {
+    const uint8_t *p; int size;
+    __device__ __forceinline__ unsigned get() {                   // ulcDecoder.c:82-88, low nybble first
+        unsigned x = p[size >> 3];
+        unsigned n = (size & 4) ? (x >> 4) : (x & 0xF);
+        size += 4;
+        return n;
+    }
+};
+#define ESC_STOP (-1)
+#define ESC_STOP_NOISE (-2)
+__device__ __forceinline__ int get_quantizer(NybReader &r) {      // ulcDecoder.c:89-95
+    int q = (int)r.get();
+    if (q == 0xF) return ESC_STOP_NOISE;
+    if (q == 0xE) q += (int)r.get();
+    if (q == 0xE + 0xF) return ESC_STOP;
+    return q;
+}
+__device__ __forceinline__ float expand_quantizer(int q) {        // ulcDecoder.c:96-98
+    return 0x1.0p-31f * (float)((1u << (31 - 5)) >> q);
+}
+__device__ __forceinline__ uint32_t xorshift32(uint32_t s) {      // ulcDecoder.c:75-81
+    s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+    return s;
+}
+struct CoefWriter {                                               // sequential float stream -> 16-byte stores
+    float *dst; int n; float4 buf;
+    __device__ __forceinline__ void put(float v) {
+        int l = n & 3;
+        if (l == 0) buf.x = v; else if (l == 1) buf.y = v; else if (l == 2) buf.z = v; else buf.w = v;
+        n++;
+        if ((n & 3) == 0) *(float4 *)(dst + n - 4) = buf;
+    }
+};
+
+// ulcDecoder.c:99-197.  Returns 0 on a run that overruns the subblock (corrupt).
+__device__ int decode_subblock(CoefWriter &w, int N, NybReader &r, uint32_t &seed) {
+    int n, v;
+    v = get_quantizer(r);
+    if (v == ESC_STOP) { do w.put(0.0f); while (--N); return 1; }
+    float quant = expand_quantizer(v);
+    for (;;) {
+        v = (int)r.get();
+        if (v != 0x0 && v != 0x1 && v != 0x8 && v != 0xF) {
+            v = (v ^ 0x8) - 0x8;
+            v = (v < 0) ? (-v * v) : (+v * v);
+            w.put((float)v * quant);
+            if (--N == 0) break;
+            continue;
+        }
+        if (v == 0x0) {
+            n = (int)r.get() + 1;
+            if (n > N) return 0;
+            N -= n;
+            do w.put(0.0f); while (--n);
+            if (N == 0) break;
+            continue;
+        }
+        if (v == 0x1) {
+            n = (int)r.get();
+            n = (int)r.get() | (n << 4);
+            n += 33;
+            if (n > N) return 0;
+            N -= n;
+            do w.put(0.0f); while (--n);
+            if (N == 0) break;
+            continue;
+        }
+        if (v == 0x8) {
+            n = (int)r.get();
+            n = (int)r.get() | (n << 4);
+            v = (int)r.get();
+            n = (v & 1) | (n << 1);
+            v = (v >> 1) + 1;
+            n += 16;
+            if (n > N) return 0;
+            N -= n;
+            float p = (float)(v * v) * quant * (1.0f / 4);
+            do {
+                seed = xorshift32(seed);
+                if (seed & 0x80000000u) p = -p;
+                w.put(p);
+            } while (--n);
+            if (N == 0) break;
+            continue;
+        }
+        v = get_quantizer(r);
+        if (v >= 0) { quant = expand_quantizer(v); continue; }
+        if (v == ESC_STOP_NOISE) {
+            v = (int)r.get() + 1;
+            n = (int)r.get();
+            n = (int)r.get() | (n << 4);
+            float p = (float)(v * v) * quant * (1.0f / 16);
+            float rr = 1.0f + (float)(n * n) * -0x1.0p-19f;
+            do {
+                seed = xorshift32(seed);
+                if (seed & 0x80000000u) p = -p;
+                w.put(p); p *= rr;
+            } while (--N);
+            break;
+        }
+        if (v == ESC_STOP) { do w.put(0.0f); while (--N); break; }
+    }
+    return 1;
+}
+
+__global__ __launch_bounds__(64) void k_dparse(UlcxDecCtx c) {
+    int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= c.B) return;
+    uint32_t seed = c.seed[s];
+    int dead = c.dead[s];
+    for (int k = 0; k < c.K; k++) {
+        int blk = s * c.K + k;
+        if (dead) { c.bits[blk] = 0; c.wc[blk] = 0; continue; }
+        NybReader r; r.p = c.in + (size_t)blk * c.slot; r.size = 0;
+        int wc = (int)r.get();                                     // ulcDecoder.c:211-216
+        if (wc & 0x8) wc |= (int)r.get() << 4;
+        else wc |= 1 << 4;
+        CoefWriter w; w.dst = c.coef + (size_t)blk * c.C * c.BS; w.n = 0;
+        int ok = 1;
+        for (int ch = 0; ch < c.C && ok; ch++) {
+            unsigned pat = ulcx_pattern(wc);                        // (code 0000 behaves as one plain N/1 block, as in the reference)
+            do {
+                int S = c.BS >> (pat & 7);
+                if (!decode_subblock(w, S, r, seed)) { ok = 0; break; }
+                if (S == c.BS) break;                               // ulcDecoder.c:242-245
+            } while (pat >>= 4);
+        }
+        if (!ok) { dead = 1; c.bits[blk] = 0; c.wc[blk] = 0; continue; }
+        c.bits[blk] = r.size;
+        c.wc[blk] = wc;
+    }
+    c.seed[s] = seed;
+    c.dead[s] = dead;
+}
+
+// ---------------------------------------------------------------------------
+// IMDCT + overlap-add.  LDS carve (floats): lap [C][BS/2] | z [BS] (BS/2 complex) |
+// dec [BS] | tmpq [BS/2] | stage [2][BS]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
+    extern __shared__ float lds[];
+    const int BS = c.BS, C = c.C, H2 = BS / 2;
+    int s = blockIdx.x, tid = threadIdx.x;
+    float  *lap   = lds;
+    float2 *z     = (float2 *)(lap + (size_t)C * H2);
+    float  *dec   = (float *)(z + H2);
+    float  *tmpq  = dec + BS;
+    float  *stage = tmpq + H2;
+    float *glap = c.lap + (size_t)s * C * H2;
+    for (int i = tid; i < C * H2; i += WG) lap[i] = glap[i];
+    int lastSub = c.lastSub[s];
+    __syncthreads();
+
+    for (int k = 0; k < c.K; k++) {
+        int blk = s * c.K + k;
+        int wc = c.wc[blk];
+        float *outp = c.pcm + (size_t)blk * C * BS;
+        if (wc == 0) {                                              // corrupt block / dead stream
+            for (int i = tid; i < C * BS; i += WG) outp[i] = 0.0f;
+            continue;
+        }
+        const float *coefB = c.coef + (size_t)blk * C * BS;
+        int newLast = lastSub;
+        for (int ch = 0; ch < C; ch++) {
+            int last = lastSub;                                     // ulcDecoder.c:219
+            float *dst = stage + (size_t)(ch & 1) * BS;
+            float *L = lap + (size_t)ch * H2;
+            unsigned pat = ulcx_pattern(wc);
+            int off = 0, dpos = 0;
+            do {
+                int d = pat & 7, S = BS >> d, M = S >> 1;
+                int ov = S;                                         // ulcDecoder.c:234-239
+                if (pat & 8) ov >>= (wc & 7);
+                if (ov > last) ov = last;
+                last = S;
+                const float *X = coefB + (size_t)ch * BS + off;
+                const float2 *pre = c.T.pre[d];
+                // DCT-IV pre-twiddle
+                for (int n = tid; n < M; n += WG) z[n] = cmulc(make_float2(X[2 * n], X[S - 1 - 2 * n]), pre[n]);
+                __syncthreads();
+                fft1_dif(z, M, c.T.tw[d], tid);
+                // post-twiddle fused with the windowed overlap (oracle/orc_fourier.c orc_imdct):
+                //   zz[2k] = Re y[k], zz[S-1-2k] = -Im y[k];  pair p: A = lap[M-1-p], B = zz[M+p]
+                float *out = (S == BS) ? dst : dec;
+                int a = (S - ov) >> 1;
+                const float *fall = c.T.winFall + ov, *rise = c.T.winRise + ov;
+                int bits = 31 - __clz(M);
+                for (int kk = tid; kk < M / 2; kk += WG) {
+                    int k1 = kk, k2 = M - 1 - kk;
+                    int r1 = (int)(__brev((unsigned)k1) >> (32 - bits));
+                    int r2 = (int)(__brev((unsigned)k2) >> (32 - bits));
+                    float2 y1 = cmulc(z[r1], pre[k1]), y2 = cmulc(z[r2], pre[k2]);
+                    // zz[2k1] = y1.x, zz[2k1+1] = -y2.y (new lap);  zz[S-1-2k1] = -y1.y, zz[S-2-2k1] = y2.x (B values)
+                    float A0 = L[2 * k1], A1 = L[2 * k1 + 1];
+                    float Bv[2] = { -y1.y, y2.x };
+                    float Av[2] = { A0, A1 };
+                    int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        int p = pv[q];
+                        float A = Av[q], B = Bv[q];
+                        if (p < a) { out[p] = A; out[S - 1 - p] = B; }
+                        else {
+                            float cw = fall[p - a], sw = rise[p - a];
+                            float m0 = cw * A, m1 = sw * B, m2 = sw * A, m3 = cw * B;
+                            out[p] = m0 - m1;
+                            out[S - 1 - p] = m2 + m3;
+                        }
+                    }
+                    L[2 * k1] = y1.x;
+                    L[2 * k1 + 1] = -y2.y;
+                }
+                __syncthreads();
+                if (S == BS) break;                                 // ulcDecoder.c:242-245
+                // reversed-time centring FIFO in lap[M .. BS/2) (ulcDecoder.c:253-272)
+                int avail = (BS - S) >> 1;
+                for (int q = tid; q < avail; q += WG) tmpq[q] = L[H2 - 1 - q];      // queue[q], q = 0 is the oldest
+                __syncthreads();
+                for (int n = tid; n < S; n += WG)
+                    dst[dpos + n] = (n < avail) ? tmpq[n] : dec[n - avail];
+                if (S <= avail) {
+                    for (int q = tid; q < avail; q += WG)
+                        L[H2 - 1 - q] = (q < avail - S) ? tmpq[q + S] : dec[q - (avail - S)];
+                } else {
+                    for (int q = tid; q < avail; q += WG) L[H2 - 1 - q] = dec[S - avail + q];
+                }
+                __syncthreads();
+                dpos += S; off += S;
+            } while (pat >>= 4);
+            newLast = last;
+            // inverse M/S + interleave once both members of a pair (or a trailing single) are staged
+            bool pairDone = (ch & 1) || (ch == C - 1);
+            if (pairDone) {
+                __syncthreads();
+                if (ch & 1) {
+                    for (int n = tid; n < BS; n += WG) {
+                        float m = stage[n], sd = stage[BS + n];                 // ulcDecoder.c:281-289
+                        float l = m + sd, r = m - sd;
+                        if (C == 2) *(float2 *)(outp + 2 * n) = make_float2(l, r);
+                        else { outp[(size_t)n * C + ch - 1] = l; outp[(size_t)n * C + ch] = r; }
+                    }
+                } else {
+                    for (int n = tid; n < BS; n += WG) outp[(size_t)n * C + ch] = stage[n];
+                }
+                __syncthreads();
+            }
+        }
+        lastSub = newLast;
+    }
+    for (int i = tid; i < C * H2; i += WG) glap[i] = lap[i];
+    if (tid == 0) c.lastSub[s] = lastSub;
+}
+
+size_t ulcx_dec_lds_bytes(int BS, int C) {
+    return sizeof(float) * ((size_t)C * (BS / 2) + BS + BS + BS / 2 + 2 * (size_t)BS);
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)
+
+int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev) {
+    int stage = 0;
+    if (ev) CK(hipEventRecord(ev[stage++], st));
+    hipLaunchKernelGGL(k_dparse, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
+    if (ev) CK(hipEventRecord(ev[stage++], st));
+    size_t lds = ulcx_dec_lds_bytes(c.BS, c.C);
+    if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_dimdct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_dimdct, dim3(c.B), dim3(WG), lds, st, c);
+    if (ev) CK(hipEventRecord(ev[stage++], st));
+    CK(hipGetLastError());
+    return ULCX_OK;
+}

@@ -1,0 +1,988 @@
+// ulcx_enc.hip — batched ulc-codec encoder for gfx950 (MI355X), hand-written HIP.
+//
+// One call encodes K consecutive blocks of B independent streams.  Pipeline
+// (reference call stack SURVEY.md §3A):
+//   wc_energy / wc_forward / wc_backward / wc_integrate / wc_decide
+//        transient detector -> WindowCtrl per block   (ulcEncoder_WindowControl.c:41-239)
+//   xf   one workgroup per block: frames from the input timeline (closed form of the
+//        lapping FIFO, BlockTransform.c:175-224), sine window, MDCT+MDST through two
+//        DCT-IV = complex FFTs staged entirely in LDS, normalise, keys, per-line
+//        energies                                      (BlockTransform.c:229-281)
+//   cplx        ordered f32 sums -> BlockComplexity, nOutCoef (BlockTransform.c:279-325, ulcEncoder.c:140-158)
+//   nbark/nline noise log-spectrum                     (ulcEncoder_Psyopt.c:168-250)
+//   pbark/keys  masking levels + final importance keys (ulcEncoder_Psyopt.c:60-155, BlockTransform.c:337-345)
+//   select      top-nOutCoef set by LDS radix select; exact heapsort emulation only
+//               for tie groups straddling the cut      (BlockTransform.c:20-77)
+//   encode/pack nybble stream                          (ulcEncoder_Encode.c:23-360, ulcEncoder_NoiseFill.c)
+// All float arithmetic is written in the reference's operation order and this file is
+// compiled with -ffp-contract=off: no fused multiply-add is formed anywhere except the
+// explicit ones inside the glibc restatements (ulcx_libm.h).
+#include "ulcx_internal.h"
+#include "ulcx_libm.h"
+
+#define WG 256
+#include "ulcx_fft.h"
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fastlog(float x) {              // ulcHelper.h:127-136
+    uint32_t b = __float_as_uint(x);
+    int e = (int)(b >> 23) - 127;
+    float m = __uint_as_float((127u << 23) | (b & 0x7FFFFFu));
+    return -1.7417939f + (2.8212026f + (-1.4699568f + (0.44717955f - 0.056570851f * m) * m) * m) * m + 0.6931471806f * e;
+}
+__device__ __forceinline__ int quant_u(float v) {                // ulcHelper.h:51-72
+    return (v >= 0.5f) ? (int)(0.5f + sqrtf(v - 0.25f)) : 0;
+}
+__device__ __forceinline__ int quant_coef_u(float v, int lim) { int q = quant_u(v); return q < lim ? q : lim; }
+__device__ __forceinline__ int quant_coef(float v, int lim) { int q = quant_coef_u(fabsf(v), lim); return v < 0.0f ? -q : q; }
+
+// pointer to the C interleaved samples at time trel (relative to this call's first
+// sample; negative = the two blocks kept from previous calls)
+__device__ __forceinline__ const float *smp_ptr(const UlcxEncCtx &c, int s, int trel) {
+    if (trel < 0) return c.hist + ((size_t)s * 2 * c.BS + (trel + 2 * c.BS)) * c.C;
+    return c.pcm + ((size_t)s * c.K * c.BS + trel) * c.C;
+}
+// sample after the encoder's M/S step (BlockTransform.c:102-110)
+__device__ __forceinline__ float ms_sample(const float *p, int ch, int C) {
+    if (ch & 1) { float a = p[ch - 1], b = p[ch]; return (a - b) * 0.5f; }
+    if (ch + 1 < C) { float a = p[ch], b = p[ch + 1]; return (a + b) * 0.5f; }
+    return p[ch];
+}
+// ---------------------------------------------------------------------------
+// Window control
+// ---------------------------------------------------------------------------
+// WindowControl.c:31-70: E[n] = sum_ch (hp^2, bp^2) of the 3-tap FIRs centred on the
+// Old/New boundary; then the sqrt of :80-81 (parallel part of the recurrence).
+__global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c) {
+    size_t gid = (size_t)blockIdx.x * WG + threadIdx.x;
+    size_t total = (size_t)c.B * c.K * c.BS;
+    if (gid >= total) return;
+    int s = (int)(gid / ((size_t)c.K * c.BS));
+    int r = (int)(gid % ((size_t)c.K * c.BS));           // k*BS + n
+    int t = r - c.BS / 2;                                // centre sample
+    const float *p0 = smp_ptr(c, s, t - 1), *p1 = smp_ptr(c, s, t), *p2 = smp_ptr(c, s, t + 1);
+    float ehp = 0.0f, ebp = 0.0f;
+    for (int ch = 0; ch < c.C; ch++) {
+        float t0 = ms_sample(p0, ch, c.C), t1 = ms_sample(p1, ch, c.C), t2 = ms_sample(p2, ch, c.C);
+        float hp = -t0 + 2 * t1 - t2;
+        float bp = -t0 + t2;
+        ehp += hp * hp;
+        ebp += bp * bp;
+    }
+    c.env[(size_t)s * c.maxK * c.BS + r] = make_float2(sqrtf(ehp), sqrtf(ebp));
+}
+
+// WindowControl.c:72-88: forward one-pole smear, the only sample-rate recurrence that
+// crosses blocks.  One lane per (stream, filter); strictly sequential in time.
+__global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c) {
+    int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= c.B * 2) return;
+    int s = gid >> 1, f = gid & 1;
+    float *v = (float *)(c.env + (size_t)s * c.maxK * c.BS) + f;
+    float env = c.wcs[s].tf[f];
+    float cc = f ? c.cBP : c.cHP;
+    int n = c.K * c.BS;
+    for (int i = 0; i < n; i += 8) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = v[2 * (i + j)];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { float d = x[j] - env; env += d * cc; x[j] = env; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[2 * (i + j)] = x[j];
+    }
+    // state for the next call is written by k_state_update (reads env's last element)
+}
+
+// WindowControl.c:90-104: backward sweep from each block's forward end state.
+__global__ __launch_bounds__(64) void k_wc_backward(UlcxEncCtx c) {
+    int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= c.B * c.K) return;
+    int s = gid / c.K, k = gid % c.K;
+    float2 *e = c.env + (size_t)s * c.maxK * c.BS + (size_t)k * c.BS;
+    float2 last = e[c.BS - 1];
+    float pHP = last.x, pBP = last.y;
+    for (int n = c.BS - 1; n >= 0; n -= 4) {
+        float2 x[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[j] = e[n - j];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float dHP = x[j].x - pHP, dBP = x[j].y - pBP;
+            pHP += dHP * c.qHP;
+            pBP += dBP * c.qBP;
+            float a = dHP * pBP, b = dBP * pHP;
+            x[j].x = a * a + b * b;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) e[n - j].x = x[j].x;
+    }
+}
+
+// WindowControl.c:106-134: 8 bins per block, smoothing state carried across blocks.
+__global__ __launch_bounds__(64) void k_wc_integrate(UlcxEncCtx c) {
+    int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= c.B) return;
+    float env = c.wcs[s].tf[2];
+    float *bins = c.bins + (size_t)s * (c.maxK + 1) * 16;
+    for (int i = 0; i < 8; i++) { bins[i] = c.wcs[s].binSum[i]; bins[8 + i] = c.wcs[s].binW[i]; }
+    const float2 *e = c.env + (size_t)s * c.maxK * c.BS;
+    int bin = c.BS / 8;
+    for (int k = 0; k < c.K; k++) {
+        float *o = bins + (size_t)(k + 1) * 16;
+        for (int i = 0; i < 8; i++) {
+            float sum = 0.0f, sw = 0.0f;
+            const float2 *p = e + (size_t)k * c.BS + (size_t)i * bin;
+            for (int n = 0; n < bin; n += 4) {
+                float x[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) x[j] = p[n + j].x;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { float d = x[j] - env; env += d * c.cBlk; sum += env; sw += 1; }
+            }
+            o[i] = sum; o[8 + i] = sw;
+        }
+    }
+    c.wcs[s].tf[2] = env;                 // only this kernel reads tf[2]
+}
+
+// WindowControl.c:156-238: decision from the bins of block k (R) and k-1 (L).
+__global__ __launch_bounds__(64) void k_wc_decide(UlcxEncCtx c) {
+    int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= c.B * c.K) return;
+    int s = gid / c.K, k = gid % c.K;
+    const float *L = c.bins + ((size_t)s * (c.maxK + 1) + k) * 16;
+    const float *R = L + 16;
+    int log2sub = c.lgBS - 3;
+    int decimation = 1;
+    float ratio = 0.0f;
+    int nSeg = 8, segSize = 1;
+    if (log2sub < 6) { int sh = 6 - log2sub; nSeg >>= sh; segSize <<= sh; log2sub = 6; }
+    for (;;) {
+        log2sub++;
+        int maxSeg = 0;
+        float maxRatio = -1000.0f;
+        for (int seg = 0; seg < nSeg; seg++) {
+            float Ls = 0.0f, Lw = 0.0f, Rs = 0.0f, Rw = 0.0f;
+            for (int n = 0; n < segSize; n++) {
+                // Src[n - SegmentSize] walks back from R's segment start into L (WindowControl.c:187-191)
+                int ri = seg * segSize + n;
+                int li = ri - segSize;
+                float lS = (li >= 0) ? R[li] : L[8 + li];
+                float lW = (li >= 0) ? R[8 + li] : L[16 + li];
+                Ls += lS; Lw += lW;
+                Rs += R[ri]; Rw += R[8 + ri];
+            }
+            Ls = (Ls != 0.0f) ? ulcx_logf(Ls / Lw) : -100.0f;
+            Rs = (Rs != 0.0f) ? ulcx_logf(Rs / Rw) : -100.0f;
+            float r = fabsf(Rs - Ls);
+            if (r > maxRatio) { maxSeg = seg; maxRatio = r; }
+        }
+        if (maxRatio - ratio < 0x1.62E430p-1f) break;
+        decimation = nSeg + maxSeg;
+        ratio = maxRatio;
+        if (nSeg > 1 && ratio < 0x1.62E430p-1f) { nSeg /= 2; segSize *= 2; }
+        else break;
+    }
+    int wc;
+    if (ratio < 0x1.62E430p-2f) wc = 0x10;
+    else {
+        ratio *= 0x1.715476p0f;
+        int scale = (ratio < 0.5f) ? 0 : (ratio >= 6.5f) ? 7 : (int)rintf(ratio);   // lrintf: round-to-nearest-even
+        if (log2sub - scale < 6) scale = log2sub - 6;
+        wc = scale + 0x8 * (decimation != 1) + 0x10 * decimation;
+    }
+    int *row = c.wcArr + (size_t)s * (c.maxK + 2);
+    if (k == 0) { row[0] = c.wcs[s].wcPrev; row[1] = c.wcs[s].wcCur; }
+    row[k + 2] = wc;
+}
+
+// ---------------------------------------------------------------------------
+// Transform + per-coefficient analysis
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int first_overlap(int wc, int BS) {   // BlockTransform.c:124-128
+    unsigned p = ulcx_pattern(wc);
+    int ov = BS >> (p & 7);
+    if (p & 8) ov >>= (wc & 7);
+    return ov;
+}
+
+__global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c) {
+    extern __shared__ float lds[];
+    const int BS = c.BS, C = c.C;
+    int blk = blockIdx.x;
+    int s = blk / c.K, k = blk % c.K;
+    int tid = threadIdx.x;
+    float  *f    = lds;                               // 2*BS  windowed frame
+    float2 *zc   = (float2 *)(lds + 2 * BS);          // BS/2 complex
+    float2 *zs   = zc + BS / 2;                       // BS/2 complex
+    float  *amp2 = (float *)(zs + BS / 2);            // BS/2
+    int    &s_nnz = *(int *)(amp2 + BS / 2);          // (kept inside the dynamic region: no static LDS in front of it)
+    if (tid == 0) s_nnz = 0;
+    for (int i = tid; i < BS / 2; i += WG) amp2[i] = 0.0f;
+
+    const int *wrow = c.wcArr + (size_t)s * (c.maxK + 2) + k;
+    int wcPrev = wrow[0], wc = wrow[1], wcNext = wrow[2];
+    int nextOv = first_overlap(wcNext, BS);
+    // right-edge overlap of the previous block's last subblock = left overlap of our first
+    int ovFirst;
+    {
+        unsigned pp = ulcx_pattern(wcPrev);
+        int lastS = BS;
+        do { lastS = BS >> (pp & 7); } while (pp >>= 4);
+        ovFirst = first_overlap(wc, BS);
+        if (ovFirst > lastS) ovFirst = lastS;
+    }
+    size_t cb = (size_t)C * BS;
+    float *coefO = c.coef + (size_t)blk * cb;
+    float *keyO  = c.key  + (size_t)blk * cb;
+    float *nsumO = c.nsum + (size_t)blk * (cb / 2);
+    int nnz = 0;
+    __syncthreads();
+
+    for (int ch = 0; ch < C; ch++) {
+        unsigned pat = ulcx_pattern(wc);
+        int off = 0, ovL = ovFirst;
+        do {
+            int S = BS >> (pat & 7);
+            int d = pat & 7;
+            pat >>= 4;
+            int ov;
+            if (pat) { ov = BS >> (pat & 7); if (pat & 8) ov >>= (wc & 7); }
+            else ov = nextOv;
+            if (ov > S) ov = S;
+            const int M = S >> 1;
+
+            // 1. windowed frame f[0..2S): closed form of the lapping FIFO (BlockTransform.c:175-224):
+            //    subblock span starts at b = (k-1.5)BS + off; frame = [b - S/2, b + 3S/2)
+            int t0 = (k - 1) * BS - BS / 2 + off - S / 2;
+            int aL = (S - ovL) >> 1, aR = (S - ov) >> 1;
+            const float *rise = c.T.winRise + ovL, *fall = c.T.winFall + ov;
+            for (int i = tid; i < 2 * S; i += WG) {
+                float x = ms_sample(smp_ptr(c, s, t0 + i), ch, C);
+                float v;
+                if (i < S) v = (i < aL) ? 0.0f : (i < aL + ovL) ? x * rise[i - aL] : x;
+                else { int n = i - S; v = (n < aR) ? x : (n < aR + ov) ? x * fall[n - aR] : 0.0f; }
+                f[i] = v;
+            }
+            __syncthreads();
+
+            // 2. TDAC fold + DCT-IV pre-twiddle (oracle/orc_fourier.c: v[], reversed w[])
+            const float2 *pre = c.T.pre[d];
+            const float *Lp = f, *Rp = f + S;
+            for (int n = tid; n < M; n += WG) {
+                int m1 = 2 * n, m2 = S - 1 - 2 * n;
+                float v1, v2, w1, w2;                 // v[m1], v[m2], w[m1], w[m2]
+                if (m1 < M) {                         // m1 in first half, m2 in second half
+                    float ra = Rp[M - 1 - m1], rb = Rp[M + m1];
+                    v1 = ra + rb; w1 = ra - rb;
+                    float la = Lp[S - 1 - (m2 - M)], lb = Lp[m2 - M];
+                    v2 = la - lb; w2 = lb + la;
+                } else {
+                    float la = Lp[S - 1 - (m1 - M)], lb = Lp[m1 - M];
+                    v1 = la - lb; w1 = lb + la;
+                    float ra = Rp[M - 1 - m2], rb = Rp[M + m2];
+                    v2 = ra + rb; w2 = ra - rb;
+                }
+                float2 P = pre[n];
+                zc[n] = cmulc(make_float2(v1, v2), P);        // u = v      : (u[2n], u[S-1-2n])
+                zs[n] = cmulc(make_float2(w2, w1), P);        // u = rev(w) : (w[S-1-2n], w[2n])
+            }
+            __syncthreads();
+
+            // 3. two M-point FFTs in LDS
+            fft2_dif(zc, zs, M, c.T.tw[d], tid);
+
+            // 4. post-twiddle + normalise + keys + per-line energies (BlockTransform.c:243-281)
+            int bits = 31 - __clz(M);
+            float norm = 2.0f / S;
+            for (int kk = tid; kk < M / 2; kk += WG) {
+                int k1 = kk, k2 = M - 1 - kk;
+                int r1 = (int)(__brev((unsigned)k1) >> (32 - bits));
+                int r2 = (int)(__brev((unsigned)k2) >> (32 - bits));
+                float2 P1 = pre[k1], P2 = pre[k2];
+                float2 yc1 = cmulc(zc[r1], P1), yc2 = cmulc(zc[r2], P2);
+                float2 ys1 = cmulc(zs[r1], P1), ys2 = cmulc(zs[r2], P2);
+                // pair j = k1: coefficients 2k1, 2k1+1 ; pair j = k2: coefficients 2k2, 2k2+1
+                float mdct[4] = { yc1.x, -yc2.y, yc2.x, -yc1.y };
+                float mdst[4] = { ys1.x,  ys2.y, ys2.x,  ys1.y };
+                int   jj[2]   = { k1, k2 };
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    float re0 = mdct[2*p] * norm,   im0 = mdst[2*p] * norm;
+                    float re1 = mdct[2*p+1] * norm, im1 = mdst[2*p+1] * norm;
+                    float re0s = re0 * re0, im0s = im0 * im0, re1s = re1 * re1, im1s = im1 * im1;
+                    float a0 = re0s + im0s, a1 = re1s + im1s;
+                    float k0v, k1v;
+                    if (fabsf(re0) < 0.5f * ULCX_COEF_EPS) k0v = __uint_as_float(0xff800000u); else { k0v = fastlog(re0s); nnz++; }
+                    if (fabsf(re1) < 0.5f * ULCX_COEF_EPS) k1v = __uint_as_float(0xff800000u); else { k1v = fastlog(re1s); nnz++; }
+                    int j = jj[p];
+                    size_t gi = (size_t)ch * BS + off + 2 * j;
+                    *(float2 *)(coefO + gi) = make_float2(re0, re1);
+                    *(float2 *)(keyO + gi)  = make_float2(k0v, k1v);
+                    nsumO[(size_t)ch * (BS / 2) + off / 2 + j] = a0 + a1;             // (0 + a0) + a1
+                    float am = amp2[off / 2 + j];
+                    am += a0; am += a1;                                            // channel order preserved
+                    amp2[off / 2 + j] = am;
+                }
+            }
+            __syncthreads();
+            off += S; ovL = ov;
+        } while (pat);
+    }
+    // wave-reduce the non-zero count
+    for (int o = 32; o > 0; o >>= 1) nnz += __shfl_down(nnz, o);
+    if ((tid & 63) == 0) atomicAdd(&s_nnz, nnz);
+    float *ampO = c.amp2 + (size_t)blk * (BS / 2);
+    for (int i = tid; i < BS / 2; i += WG) ampO[i] = amp2[i];
+    __syncthreads();
+    if (tid == 0) c.nnz[blk] = s_nnz;
+}
+
+// ---------------------------------------------------------------------------
+// Block complexity + nOutCoef (BlockTransform.c:279-325, ulcEncoder.c:93-158)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_cplx(UlcxEncCtx c) {
+    int blk = blockIdx.x * 64 + threadIdx.x;
+    if (blk >= c.B * c.K) return;
+    int n = c.C * c.BS;
+    const float4 *p = (const float4 *)(c.coef + (size_t)blk * n);
+    float cx = 0.0f, cw = 0.0f;
+    for (int i = 0; i < n / 4; i++) {
+        float4 v = p[i];
+        cx += v.x * v.x; cw += fabsf(v.x);
+        cx += v.y * v.y; cw += fabsf(v.y);
+        cx += v.z * v.z; cw += fabsf(v.z);
+        cx += v.w * v.w; cw += fabsf(v.w);
+    }
+    if (cx != 0.0f) {
+        cx = ulcx_logf((cw * cw) / cx) / c.cplxScale;
+        if (cx < 0.0f) cx = 0.0f;
+        if (cx > 1.0f) cx = 1.0f;
+    }
+    c.cplx[blk] = cx;
+    int maxCoef = c.nnz[blk];
+    if (c.mode == ULCX_MODE_VBR) {
+        int nT = maxCoef;
+        if (c.vbrTarget > 0.0f) {
+            float ft = (c.C * c.BS) * cx / c.vbrTarget;
+            if (ft < maxCoef) nT = (int)ft;
+        }
+        c.nout[blk] = nT;
+    } else {
+        // CBR/ABR binary search state (ulcEncoder.c:96-101)
+        float kbps = c.p0;
+        if (c.mode == ULCX_MODE_ABR) kbps = c.p0 * cx / c.p1;
+        int budget = (int)((c.BS * kbps) * 1000.0f / c.rateHz);
+        c.cbrLo[blk] = 0; c.cbrHi[blk] = maxCoef;
+        c.cbrDone[blk] = (0 < maxCoef) ? 0 : 1;
+        c.nout[blk] = (0 < maxCoef) ? (int)((unsigned)(0 + maxCoef) / 2u) : 0;
+        c.cbrBudget[blk] = budget;
+    }
+    int s = blk / c.K, k = blk % c.K;
+    if (c.wcOut)   c.wcOut[blk]   = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+    if (c.cplxOut) c.cplxOut[blk] = cx;
+}
+
+// ---------------------------------------------------------------------------
+// Bark-band levels.  Both routines accumulate three binary64 running sums line by
+// line, a "low" and a "high" cursor per band (Psyopt.c:23-51); kept sequential, one
+// lane per (block[,channel],subblock).
+// ---------------------------------------------------------------------------
+struct LineSum { int end; double fl, pk, pw; };
+__device__ __forceinline__ void linesum_advance(const float *src, LineSum &ls, int end) {
+    double fl = ls.fl, pk = ls.pk, pw = ls.pw;
+    for (int l = ls.end; l < end; l++) {
+        float vf = src[l];
+        double v = (double)vf;
+        double vl = (double)fastlog(0x1.0p-126f + vf);
+        fl += vl;
+        pk += vl * v;
+        pw += v;
+    }
+    ls.end = end; ls.fl = fl; ls.pk = pk; ls.pw = pw;
+}
+
+// unit geometry: subblock j of WindowCtrl wc -> size shift d, coefficient offset off
+__device__ __forceinline__ bool unit_geom(int wc, int j, int BS, int &d, int &off, int &S) {
+    unsigned pat = ulcx_pattern(wc);
+    off = 0;
+    for (int i = 0;; i++) {
+        d = pat & 7; S = BS >> d;
+        if (i == j) return true;
+        off += S;
+        pat >>= 4;
+        if (!pat) return false;
+    }
+}
+
+// Psyopt.c:185-225
+__global__ __launch_bounds__(64) void k_nbark(UlcxEncCtx c) {
+    int gid = blockIdx.x * 64 + threadIdx.x;
+    int nUnits = c.B * c.K * c.C * 4;
+    if (gid >= nUnits) return;
+    int j = gid & 3, ch = (gid >> 2) % c.C, blk = gid / (4 * c.C);
+    int s = blk / c.K, k = blk % c.K;
+    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+    int d, off, S;
+    if (!unit_geom(wc, j, c.BS, d, off, S)) return;
+    int N = S / 2;
+    const float *data = c.nsum + (size_t)blk * (c.C * c.BS / 2) + (size_t)ch * (c.BS / 2) + off / 2;
+    float *bark = c.barkN + (size_t)gid * ULCX_NBARK;
+    float level = -100.0f;
+    LineSum lo = {0, 0.0, 0.0, 0.0}, hi = {0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < ULCX_NBARK; b++) {
+        int l0 = c.T.nBeg[d][b], l1 = c.T.nEnd[d][b];
+        linesum_advance(data, lo, l0);
+        linesum_advance(data, hi, l1);
+        double sf = hi.fl - lo.fl, sp = hi.pk - lo.pk, sw = hi.pw - lo.pw;
+        if (sw > 0.0) {
+            double scale = 1.0 / (double)(l1 - l0);
+            sp = sp / sw;
+            sf = sf * scale;
+            level = 0.5f * (float)(ulcx_log(sw * scale) + sf - sp);
+        }
+        bark[b] = level;
+    }
+    (void)N;
+}
+
+// Psyopt.c:236-248: per-line interpolation + {w, w*(log+ln2)} pairs
+__global__ __launch_bounds__(WG) void k_nline(UlcxEncCtx c) {
+    size_t gid = (size_t)blockIdx.x * WG + threadIdx.x;
+    int half = c.BS / 2;
+    size_t total = (size_t)c.B * c.K * c.C * half;
+    if (gid >= total) return;
+    int jp = (int)(gid % half);
+    int ch = (int)((gid / half) % c.C);
+    int blk = (int)(gid / ((size_t)half * c.C));
+    int s = blk / c.K, k = blk % c.K;
+    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+    unsigned pat = ulcx_pattern(wc);
+    int off = 0, d = 0, S = c.BS, j = 0;
+    for (;; j++) { d = pat & 7; S = c.BS >> d; if (2 * jp < off + S) break; off += S; pat >>= 4; }
+    int line = jp - off / 2;
+    const float *bark = c.barkN + ((size_t)(blk * c.C + ch) * 4 + j) * ULCX_NBARK;
+    int bi = c.T.bandIdx[d][line];
+    float fr = c.T.bandFrac[d][line];
+    float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
+    float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
+    float noise = L * (1.0f - fr) + R * fr;
+    float w = ulcx_expf(0.5f * noise);
+    float2 o = make_float2(w, w * (noise + 0x1.62E430p-1f));
+    *(float2 *)(c.npair + (size_t)blk * (c.C * c.BS) + (size_t)ch * c.BS + 2 * jp) = o;
+}
+
+// Psyopt.c:86-137 on the channel-summed energies
+__global__ __launch_bounds__(64) void k_pbark(UlcxEncCtx c) {
+    int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= c.B * c.K * 4) return;
+    int j = gid & 3, blk = gid >> 2;
+    int s = blk / c.K, k = blk % c.K;
+    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+    int d, off, S;
+    if (!unit_geom(wc, j, c.BS, d, off, S)) return;
+    const float *data = c.amp2 + (size_t)blk * (c.BS / 2) + off / 2;
+    float *bark = c.barkP + (size_t)gid * ULCX_NBARK;
+    float unmask = 0.0f;
+    LineSum lo = {0, 0.0, 0.0, 0.0}, hi = {0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < ULCX_NBARK; b++) {
+        int l0 = c.T.pBeg[d][b], l1 = c.T.pEnd[d][b];
+        linesum_advance(data, lo, l0);
+        linesum_advance(data, hi, l1);
+        double sf = hi.fl - lo.fl, sp = hi.pk - lo.pk, sw = hi.pw - lo.pw;
+        if (sw > 0.0) {
+            sp = sp / sw;
+            sf = sf / (double)(l1 - l0);
+            unmask = (float)(sp - sf - ulcx_log(sw));
+        }
+        bark[b] = unmask;
+    }
+}
+
+// Psyopt.c:140-150 + BlockTransform.c:337-345
+__global__ __launch_bounds__(WG) void k_keys(UlcxEncCtx c) {
+    size_t gid = (size_t)blockIdx.x * WG + threadIdx.x;
+    int half = c.BS / 2;
+    size_t total = (size_t)c.B * c.K * half;
+    if (gid >= total) return;
+    int jp = (int)(gid % half);
+    int blk = (int)(gid / half);
+    int s = blk / c.K, k = blk % c.K;
+    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+    unsigned pat = ulcx_pattern(wc);
+    int off = 0, d = 0, S = c.BS, j = 0;
+    for (;; j++) { d = pat & 7; S = c.BS >> d; if (2 * jp < off + S) break; off += S; pat >>= 4; }
+    int line = jp - off / 2;
+    const float *bark = c.barkP + ((size_t)blk * 4 + j) * ULCX_NBARK;
+    int bi = c.T.bandIdx[d][line];
+    float fr = c.T.bandFrac[d][line];
+    float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
+    float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
+    float m = L * (1.0f - fr) + R * fr;
+    if (c.mask) c.mask[(size_t)blk * half + jp] = m;
+    float *key = c.key + (size_t)blk * (c.C * c.BS) + 2 * jp;
+    for (int ch = 0; ch < c.C; ch++) {
+        float2 v = *(float2 *)(key + (size_t)ch * c.BS);
+        float t0 = 2 * v.x + m, t1 = 2 * v.y + m;
+        if (ch & 1) { t0 = t0 + -0x1.62E430p0f; t1 = t1 + -0x1.62E430p0f; }
+        *(float2 *)(key + (size_t)ch * c.BS) = make_float2(t0, t1);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Selection of the nOutCoef most important coefficients.
+// The reference heapsorts all keys into ranks (BlockTransform.c:20-77) but ranks are
+// only ever consumed as "rank < nOutCoef" (Encode.c:108,220), so the sort is a
+// selection: find the k-th largest key T by a 4x8-bit radix select in LDS; the kept
+// set is {key > T} plus the tie group {key == T} when it fits entirely.  Only when the
+// tie group straddles the cut is the exact heapsort pop order needed (k_heapsel).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t key_ord(float f) {          // ascending order-preserving map
+    uint32_t u = __float_as_uint(f);
+    if ((u << 1) == 0) u = 0;                                   // -0 and +0 compare equal in the reference
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
+    __shared__ int hist[256];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_need;
+    int blk = blockIdx.x, tid = threadIdx.x;
+    if (!finalPass && c.cbrDone[blk]) return;        // rate search already converged: wait for the final pass
+    int N = c.C * c.BS;
+    int kSel = c.nout[blk];
+    const float *key = c.key + (size_t)blk * N;
+    uint32_t *keep = c.keep + (size_t)blk * (N / 32);
+    if (kSel <= 0) {
+        for (int i = tid; i < N / 32; i += WG) keep[i] = 0;
+        return;
+    }
+    uint32_t prefix = 0, pmask = 0;
+    int need = kSel;                     // how many still to take from the current candidate set
+    for (int pass = 0; pass < 4; pass++) {
+        int shift = 24 - 8 * pass;
+        hist[tid] = 0;                   // WG == 256 bins
+        __syncthreads();
+        for (int i = tid; i < N; i += WG) {
+            uint32_t u = key_ord(key[i]);
+            if ((u & pmask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0, dgt = 255;
+            for (; dgt > 0; dgt--) { if (acc + hist[dgt] >= need) break; acc += hist[dgt]; }
+            s_prefix = prefix | ((uint32_t)dgt << shift);
+            s_need = need - acc;
+        }
+        __syncthreads();
+        prefix = s_prefix; need = s_need;
+        pmask |= 0xFFu << shift;
+        __syncthreads();
+    }
+    // prefix = ordered bits of threshold T; need = r (how many of the T-ties are kept); e = hist count
+    int e = hist[prefix & 255];
+    bool straddle = (need < e);
+    for (int i = tid; i < N; i += WG) {
+        uint32_t u = key_ord(key[i]);
+        bool kp = (u >= prefix);          // tie group fully in when not straddling
+        unsigned long long m = __ballot(kp);
+        int lane = tid & 63;
+        if (lane == 0)  keep[i >> 5] = (uint32_t)m;
+        if (lane == 32) keep[i >> 5] = (uint32_t)(m >> 32);
+    }
+    if (straddle && tid == 0) {
+        int slot = atomicAdd(c.fbCount, 1);
+        c.fbList[slot] = blk;
+    }
+}
+
+// Exact emulation of the reference's min-heap heapsort for the (rare) blocks whose
+// threshold tie group straddles the cut: ranks are assigned N-1 downwards in pop
+// order, so the kept set is everything still in the heap after N-k pops.
+// One lane per block; heap of {key, index} in LDS when it fits, else in HBM scratch.
+struct HeapEnt { float v; int i; };
+template <typename P>
+__device__ void heap_sift(P h, int root, int n) {
+    int child = 2 * root + 1;
+    if (child >= n) return;
+    HeapEnt r = h[root];
+    for (;;) {
+        HeapEnt cN = h[child];
+        if (child + 1 < n) { HeapEnt c2 = h[child + 1]; if (c2.v < cN.v) { cN = c2; child++; } }
+        if (cN.v > r.v) break;
+        h[root] = cN;
+        root = child; child = 2 * root + 1;
+        if (child >= n) break;
+    }
+    h[root] = r;
+}
+__global__ __launch_bounds__(64) void k_heapsel(UlcxEncCtx c, int ldsEntries) {
+    extern __shared__ HeapEnt hl[];
+    int count = *c.fbCount;
+    int N = c.C * c.BS;
+    bool useLds = (N <= ldsEntries);
+    HeapEnt *h = useLds ? hl : (HeapEnt *)c.heapScratch + (size_t)blockIdx.x * N;
+    for (int idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        int blk = c.fbList[idx];
+        int kSel = c.nout[blk];
+        const float *key = c.key + (size_t)blk * N;
+        uint32_t *keep = c.keep + (size_t)blk * (N / 32);
+        for (int i = threadIdx.x; i < N; i += 64) { h[i].v = key[i]; h[i].i = i; }
+        for (int i = threadIdx.x; i < N / 32; i += 64) keep[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int n = N / 2 - 1; n >= 0; n--) heap_sift(h, n, N);
+            int pops = N - kSel;
+            int n = N - 1;
+            for (int p = 0; p < pops; p++, n--) {
+                int gone = h[0].i;
+                keep[gone >> 5] &= ~(1u << (gone & 31));
+                if (n > 0) { h[0] = h[n]; heap_sift(h, 0, n); }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Encode pass: one lane per (block, channel, subblock) unit writes that unit's
+// nybbles into a staging row; k_pack concatenates (Encode.c:319-360).
+// ---------------------------------------------------------------------------
+struct NybWriter {
+    uint8_t *dst; int n; unsigned long long acc; int cap;
+    __device__ __forceinline__ void put(unsigned x) {
+        acc |= (unsigned long long)(x & 0xF) << ((n & 15) * 4);
+        n++;
+        if ((n & 15) == 0) { if (n / 2 <= cap) *(unsigned long long *)(dst + n / 2 - 8) = acc; acc = 0; }
+    }
+    __device__ __forceinline__ void flush() {
+        if (n & 15) { int base = (n & ~15) / 2; if (base + 8 <= cap) *(unsigned long long *)(dst + base) = acc; }
+    }
+};
+__device__ __forceinline__ void put_quantizer(NybWriter &w, int qi, bool lead) {      // Encode.c:32-45
+    int s = qi - 5;
+    if (lead) w.put(0xF);
+    if (s < 0xE) w.put((unsigned)s);
+    else { w.put(0xE); w.put((unsigned)(s - 0xE)); }
+}
+__device__ __forceinline__ int build_quantizer(float maxv) {                         // Encode.c:50-87
+    int q = (int)(0x1.657006p2f + -0x1.715476p0f * ulcx_logf(maxv));
+    if (q < 5) q = 5;
+    if (q > 31) q = 31;
+    return q;
+}
+__device__ __forceinline__ bool kept(const uint32_t *keep, int i) { return (keep[i >> 5] >> (i & 31)) & 1; }
+// first kept index in [i, end), or end
+__device__ __forceinline__ int next_kept(const uint32_t *keep, int i, int end) {
+    while (i < end) {
+        uint32_t w = keep[i >> 5] >> (i & 31);
+        if (w) { i += __ffs(w) - 1; return i < end ? i : end; }
+        i = (i | 31) + 1;
+    }
+    return end;
+}
+// NoiseFill.c:15-36 (pairs is the block-level {w, w*log} array, Band a block-level index)
+__device__ int get_noise_q(const float *pairs, int band, int n, float q) {
+    const float2 *d = (const float2 *)(pairs + (band / 2) * 2);
+    n = (n + (band & 1) + 1) / 2;
+    float sum = 0.0f, sumw = 0.0f;
+    for (int i = 0; i < n; i++) { float2 p = d[i]; sum += p.y; sumw += p.x; }
+    if (sum == 0.0f) return 0;
+    float amp = ulcx_expf(sum / sumw);
+    return quant_coef_u(amp * q, 8);
+}
+// NoiseFill.c:41-94
+__device__ void get_hfext(const float *pairs, int band, int n, float q, int &noiseQ, int &noiseDecay) {
+    const float2 *d = (const float2 *)(pairs + (band / 2) * 2);
+    n = (n + (band & 1) + 1) / 2;
+    float sx = 0.0f, sx2 = 0.0f, sxy = 0.0f, sy = 0.0f, sw = 0.0f;
+    for (int i = 0; i < n; i++) {
+        float x = i * 2.0f;
+        float2 p = d[i];
+        float wx = p.x * x;
+        sx += wx;
+        sx2 += wx * x;
+        sxy += x * p.y;
+        sy += p.y;
+        sw += p.x;
+    }
+    float det = sw * sx2 - sx * sx;
+    if (det == 0.0f) { noiseQ = noiseDecay = 0; return; }
+    float amp = (sx2 * sy - sx * sxy) / det;
+    float dec = (sw * sxy - sx * sy) / det;
+    amp = ulcx_expf(amp);
+    dec = (dec < 0.0f) ? ulcx_expf(dec) : 1.0f;
+    int nq = quant_coef_u(amp * q * 4.0f, 16);
+    int nd = quant_u((dec - 1.0f) * -0x1.0p19f);
+    if (!nd) return;
+    if (nd > 0xFF) nd = 0xFF;
+    noiseQ = nq; noiseDecay = nd;
+}
+
+// Encode.c:92-197
+__device__ int write_zone(NybWriter &w, int cur, int end, float quant, const float *coef, const float *pairs,
+                          const uint32_t *keep, int nextCoded) {
+    for (;;) {
+        cur = next_kept(keep, cur, end);
+        if (cur >= end) break;
+        if (fabsf(coef[cur] * quant) < 2.5f) { cur++; continue; }
+        int n = 0, v = 0;
+        int zr = cur - nextCoded;
+        while (zr) {
+            if (zr <= 2) {
+                int q1 = quant_coef(coef[nextCoded] * quant, 7);
+                int q2 = 0;
+                if (zr >= 2) q2 = quant_coef(coef[nextCoded + 1] * quant, 7);
+                if (abs(q1) > 1 && (zr < 2 || abs(q2) > 1)) {
+                    w.put((unsigned)q1);
+                    if (zr >= 2) w.put((unsigned)q2);
+                    nextCoded += zr;
+                    break;
+                }
+            }
+            int nq = 0;
+            if (zr >= 16) {
+                v = zr - 16; if (v > 0x1FF) v = 0x1FF;
+                n = v + 16;
+                nq = get_noise_q(pairs, nextCoded, n, quant);
+            }
+            if (nq) {
+                w.put(0x8); w.put((unsigned)(v >> 5)); w.put((unsigned)(v >> 1)); w.put((unsigned)((v & 1) | ((nq - 1) << 1)));
+            } else if (zr < 33) {
+                v = zr - 1; if (v > 0xF) v = 0xF;
+                n = v + 1;
+                w.put(0x0); w.put((unsigned)v);
+            } else {
+                v = zr - 33; if (v > 0xFF) v = 0xFF;
+                n = v + 33;
+                w.put(0x1); w.put((unsigned)(v >> 4)); w.put((unsigned)v);
+            }
+            nextCoded += n;
+            zr -= n;
+        }
+        w.put((unsigned)quant_coef(coef[cur] * quant, 7));
+        nextCoded++;
+        cur++;
+    }
+    return nextCoded;
+}
+
+// Encode.c:200-313
+__global__ __launch_bounds__(64) void k_encode_units(UlcxEncCtx c, int finalPass) {
+    int gid = blockIdx.x * 64 + threadIdx.x;
+    int nUnits = c.B * c.K * c.C * 4;
+    if (gid >= nUnits) return;
+    int j = gid & 3, ch = (gid >> 2) % c.C, blk = gid / (4 * c.C);
+    if (!finalPass && c.cbrDone[blk]) return;
+    int s = blk / c.K, k = blk % c.K;
+    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+    int d, off, S;
+    if (!unit_geom(wc, j, c.BS, d, off, S)) { c.unitNyb[gid] = 0; return; }
+    int N = c.C * c.BS;
+    const float *coef = c.coef + (size_t)blk * N;
+    const float *pairs = c.npair + (size_t)blk * N;
+    const uint32_t *keep = c.keep + (size_t)blk * (N / 32);
+    NybWriter w;
+    w.cap = 2 * S + 8;
+    w.dst = c.unitBuf + (size_t)blk * c.C * c.unitCap + (size_t)ch * c.unitCap + 2 * off + 8 * j;
+    w.n = 0; w.acc = 0;
+
+    int idx = ch * c.BS + off;
+    int end = idx + S;
+    int nextCoded = idx;
+    int prevQ = -1, zoneStart = -1;
+    float qmin = 1000.0f, qmax = -1000.0f;
+    do {
+        idx = next_kept(keep, idx, end);
+        float nmin = 0.0f, nmax = qmax, lvl = 0.0f;
+        if (idx < end) {
+            lvl = fabsf(coef[idx]);
+            nmin = (lvl < qmin) ? lvl : qmin;
+            nmax = (lvl > qmax) ? lvl : qmax;
+            if (zoneStart == -1) zoneStart = idx;
+        }
+        if (nmax > nmin * 4.0f) {
+            int qi = build_quantizer(qmax);
+            if (qi != prevQ) { put_quantizer(w, qi, prevQ != -1); prevQ = qi; }
+            nextCoded = write_zone(w, zoneStart, idx, (float)(1u << qi), coef, pairs, keep, nextCoded);
+            zoneStart = idx;
+            qmin = qmax = lvl;
+        } else { qmin = nmin; qmax = nmax; }
+    } while (++idx <= end);
+
+    int n = end - nextCoded;
+    if (n > 4) {
+        if (prevQ != -1) w.put(0xF);
+        int nq = 0, nd = 0;
+        if (prevQ != -1 && n >= 16) get_hfext(pairs, nextCoded, n, (float)(1u << prevQ), nq, nd);
+        if (nq) { w.put(0xF); w.put((unsigned)(nq - 1)); w.put((unsigned)(nd >> 4)); w.put((unsigned)nd); }
+        else { w.put(0xE); w.put(0xF); }
+    } else if (n > 0) {
+        w.put(0x0); w.put((unsigned)(n - 1));
+    }
+    w.flush();
+    c.unitNyb[gid] = w.n;
+}
+
+// Encode.c:329-359: header nybble(s) + units in (channel, subblock) order, byte aligned.
+// One wave per block.
+__global__ __launch_bounds__(64) void k_pack(UlcxEncCtx c, int finalPass) {
+    int blk = blockIdx.x, lane = threadIdx.x;
+    if (!finalPass && c.cbrDone[blk]) return;
+    int s = blk / c.K, k = blk % c.K;
+    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+    int nU = c.C * 4;
+    const int *un = c.unitNyb + (size_t)blk * nU;
+    int hdr = (wc & 8) ? 2 : 1;
+    // total size (serial prefix over <= 4*C units, tiny)
+    int total = hdr;
+    for (int u = 0; u < nU; u++) total += un[u];
+    int bitsTot = ((total * 4) + 7) & ~7;
+    if (!finalPass) {
+        // rate-control probe: only the size matters (ulcEncoder.c:100-110)
+        if (lane == 0) {
+            int budget = c.cbrBudget[blk];
+            int lo = c.cbrLo[blk], hi = c.cbrHi[blk], nOut = c.nout[blk];
+            bool stop = false;
+            if (bitsTot < budget) lo = nOut;
+            else if (bitsTot > budget) hi = nOut - 1;
+            else { lo = nOut; stop = true; }
+            if (stop || !(lo < hi - 1)) { c.cbrDone[blk] = 1; c.nout[blk] = lo; }   // final pass encodes at Lo (ulcEncoder.c:113-114)
+            else c.nout[blk] = (int)((unsigned)(lo + hi) / 2u);
+            c.cbrLo[blk] = lo; c.cbrHi[blk] = hi;
+        }
+        return;
+    }
+    uint8_t *out = c.out + (size_t)blk * c.slot;
+    int nBytes = bitsTot / 8;
+    const uint8_t *ub = c.unitBuf + (size_t)blk * c.C * c.unitCap;
+    for (int b = lane; b < nBytes; b += 64) {
+        unsigned byte = 0;
+        for (int h = 0; h < 2; h++) {
+            int q = 2 * b + h;                 // nybble index in the block
+            unsigned nyb = 0;
+            if (q < hdr) nyb = (q == 0) ? (wc & 0xF) : ((wc >> 4) & 0xF);
+            else if (q < total) {
+                int r = q - hdr;
+                int u = 0;
+                while (r >= un[u]) { r -= un[u]; u++; }
+                int ch = u >> 2, j = u & 3;
+                int d, off, S;
+                unit_geom(wc, j, c.BS, d, off, S);
+                const uint8_t *src = ub + (size_t)ch * c.unitCap + 2 * off + 8 * j;
+                nyb = (src[r >> 1] >> ((r & 1) * 4)) & 0xF;
+            }
+            byte |= nyb << (4 * h);
+        }
+        if (b < c.slot) out[b] = (uint8_t)byte;
+    }
+    if (lane == 0) c.bits[blk] = bitsTot;
+}
+
+// ---------------------------------------------------------------------------
+// Persistent state for the next call (ulcEncoder_BlockTransform.c:93, :114)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_state_update(UlcxEncCtx c) {
+    int s = blockIdx.x, tid = threadIdx.x;
+    int n = 2 * c.BS * c.C;                     // floats of history
+    float *h = c.hist + (size_t)s * n;
+    int newF = c.K * c.BS * c.C;
+    const float *p = c.pcm + (size_t)s * newF;
+    if (c.K >= 2) {
+        for (int i = tid; i < n; i += WG) h[i] = p[newF - n + i];
+    } else {
+        int half = n / 2;                       // disjoint per-thread index sets: no hazard
+        for (int i = tid; i < half; i += WG) { h[i] = h[half + i]; h[half + i] = p[i]; }
+    }
+    if (tid == 0) {
+        UlcxWcState &w = c.wcs[s];
+        const int *row = c.wcArr + (size_t)s * (c.maxK + 2);
+        w.wcPrev = row[c.K];
+        w.wcCur = row[c.K + 1];
+        const float *bins = c.bins + ((size_t)s * (c.maxK + 1) + c.K) * 16;
+        for (int i = 0; i < 8; i++) { w.binSum[i] = bins[i]; w.binW[i] = bins[8 + i]; }
+    }
+}
+// forward-filter end states must be captured before k_wc_backward overwrites .x
+__global__ __launch_bounds__(64) void k_wc_save_fwd(UlcxEncCtx c) {
+    int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= c.B) return;
+    float2 last = c.env[(size_t)gid * c.maxK * c.BS + (size_t)c.K * c.BS - 1];
+    c.wcs[gid].tf[0] = last.x;
+    c.wcs[gid].tf[1] = last.y;
+}
+
+// ---------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------
+size_t ulcx_enc_xf_lds_bytes(int BS) { return (size_t)BS * 18 + 16; }   // 2BS + BS + BS + BS/2 floats + counter
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)
+
+int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev) {
+    int NB = c.B * c.K;
+    int stage = 0;
+#define MARK() do { if (ev) CK(hipEventRecord(ev[stage++], st)); } while (0)
+    MARK();
+    // --- window control
+    {
+        size_t tot = (size_t)NB * c.BS;
+        hipLaunchKernelGGL(k_wc_energy, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);
+        hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, st, c);
+        hipLaunchKernelGGL(k_wc_save_fwd, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
+        hipLaunchKernelGGL(k_wc_backward, dim3((NB + 63) / 64), dim3(64), 0, st, c);
+        hipLaunchKernelGGL(k_wc_integrate, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
+        hipLaunchKernelGGL(k_wc_decide, dim3((NB + 63) / 64), dim3(64), 0, st, c);
+    }
+    MARK();
+    // --- transform
+    {
+        size_t lds = ulcx_enc_xf_lds_bytes(c.BS);
+        if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_xf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_xf, dim3(NB), dim3(WG), lds, st, c);
+    }
+    MARK();
+    hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c);
+    MARK();
+    {
+        int nUnits = NB * c.C * 4;
+        hipLaunchKernelGGL(k_nbark, dim3((nUnits + 63) / 64), dim3(64), 0, st, c);
+        size_t tot = (size_t)NB * c.C * (c.BS / 2);
+        hipLaunchKernelGGL(k_nline, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);
+    }
+    MARK();
+    {
+        hipLaunchKernelGGL(k_pbark, dim3((NB * 4 + 63) / 64), dim3(64), 0, st, c);
+        size_t tot = (size_t)NB * (c.BS / 2);
+        hipLaunchKernelGGL(k_keys, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);
+    }
+    MARK();
+    // --- selection + encode pass(es)
+    int N = c.C * c.BS;
+    int ldsEntries = ((size_t)N * 8 <= ULCX_HEAP_LDS_BYTES) ? N : 0;
+    size_t heapLds = ldsEntries ? (size_t)N * 8 : 0;
+    if (heapLds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_heapsel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heapLds));
+    int fbGrid = NB < ULCX_HEAP_GRID ? NB : ULCX_HEAP_GRID;
+    int nUnits = NB * c.C * 4;
+    // VBR: one pass.  CBR/ABR: the reference's binary search (ulcEncoder.c:98-110) needs at most
+    // ceil(log2(MaxCoef))+1 probes; every block runs its own search in lock step, then one final pass.
+    int probes = 0;
+    if (c.mode != ULCX_MODE_VBR) { probes = 2; int m = N; while (m > 1) { probes++; m >>= 1; } }
+    for (int p = 0; p <= probes; p++) {
+        int fin = (p == probes) ? 1 : 0;
+        CK(hipMemsetAsync(c.fbCount, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_select, dim3(NB), dim3(WG), 0, st, c, fin);
+        hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, st, c, ldsEntries);
+        if (p == 0) MARK();
+        hipLaunchKernelGGL(k_encode_units, dim3((nUnits + 63) / 64), dim3(64), 0, st, c, fin);
+        hipLaunchKernelGGL(k_pack, dim3(NB), dim3(64), 0, st, c, fin);
+    }
+    MARK();
+    hipLaunchKernelGGL(k_state_update, dim3(c.B), dim3(WG), 0, st, c);
+    MARK();
+    CK(hipGetLastError());
+    return ULCX_OK;
+}

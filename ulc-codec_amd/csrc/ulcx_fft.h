@@ -1,0 +1,97 @@
+// ulcx_fft.h — LDS-resident complex FFT used by the forward and inverse transforms.
+// "fourier spec v1" (oracle/orc_fourier.c): radix-2 decimation in
+// frequency, in place, natural-order input, bit-reversed output, twiddle table
+// W[j] = (cos, sin)(2 pi j / M); every complex multiply is 4 binary32 products and 2
+// sums, each individually rounded (file compiled with -ffp-contract=off).
+// Requires WG (workgroup size) to be defined by the includer.
+#pragma once
+#include <hip/hip_runtime.h>
+
+__device__ __forceinline__ float2 cmulc(float2 d, float2 w) {    // d * conj(w), 4 mul + 2 add, unfused
+    float m0 = d.x * w.x, m1 = d.y * w.y, m2 = d.y * w.x, m3 = d.x * w.y;
+    return make_float2(m0 + m1, m2 - m3);
+}
+
+
+// In-place radix-2 DIF FFT of two M-point arrays held in LDS ("fourier spec v1",
+// oracle/orc_fourier.c), executed as merged radix-2^2 passes: each thread carries four
+// points through two consecutive radix-2 stages in registers, which is arithmetically
+// identical to the two separate stages.
+__device__ void fft2_dif(float2 *za, float2 *zb, int M, const float2 *__restrict__ tw, int tid) {
+    int h = M >> 1;
+    int quarter = M >> 2;
+    while (h >= 2) {
+        int q = h >> 1;
+        int stepA = M / (2 * h), stepB = stepA * 2;
+        for (int g = tid; g < 2 * quarter; g += WG) {
+            float2 *z = (g < quarter) ? za : zb;
+            int gg = (g < quarter) ? g : g - quarter;
+            int j = gg & (q - 1);
+            int p0 = (gg - j) * 4 + j;            // (gg / q) * 2h + j, 2h = 4q
+            int p1 = p0 + q, p2 = p0 + h, p3 = p2 + q;
+            float2 x0 = z[p0], x1 = z[p1], x2 = z[p2], x3 = z[p3];
+            float2 wA0 = tw[j * stepA], wA1 = tw[(j + q) * stepA], wB = tw[j * stepB];
+            float2 y0 = make_float2(x0.x + x2.x, x0.y + x2.y);
+            float2 y2 = cmulc(make_float2(x0.x - x2.x, x0.y - x2.y), wA0);
+            float2 y1 = make_float2(x1.x + x3.x, x1.y + x3.y);
+            float2 y3 = cmulc(make_float2(x1.x - x3.x, x1.y - x3.y), wA1);
+            z[p0] = make_float2(y0.x + y1.x, y0.y + y1.y);
+            z[p1] = cmulc(make_float2(y0.x - y1.x, y0.y - y1.y), wB);
+            z[p2] = make_float2(y2.x + y3.x, y2.y + y3.y);
+            z[p3] = cmulc(make_float2(y2.x - y3.x, y2.y - y3.y), wB);
+        }
+        __syncthreads();
+        h >>= 2;
+    }
+    if (h == 1) {
+        float2 w0 = tw[0];
+        int half = M >> 1;
+        for (int g = tid; g < 2 * half; g += WG) {
+            float2 *z = (g < half) ? za : zb;
+            int p = 2 * ((g < half) ? g : g - half);
+            float2 a = z[p], b = z[p + 1];
+            z[p] = make_float2(a.x + b.x, a.y + b.y);
+            z[p + 1] = cmulc(make_float2(a.x - b.x, a.y - b.y), w0);
+        }
+        __syncthreads();
+    }
+}
+
+
+// single-array variant (decoder)
+__device__ void fft1_dif(float2 *z, int M, const float2 *__restrict__ tw, int tid) {
+    int h = M >> 1;
+    int quarter = M >> 2;
+    while (h >= 2) {
+        int q = h >> 1;
+        int stepA = M / (2 * h), stepB = stepA * 2;
+        for (int gg = tid; gg < quarter; gg += WG) {
+            int j = gg & (q - 1);
+            int p0 = (gg - j) * 4 + j;
+            int p1 = p0 + q, p2 = p0 + h, p3 = p2 + q;
+            float2 x0 = z[p0], x1 = z[p1], x2 = z[p2], x3 = z[p3];
+            float2 wA0 = tw[j * stepA], wA1 = tw[(j + q) * stepA], wB = tw[j * stepB];
+            float2 y0 = make_float2(x0.x + x2.x, x0.y + x2.y);
+            float2 y2 = cmulc(make_float2(x0.x - x2.x, x0.y - x2.y), wA0);
+            float2 y1 = make_float2(x1.x + x3.x, x1.y + x3.y);
+            float2 y3 = cmulc(make_float2(x1.x - x3.x, x1.y - x3.y), wA1);
+            z[p0] = make_float2(y0.x + y1.x, y0.y + y1.y);
+            z[p1] = cmulc(make_float2(y0.x - y1.x, y0.y - y1.y), wB);
+            z[p2] = make_float2(y2.x + y3.x, y2.y + y3.y);
+            z[p3] = cmulc(make_float2(y2.x - y3.x, y2.y - y3.y), wB);
+        }
+        __syncthreads();
+        h >>= 2;
+    }
+    if (h == 1) {
+        float2 w0 = tw[0];
+        int half = M >> 1;
+        for (int g = tid; g < half; g += WG) {
+            int p = 2 * g;
+            float2 a = z[p], b = z[p + 1];
+            z[p] = make_float2(a.x + b.x, a.y + b.y);
+            z[p + 1] = cmulc(make_float2(a.x - b.x, a.y - b.y), w0);
+        }
+        __syncthreads();
+    }
+}

@@ -1,0 +1,115 @@
+// ulcx_internal.h — structures shared by the host API (ulcx_api.cpp) and the HIP
+// kernels (ulcx_enc.hip / ulcx_dec.hip).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ulc_amd.h"
+
+#define ULCX_NBARK 25
+#define ULCX_MAX_SUB 4
+#define ULCX_MAX_BS_DEVICE 8192        // LDS budget of the transform kernels
+#define ULCX_COEF_EPS (0x1.0p-31f)     // include/ulcEncoder.h:36
+#define ULCX_HEAP_LDS_BYTES (128 * 1024)
+#define ULCX_HEAP_GRID 256
+
+// Host-precomputed, data-independent tables: everything
+// the reference evaluates with sinhf/asinhf/cos/sin or expf on arguments that depend
+// only on (BlockSize, RateHz).  Built with the HOST libm in ulcx_tables.cpp, one
+// set per encoder/decoder, resident in HBM (hot in L2).  Index d = log2(BS/S).
+struct UlcxTables {
+    const float2 *pre[ULCX_MAX_SUB];     // DCT-IV pre/post twiddle P[n] = (cos,sin)(pi(8n+1)/(8S)), n < S/2
+    const float2 *tw[ULCX_MAX_SUB];      // FFT twiddle W[j] = (cos,sin)(2 pi j / (S/2)), j < S/4
+    const float  *winFall;               // ramp for overlap Ov (power of two) at [Ov + i], i < Ov
+    const float  *winRise;
+    const int    *bandIdx[ULCX_MAX_SUB]; // per line < S/2: (int)Bark(line)         Psyopt.c:141-143,237-239
+    const float  *bandFrac[ULCX_MAX_SUB];//               Bark(line) - (int)Bark(line)
+    // Bark band edges per subblock size (lines of the S/2-line pseudo-DFT)
+    short nBeg[ULCX_MAX_SUB][ULCX_NBARK], nEnd[ULCX_MAX_SUB][ULCX_NBARK];   // noise:  [b, b+2)        Psyopt.c:198-205
+    short pBeg[ULCX_MAX_SUB][ULCX_NBARK], pEnd[ULCX_MAX_SUB][ULCX_NBARK];   // psycho: [b-.75, b+.25)  Psyopt.c:109-116
+};
+
+struct UlcxWcState {                     // per stream, persistent (ulcEncoder.h:65-77)
+    float tf[3];                         // TransientFilter
+    int   wcPrev, wcCur;                 // WindowCtrl of block k0-1 and k0 (k0 = next call's first block)
+    float binSum[8], binW[8];            // TransientBuffer R half of the last analysed block
+    int   pad;
+};
+
+struct UlcxEncCtx {
+    // geometry
+    int B, K, C, BS, lgBS;               // streams, blocks this call, channels, block size
+    int maxK;                            // allocation stride for per-call arrays
+    int slot;                            // bytes per output slot
+    int unitCap;                         // bytes per (chan,subblock) nybble staging row = 2*BS+32 per channel
+    int mode; float p0, p1;              // rate control
+    float vbrTarget;                     // 0x1.E4EFB7p3f*logf(100/Quality) (host libm), ulcEncoder.c:144
+    // window-control constants (1 - rate), host expf: WindowControl.c:75,76,94,95,120
+    float cHP, cBP, qHP, qBP, cBlk;
+    float cplxScale;                     // BlockTransform.c:320
+    int   rateHz;
+    UlcxTables T;
+    // inputs / outputs of this call
+    const float *pcm; uint8_t *out; int32_t *bits; int32_t *wcOut; float *cplxOut;
+    // persistent state
+    float *hist;                         // [B][2*BS][C] previous two input blocks (raw, interleaved)
+    UlcxWcState *wcs;                    // [B]
+    // per-call scratch
+    float2 *env;                         // [B][maxK*BS] {hp,bp} energies -> envelopes -> transient curve (.x)
+    float  *bins;                        // [B][maxK+1][16] {Sum[8],SumW[8]}; row 0 = previous block
+    int    *wcArr;                       // [B][maxK+2] WindowCtrl of blocks k0-1 .. k0+K
+    float  *coef;                        // [NB][C*BS]   normalised MDCT (TransformBuffer)
+    float  *key;                         // [NB][C*BS]   importance keys
+    float  *nsum;                        // [NB][C*BS/2] per-line |X|^2 (noise input)
+    float  *npair;                       // [NB][C*BS]   {w, w*log} pairs (TransformNoise)
+    float  *amp2;                        // [NB][BS/2]
+    float  *mask;                        // [NB][BS/2]   (debug only; keys kernel recomputes)
+    float  *barkN;                       // [NB][C*4][25]
+    float  *barkP;                       // [NB][4][25]
+    int    *nnz;                         // [NB]
+    float  *cplx;                        // [NB]
+    int    *nout;                        // [NB]   nOutCoef of the current pass
+    int    *cbrLo, *cbrHi, *cbrDone;     // [NB]
+    uint32_t *keep;                      // [NB][C*BS/32]
+    int    *fbList; int *fbCount;        // tie-straddle fallback list
+    uint8_t *unitBuf;                    // [NB][C][unitCap]
+    int    *unitNyb;                     // [NB][C*4]
+    int    *cbrBudget;                   // [NB] bit budget (ulcEncoder.c:96)
+    void   *heapScratch;                 // [ULCX_HEAP_GRID][C*BS] {key,idx} heaps, only when C*BS*8 exceeds the LDS budget
+};
+
+struct UlcxDecCtx {
+    int B, K, C, BS, lgBS, maxK;
+    int slot;
+    UlcxTables T;
+    const uint8_t *in; float *pcm; int32_t *bits;
+    // persistent
+    float *lap;                          // [B][C][BS/2] TransformInvLap
+    int   *lastSub;                      // [B] LastSubBlockSize
+    uint32_t *seed;                      // [B] noise RNG state (ulcDecoder.c:75-81)
+    int   *dead;                         // [B] stream hit a corrupt block
+    // per-call scratch
+    float *coef;                         // [NB][C*BS] dequantised coefficients
+    int   *wc;                           // [NB] WindowCtrl per block (0 = corrupt)
+};
+
+// ulcHelper.h:24-46
+__host__ __device__ static inline unsigned ulcx_pattern(int wc) {
+    switch ((wc >> 4) & 15) {
+        case 0: return 0x0000; case 1: return 0x0008; case 2: return 0x0019; case 3: return 0x0091;
+        case 4: return 0x012A; case 5: return 0x01A2; case 6: return 0x02A1; case 7: return 0x0A21;
+        case 8: return 0x123B; case 9: return 0x12B3; case 10: return 0x13B2; case 11: return 0x1B32;
+        case 12: return 0x23B1; case 13: return 0x2B31; case 14: return 0x3B21; default: return 0xB321;
+    }
+}
+
+// host side (ulcx_tables.cpp)
+struct UlcxHostTables;
+int  ulcx_tables_build(UlcxTables *devT, void **devBlob, int BS, int rateHz, bool forEncoder);
+void ulcx_set_error(const char *fmt, ...);
+
+// launchers (ulcx_enc.hip / ulcx_dec.hip)
+#define ULCX_ENC_STAGES 8
+#define ULCX_DEC_STAGES 2
+int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */);
+int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev);
+size_t ulcx_enc_xf_lds_bytes(int BS);
