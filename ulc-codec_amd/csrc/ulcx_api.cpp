@@ -224,8 +224,7 @@ extern "C" int ulcx_encoder_debug_fetch(ulcx_encoder *e, int nBlocks, float *h_c
     return ULCX_OK;
 }
 
-static const char *kEncStage[ULCX_ENC_STAGES] = { "window_ctrl", "transform", "complexity", "noise_spectrum", "psycho_keys", "select", "encode_pack", "state_update" };
-extern "C" const char *ulcx_encoder_stage_name(int i) { return (i >= 0 && i < ULCX_ENC_STAGES) ? kEncStage[i] : ""; }
+extern "C" const char *ulcx_encoder_stage_name(int i) { return (i >= 0 && i < ULCX_ENC_STAGES) ? ulcx_enc_stage_names[i] : ""; }
 extern "C" int ulcx_encoder_stage_ms(ulcx_encoder *e, float *ms, int maxStages) {
     if (!e || !e->evRecorded) return 0;
     int n = 0;
@@ -323,7 +322,7 @@ extern "C" int ulcx_decode_host(ulcx_decoder *e, const uint8_t *h_in, int slotBy
     CKR(hipMemcpy(h_bits, e->d_bits, sizeof(int32_t) * NB, hipMemcpyDeviceToHost));
     return ULCX_OK;
 }
-static const char *kDecStage[ULCX_DEC_STAGES] = { "parse_dequant", "imdct_ola" };
+static const char *kDecStage[ULCX_DEC_STAGES] = { "k_dparse", "k_dimdct" };
 extern "C" const char *ulcx_decoder_stage_name(int i) { return (i >= 0 && i < ULCX_DEC_STAGES) ? kDecStage[i] : ""; }
 extern "C" int ulcx_decoder_stage_ms(ulcx_decoder *e, float *ms, int maxStages) {
     if (!e || !e->evRecorded) return 0;

@@ -922,6 +922,14 @@ size_t ulcx_enc_xf_lds_bytes(int BS) { return (size_t)BS * 18 + 16; }   // 2BS +
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)
 
+// Per-kernel hipEvents (on the launch stream) bracket every kernel of the first pass so
+// bench.py can price each one against the roofline live; ev holds ULCX_ENC_STAGES+1 events.
+const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES] = {
+    "k_wc_energy", "k_wc_forward", "k_wc_save_fwd", "k_wc_backward", "k_wc_integrate", "k_wc_decide",
+    "k_xf", "k_cplx", "k_nbark", "k_nline", "k_pbark", "k_keys",
+    "k_select", "k_heapsel", "k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update",
+};
+
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev) {
     int NB = c.B * c.K;
     int stage = 0;
@@ -930,59 +938,52 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev) {
     // --- window control
     {
         size_t tot = (size_t)NB * c.BS;
-        hipLaunchKernelGGL(k_wc_energy, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);
-        hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, st, c);
-        hipLaunchKernelGGL(k_wc_save_fwd, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
-        hipLaunchKernelGGL(k_wc_backward, dim3((NB + 63) / 64), dim3(64), 0, st, c);
-        hipLaunchKernelGGL(k_wc_integrate, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
-        hipLaunchKernelGGL(k_wc_decide, dim3((NB + 63) / 64), dim3(64), 0, st, c);
+        hipLaunchKernelGGL(k_wc_energy, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);        MARK();
+        hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, st, c);                   MARK();
+        hipLaunchKernelGGL(k_wc_save_fwd, dim3((c.B + 63) / 64), dim3(64), 0, st, c);                      MARK();
+        hipLaunchKernelGGL(k_wc_backward, dim3((NB + 63) / 64), dim3(64), 0, st, c);                       MARK();
+        hipLaunchKernelGGL(k_wc_integrate, dim3((c.B + 63) / 64), dim3(64), 0, st, c);                     MARK();
+        hipLaunchKernelGGL(k_wc_decide, dim3((NB + 63) / 64), dim3(64), 0, st, c);                         MARK();
     }
-    MARK();
     // --- transform
     {
         size_t lds = ulcx_enc_xf_lds_bytes(c.BS);
         if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_xf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_xf, dim3(NB), dim3(WG), lds, st, c);
+        hipLaunchKernelGGL(k_xf, dim3(NB), dim3(WG), lds, st, c);                                          MARK();
     }
-    MARK();
-    hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c);
-    MARK();
+    hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c);                                  MARK();
+    int nUnits = NB * c.C * 4;
     {
-        int nUnits = NB * c.C * 4;
-        hipLaunchKernelGGL(k_nbark, dim3((nUnits + 63) / 64), dim3(64), 0, st, c);
+        hipLaunchKernelGGL(k_nbark, dim3((nUnits + 63) / 64), dim3(64), 0, st, c);                         MARK();
         size_t tot = (size_t)NB * c.C * (c.BS / 2);
-        hipLaunchKernelGGL(k_nline, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);
+        hipLaunchKernelGGL(k_nline, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);            MARK();
     }
-    MARK();
     {
-        hipLaunchKernelGGL(k_pbark, dim3((NB * 4 + 63) / 64), dim3(64), 0, st, c);
+        hipLaunchKernelGGL(k_pbark, dim3((NB * 4 + 63) / 64), dim3(64), 0, st, c);                         MARK();
         size_t tot = (size_t)NB * (c.BS / 2);
-        hipLaunchKernelGGL(k_keys, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);
+        hipLaunchKernelGGL(k_keys, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);             MARK();
     }
-    MARK();
     // --- selection + encode pass(es)
     int N = c.C * c.BS;
     int ldsEntries = ((size_t)N * 8 <= ULCX_HEAP_LDS_BYTES) ? N : 0;
     size_t heapLds = ldsEntries ? (size_t)N * 8 : 0;
     if (heapLds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_heapsel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heapLds));
     int fbGrid = NB < ULCX_HEAP_GRID ? NB : ULCX_HEAP_GRID;
-    int nUnits = NB * c.C * 4;
     // VBR: one pass.  CBR/ABR: the reference's binary search (ulcEncoder.c:98-110) needs at most
     // ceil(log2(MaxCoef))+1 probes; every block runs its own search in lock step, then one final pass.
     int probes = 0;
     if (c.mode != ULCX_MODE_VBR) { probes = 2; int m = N; while (m > 1) { probes++; m >>= 1; } }
     for (int p = 0; p <= probes; p++) {
         int fin = (p == probes) ? 1 : 0;
+        bool ev0 = (p == 0);
         CK(hipMemsetAsync(c.fbCount, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_select, dim3(NB), dim3(WG), 0, st, c, fin);
-        hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, st, c, ldsEntries);
-        if (p == 0) MARK();
-        hipLaunchKernelGGL(k_encode_units, dim3((nUnits + 63) / 64), dim3(64), 0, st, c, fin);
-        hipLaunchKernelGGL(k_pack, dim3(NB), dim3(64), 0, st, c, fin);
+        hipLaunchKernelGGL(k_select, dim3(NB), dim3(WG), 0, st, c, fin);                                   if (ev0) MARK();
+        hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, st, c, ldsEntries);                 if (ev0) MARK();
+        hipLaunchKernelGGL(k_encode_units, dim3((nUnits + 63) / 64), dim3(64), 0, st, c, fin);             if (ev0) MARK();
+        hipLaunchKernelGGL(k_pack, dim3(NB), dim3(64), 0, st, c, fin);                                     if (ev0) MARK();
     }
-    MARK();
-    hipLaunchKernelGGL(k_state_update, dim3(c.B), dim3(WG), 0, st, c);
-    MARK();
+    MARK();   // cbr_probe_passes (empty interval for VBR)
+    hipLaunchKernelGGL(k_state_update, dim3(c.B), dim3(WG), 0, st, c);                                     MARK();
     CK(hipGetLastError());
     return ULCX_OK;
 }

@@ -108,7 +108,8 @@ int  ulcx_tables_build(UlcxTables *devT, void **devBlob, int BS, int rateHz, boo
 void ulcx_set_error(const char *fmt, ...);
 
 // launchers (ulcx_enc.hip / ulcx_dec.hip)
-#define ULCX_ENC_STAGES 8
+#define ULCX_ENC_STAGES 18
+extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES];
 #define ULCX_DEC_STAGES 2
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */);
 int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev);

@@ -124,8 +124,8 @@ class BatchEncoder:
         return dict(coef=coef, noise=noise, keys=keys, keep=keep, nout=nout)
 
     def stage_ms(self):
-        ms = np.zeros(16, np.float32)
-        n = lib().ulcx_encoder_stage_ms(self.h, _p(ms, _f32p), 16)
+        ms = np.zeros(32, np.float32)
+        n = lib().ulcx_encoder_stage_ms(self.h, _p(ms, _f32p), 32)
         return {lib().ulcx_encoder_stage_name(i).decode(): float(ms[i]) for i in range(n)}
 
 
