@@ -55,7 +55,7 @@ def make_pcm(torch, B, n, device, seed):
     return pcm.contiguous()          # [B][n][2] f32
 
 
-def cpu_baseline(sample_pcm, n_blocks, target_seconds=12.0):
+def cpu_baseline(sample_pcm, n_blocks, target_seconds=4.0):
     """Oracle (kind 'port') encode+decode on the host cores.  sample_pcm: numpy [S][n][C]."""
     import numpy as np
     from ulc_testlib import oracle, ptr, f32p, u8p, i32p

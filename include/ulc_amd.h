@@ -144,6 +144,10 @@ int  ulcx_encode_host(ulcx_encoder *enc, int mode, float param0, float param1,
 int  ulcx_encoder_debug_fetch(ulcx_encoder *enc, int nBlocks, float *h_coef, float *h_noise, float *h_keys,
                               uint8_t *h_keep, int32_t *h_nout);
 
+/* Number of blocks of the last call (final pass) whose threshold tie group straddled the
+ * cut and went through the exact heapsort emulation (BlockTransform.c:20-77).  Test hook. */
+int  ulcx_encoder_last_fallbacks(ulcx_encoder *enc);
+
 int  ulcx_decoder_create(ulcx_decoder **dec, int device, int nStreams, int nChan, int BlockSize, int maxBlocksPerCall);
 void ulcx_decoder_destroy(ulcx_decoder *dec);
 int  ulcx_decoder_reset(ulcx_decoder *dec);

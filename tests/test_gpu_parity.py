@@ -82,6 +82,40 @@ def test_encode_cbr_abr_bit_exact(bs, ch, rate, mode, p0, p1):
     enc.close()
 
 
+@pytest.mark.parametrize("mode,p0", [(0, 50.0), (1, 96.0)])
+def test_encode_tie_straddle_uses_exact_heapsort_order(mode, p0):
+    """Key ties straddling the cut need the exact heapsort emulation (SURVEY.md §7 hard part 2).
+    Natural ties are rare (~4e-4 per block), so force them: a 4-channel stream whose two
+    stereo pairs are identical makes every key of channel 0 tie with channel 2 (and 1 with 3);
+    about every other block then has its threshold tie group straddling the cut."""
+    amd = _amd()
+    bs, rate, B, K = 512, 44100, 8, 12
+    base = _streams(B, K, bs, 2, rate, True, seed=77)
+    pcm = np.concatenate([base, base], axis=2)               # [B][n][4] = (L, R, L, R)
+    enc = amd.BatchEncoder(B, 4, bs, rate, K)
+    res = enc.encode(pcm, mode, p0)
+    nfb = enc.last_fallbacks()
+    dbg = enc.debug_fetch()
+    for s in range(B):
+        ref = oracle_encode_debug(pcm[s], bs, rate, mode, p0, slot=enc.slot)
+        _compare_encode(res, ref, s, 0, K, dbg, "forced-ties")
+    assert nfb >= B, f"only {nfb} tie-straddle blocks: the heapsort path is not covered"
+    enc.close()
+
+
+def test_encode_many_blocks_bit_exact():
+    """A few thousand blocks of the bench shape, every byte compared with the oracle."""
+    amd = _amd()
+    bs, ch, rate, B, K = 2048, 2, 44100, 96, 24
+    pcm = _streams(B, K, bs, ch, rate, True, seed=2024)
+    enc = amd.BatchEncoder(B, ch, bs, rate, K)
+    res = enc.encode(pcm, amd.MODE_VBR, 50.0)
+    for s in range(B):
+        ref = oracle_encode_debug(pcm[s], bs, rate, 0, 50.0, slot=enc.slot)
+        _compare_encode(res, ref, s, 0, K, None, "many-blocks")
+    enc.close()
+
+
 @pytest.mark.parametrize("bs,ch,rate,q", [(2048, 2, 44100, 50.0), (2048, 1, 44100, 80.0), (4096, 2, 48000, 60.0), (256, 2, 44100, 90.0)])
 def test_decode_bit_exact(bs, ch, rate, q):
     amd = _amd()

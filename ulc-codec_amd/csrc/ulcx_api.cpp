@@ -128,7 +128,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     size_t B = nStreams, K = maxBlocksPerCall, NB = B * K, cb = (size_t)nChan * BlockSize;
     DA(c.hist, B * 2 * BlockSize * nChan, true);
     DA(c.wcs, B, true);
-    DA(c.env, B * K * BlockSize, false);
+    DA(c.env, ((B + 63) / 64) * 64 * K * BlockSize, true);
     DA(c.bins, B * (K + 1) * 16, true);
     DA(c.wcArr, B * (K + 2), true);
     DA(c.coef, NB * cb, false);
@@ -142,6 +142,11 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.nnz, NB, true);
     DA(c.cplx, NB, true);
     DA(c.nout, NB, true);
+    DA(c.slow, NB, true);
+    // experimental fused select+encode+pack kernel (k_selenc): measured slower than the lane-per-unit
+    // kernels on MI355X (profiles/r01 notes in DESIGN.md §6), so opt-in only.
+    c.useFused = 0;
+    if (const char *ev = getenv("ULCX_FUSED")) if (ev[0] == '1' && (size_t)cb * 8 + cb / 8 + 2048 * (size_t)nChan + 2048 <= 150 * 1024) c.useFused = 1;
     DA(c.cbrLo, NB, true); DA(c.cbrHi, NB, true); DA(c.cbrDone, NB, true); DA(c.cbrBudget, NB, true);
     DA(c.keep, NB * cb / 32, true);
     DA(c.fbList, NB, true);
@@ -224,6 +229,14 @@ extern "C" int ulcx_encoder_debug_fetch(ulcx_encoder *e, int nBlocks, float *h_c
     return ULCX_OK;
 }
 
+extern "C" int ulcx_encoder_last_fallbacks(ulcx_encoder *e) {
+    if (!e) return ULCX_ERR_ARG;
+    CKR(hipSetDevice(e->device));
+    CKR(hipDeviceSynchronize());
+    int n = 0;
+    CKR(hipMemcpy(&n, e->ctx.fbCount, sizeof(int), hipMemcpyDeviceToHost));
+    return n;
+}
 extern "C" const char *ulcx_encoder_stage_name(int i) { return (i >= 0 && i < ULCX_ENC_STAGES) ? ulcx_enc_stage_names[i] : ""; }
 extern "C" int ulcx_encoder_stage_ms(ulcx_encoder *e, float *ms, int maxStages) {
     if (!e || !e->evRecorded) return 0;
@@ -280,6 +293,26 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     DA(c.dead, B, true);
     DA(c.coef, NB * cb, false);
     DA(c.wc, NB, true);
+    DA(c.draws, NB, true);
+    DA(c.blockSeed, NB, true);
+    DA(c.unitStart, NB * nChan * 4, true);
+    DA(c.unitDraws, NB * nChan * 4, true);
+    {
+        // columns of T^(2^i) for the xorshift32 step T (ulcDecoder.c:75-81): J0[c] = T(e_c), J(i+1) = J(i)*J(i)
+        std::vector<uint32_t> J(32 * 32);
+        auto step = [](uint32_t s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; };
+        for (int cbit = 0; cbit < 32; cbit++) J[cbit] = step(1u << cbit);
+        for (int i = 1; i < 32; i++)
+            for (int cbit = 0; cbit < 32; cbit++) {
+                uint32_t v = J[(i - 1) * 32 + cbit], r = 0;
+                for (int b = 0; b < 32; b++) if (v >> b & 1) r ^= J[(i - 1) * 32 + b];
+                J[i * 32 + cbit] = r;
+            }
+        uint32_t *dj = nullptr;
+        DA(dj, 32 * 32, false);
+        if (hipMemcpy(dj, J.data(), sizeof(uint32_t) * J.size(), hipMemcpyHostToDevice) != hipSuccess) { ulcx_set_error("hipMemcpy(jump)"); cleanup(e); return ULCX_ERR_HIP; }
+        c.jump = dj;
+    }
     for (auto &v : e->ev) { if (hipEventCreate(&v) != hipSuccess) { ulcx_set_error("hipEventCreate failed"); cleanup(e); return ULCX_ERR_HIP; } }
     e->evOk = true;
     rc = dec_reset_state(e);
@@ -322,7 +355,7 @@ extern "C" int ulcx_decode_host(ulcx_decoder *e, const uint8_t *h_in, int slotBy
     CKR(hipMemcpy(h_bits, e->d_bits, sizeof(int32_t) * NB, hipMemcpyDeviceToHost));
     return ULCX_OK;
 }
-static const char *kDecStage[ULCX_DEC_STAGES] = { "k_dparse", "k_dimdct" };
+static const char *kDecStage[ULCX_DEC_STAGES] = { "k_dscan", "k_dseed", "k_dgen", "k_dimdct" };
 extern "C" const char *ulcx_decoder_stage_name(int i) { return (i >= 0 && i < ULCX_DEC_STAGES) ? kDecStage[i] : ""; }
 extern "C" int ulcx_decoder_stage_ms(ulcx_decoder *e, float *ms, int maxStages) {
     if (!e || !e->evRecorded) return 0;

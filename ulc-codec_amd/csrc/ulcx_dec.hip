@@ -1,9 +1,12 @@
 // ulcx_dec.hip — batched ulc-codec decoder for gfx950 (MI355X), hand-written HIP.
 //
-//   k_dparse  nybble parser + dequantiser + noise synthesis
-//             (libulc/ulcDecoder.c:75-197; syntax FormatSpecs.md:57-141).  The syntax is
-//             a sequential state machine and the noise RNG is one chain per stream, so
-//             this runs one lane per stream, blocks in order.
+//   k_dscan / k_dseed / k_dgen
+//             nybble parser + dequantiser + noise synthesis
+//             (libulc/ulcDecoder.c:75-197; syntax FormatSpecs.md:57-141).  The syntax is a
+//             sequential state machine per (channel, subblock) unit and the noise RNG is one
+//             chain per stream; the chain is cut by counting draws per unit (scan) and
+//             jumping the xorshift state ahead (GF(2) matrix powers), so generation runs
+//             one lane per unit over the whole batch.
 //   k_dimdct  one workgroup per stream, blocks in order, lapping state resident in LDS:
 //             IMDCT (one DCT-IV = complex FFT in LDS), sine-window overlap-add, the
 //             reversed-time centring FIFO, inverse M/S, interleave
@@ -51,17 +54,22 @@ struct CoefWriter {                                               // sequential 
 };
 
 // ulcDecoder.c:99-197.  Returns 0 on a run that overruns the subblock (corrupt).
-__device__ int decode_subblock(CoefWriter &w, int N, NybReader &r, uint32_t &seed) {
+// GEN = false: syntax walk only, counting the RNG draws the subblock consumes (one per
+// noise coefficient, ulcDecoder.c:156-160,181-184); GEN = true: also emits coefficients.
+template <bool GEN>
+__device__ int decode_subblock(CoefWriter &w, int N, NybReader &r, uint32_t &seed, int &draws) {
     int n, v;
     v = get_quantizer(r);
-    if (v == ESC_STOP) { do w.put(0.0f); while (--N); return 1; }
+    if (v == ESC_STOP) { if (GEN) { do w.put(0.0f); while (--N); } return 1; }
     float quant = expand_quantizer(v);
     for (;;) {
         v = (int)r.get();
         if (v != 0x0 && v != 0x1 && v != 0x8 && v != 0xF) {
-            v = (v ^ 0x8) - 0x8;
-            v = (v < 0) ? (-v * v) : (+v * v);
-            w.put((float)v * quant);
+            if (GEN) {
+                v = (v ^ 0x8) - 0x8;
+                v = (v < 0) ? (-v * v) : (+v * v);
+                w.put((float)v * quant);
+            }
             if (--N == 0) break;
             continue;
         }
@@ -69,7 +77,7 @@ __device__ int decode_subblock(CoefWriter &w, int N, NybReader &r, uint32_t &see
             n = (int)r.get() + 1;
             if (n > N) return 0;
             N -= n;
-            do w.put(0.0f); while (--n);
+            if (GEN) { do w.put(0.0f); while (--n); }
             if (N == 0) break;
             continue;
         }
@@ -79,7 +87,7 @@ __device__ int decode_subblock(CoefWriter &w, int N, NybReader &r, uint32_t &see
             n += 33;
             if (n > N) return 0;
             N -= n;
-            do w.put(0.0f); while (--n);
+            if (GEN) { do w.put(0.0f); while (--n); }
             if (N == 0) break;
             continue;
         }
@@ -92,12 +100,15 @@ __device__ int decode_subblock(CoefWriter &w, int N, NybReader &r, uint32_t &see
             n += 16;
             if (n > N) return 0;
             N -= n;
-            float p = (float)(v * v) * quant * (1.0f / 4);
-            do {
-                seed = xorshift32(seed);
-                if (seed & 0x80000000u) p = -p;
-                w.put(p);
-            } while (--n);
+            draws += n;
+            if (GEN) {
+                float p = (float)(v * v) * quant * (1.0f / 4);
+                do {
+                    seed = xorshift32(seed);
+                    if (seed & 0x80000000u) p = -p;
+                    w.put(p);
+                } while (--n);
+            }
             if (N == 0) break;
             continue;
         }
@@ -107,48 +118,108 @@ __device__ int decode_subblock(CoefWriter &w, int N, NybReader &r, uint32_t &see
             v = (int)r.get() + 1;
             n = (int)r.get();
             n = (int)r.get() | (n << 4);
-            float p = (float)(v * v) * quant * (1.0f / 16);
-            float rr = 1.0f + (float)(n * n) * -0x1.0p-19f;
-            do {
-                seed = xorshift32(seed);
-                if (seed & 0x80000000u) p = -p;
-                w.put(p); p *= rr;
-            } while (--N);
+            draws += N;
+            if (GEN) {
+                float p = (float)(v * v) * quant * (1.0f / 16);
+                float rr = 1.0f + (float)(n * n) * -0x1.0p-19f;
+                do {
+                    seed = xorshift32(seed);
+                    if (seed & 0x80000000u) p = -p;
+                    w.put(p); p *= rr;
+                } while (--N);
+            }
             break;
         }
-        if (v == ESC_STOP) { do w.put(0.0f); while (--N); break; }
+        if (v == ESC_STOP) { if (GEN) { do w.put(0.0f); while (--N); } break; }
     }
     return 1;
 }
 
-__global__ __launch_bounds__(64) void k_dparse(UlcxDecCtx c) {
+// Pass 1 — one lane per block: walk the syntax, record where each (channel, subblock)
+// unit starts (nybble offset) and how many RNG draws precede it inside the block.
+__global__ __launch_bounds__(64) void k_dscan(UlcxDecCtx c) {
+    int blk = blockIdx.x * 64 + threadIdx.x;
+    if (blk >= c.B * c.K) return;
+    NybReader r; r.p = c.in + (size_t)blk * c.slot; r.size = 0;
+    int wc = (int)r.get();                                         // ulcDecoder.c:211-216
+    if (wc & 0x8) wc |= (int)r.get() << 4;
+    else wc |= 1 << 4;
+    CoefWriter w; w.dst = nullptr; w.n = 0;
+    uint32_t seed = 0;
+    int draws = 0, ok = 1;
+    int *ustart = c.unitStart + (size_t)blk * c.C * 4;
+    int *udraw  = c.unitDraws + (size_t)blk * c.C * 4;
+    for (int ch = 0; ch < c.C && ok; ch++) {
+        unsigned pat = ulcx_pattern(wc);                            // (code 0000 behaves as one plain N/1 block, as in the reference)
+        int j = 0;
+        do {
+            int S = c.BS >> (pat & 7);
+            ustart[ch * 4 + j] = r.size;
+            udraw[ch * 4 + j] = draws;
+            if (!decode_subblock<false>(w, S, r, seed, draws)) { ok = 0; break; }
+            if (S == c.BS) break;                                   // ulcDecoder.c:242-245
+            j++;
+        } while (pat >>= 4);
+    }
+    c.bits[blk] = ok ? r.size : 0;
+    c.wc[blk] = ok ? wc : 0;
+    c.draws[blk] = draws;
+}
+
+// xorshift32 is linear over GF(2): state after n draws = T^n * state.  jump[i] holds the
+// 32 columns of T^(2^i) (host-built, ulcx_api.cpp), so a jump costs popcount(n) mat-vecs.
+__device__ __forceinline__ uint32_t rng_jump(const uint32_t *__restrict__ jump, uint32_t s, uint32_t n) {
+    for (int i = 0; n; i++, n >>= 1) {
+        if (n & 1) {
+            const uint32_t *J = jump + i * 32;
+            uint32_t r = 0, t = s;
+            while (t) { int b = __ffs(t) - 1; r ^= J[b]; t &= t - 1; }
+            s = r;
+        }
+    }
+    return s;
+}
+
+// Pass 2 — one lane per stream: the RNG chain across blocks (ulcDecoder.c:75-81 keeps one
+// seed for the life of the stream) and "a corrupt block ends the stream" (ulcDecodeTool.c:154-157).
+__global__ __launch_bounds__(64) void k_dseed(UlcxDecCtx c) {
     int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= c.B) return;
     uint32_t seed = c.seed[s];
     int dead = c.dead[s];
     for (int k = 0; k < c.K; k++) {
         int blk = s * c.K + k;
+        if (!dead && c.wc[blk] == 0) dead = 1;
         if (dead) { c.bits[blk] = 0; c.wc[blk] = 0; continue; }
-        NybReader r; r.p = c.in + (size_t)blk * c.slot; r.size = 0;
-        int wc = (int)r.get();                                     // ulcDecoder.c:211-216
-        if (wc & 0x8) wc |= (int)r.get() << 4;
-        else wc |= 1 << 4;
-        CoefWriter w; w.dst = c.coef + (size_t)blk * c.C * c.BS; w.n = 0;
-        int ok = 1;
-        for (int ch = 0; ch < c.C && ok; ch++) {
-            unsigned pat = ulcx_pattern(wc);                        // (code 0000 behaves as one plain N/1 block, as in the reference)
-            do {
-                int S = c.BS >> (pat & 7);
-                if (!decode_subblock(w, S, r, seed)) { ok = 0; break; }
-                if (S == c.BS) break;                               // ulcDecoder.c:242-245
-            } while (pat >>= 4);
-        }
-        if (!ok) { dead = 1; c.bits[blk] = 0; c.wc[blk] = 0; continue; }
-        c.bits[blk] = r.size;
-        c.wc[blk] = wc;
+        c.blockSeed[blk] = seed;
+        seed = rng_jump(c.jump, seed, (uint32_t)c.draws[blk]);
     }
     c.seed[s] = seed;
     c.dead[s] = dead;
+}
+
+// Pass 3 — one lane per (block, channel, subblock): dequantise + noise synthesis.
+__global__ __launch_bounds__(64) void k_dgen(UlcxDecCtx c) {
+    int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= c.B * c.K * c.C * 4) return;
+    int j = gid & 3, ch = (gid >> 2) % c.C, blk = gid / (4 * c.C);
+    int wc = c.wc[blk];
+    if (wc == 0) return;
+    unsigned pat = ulcx_pattern(wc);
+    int off = 0, S = c.BS;
+    for (int i = 0;; i++) {
+        S = c.BS >> (pat & 7);
+        if (i == j) break;
+        if (S == c.BS) return;
+        off += S;
+        pat >>= 4;
+        if (!pat) return;
+    }
+    NybReader r; r.p = c.in + (size_t)blk * c.slot; r.size = c.unitStart[(size_t)blk * c.C * 4 + ch * 4 + j];
+    uint32_t seed = rng_jump(c.jump, c.blockSeed[blk], (uint32_t)c.unitDraws[(size_t)blk * c.C * 4 + ch * 4 + j]);
+    CoefWriter w; w.dst = c.coef + (size_t)blk * c.C * c.BS + (size_t)ch * c.BS + off; w.n = 0;
+    int draws = 0;
+    decode_subblock<true>(w, S, r, seed, draws);
 }
 
 // ---------------------------------------------------------------------------
@@ -278,7 +349,12 @@ size_t ulcx_dec_lds_bytes(int BS, int C) {
 int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev) {
     int stage = 0;
     if (ev) CK(hipEventRecord(ev[stage++], st));
-    hipLaunchKernelGGL(k_dparse, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
+    int NB = c.B * c.K;
+    hipLaunchKernelGGL(k_dscan, dim3((NB + 63) / 64), dim3(64), 0, st, c);
+    if (ev) CK(hipEventRecord(ev[stage++], st));
+    hipLaunchKernelGGL(k_dseed, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
+    if (ev) CK(hipEventRecord(ev[stage++], st));
+    hipLaunchKernelGGL(k_dgen, dim3((NB * c.C * 4 + 63) / 64), dim3(64), 0, st, c);
     if (ev) CK(hipEventRecord(ev[stage++], st));
     size_t lds = ulcx_dec_lds_bytes(c.BS, c.C);
     if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_dimdct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -53,61 +53,93 @@ __device__ __forceinline__ float ms_sample(const float *p, int ch, int C) {
 // ---------------------------------------------------------------------------
 // Window control
 // ---------------------------------------------------------------------------
+// Scratch layout for the transient detector: env[(sg*T + t)*64 + sl], stream s = sg*64+sl,
+// T = maxK*BS, i.e. time-major inside groups of 64 streams, so the kernels that walk time
+// with one lane per stream touch one contiguous 512-byte row per step.
+__device__ __forceinline__ size_t env_idx(const UlcxEncCtx &c, int s, int t) {
+    return ((size_t)(s >> 6) * c.maxK * c.BS + t) * 64 + (s & 63);
+}
+
 // WindowControl.c:31-70: E[n] = sum_ch (hp^2, bp^2) of the 3-tap FIRs centred on the
 // Old/New boundary; then the sqrt of :80-81 (parallel part of the recurrence).
+// One workgroup = 64 streams x 64 time steps; input rows are read along time
+// (coalesced), transposed through LDS, written stream-minor.
 __global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c) {
-    size_t gid = (size_t)blockIdx.x * WG + threadIdx.x;
-    size_t total = (size_t)c.B * c.K * c.BS;
-    if (gid >= total) return;
-    int s = (int)(gid / ((size_t)c.K * c.BS));
-    int r = (int)(gid % ((size_t)c.K * c.BS));           // k*BS + n
+    __shared__ float2 tile[64][65];
+    int tiles_t = (c.K * c.BS) / 64;
+    int sg = blockIdx.x / tiles_t, tt = blockIdx.x % tiles_t;
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int r = tt * 64 + lane;                              // k*BS + n
     int t = r - c.BS / 2;                                // centre sample
-    const float *p0 = smp_ptr(c, s, t - 1), *p1 = smp_ptr(c, s, t), *p2 = smp_ptr(c, s, t + 1);
-    float ehp = 0.0f, ebp = 0.0f;
-    for (int ch = 0; ch < c.C; ch++) {
-        float t0 = ms_sample(p0, ch, c.C), t1 = ms_sample(p1, ch, c.C), t2 = ms_sample(p2, ch, c.C);
-        float hp = -t0 + 2 * t1 - t2;
-        float bp = -t0 + t2;
-        ehp += hp * hp;
-        ebp += bp * bp;
+    for (int sl = wv; sl < 64; sl += 4) {
+        int s = sg * 64 + sl;
+        float2 v = make_float2(0.0f, 0.0f);
+        if (s < c.B) {
+            const float *p0 = smp_ptr(c, s, t - 1), *p1 = smp_ptr(c, s, t), *p2 = smp_ptr(c, s, t + 1);
+            float ehp = 0.0f, ebp = 0.0f;
+            for (int ch = 0; ch < c.C; ch++) {
+                float t0 = ms_sample(p0, ch, c.C), t1 = ms_sample(p1, ch, c.C), t2 = ms_sample(p2, ch, c.C);
+                float hp = -t0 + 2 * t1 - t2;
+                float bp = -t0 + t2;
+                ehp += hp * hp;
+                ebp += bp * bp;
+            }
+            v = make_float2(sqrtf(ehp), sqrtf(ebp));
+        }
+        tile[lane][sl] = v;
     }
-    c.env[(size_t)s * c.maxK * c.BS + r] = make_float2(sqrtf(ehp), sqrtf(ebp));
+    __syncthreads();
+    float2 *dst = c.env + ((size_t)sg * c.maxK * c.BS + (size_t)tt * 64) * 64;
+    for (int tl = wv; tl < 64; tl += 4) dst[(size_t)tl * 64 + lane] = tile[tl][lane];
 }
 
 // WindowControl.c:72-88: forward one-pole smear, the only sample-rate recurrence that
-// crosses blocks.  One lane per (stream, filter); strictly sequential in time.
+// crosses blocks.  One lane per stream (both filters), strictly sequential in time.
 __global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c) {
-    int gid = blockIdx.x * 64 + threadIdx.x;
-    if (gid >= c.B * 2) return;
-    int s = gid >> 1, f = gid & 1;
-    float *v = (float *)(c.env + (size_t)s * c.maxK * c.BS) + f;
-    float env = c.wcs[s].tf[f];
-    float cc = f ? c.cBP : c.cHP;
+    int s = blockIdx.x * 64 + threadIdx.x;
+    bool live = s < c.B;
+    float2 *v = c.env + env_idx(c, s, 0);
+    float eh = live ? c.wcs[s].tf[0] : 0.0f, eb = live ? c.wcs[s].tf[1] : 0.0f;
     int n = c.K * c.BS;
-    for (int i = 0; i < n; i += 8) {
-        float x[8];
+    constexpr int U = 16, D = 4;          // D batches of U steps in flight: one wave per CU must cover HBM latency by itself
+    float2 x[D][U];
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = v[2 * (i + j)];
+    for (int b = 0; b < D - 1; b++)
 #pragma unroll
-        for (int j = 0; j < 8; j++) { float d = x[j] - env; env += d * cc; x[j] = env; }
+        for (int j = 0; j < U; j++) { int t = b * U + j; x[b][j] = v[(size_t)(t < n ? t : 0) * 64]; }
+    for (int i = 0; i < n; i += D * U) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[2 * (i + j)] = x[j];
+        for (int b = 0; b < D; b++) {
+            int base = i + b * U;
+            int pf = base + (D - 1) * U;            // batch to prefetch into the slot freed last
+#pragma unroll
+            for (int j = 0; j < U; j++) { int t = pf + j; x[(b + D - 1) % D][j] = v[(size_t)(t < n ? t : 0) * 64]; }
+            if (base < n) {
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    float dh = x[b][j].x - eh; eh += dh * c.cHP;
+                    float db = x[b][j].y - eb; eb += db * c.cBP;
+                    x[b][j] = make_float2(eh, eb);
+                }
+#pragma unroll
+                for (int j = 0; j < U; j++) v[(size_t)(base + j) * 64] = x[b][j];
+            }
+        }
     }
-    // state for the next call is written by k_state_update (reads env's last element)
+    if (live) { c.wcs[s].tf[0] = eh; c.wcs[s].tf[1] = eb; }          // state for the next call
 }
 
 // WindowControl.c:90-104: backward sweep from each block's forward end state.
 __global__ __launch_bounds__(64) void k_wc_backward(UlcxEncCtx c) {
-    int gid = blockIdx.x * 64 + threadIdx.x;
-    if (gid >= c.B * c.K) return;
-    int s = gid / c.K, k = gid % c.K;
-    float2 *e = c.env + (size_t)s * c.maxK * c.BS + (size_t)k * c.BS;
-    float2 last = e[c.BS - 1];
+    int sl = threadIdx.x;
+    int k = blockIdx.x % c.K, sg = blockIdx.x / c.K;
+    float2 *e = c.env + ((size_t)sg * c.maxK * c.BS + (size_t)k * c.BS) * 64 + sl;
+    float2 last = e[(size_t)(c.BS - 1) * 64];
     float pHP = last.x, pBP = last.y;
     for (int n = c.BS - 1; n >= 0; n -= 4) {
         float2 x[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) x[j] = e[n - j];
+        for (int j = 0; j < 4; j++) x[j] = e[(size_t)(n - j) * 64];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             float dHP = x[j].x - pHP, dBP = x[j].y - pBP;
@@ -117,35 +149,46 @@ __global__ __launch_bounds__(64) void k_wc_backward(UlcxEncCtx c) {
             x[j].x = a * a + b * b;
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) e[n - j].x = x[j].x;
+        for (int j = 0; j < 4; j++) e[(size_t)(n - j) * 64].x = x[j].x;
     }
 }
 
 // WindowControl.c:106-134: 8 bins per block, smoothing state carried across blocks.
 __global__ __launch_bounds__(64) void k_wc_integrate(UlcxEncCtx c) {
     int s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= c.B) return;
-    float env = c.wcs[s].tf[2];
-    float *bins = c.bins + (size_t)s * (c.maxK + 1) * 16;
-    for (int i = 0; i < 8; i++) { bins[i] = c.wcs[s].binSum[i]; bins[8 + i] = c.wcs[s].binW[i]; }
-    const float2 *e = c.env + (size_t)s * c.maxK * c.BS;
-    int bin = c.BS / 8;
-    for (int k = 0; k < c.K; k++) {
-        float *o = bins + (size_t)(k + 1) * 16;
-        for (int i = 0; i < 8; i++) {
-            float sum = 0.0f, sw = 0.0f;
-            const float2 *p = e + (size_t)k * c.BS + (size_t)i * bin;
-            for (int n = 0; n < bin; n += 4) {
-                float x[4];
+    bool live = s < c.B;
+    int sc = live ? s : 0;
+    float env = c.wcs[sc].tf[2];
+    float *bins = c.bins + (size_t)sc * (c.maxK + 1) * 16;
+    if (live) for (int i = 0; i < 8; i++) { bins[i] = c.wcs[s].binSum[i]; bins[8 + i] = c.wcs[s].binW[i]; }
+    const float2 *e = c.env + env_idx(c, s, 0);
+    int bin = c.BS / 8;                   // >= 32, multiple of U
+    int n = c.K * c.BS;
+    constexpr int U = 16, D = 4;
+    float x[D][U];
 #pragma unroll
-                for (int j = 0; j < 4; j++) x[j] = p[n + j].x;
+    for (int b = 0; b < D - 1; b++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) { float d = x[j] - env; env += d * c.cBlk; sum += env; sw += 1; }
+        for (int j = 0; j < U; j++) { int t = b * U + j; x[b][j] = e[(size_t)(t < n ? t : 0) * 64].x; }
+    float sum = 0.0f, sw = 0.0f;
+    for (int i = 0; i < n; i += D * U) {
+#pragma unroll
+        for (int b = 0; b < D; b++) {
+            int base = i + b * U;
+            int pf = base + (D - 1) * U;
+#pragma unroll
+            for (int j = 0; j < U; j++) { int t = pf + j; x[(b + D - 1) % D][j] = e[(size_t)(t < n ? t : 0) * 64].x; }
+#pragma unroll
+            for (int j = 0; j < U; j++) { float d = x[b][j] - env; env += d * c.cBlk; sum += env; sw += 1; }
+            int done = base + U;
+            if (done % bin == 0) {        // bin boundary (bins never straddle a batch)
+                int gbin = done / bin - 1;            // global bin index = k*8 + i
+                if (live) { float *o = bins + (size_t)(gbin / 8 + 1) * 16; o[gbin & 7] = sum; o[8 + (gbin & 7)] = sw; }
+                sum = 0.0f; sw = 0.0f;
             }
-            o[i] = sum; o[8 + i] = sw;
         }
     }
-    c.wcs[s].tf[2] = env;                 // only this kernel reads tf[2]
+    if (live) c.wcs[s].tf[2] = env;       // only this kernel reads tf[2]
 }
 
 // WindowControl.c:156-238: decision from the bins of block k (R) and k-1 (L).
@@ -630,8 +673,9 @@ __global__ __launch_bounds__(64) void k_heapsel(UlcxEncCtx c, int ldsEntries) {
         int kSel = c.nout[blk];
         const float *key = c.key + (size_t)blk * N;
         uint32_t *keep = c.keep + (size_t)blk * (N / 32);
+        uint32_t *kb = useLds ? (uint32_t *)(hl + N) : keep;        // kept-set bitmap (LDS copy when the heap is in LDS)
         for (int i = threadIdx.x; i < N; i += 64) { h[i].v = key[i]; h[i].i = i; }
-        for (int i = threadIdx.x; i < N / 32; i += 64) keep[i] = 0xFFFFFFFFu;
+        for (int i = threadIdx.x; i < N / 32; i += 64) kb[i] = 0xFFFFFFFFu;
         __syncthreads();
         if (threadIdx.x == 0) {
             for (int n = N / 2 - 1; n >= 0; n--) heap_sift(h, n, N);
@@ -639,10 +683,12 @@ __global__ __launch_bounds__(64) void k_heapsel(UlcxEncCtx c, int ldsEntries) {
             int n = N - 1;
             for (int p = 0; p < pops; p++, n--) {
                 int gone = h[0].i;
-                keep[gone >> 5] &= ~(1u << (gone & 31));
+                kb[gone >> 5] &= ~(1u << (gone & 31));
                 if (n > 0) { h[0] = h[n]; heap_sift(h, 0, n); }
             }
         }
+        __syncthreads();
+        if (useLds) for (int i = threadIdx.x; i < N / 32; i += 64) keep[i] = kb[i];
         __syncthreads();
     }
 }
@@ -685,21 +731,45 @@ __device__ __forceinline__ int next_kept(const uint32_t *keep, int i, int end) {
     return end;
 }
 // NoiseFill.c:15-36 (pairs is the block-level {w, w*log} array, Band a block-level index)
-__device__ int get_noise_q(const float *pairs, int band, int n, float q) {
+__device__ __forceinline__ int get_noise_q(const float *pairs, int band, int n, float q) {
     const float2 *d = (const float2 *)(pairs + (band / 2) * 2);
     n = (n + (band & 1) + 1) / 2;
     float sum = 0.0f, sumw = 0.0f;
-    for (int i = 0; i < n; i++) { float2 p = d[i]; sum += p.y; sumw += p.x; }
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {                    // loads batched, adds in the reference's order
+        float2 p[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) p[j] = d[i + j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { sum += p[j].y; sumw += p[j].x; }
+    }
+    for (; i < n; i++) { float2 p = d[i]; sum += p.y; sumw += p.x; }
     if (sum == 0.0f) return 0;
     float amp = ulcx_expf(sum / sumw);
     return quant_coef_u(amp * q, 8);
 }
 // NoiseFill.c:41-94
-__device__ void get_hfext(const float *pairs, int band, int n, float q, int &noiseQ, int &noiseDecay) {
+__device__ __forceinline__ void get_hfext(const float *pairs, int band, int n, float q, int &noiseQ, int &noiseDecay) {
     const float2 *d = (const float2 *)(pairs + (band / 2) * 2);
     n = (n + (band & 1) + 1) / 2;
     float sx = 0.0f, sx2 = 0.0f, sxy = 0.0f, sy = 0.0f, sw = 0.0f;
-    for (int i = 0; i < n; i++) {
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        float2 p[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) p[j] = d[i + j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float x = (i + j) * 2.0f;
+            float wx = p[j].x * x;
+            sx += wx;
+            sx2 += wx * x;
+            sxy += x * p[j].y;
+            sy += p[j].y;
+            sw += p[j].x;
+        }
+    }
+    for (; i < n; i++) {
         float x = i * 2.0f;
         float2 p = d[i];
         float wx = p.x * x;
@@ -723,7 +793,7 @@ __device__ void get_hfext(const float *pairs, int band, int n, float q, int &noi
 }
 
 // Encode.c:92-197
-__device__ int write_zone(NybWriter &w, int cur, int end, float quant, const float *coef, const float *pairs,
+__device__ __forceinline__ int write_zone(NybWriter &w, int cur, int end, float quant, const float *coef, const float *pairs,
                           const uint32_t *keep, int nextCoded) {
     for (;;) {
         cur = next_kept(keep, cur, end);
@@ -777,6 +847,7 @@ __global__ __launch_bounds__(64) void k_encode_units(UlcxEncCtx c, int finalPass
     if (gid >= nUnits) return;
     int j = gid & 3, ch = (gid >> 2) % c.C, blk = gid / (4 * c.C);
     if (!finalPass && c.cbrDone[blk]) return;
+    if (c.useFused && !c.slow[blk]) return;
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     int d, off, S;
@@ -832,6 +903,7 @@ __global__ __launch_bounds__(64) void k_encode_units(UlcxEncCtx c, int finalPass
 __global__ __launch_bounds__(64) void k_pack(UlcxEncCtx c, int finalPass) {
     int blk = blockIdx.x, lane = threadIdx.x;
     if (!finalPass && c.cbrDone[blk]) return;
+    if (c.useFused && !c.slow[blk]) return;
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     int nU = c.C * 4;
@@ -883,6 +955,194 @@ __global__ __launch_bounds__(64) void k_pack(UlcxEncCtx c, int finalPass) {
 }
 
 // ---------------------------------------------------------------------------
+// Fast path: select + encode + pack fused, one workgroup per block, everything the
+// serial bitstream state machine touches (coefficients, noise pairs, kept-set bitmap,
+// nybble staging) resident in LDS.  Blocks whose threshold tie group straddles the cut,
+// or whose nybbles overflow the LDS staging, are left to the slow path
+// (k_heapsel -> k_encode_units -> k_pack restricted to blocks flagged in c.slow).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_selenc(UlcxEncCtx c, int finalPass, int stageBytes) {
+    extern __shared__ uint32_t sm[];
+    const int N = c.C * c.BS;
+    int blk = blockIdx.x, tid = threadIdx.x;
+    uint32_t *ukey  = sm;                               // N  (ordered keys; later the noise pairs)
+    float    *coefL = (float *)(sm + N);                // N
+    uint32_t *keepL = sm + 2 * N;                       // N/32
+    uint8_t  *stage = (uint8_t *)(keepL + N / 32);      // stageBytes
+    int      *hist  = (int *)(stage + stageBytes);      // 256
+    int      *unitN = hist + 256;                       // C*4
+    int      *misc  = unitN + c.C * 4;                  // [0]=prefix [1]=need [2]=overflow
+    if (tid == 0) c.slow[blk] = 0;
+    if (!finalPass && c.cbrDone[blk]) return;
+    int s = blk / c.K, k = blk % c.K;
+    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+    int kSel = c.nout[blk];
+    const float *keyG = c.key + (size_t)blk * N;
+    for (int i = tid; i < N; i += WG) ukey[i] = key_ord(keyG[i]);
+    if (tid == 0) misc[2] = 0;
+    __syncthreads();
+
+    // --- radix select of the kSel-th largest key (see k_select)
+    bool straddle = false;
+    if (kSel <= 0) {
+        for (int i = tid; i < N / 32; i += WG) keepL[i] = 0;
+    } else {
+        uint32_t prefix = 0, pmask = 0;
+        int need = kSel;
+        for (int pass = 0; pass < 4; pass++) {
+            int shift = 24 - 8 * pass;
+            hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < N; i += WG) {
+                uint32_t u = ukey[i];
+                if ((u & pmask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                // suffix scan over 256 bins by one wave: lane l owns bins 4l..4l+3
+                int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                int tot = h0 + h1 + h2 + h3;
+                int suf = tot;                           // inclusive suffix sum over lanes >= tid
+                for (int o = 1; o < 64; o <<= 1) { int t = __shfl_down(suf, o); if (tid + o < 64) suf += t; }
+                int above = suf - tot;                   // count in bins of higher lanes
+                // digit d is chosen when (count above d) < need <= (count above d) + hist[d]
+                int a3 = above, a2 = above + h3, a1 = a2 + h2, a0 = a1 + h1;
+                int dsel = -1, acc = 0;
+                if (a3 < need && need <= a3 + h3) { dsel = 4 * tid + 3; acc = a3; }
+                else if (a2 < need && need <= a2 + h2) { dsel = 4 * tid + 2; acc = a2; }
+                else if (a1 < need && need <= a1 + h1) { dsel = 4 * tid + 1; acc = a1; }
+                else if (a0 < need && need <= a0 + h0) { dsel = 4 * tid + 0; acc = a0; }
+                if (dsel >= 0) { misc[0] = (int)(prefix | ((uint32_t)dsel << shift)); misc[1] = need - acc; }
+            }
+            __syncthreads();
+            prefix = (uint32_t)misc[0]; need = misc[1];
+            pmask |= 0xFFu << shift;
+            __syncthreads();
+        }
+        int e = hist[prefix & 255];
+        straddle = (need < e);
+        for (int i = tid; i < N; i += WG) {
+            bool kp = (ukey[i] >= prefix);
+            unsigned long long m = __ballot(kp);
+            int lane = tid & 63;
+            if (lane == 0)  keepL[i >> 5] = (uint32_t)m;
+            if (lane == 32) keepL[i >> 5] = (uint32_t)(m >> 32);
+        }
+    }
+    if (straddle) {                                       // exact heap order needed: slow path
+        if (tid == 0) { int slot = atomicAdd(c.fbCount, 1); c.fbList[slot] = blk; c.slow[blk] = 1; }
+        return;
+    }
+    __syncthreads();
+
+    // --- stage coefficients and noise pairs in LDS
+    float *pairL = (float *)ukey;
+    {
+        const float4 *cg = (const float4 *)(c.coef + (size_t)blk * N);
+        const float4 *pg = (const float4 *)(c.npair + (size_t)blk * N);
+        for (int i = tid; i < N / 4; i += WG) { ((float4 *)coefL)[i] = cg[i]; ((float4 *)pairL)[i] = pg[i]; }
+    }
+    // unit geometry
+    int nsub = 0; { unsigned p = ulcx_pattern(wc); do nsub++; while (p >>= 4); }
+    int nU = c.C * nsub;
+    int cap = (stageBytes / nU) & ~7;
+    __syncthreads();
+
+    // --- serial bitstream state machine, one lane per (channel, subblock) unit (Encode.c:200-313)
+    for (int u = tid; u < c.C * 4; u += WG) {
+        int ch = u >> 2, j = u & 3;
+        if (j >= nsub) { unitN[u] = 0; continue; }
+        int d, off, S;
+        unit_geom(wc, j, c.BS, d, off, S);
+        NybWriter w;
+        w.cap = cap;
+        w.dst = stage + (size_t)(ch * nsub + j) * cap;
+        w.n = 0; w.acc = 0;
+        int idx = ch * c.BS + off;
+        int end = idx + S;
+        int nextCoded = idx;
+        int prevQ = -1, zoneStart = -1;
+        float qmin = 1000.0f, qmax = -1000.0f;
+        do {
+            idx = next_kept(keepL, idx, end);
+            float nmin = 0.0f, nmax = qmax, lvl = 0.0f;
+            if (idx < end) {
+                lvl = fabsf(coefL[idx]);
+                nmin = (lvl < qmin) ? lvl : qmin;
+                nmax = (lvl > qmax) ? lvl : qmax;
+                if (zoneStart == -1) zoneStart = idx;
+            }
+            if (nmax > nmin * 4.0f) {
+                int qi = build_quantizer(qmax);
+                if (qi != prevQ) { put_quantizer(w, qi, prevQ != -1); prevQ = qi; }
+                nextCoded = write_zone(w, zoneStart, idx, (float)(1u << qi), coefL, pairL, keepL, nextCoded);
+                zoneStart = idx;
+                qmin = qmax = lvl;
+            } else { qmin = nmin; qmax = nmax; }
+        } while (++idx <= end);
+        int n = end - nextCoded;
+        if (n > 4) {
+            if (prevQ != -1) w.put(0xF);
+            int nq = 0, nd = 0;
+            if (prevQ != -1 && n >= 16) get_hfext(pairL, nextCoded, n, (float)(1u << prevQ), nq, nd);
+            if (nq) { w.put(0xF); w.put((unsigned)(nq - 1)); w.put((unsigned)(nd >> 4)); w.put((unsigned)nd); }
+            else { w.put(0xE); w.put(0xF); }
+        } else if (n > 0) {
+            w.put(0x0); w.put((unsigned)(n - 1));
+        }
+        w.flush();
+        unitN[u] = w.n;
+        if ((w.n + 1) / 2 > cap) misc[2] = 1;            // staging overflow (benign race: any writer sets 1)
+    }
+    __syncthreads();
+
+    int hdr = (wc & 8) ? 2 : 1;
+    int total = hdr;
+    for (int u = 0; u < c.C * 4; u++) total += unitN[u];
+    int bitsTot = ((total * 4) + 7) & ~7;
+    if (!finalPass) {                                     // rate-control probe (ulcEncoder.c:100-110); size is exact even on overflow
+        if (tid == 0) {
+            int budget = c.cbrBudget[blk];
+            int lo = c.cbrLo[blk], hi = c.cbrHi[blk], nOut = kSel;
+            bool stop = false;
+            if (bitsTot < budget) lo = nOut;
+            else if (bitsTot > budget) hi = nOut - 1;
+            else { lo = nOut; stop = true; }
+            if (stop || !(lo < hi - 1)) { c.cbrDone[blk] = 1; c.nout[blk] = lo; }
+            else c.nout[blk] = (int)((unsigned)(lo + hi) / 2u);
+            c.cbrLo[blk] = lo; c.cbrHi[blk] = hi;
+        }
+        return;
+    }
+    for (int i = tid; i < N / 32; i += WG) c.keep[(size_t)blk * (N / 32) + i] = keepL[i];
+    if (misc[2]) {                                        // too many nybbles for LDS staging: slow path re-encodes from HBM
+        if (tid == 0) c.slow[blk] = 2;
+        return;
+    }
+    // --- pack (Encode.c:329-359)
+    uint8_t *out = c.out + (size_t)blk * c.slot;
+    int nBytes = bitsTot / 8;
+    for (int b = tid; b < nBytes; b += WG) {
+        unsigned byte = 0;
+        for (int h = 0; h < 2; h++) {
+            int q = 2 * b + h;
+            unsigned nyb = 0;
+            if (q < hdr) nyb = (q == 0) ? (wc & 0xF) : ((wc >> 4) & 0xF);
+            else if (q < total) {
+                int r = q - hdr;
+                int u = 0;
+                while (r >= unitN[u]) { r -= unitN[u]; u++; }
+                const uint8_t *src = stage + (size_t)((u >> 2) * nsub + (u & 3)) * cap;
+                nyb = (src[r >> 1] >> ((r & 1) * 4)) & 0xF;
+            }
+            byte |= nyb << (4 * h);
+        }
+        if (b < c.slot) out[b] = (uint8_t)byte;
+    }
+    if (tid == 0) c.bits[blk] = bitsTot;
+}
+
+// ---------------------------------------------------------------------------
 // Persistent state for the next call (ulcEncoder_BlockTransform.c:93, :114)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void k_state_update(UlcxEncCtx c) {
@@ -906,15 +1166,6 @@ __global__ __launch_bounds__(WG) void k_state_update(UlcxEncCtx c) {
         for (int i = 0; i < 8; i++) { w.binSum[i] = bins[i]; w.binW[i] = bins[8 + i]; }
     }
 }
-// forward-filter end states must be captured before k_wc_backward overwrites .x
-__global__ __launch_bounds__(64) void k_wc_save_fwd(UlcxEncCtx c) {
-    int gid = blockIdx.x * 64 + threadIdx.x;
-    if (gid >= c.B) return;
-    float2 last = c.env[(size_t)gid * c.maxK * c.BS + (size_t)c.K * c.BS - 1];
-    c.wcs[gid].tf[0] = last.x;
-    c.wcs[gid].tf[1] = last.y;
-}
-
 // ---------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------
@@ -925,9 +1176,9 @@ size_t ulcx_enc_xf_lds_bytes(int BS) { return (size_t)BS * 18 + 16; }   // 2BS +
 // Per-kernel hipEvents (on the launch stream) bracket every kernel of the first pass so
 // bench.py can price each one against the roofline live; ev holds ULCX_ENC_STAGES+1 events.
 const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES] = {
-    "k_wc_energy", "k_wc_forward", "k_wc_save_fwd", "k_wc_backward", "k_wc_integrate", "k_wc_decide",
+    "k_wc_energy", "k_wc_forward", "k_wc_backward", "k_wc_integrate", "k_wc_decide",
     "k_xf", "k_cplx", "k_nbark", "k_nline", "k_pbark", "k_keys",
-    "k_select", "k_heapsel", "k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update",
+    "k_selenc", "k_heapsel", "k_encode_units(slow path)", "k_pack(slow path)", "cbr_probe_passes", "k_state_update",
 };
 
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev) {
@@ -937,11 +1188,10 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev) {
     MARK();
     // --- window control
     {
-        size_t tot = (size_t)NB * c.BS;
-        hipLaunchKernelGGL(k_wc_energy, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);        MARK();
-        hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, st, c);                   MARK();
-        hipLaunchKernelGGL(k_wc_save_fwd, dim3((c.B + 63) / 64), dim3(64), 0, st, c);                      MARK();
-        hipLaunchKernelGGL(k_wc_backward, dim3((NB + 63) / 64), dim3(64), 0, st, c);                       MARK();
+        int SG = (c.B + 63) / 64;
+        hipLaunchKernelGGL(k_wc_energy, dim3((unsigned)(SG * ((c.K * c.BS) / 64))), dim3(WG), 0, st, c);   MARK();
+        hipLaunchKernelGGL(k_wc_forward, dim3(SG), dim3(64), 0, st, c);                                    MARK();
+        hipLaunchKernelGGL(k_wc_backward, dim3(SG * c.K), dim3(64), 0, st, c);                             MARK();
         hipLaunchKernelGGL(k_wc_integrate, dim3((c.B + 63) / 64), dim3(64), 0, st, c);                     MARK();
         hipLaunchKernelGGL(k_wc_decide, dim3((NB + 63) / 64), dim3(64), 0, st, c);                         MARK();
     }
@@ -966,7 +1216,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev) {
     // --- selection + encode pass(es)
     int N = c.C * c.BS;
     int ldsEntries = ((size_t)N * 8 <= ULCX_HEAP_LDS_BYTES) ? N : 0;
-    size_t heapLds = ldsEntries ? (size_t)N * 8 : 0;
+    size_t heapLds = ldsEntries ? (size_t)N * 8 + (size_t)N / 8 : 0;
     if (heapLds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_heapsel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heapLds));
     int fbGrid = NB < ULCX_HEAP_GRID ? NB : ULCX_HEAP_GRID;
     // VBR: one pass.  CBR/ABR: the reference's binary search (ulcEncoder.c:98-110) needs at most
@@ -977,7 +1227,14 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev) {
         int fin = (p == probes) ? 1 : 0;
         bool ev0 = (p == 0);
         CK(hipMemsetAsync(c.fbCount, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_select, dim3(NB), dim3(WG), 0, st, c, fin);                                   if (ev0) MARK();
+        if (c.useFused) {
+            int stageBytes = 2048 * c.C;
+            size_t lds = (size_t)N * 8 + N / 8 + stageBytes + 256 * 4 + c.C * 16 + 16;
+            if (p == 0 && lds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_selenc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_selenc, dim3(NB), dim3(WG), lds, st, c, fin, stageBytes);                 if (ev0) MARK();
+        } else {
+            hipLaunchKernelGGL(k_select, dim3(NB), dim3(WG), 0, st, c, fin);                               if (ev0) MARK();
+        }
         hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, st, c, ldsEntries);                 if (ev0) MARK();
         hipLaunchKernelGGL(k_encode_units, dim3((nUnits + 63) / 64), dim3(64), 0, st, c, fin);             if (ev0) MARK();
         hipLaunchKernelGGL(k_pack, dim3(NB), dim3(64), 0, st, c, fin);                                     if (ev0) MARK();

@@ -54,7 +54,7 @@ struct UlcxEncCtx {
     float *hist;                         // [B][2*BS][C] previous two input blocks (raw, interleaved)
     UlcxWcState *wcs;                    // [B]
     // per-call scratch
-    float2 *env;                         // [B][maxK*BS] {hp,bp} energies -> envelopes -> transient curve (.x)
+    float2 *env;                         // [ceil(B/64)][maxK*BS][64] {hp,bp} energies -> envelopes -> transient curve (.x)
     float  *bins;                        // [B][maxK+1][16] {Sum[8],SumW[8]}; row 0 = previous block
     int    *wcArr;                       // [B][maxK+2] WindowCtrl of blocks k0-1 .. k0+K
     float  *coef;                        // [NB][C*BS]   normalised MDCT (TransformBuffer)
@@ -74,6 +74,8 @@ struct UlcxEncCtx {
     uint8_t *unitBuf;                    // [NB][C][unitCap]
     int    *unitNyb;                     // [NB][C*4]
     int    *cbrBudget;                   // [NB] bit budget (ulcEncoder.c:96)
+    int    *slow;                        // [NB] 0 = done by the fused fast path, 1 = tie straddle, 2 = staging overflow
+    int     useFused;                    // fused select+encode+pack kernel usable (LDS fits)
     void   *heapScratch;                 // [ULCX_HEAP_GRID][C*BS] {key,idx} heaps, only when C*BS*8 exceeds the LDS budget
 };
 
@@ -90,6 +92,10 @@ struct UlcxDecCtx {
     // per-call scratch
     float *coef;                         // [NB][C*BS] dequantised coefficients
     int   *wc;                           // [NB] WindowCtrl per block (0 = corrupt)
+    int   *draws;                        // [NB] RNG draws consumed by the block
+    uint32_t *blockSeed;                 // [NB] RNG state at the start of the block
+    int   *unitStart, *unitDraws;        // [NB][C*4] nybble offset / draws before each (chan,subblock) unit
+    const uint32_t *jump;                // [32][32] columns of T^(2^i), T = one xorshift32 step
 };
 
 // ulcHelper.h:24-46
@@ -108,9 +114,9 @@ int  ulcx_tables_build(UlcxTables *devT, void **devBlob, int BS, int rateHz, boo
 void ulcx_set_error(const char *fmt, ...);
 
 // launchers (ulcx_enc.hip / ulcx_dec.hip)
-#define ULCX_ENC_STAGES 18
+#define ULCX_ENC_STAGES 17
 extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES];
-#define ULCX_DEC_STAGES 2
+#define ULCX_DEC_STAGES 4
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */);
 int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev);
 size_t ulcx_enc_xf_lds_bytes(int BS);

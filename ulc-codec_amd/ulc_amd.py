@@ -19,7 +19,7 @@ EXPORTS = [
     "ulcx_last_error", "ulcx_device_count", "ulcx_encoder_create", "ulcx_encoder_destroy", "ulcx_encoder_reset",
     "ulcx_encoder_slot_bytes", "ulcx_encode_dev", "ulcx_encode_host", "ulcx_encoder_debug_fetch",
     "ulcx_decoder_create", "ulcx_decoder_destroy", "ulcx_decoder_reset", "ulcx_decode_dev", "ulcx_decode_host",
-    "ulcx_encoder_stage_ms", "ulcx_encoder_stage_name", "ulcx_decoder_stage_ms", "ulcx_decoder_stage_name",
+    "ulcx_encoder_last_fallbacks", "ulcx_encoder_stage_ms", "ulcx_encoder_stage_name", "ulcx_decoder_stage_ms", "ulcx_decoder_stage_name",
 ]
 
 _lib = None
@@ -45,6 +45,7 @@ def lib():
         l.ulcx_decoder_reset.argtypes = [C.c_void_p]
         l.ulcx_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         l.ulcx_decode_host.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, _f32p, _i32p]
+        l.ulcx_encoder_last_fallbacks.argtypes = [C.c_void_p]
         l.ulcx_encoder_stage_ms.argtypes = [C.c_void_p, _f32p, C.c_int]
         l.ulcx_decoder_stage_ms.argtypes = [C.c_void_p, _f32p, C.c_int]
         l.ulcx_encoder_stage_name.restype = C.c_char_p
@@ -122,6 +123,9 @@ class BatchEncoder:
         _check(lib().ulcx_encoder_debug_fetch(self.h, K, _p(coef, _f32p), _p(noise, _f32p), _p(keys, _f32p),
                                               _p(keep, _u8p), _p(nout, _i32p)), "ulcx_encoder_debug_fetch")
         return dict(coef=coef, noise=noise, keys=keys, keep=keep, nout=nout)
+
+    def last_fallbacks(self):
+        return lib().ulcx_encoder_last_fallbacks(self.h)
 
     def stage_ms(self):
         ms = np.zeros(32, np.float32)
