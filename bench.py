@@ -124,8 +124,11 @@ def main():
     torch.cuda.set_device(dev)
     B, K = args.streams, args.blocks
     n = K * BS
-    # independent streams shard across ranks by plain batch split: each rank owns its own B streams (weak scaling)
-    pcm = make_pcm(torch, B, n, dev, seed=1234 + rank)
+    # independent streams shard across ranks by plain batch split (shard.py): rank r owns global streams
+    # [r*B, (r+1)*B) — per-GPU work fixed as N grows (weak scaling), no collective on the data path
+    import shard
+    ids = shard.weak_scaling_ids(B, rank)
+    pcm = make_pcm(torch, B, n, dev, seed=1234 + ids[0])
     enc = ulc_amd.BatchEncoder(B, CH, BS, RATE, K, device=dev.index)
     dec = ulc_amd.BatchDecoder(B, CH, BS, K, device=dev.index)
     slot = enc.slot
@@ -162,15 +165,11 @@ def main():
         step(); torch.cuda.synchronize(dev)
         for k_, v in enc.stage_ms().items(): acc_enc[k_] = acc_enc.get(k_, 0.0) + v / nacc
         for k_, v in dec.stage_ms().items(): acc_dec[k_] = acc_dec.get(k_, 0.0) + v / nacc
-    if dist is not None:
-        tt = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+    el = shard.max_over_ranks(el, dist, dev)
     bits_host = d_bits.cpu().numpy()
     dbits_host = d_dbits.cpu().numpy()
     ok = bool((dbits_host > 0).all() and (dbits_host <= bits_host).all())
-    samples_per_step = B * K * BS * CH * world
-    value = samples_per_step * args.steps / el / 1e6
+    value = shard.whole_job_throughput(B * K * BS * CH * args.steps, world, el) / 1e6
 
     # ---- roofline of the dominant kernel (algorithmic bytes: SURVEY.md §8d / BASELINE.md §4)
     mean_bytes = float(bits_host.mean()) / 8.0

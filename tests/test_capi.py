@@ -1,0 +1,95 @@
+"""C-ABI boundary without a GPU: libulc_amd.so loads, exports every symbol include/ulc_amd.h
+declares, keeps the reference's struct ABI, validates arguments like the reference, fails
+loudly (no CPU fallback) when no device exists, and — where /root/reference is mounted —
+the reference's own tools compile against the reference's own headers and link against it
+unchanged."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ulc-codec_amd"))
+LIB = os.path.join(ROOT, "ulc-codec_amd", "libulc_amd.so")
+REF = "/root/reference"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "ulc-codec_amd"), "-j8"], stdout=subprocess.DEVNULL)
+    return C.CDLL(LIB)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "ulc_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(ULC_\w+|ulcx_\w+)\s*\(", hdr))
+    assert len(names) >= 26
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    import ulc_amd
+    assert set(ulc_amd.EXPORTS) <= names
+
+
+def test_struct_abi_matches_reference_layout():
+    """sizeof/offsets from SURVEY.md §8a T1/T2 (x86-64): 104 and 48 bytes."""
+    class Enc(C.Structure):
+        _fields_ = [("RateHz", C.c_int), ("nChan", C.c_int), ("BlockSize", C.c_int), ("WindowCtrl", C.c_int), ("NextWindowCtrl", C.c_int),
+                    ("BlockComplexity", C.c_float), ("TransientFilter", C.c_float * 3), ("BufferData", C.c_void_p), ("SampleBuffer", C.c_void_p),
+                    ("TransformBuffer", C.c_void_p), ("TransformNoise", C.c_void_p), ("TransformFwdLap", C.c_void_p), ("TransformTemp", C.c_void_p),
+                    ("TransformIndex", C.c_void_p), ("TransientBuffer", C.c_void_p)]
+    class Dec(C.Structure):
+        _fields_ = [("nChan", C.c_int), ("BlockSize", C.c_int), ("LastSubBlockSize", C.c_int), ("BufferData", C.c_void_p),
+                    ("TransformBuffer", C.c_void_p), ("TransformTemp", C.c_void_p), ("TransformInvLap", C.c_void_p)]
+    assert C.sizeof(Enc) == 104 and Enc.BlockComplexity.offset == 20 and Enc.BufferData.offset == 40 and Enc.TransformTemp.offset == 80
+    assert C.sizeof(Dec) == 48 and Dec.BufferData.offset == 16 and Dec.TransformInvLap.offset == 40
+    # and the C compiler agrees for our own header
+    src = '#include <stddef.h>\n#include "ulc_amd.h"\n_Static_assert(sizeof(struct ULC_EncoderState_t)==104,"enc");\n' \
+          '_Static_assert(offsetof(struct ULC_EncoderState_t,TransientBuffer)==96,"tb");\n_Static_assert(sizeof(struct ULC_DecoderState_t)==48,"dec");\nint main(void){return 0;}\n'
+    p = subprocess.run(["gcc", "-x", "c", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-"], input=src.encode(), capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+
+
+def test_argument_validation_and_loud_failure_without_gpu(lib):
+    lib.ulcx_last_error.restype = C.c_char_p
+    h = C.c_void_p()
+    # same validation as ulcEncoder.c:32-34 (checked before any device work)
+    for (b, c, bs) in [(1, 0, 2048), (1, 256, 2048), (1, 2, 128), (1, 2, 65536), (1, 2, 3000), (0, 2, 2048)]:
+        assert lib.ulcx_encoder_create(C.byref(h), 0, b, c, bs, 44100, 1) == -1
+        assert lib.ulcx_decoder_create(C.byref(h), 0, b, c, bs, 1) == -1
+    if lib.ulcx_device_count() > 0:
+        pytest.skip("GPU present: the no-device path is not reachable here")
+    assert lib.ulcx_encoder_create(C.byref(h), 0, 1, 2, 2048, 44100, 1) == -2      # ULCX_ERR_NO_DEVICE, never a CPU fallback
+    assert b"device" in lib.ulcx_last_error().lower() or b"hip" in lib.ulcx_last_error().lower()
+    assert not h.value
+
+
+def test_product_does_not_link_or_import_the_oracle():
+    out = subprocess.check_output(["ldd", LIB]).decode() + subprocess.check_output(["nm", "-D", LIB]).decode()
+    assert "liboracle" not in out and "orc_" not in out
+    for dp, _, fs in os.walk(os.path.join(ROOT, "ulc-codec_amd")):
+        for f in fs:
+            if f.endswith((".c", ".cpp", ".hip", ".h", ".py")) and "build" not in dp:
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "ulc_oracle.h" not in txt and "liboracle" not in txt and "import ulc_testlib" not in txt, f
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "tools")), reason="reference tree not mounted")
+@pytest.mark.parametrize("tool", ["ulcEncodeTool", "ulcDecodeTool"])
+def test_reference_tools_link_unchanged(tool, lib, tmp_path):
+    """tools/ulcEncodeTool.c / ulcDecodeTool.c compiled from /root/reference against the
+    reference's OWN headers, linked against libulc_amd.so instead of libulc + libfourier."""
+    exe = tmp_path / tool.lower()
+    srcs = [f"{REF}/tools/{tool}.c", f"{REF}/tools/WavIO_Reader.c", f"{REF}/tools/WavIO_Writer.c", f"{REF}/tools/WavIO_Helper.c", f"{REF}/tools/MiniRIFF.c"]
+    cmd = ["gcc", "-O2", f"-I{REF}/include", f"-I{REF}/tools", "-o", str(exe)] + srcs + \
+          [f"-L{os.path.dirname(LIB)}", "-lulc_amd", f"-Wl,-rpath,{os.path.dirname(LIB)}", "-lm"]
+    p = subprocess.run(cmd, capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+    und = subprocess.check_output(["nm", "-u", str(exe)]).decode()
+    assert "ULC_" in und and "Fourier_" not in und
+    # runs far enough to print its usage text (no GPU needed for that)
+    r = subprocess.run([str(exe)], capture_output=True, env=dict(os.environ, LD_LIBRARY_PATH=os.path.dirname(LIB) + ":/opt/rocm/lib"))
+    assert b"sage" in r.stdout + r.stderr or r.returncode in (0, 1, 255)
