@@ -21,6 +21,7 @@ struct ulcx_encoder {
     hipEvent_t ev[ULCX_ENC_STAGES + 1];
     bool evOk, evRecorded;
     int lastK;
+    hipStream_t side; hipEvent_t evFork, evJoin; bool sideOk;
     // staging for the host-pointer API
     float *d_pcm; uint8_t *d_out; int32_t *d_bits, *d_wc; float *d_cplx;
 };
@@ -80,6 +81,7 @@ static void cleanup(ulcx_encoder *e) {
     for (void *p : e->allocs) hipFree(p);
     if (e->tables) hipFree(e->tables);
     if (e->evOk) for (auto &v : e->ev) hipEventDestroy(v);
+    if (e->sideOk) { hipStreamDestroy(e->side); hipEventDestroy(e->evFork); hipEventDestroy(e->evJoin); }
     delete e;
 }
 
@@ -108,7 +110,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     if (rc) return rc;
     ulcx_encoder *e = new ulcx_encoder();
     e->device = device; e->B = nStreams; e->C = nChan; e->BS = BlockSize; e->rate = RateHz; e->maxK = maxBlocksPerCall;
-    e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->lastK = 0;
+    e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->lastK = 0; e->sideOk = false; e->side = nullptr;
     e->d_pcm = nullptr; e->d_out = nullptr; e->d_bits = nullptr; e->d_wc = nullptr; e->d_cplx = nullptr;
     UlcxEncCtx &c = e->ctx;
     memset(&c, 0, sizeof(c));
@@ -146,7 +148,13 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     // experimental fused select+encode+pack kernel (k_selenc): measured slower than the lane-per-unit
     // kernels on MI355X (profiles/r01 notes in DESIGN.md §6), so opt-in only.
     c.useFused = 0;
-    if (const char *ev = getenv("ULCX_FUSED")) if (ev[0] == '1' && (size_t)cb * 8 + cb / 8 + 2048 * (size_t)nChan + 2048 <= 150 * 1024) c.useFused = 1;
+    c.useWave = 0;        // k_encode_wave: correct but latency-bound; opt-in with ULCX_WAVE=1
+    c.useGapSums = ((size_t)cb * 4 + cb / 8 <= 150 * 1024) ? 1 : 0;
+    if (const char *ev = getenv("ULCX_GAPSUMS")) c.useGapSums = (ev[0] != '0');
+    DA(c.gapSum, NB * cb, false);
+    DA(c.tailSum, NB * nChan * 4 * 8, true);
+    if (const char *ev = getenv("ULCX_WAVE")) c.useWave = (ev[0] != '0');
+    if (const char *ev = getenv("ULCX_FUSED")) if (ev[0] == '1' && (size_t)cb * 8 + cb / 8 + 2048 * (size_t)nChan + 2048 <= 150 * 1024) { c.useFused = 1; c.useWave = 0; }
     DA(c.cbrLo, NB, true); DA(c.cbrHi, NB, true); DA(c.cbrDone, NB, true); DA(c.cbrBudget, NB, true);
     DA(c.keep, NB * cb / 32, true);
     DA(c.fbList, NB, true);
@@ -161,6 +169,15 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     }
     for (auto &v : e->ev) { if (hipEventCreate(&v) != hipSuccess) { ulcx_set_error("hipEventCreate failed"); cleanup(e); return ULCX_ERR_HIP; } }
     e->evOk = true;
+    {
+        const char *evs = getenv("ULCX_ASYNC_FB");
+        if (!(evs && evs[0] == '0')) {
+            if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess &&
+                hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming) == hipSuccess) e->sideOk = true;
+        }
+    }
+    DA(c.isFb, NB, true);
     rc = enc_reset_state(e);
     if (rc) { cleanup(e); return rc; }
     *out = e;
@@ -180,7 +197,7 @@ extern "C" int ulcx_encode_dev(ulcx_encoder *e, int mode, float p0, float p1, co
     c.K = nBlocks; c.mode = mode; c.p0 = p0; c.p1 = p1;
     c.vbrTarget = (mode == ULCX_MODE_VBR) ? 0x1.E4EFB7p3f * logf(100.0f / p0) : 0.0f;     // ulcEncoder.c:144 (host libm, data independent)
     c.pcm = d_pcm; c.out = d_out; c.bits = d_bits; c.wcOut = d_wc; c.cplxOut = d_cplx;
-    int rc = ulcx_enc_launch(c, (hipStream_t)hipStream, e->ev);
+    int rc = ulcx_enc_launch(c, (hipStream_t)hipStream, e->ev, e->sideOk ? e->side : nullptr, e->evFork, e->evJoin);
     e->evRecorded = (rc == ULCX_OK);
     e->lastK = nBlocks;
     return rc;

@@ -200,9 +200,11 @@ __global__ __launch_bounds__(64) void k_dseed(UlcxDecCtx c) {
 
 // Pass 3 — one lane per (block, channel, subblock): dequantise + noise synthesis.
 __global__ __launch_bounds__(64) void k_dgen(UlcxDecCtx c) {
-    int gid = blockIdx.x * 64 + threadIdx.x;
-    if (gid >= c.B * c.K * c.C * 4) return;
-    int j = gid & 3, ch = (gid >> 2) % c.C, blk = gid / (4 * c.C);
+    int tid0 = blockIdx.x * 64 + threadIdx.x;
+    int nBC = c.B * c.K * c.C;
+    if (tid0 >= nBC * 4) return;
+    // subblock index slowest: waves of j >= 1 are empty for un-decimated blocks
+    int j = tid0 / nBC, rem = tid0 - j * nBC, blk = rem / c.C, ch = rem - blk * c.C;
     int wc = c.wc[blk];
     if (wc == 0) return;
     unsigned pat = ulcx_pattern(wc);

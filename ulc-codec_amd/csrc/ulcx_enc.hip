@@ -463,10 +463,12 @@ __device__ __forceinline__ bool unit_geom(int wc, int j, int BS, int &d, int &of
 
 // Psyopt.c:185-225
 __global__ __launch_bounds__(64) void k_nbark(UlcxEncCtx c) {
-    int gid = blockIdx.x * 64 + threadIdx.x;
-    int nUnits = c.B * c.K * c.C * 4;
-    if (gid >= nUnits) return;
-    int j = gid & 3, ch = (gid >> 2) % c.C, blk = gid / (4 * c.C);
+    int tid0 = blockIdx.x * 64 + threadIdx.x;
+    int nBC = c.B * c.K * c.C;
+    if (tid0 >= nBC * 4) return;
+    // subblock index slowest: waves of j >= 1 are empty for un-decimated blocks and exit at once
+    int j = tid0 / nBC, rem = tid0 - j * nBC, blk = rem / c.C, ch = rem - blk * c.C;
+    int gid = (blk * c.C + ch) * 4 + j;
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     int d, off, S;
@@ -520,9 +522,11 @@ __global__ __launch_bounds__(WG) void k_nline(UlcxEncCtx c) {
 
 // Psyopt.c:86-137 on the channel-summed energies
 __global__ __launch_bounds__(64) void k_pbark(UlcxEncCtx c) {
-    int gid = blockIdx.x * 64 + threadIdx.x;
-    if (gid >= c.B * c.K * 4) return;
-    int j = gid & 3, blk = gid >> 2;
+    int tid0 = blockIdx.x * 64 + threadIdx.x;
+    int NBk = c.B * c.K;
+    if (tid0 >= NBk * 4) return;
+    int j = tid0 / NBk, blk = tid0 - j * NBk;
+    int gid = blk * 4 + j;
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     int d, off, S;
@@ -601,6 +605,7 @@ __global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
     uint32_t *keep = c.keep + (size_t)blk * (N / 32);
     if (kSel <= 0) {
         for (int i = tid; i < N / 32; i += WG) keep[i] = 0;
+        if (tid == 0) c.isFb[blk] = 0;
         return;
     }
     uint32_t prefix = 0, pmask = 0;
@@ -636,9 +641,72 @@ __global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
         if (lane == 0)  keep[i >> 5] = (uint32_t)m;
         if (lane == 32) keep[i >> 5] = (uint32_t)(m >> 32);
     }
+    if (tid == 0) c.isFb[blk] = straddle ? 1 : 0;
     if (straddle && tid == 0) {
         int slot = atomicAdd(c.fbCount, 1);
         c.fbList[slot] = blk;
+    }
+}
+
+// One WAVE per block, keys held in registers (R = N/64 per lane): no workgroup barriers,
+// the 256-bin histogram of each radix pass lives in a private 1 KB LDS slice.
+template <int R>
+__global__ __launch_bounds__(64) void k_select_wave(UlcxEncCtx c, int finalPass) {
+    __shared__ int hist[256];
+    int blk = blockIdx.x, lane = threadIdx.x;
+    if (!finalPass && c.cbrDone[blk]) return;
+    const int N = R * 64;
+    int kSel = c.nout[blk];
+    const float *key = c.key + (size_t)blk * N;
+    uint32_t *keep = c.keep + (size_t)blk * (N / 32);
+    if (lane == 0) c.isFb[blk] = 0;
+    if (kSel <= 0) {
+        for (int i = lane; i < N / 32; i += 64) keep[i] = 0;
+        return;
+    }
+    uint32_t u[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) u[r] = key_ord(key[r * 64 + lane]);
+    uint32_t prefix = 0, pmask = 0;
+    int need = kSel, e = 0;
+    for (int pass = 0; pass < 4; pass++) {
+        int shift = 24 - 8 * pass;
+        hist[lane] = 0; hist[lane + 64] = 0; hist[lane + 128] = 0; hist[lane + 192] = 0;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if ((u[r] & pmask) == prefix) atomicAdd(&hist[(u[r] >> shift) & 255], 1);
+        __builtin_amdgcn_wave_barrier();
+        int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+        int tot = h0 + h1 + h2 + h3;
+        int suf = tot;
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_down(suf, o); if (lane + o < 64) suf += t; }
+        int above = suf - tot;
+        int a3 = above, a2 = above + h3, a1 = a2 + h2, a0 = a1 + h1;
+        int dsel = -1, acc = 0, hh = 0;
+        if (a3 < need && need <= a3 + h3) { dsel = 4 * lane + 3; acc = a3; hh = h3; }
+        else if (a2 < need && need <= a2 + h2) { dsel = 4 * lane + 2; acc = a2; hh = h2; }
+        else if (a1 < need && need <= a1 + h1) { dsel = 4 * lane + 1; acc = a1; hh = h1; }
+        else if (a0 < need && need <= a0 + h0) { dsel = 4 * lane + 0; acc = a0; hh = h0; }
+        unsigned long long who = __ballot(dsel >= 0);
+        int src = __ffsll((long long)who) - 1;
+        dsel = __shfl(dsel, src); acc = __shfl(acc, src); e = __shfl(hh, src);
+        prefix |= (uint32_t)dsel << shift;
+        need -= acc;
+        pmask |= 0xFFu << shift;
+        __builtin_amdgcn_wave_barrier();
+    }
+    bool straddle = (need < e);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        unsigned long long m = __ballot(u[r] >= prefix);
+        if (lane == 0)  keep[2 * r] = (uint32_t)m;
+        if (lane == 32) keep[2 * r + 1] = (uint32_t)(m >> 32);
+    }
+    if (straddle && lane == 0) {
+        int slot = atomicAdd(c.fbCount, 1);
+        c.fbList[slot] = blk;
+        c.isFb[blk] = 1;
     }
 }
 
@@ -690,6 +758,120 @@ __global__ __launch_bounds__(64) void k_heapsel(UlcxEncCtx c, int ldsEntries) {
         __syncthreads();
         if (useLds) for (int i = threadIdx.x; i < N / 32; i += 64) keep[i] = kb[i];
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Speculative, massively parallel evaluation of the ordered f32 sums the bitstream state
+// machine needs (NoiseFill.c:15-36, :41-62): for every kept coefficient the noise-run sums
+// of the gap in front of it, assuming the gap starts right after the previous kept
+// coefficient; for every unit the five HF-extension sums of the tail after its last kept
+// coefficient.  Same loops, same order as get_noise_q/get_hfext, so the values are the ones
+// the serial kernel would compute; it checks the assumption and recomputes if it is off
+// (a kept coefficient collapsed, a noise run fell back to a zero run, ...).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_gapsums(UlcxEncCtx c, int finalPass) {
+    extern __shared__ uint32_t gsm[];
+    int blk = blockIdx.x, tid = threadIdx.x;
+    if (!finalPass && c.cbrDone[blk]) return;
+    if (c.fbMode == 1 && c.isFb[blk]) return;
+    if (c.fbMode == 2 && !c.isFb[blk]) return;
+    const int N = c.C * c.BS;
+    float *pairs = (float *)gsm;                           // N floats: the block's {w, w*log} pairs
+    uint32_t *kw = gsm + N;                                // keep words of the block
+    int s = blk / c.K, k = blk % c.K;
+    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+    const uint32_t *keepB = c.keep + (size_t)blk * (N / 32);
+    for (int i = tid; i < N / 32; i += WG) kw[i] = keepB[i];
+    {
+        const float4 *pg = (const float4 *)(c.npair + (size_t)blk * N);
+        for (int i = tid; i < N / 4; i += WG) ((float4 *)pairs)[i] = pg[i];
+    }
+    __syncthreads();
+    float2 *gs = c.gapSum + (size_t)blk * N;
+    // gaps in front of kept coefficients
+    for (int i = tid; i < N; i += WG) {
+        if (!((kw[i >> 5] >> (i & 31)) & 1)) continue;
+        // start of the unit containing i
+        int ch = i / c.BS, r = i - ch * c.BS;
+        unsigned pat = ulcx_pattern(wc);
+        int off = 0;
+        for (;;) { int S = c.BS >> (pat & 7); if (r < off + S) break; off += S; pat >>= 4; }
+        int us = ch * c.BS + off;
+        // previous kept index in [us, i)
+        int prev = us - 1;
+        {
+            int w = i >> 5;
+            uint32_t m = kw[w] & ((1u << (i & 31)) - 1);
+            for (;;) {
+                if (m) { prev = (w << 5) + 31 - __clz(m); break; }
+                if ((w << 5) <= us) break;
+                w--; m = kw[w];
+            }
+            if (prev < us) prev = us - 1;
+        }
+        int start = prev + 1, zr = i - start;
+        if (zr < 16) continue;
+        int v = zr - 16; if (v > 0x1FF) v = 0x1FF;
+        int n = v + 16;
+        const float2 *d = (const float2 *)(pairs + (start / 2) * 2);
+        int np = (n + (start & 1) + 1) / 2;
+        float sum = 0.0f, sumw = 0.0f;
+        int q = 0;
+        for (; q + 8 <= np; q += 8) {
+            float2 p[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) p[u] = d[q + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { sum += p[u].y; sumw += p[u].x; }
+        }
+        for (; q < np; q++) { float2 p = d[q]; sum += p.y; sumw += p.x; }
+        gs[i] = make_float2(sum, sumw);
+    }
+    // tails: 8 threads per unit, 5 of them carry one chain each
+    int nU = c.C * 4;
+    for (int t = tid; t < nU * 8; t += WG) {
+        int u = t >> 3, chain = t & 7;
+        int ch = u >> 2, j = u & 3;
+        int d0, off, S;
+        float *ts = c.tailSum + ((size_t)blk * nU + u) * 8;
+        if (!unit_geom(wc, j, c.BS, d0, off, S)) continue;
+        int us = ch * c.BS + off, ue = us + S;
+        // last kept index in [us, ue)
+        int last = us - 1;
+        for (int w = (ue - 1) >> 5; (w << 5) + 31 >= us; w--) {
+            uint32_t m = kw[w];
+            if (m) { last = (w << 5) + 31 - __clz(m); break; }
+            if (w == 0) break;
+        }
+        if (last < us) last = us - 1;
+        int start = last + 1, n = ue - start;
+        if (chain == 5) ts[5] = __int_as_float(start);
+        if (n < 16 || chain >= 5) continue;
+        const float2 *d = (const float2 *)(pairs + (start / 2) * 2);
+        int np = (n + (start & 1) + 1) / 2;
+        float acc = 0.0f;
+        int q = 0;
+        for (; q + 8 <= np; q += 8) {
+            float2 pv[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) pv[e] = d[q + e];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float x = (q + e) * 2.0f;
+                float wx = pv[e].x * x;
+                float term = (chain == 0) ? wx : (chain == 1) ? wx * x : (chain == 2) ? x * pv[e].y : (chain == 3) ? pv[e].y : pv[e].x;
+                acc += term;
+            }
+        }
+        for (; q < np; q++) {
+            float2 pv = d[q];
+            float x = q * 2.0f;
+            float wx = pv.x * x;
+            float term = (chain == 0) ? wx : (chain == 1) ? wx * x : (chain == 2) ? x * pv.y : (chain == 3) ? pv.y : pv.x;
+            acc += term;
+        }
+        ts[chain] = acc;
     }
 }
 
@@ -748,6 +930,26 @@ __device__ __forceinline__ int get_noise_q(const float *pairs, int band, int n, 
     float amp = ulcx_expf(sum / sumw);
     return quant_coef_u(amp * q, 8);
 }
+// get_noise_q with the sums already evaluated (k_gapsums)
+__device__ __forceinline__ int noise_q_from_sums(float sum, float sumw, float q) {
+    if (sum == 0.0f) return 0;
+    float amp = ulcx_expf(sum / sumw);
+    return quant_coef_u(amp * q, 8);
+}
+// get_hfext with the five sums already evaluated (k_gapsums)
+__device__ __forceinline__ void hfext_from_sums(float sx, float sx2, float sxy, float sy, float sw, float q, int &noiseQ, int &noiseDecay) {
+    float det = sw * sx2 - sx * sx;
+    if (det == 0.0f) { noiseQ = noiseDecay = 0; return; }
+    float amp = (sx2 * sy - sx * sxy) / det;
+    float dec = (sw * sxy - sx * sy) / det;
+    amp = ulcx_expf(amp);
+    dec = (dec < 0.0f) ? ulcx_expf(dec) : 1.0f;
+    int nq = quant_coef_u(amp * q * 4.0f, 16);
+    int nd = quant_u((dec - 1.0f) * -0x1.0p19f);
+    if (!nd) return;
+    if (nd > 0xFF) nd = 0xFF;
+    noiseQ = nq; noiseDecay = nd;
+}
 // NoiseFill.c:41-94
 __device__ __forceinline__ void get_hfext(const float *pairs, int band, int n, float q, int &noiseQ, int &noiseDecay) {
     const float2 *d = (const float2 *)(pairs + (band / 2) * 2);
@@ -794,13 +996,16 @@ __device__ __forceinline__ void get_hfext(const float *pairs, int band, int n, f
 
 // Encode.c:92-197
 __device__ __forceinline__ int write_zone(NybWriter &w, int cur, int end, float quant, const float *coef, const float *pairs,
-                          const uint32_t *keep, int nextCoded) {
+                          const uint32_t *keep, int nextCoded, const float2 *gapSum = nullptr, int *lastKept = nullptr) {
     for (;;) {
         cur = next_kept(keep, cur, end);
         if (cur >= end) break;
+        int prevKept = lastKept ? *lastKept : -2;
+        if (lastKept) *lastKept = cur;
         if (fabsf(coef[cur] * quant) < 2.5f) { cur++; continue; }
         int n = 0, v = 0;
         int zr = cur - nextCoded;
+        bool specOk = gapSum && (nextCoded == prevKept + 1);      // k_gapsums assumed exactly this gap
         while (zr) {
             if (zr <= 2) {
                 int q1 = quant_coef(coef[nextCoded] * quant, 7);
@@ -817,8 +1022,10 @@ __device__ __forceinline__ int write_zone(NybWriter &w, int cur, int end, float 
             if (zr >= 16) {
                 v = zr - 16; if (v > 0x1FF) v = 0x1FF;
                 n = v + 16;
-                nq = get_noise_q(pairs, nextCoded, n, quant);
+                if (specOk) { float2 sw = gapSum[cur]; nq = noise_q_from_sums(sw.x, sw.y, quant); }
+                else nq = get_noise_q(pairs, nextCoded, n, quant);
             }
+            specOk = false;                                        // only the first run of a gap was speculated
             if (nq) {
                 w.put(0x8); w.put((unsigned)(v >> 5)); w.put((unsigned)(v >> 1)); w.put((unsigned)((v & 1) | ((nq - 1) << 1)));
             } else if (zr < 33) {
@@ -845,9 +1052,13 @@ __global__ __launch_bounds__(64) void k_encode_units(UlcxEncCtx c, int finalPass
     int gid = blockIdx.x * 64 + threadIdx.x;
     int nUnits = c.B * c.K * c.C * 4;
     if (gid >= nUnits) return;
+    // (subblock index fastest on purpose: the state machine diverges per lane, so sparse waves -
+    //  4x more of them in flight - hide its latency better than dense ones; measured 7.1 vs 9.6 ms)
     int j = gid & 3, ch = (gid >> 2) % c.C, blk = gid / (4 * c.C);
     if (!finalPass && c.cbrDone[blk]) return;
-    if (c.useFused && !c.slow[blk]) return;
+    if ((c.useFused || c.useWave) && !c.slow[blk]) return;
+    if (c.fbMode == 1 && c.isFb[blk]) return;            // tie-straddle blocks are encoded on the side stream
+    if (c.fbMode == 2 && !c.isFb[blk]) return;
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     int d, off, S;
@@ -866,6 +1077,8 @@ __global__ __launch_bounds__(64) void k_encode_units(UlcxEncCtx c, int finalPass
     int nextCoded = idx;
     int prevQ = -1, zoneStart = -1;
     float qmin = 1000.0f, qmax = -1000.0f;
+    const float2 *gapSum = c.useGapSums ? c.gapSum + (size_t)blk * N : nullptr;
+    int lastKept = idx - 1;                                  // "previous kept coefficient" before the unit = unit start - 1
     do {
         idx = next_kept(keep, idx, end);
         float nmin = 0.0f, nmax = qmax, lvl = 0.0f;
@@ -878,7 +1091,7 @@ __global__ __launch_bounds__(64) void k_encode_units(UlcxEncCtx c, int finalPass
         if (nmax > nmin * 4.0f) {
             int qi = build_quantizer(qmax);
             if (qi != prevQ) { put_quantizer(w, qi, prevQ != -1); prevQ = qi; }
-            nextCoded = write_zone(w, zoneStart, idx, (float)(1u << qi), coef, pairs, keep, nextCoded);
+            nextCoded = write_zone(w, zoneStart, idx, (float)(1u << qi), coef, pairs, keep, nextCoded, gapSum, &lastKept);
             zoneStart = idx;
             qmin = qmax = lvl;
         } else { qmin = nmin; qmax = nmax; }
@@ -888,7 +1101,11 @@ __global__ __launch_bounds__(64) void k_encode_units(UlcxEncCtx c, int finalPass
     if (n > 4) {
         if (prevQ != -1) w.put(0xF);
         int nq = 0, nd = 0;
-        if (prevQ != -1 && n >= 16) get_hfext(pairs, nextCoded, n, (float)(1u << prevQ), nq, nd);
+        if (prevQ != -1 && n >= 16) {
+            const float *ts = c.tailSum + (size_t)gid * 8;
+            if (c.useGapSums && __float_as_int(ts[5]) == nextCoded) hfext_from_sums(ts[0], ts[1], ts[2], ts[3], ts[4], (float)(1u << prevQ), nq, nd);
+            else get_hfext(pairs, nextCoded, n, (float)(1u << prevQ), nq, nd);
+        }
         if (nq) { w.put(0xF); w.put((unsigned)(nq - 1)); w.put((unsigned)(nd >> 4)); w.put((unsigned)nd); }
         else { w.put(0xE); w.put(0xF); }
     } else if (n > 0) {
@@ -898,12 +1115,315 @@ __global__ __launch_bounds__(64) void k_encode_units(UlcxEncCtx c, int finalPass
     c.unitNyb[gid] = w.n;
 }
 
+// ---------------------------------------------------------------------------
+// Fast encode pass: ONE WAVE per (block, channel, subblock) unit.
+// The reference's WriteSubBlock (Encode.c:200-313) is a serial state machine, but its
+// pieces separate cleanly once the kept coefficients are compacted:
+//   1. zone segmentation  = greedy min/max scan over the kept list (sequential, ~100 items,
+//      run uniformly by the wave on values passed through readlane);
+//   2. quantizer per zone, quantised value + "collapses" test per kept item: independent;
+//   3. the run codes of each gap between consecutive coded coefficients depend only on
+//      that gap (its zero-run length, its own noise sums, the zone's quantizer): one lane
+//      per gap, each doing its ordered f32 sums over LDS-resident {w, w*log} pairs;
+//   4. tail HF-extension fit: five ordered f32 chains -> five lanes;
+//   5. nybble positions by prefix sum, parallel emission.
+// Every float operation keeps the reference's order, so the nybbles are identical.
+// Units that exceed the LDS capacities below fall back to k_encode_units (c.slow).
+// ---------------------------------------------------------------------------
+#define E2_KCAP   768      // kept coefficients per unit
+#define E2_ZCAP   256      // quantizer zones per unit
+#define E2_NYBCAP 3072     // nybbles per unit
+
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
+    int x = v;
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(x, o); if (lane >= o) x += t; }
+    total = __shfl(x, 63);
+    return x - v;
+}
+
+// run codes of one gap (Encode.c:118-188); nybbles appended LSB-first to (lo,hi), count in cnt
+__device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const float *coefU, const float *pairL,
+                                          unsigned long long &lo, unsigned long long &hi, int &cnt) {
+    auto put = [&](unsigned x) {
+        x &= 0xF;
+        if (cnt < 16) lo |= (unsigned long long)x << (4 * cnt);
+        else if (cnt < 32) hi |= (unsigned long long)x << (4 * (cnt - 16));
+        cnt++;
+    };
+    while (zr) {
+        int n = 0, v = 0;
+        if (zr <= 2) {
+            int q1 = quant_coef(coefU[nc] * quant, 7);
+            int q2 = 0;
+            if (zr >= 2) q2 = quant_coef(coefU[nc + 1] * quant, 7);
+            if (abs(q1) > 1 && (zr < 2 || abs(q2) > 1)) {
+                put((unsigned)q1);
+                if (zr >= 2) put((unsigned)q2);
+                break;
+            }
+        }
+        int nq = 0;
+        if (zr >= 16) {
+            v = zr - 16; if (v > 0x1FF) v = 0x1FF;
+            n = v + 16;
+            nq = get_noise_q(pairL, nc, n, quant);
+        }
+        if (nq) { put(0x8); put((unsigned)(v >> 5)); put((unsigned)(v >> 1)); put((unsigned)((v & 1) | ((nq - 1) << 1))); }
+        else if (zr < 33) { v = zr - 1; if (v > 0xF) v = 0xF; n = v + 1; put(0x0); put((unsigned)v); }
+        else { v = zr - 33; if (v > 0xFF) v = 0xFF; n = v + 33; put(0x1); put((unsigned)(v >> 4)); put((unsigned)v); }
+        nc += n;
+        zr -= n;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_encode_wave(UlcxEncCtx c, int finalPass) {
+    extern __shared__ float e2[];
+    int gid = blockIdx.x, lane = threadIdx.x;
+    int j = gid & 3, ch = (gid >> 2) % c.C, blk = gid / (4 * c.C);
+    if (!finalPass && c.cbrDone[blk]) return;
+    int s = blk / c.K, k = blk % c.K;
+    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+    int d, off, S;
+    if (!unit_geom(wc, j, c.BS, d, off, S)) { if (lane == 0) c.unitNyb[gid] = 0; return; }
+    const int N = c.C * c.BS;
+    const int ubase = ch * c.BS + off;                       // unit offset inside the block arrays
+    const float *coefU = c.coef + (size_t)blk * N + ubase;
+    const float *pairG = c.npair + (size_t)blk * N + ubase;
+    const uint32_t *keepB = c.keep + (size_t)blk * (N / 32);
+
+    float    *pairL = e2;                                    // S floats
+    float    *kval  = pairL + S;                             // E2_KCAP  (later: quantised value bits)
+    float    *zmax  = kval + E2_KCAP;                        // E2_ZCAP
+    int      *zpre  = (int *)(zmax + E2_ZCAP);               // E2_ZCAP  inclusive prefix of quantizer-code nybbles
+    uint16_t *kidx  = (uint16_t *)(zpre + E2_ZCAP);          // E2_KCAP
+    uint16_t *kz    = kidx + E2_KCAP;                        // E2_KCAP
+    int8_t   *zqi   = (int8_t *)(kz + E2_KCAP);              // E2_ZCAP
+    uint8_t  *nyb   = (uint8_t *)(zqi + E2_ZCAP);            // E2_NYBCAP (one nybble per byte)
+
+    // A. noise pairs, coefficients and kept-set words of the unit -> LDS (coalesced, all loads in flight at once)
+    float    *coefL = (float *)(nyb + E2_NYBCAP);            // S floats
+    uint32_t *keepL = (uint32_t *)(coefL + S);               // S/32 + 1 words
+    for (int i = lane; i < S / 2; i += 64) ((float2 *)pairL)[i] = ((const float2 *)pairG)[i];
+    for (int i = lane; i < S / 4; i += 64) ((float4 *)coefL)[i] = ((const float4 *)coefU)[i];
+    for (int i = lane; i < S / 32; i += 64) keepL[i] = keepB[(ubase >> 5) + i];
+    __syncthreads();
+
+    // B. compact the kept coefficients (rank < nOutCoef)
+    int nK = 0;
+    for (int base = 0; base < S; base += 64) {
+        int i = base + lane;
+        bool kp = (keepL[i >> 5] >> (i & 31)) & 1;
+        float cv = coefL[i];
+        unsigned long long m = __ballot(kp);
+        int pos = nK + __popcll(m & ((1ull << lane) - 1));
+        if (kp && pos < E2_KCAP) { kidx[pos] = (uint16_t)i; kval[pos] = cv; }
+        nK += __popcll(m);
+    }
+    bool overflow = nK > E2_KCAP;
+    __syncthreads();
+
+    // C. zone segmentation: greedy scan (Encode.c:218-269), uniform across the wave
+    int nZ = 0;
+    if (!overflow) {
+        float qmin = 1000.0f, qmax = -1000.0f;
+        int zstart = -1;
+        for (int base = 0; base < nK; base += 64) {
+            float mine = (base + lane < nK) ? kval[base + lane] : 0.0f;
+            int cntc = (nK - base < 64) ? nK - base : 64;
+            for (int t = 0; t < cntc; t++) {
+                float lvl = fabsf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mine), t)));
+                float nmin = (lvl < qmin) ? lvl : qmin;
+                float nmax = (lvl > qmax) ? lvl : qmax;
+                if (zstart == -1) zstart = base + t;
+                if (nmax > nmin * 4.0f) {
+                    if (nZ < E2_ZCAP && lane == 0) zmax[nZ] = qmax;
+                    nZ++;
+                    zstart = base + t;
+                    qmin = qmax = lvl;
+                } else { qmin = nmin; qmax = nmax; }
+                if (lane == t) kz[base + t] = (uint16_t)nZ;
+            }
+        }
+        if (qmax > 0.0f * 4.0f) {                            // end sentinel: NewMin = 0 (Encode.c:226-238)
+            if (nZ < E2_ZCAP && lane == 0) zmax[nZ] = qmax;
+            nZ++;
+        }
+        if (nZ > E2_ZCAP) overflow = true;
+    }
+    __syncthreads();
+
+    // D. quantizer per zone + nybbles of its change code (Encode.c:240-244, 32-45)
+    if (!overflow) {
+        int run = 0;
+        for (int base = 0; base < nZ; base += 64) {
+            int z = base + lane;
+            int qn = 0;
+            if (z < nZ) { int qi = build_quantizer(zmax[z]); zqi[z] = (int8_t)qi; }
+            __syncthreads();
+            if (z < nZ) {
+                int qi = zqi[z];
+                int prev = (z > 0) ? zqi[z - 1] : -1;
+                if (qi != prev) qn = ((z > 0) ? 1 : 0) + ((qi - 5 < 0xE) ? 1 : 2);
+            }
+            int tot, ex = wave_excl_scan(qn, lane, tot);
+            if (z < nZ) zpre[z] = run + ex + qn;
+            run += tot;
+        }
+    }
+    __syncthreads();
+
+    // E. quantise kept items, drop the ones that collapse (Encode.c:114), compact in place
+    int nC = 0;
+    if (!overflow) {
+        for (int base = 0; base < nK; base += 64) {
+            int kk = base + lane;
+            bool coded = false; int qn = 0, idx = 0, z = 0;
+            if (kk < nK) {
+                z = kz[kk]; idx = kidx[kk];
+                float cq = kval[kk] * (float)(1u << zqi[z]);
+                coded = !(fabsf(cq) < 2.5f);
+                qn = quant_coef(cq, 7);
+            }
+            unsigned long long m = __ballot(coded);
+            int pos = nC + __popcll(m & ((1ull << lane) - 1));
+            if (coded) { kidx[pos] = (uint16_t)idx; kz[pos] = (uint16_t)z; ((int *)kval)[pos] = qn; }
+            nC += __popcll(m);
+        }
+    }
+    __syncthreads();
+
+    // F+H. gaps -> run codes; positions by prefix sum; emission
+    int total = 0;
+    if (!overflow) {
+        for (int base = 0; base < nC; base += 64) {
+            int m = base + lane;
+            unsigned long long lo = 0, hi = 0; int cnt = 0, pre = 0, z = 0, zp = -1, qn = 0;
+            if (m < nC) {
+                int idx = kidx[m];
+                int start = (m > 0) ? kidx[m - 1] + 1 : 0;
+                z = kz[m]; zp = (m > 0) ? kz[m - 1] : -1;
+                qn = ((int *)kval)[m];
+                pre = zpre[z] - ((zp >= 0) ? zpre[zp] : 0);
+                gap_codes(start, idx - start, (float)(1u << zqi[z]), coefL, pairL, lo, hi, cnt);
+            }
+            int mine = (m < nC) ? pre + cnt + 1 : 0;
+            int tot, ex = wave_excl_scan(mine, lane, tot);
+            if (cnt > 32) overflow = true;
+            int p = total + ex;
+            if (m < nC && finalPass && p + mine <= E2_NYBCAP && cnt <= 32) {
+                for (int zz = zp + 1; zz <= z; zz++) {           // quantizer codes of the zones opened since the last coded item
+                    int qi = zqi[zz], prev = (zz > 0) ? zqi[zz - 1] : -1;
+                    if (qi != prev) {
+                        if (zz > 0) nyb[p++] = 0xF;
+                        int sft = qi - 5;
+                        if (sft < 0xE) nyb[p++] = (uint8_t)sft; else { nyb[p++] = 0xE; nyb[p++] = (uint8_t)(sft - 0xE); }
+                    }
+                }
+                for (int q = 0; q < cnt; q++) nyb[p++] = (uint8_t)(((q < 16) ? (lo >> (4 * q)) : (hi >> (4 * (q - 16)))) & 0xF);
+                nyb[p++] = (uint8_t)(qn & 0xF);
+            }
+            total += tot;
+        }
+        overflow = __any(overflow);
+    }
+
+    // G. tail (Encode.c:271-312)
+    if (!overflow) {
+        int zlast = (nC > 0) ? kz[nC - 1] : -1;
+        int nextCoded = (nC > 0) ? kidx[nC - 1] + 1 : 0;
+        int n = S - nextCoded;
+        int prevQ = (nZ > 0) ? zqi[nZ - 1] : -1;
+        // quantizer codes of zones that closed after the last coded coefficient
+        int qtail = ((nZ > 0) ? zpre[nZ - 1] : 0) - ((zlast >= 0) ? zpre[zlast] : 0);
+        int nq = 0, nd = 0;
+        if (n > 4 && prevQ != -1 && n >= 16) {
+            // NoiseFill.c:41-94: five ordered f32 sums, one per lane 0..4
+            const float2 *dd = (const float2 *)(pairL + (nextCoded / 2) * 2);
+            int np = (n + (nextCoded & 1) + 1) / 2;
+            float acc = 0.0f;
+            if (lane < 5) {
+                int i = 0;
+                for (; i + 8 <= np; i += 8) {
+                    float2 pv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) pv[u] = dd[i + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        float x = (i + u) * 2.0f;
+                        float wx = pv[u].x * x;
+                        float term = (lane == 0) ? wx : (lane == 1) ? wx * x : (lane == 2) ? x * pv[u].y : (lane == 3) ? pv[u].y : pv[u].x;
+                        acc += term;
+                    }
+                }
+                for (; i < np; i++) {
+                    float2 pv = dd[i];
+                    float x = i * 2.0f;
+                    float wx = pv.x * x;
+                    float term = (lane == 0) ? wx : (lane == 1) ? wx * x : (lane == 2) ? x * pv.y : (lane == 3) ? pv.y : pv.x;
+                    acc += term;
+                }
+            }
+            float sx = __shfl(acc, 0), sx2 = __shfl(acc, 1), sxy = __shfl(acc, 2), sy = __shfl(acc, 3), sw = __shfl(acc, 4);
+            float q = (float)(1u << prevQ);
+            float det = sw * sx2 - sx * sx;
+            if (det != 0.0f) {
+                float amp = (sx2 * sy - sx * sxy) / det;
+                float dec = (sw * sxy - sx * sy) / det;
+                amp = ulcx_expf(amp);
+                dec = (dec < 0.0f) ? ulcx_expf(dec) : 1.0f;
+                int tq = quant_coef_u(amp * q * 4.0f, 16);
+                int td = quant_u((dec - 1.0f) * -0x1.0p19f);
+                if (td) { if (td > 0xFF) td = 0xFF; nq = tq; nd = td; }
+            }
+        }
+        int tailN = 0;
+        if (n > 4) tailN = ((prevQ != -1) ? 1 : 0) + (nq ? 4 : 2);
+        else if (n > 0) tailN = 2;
+        int p = total + qtail;
+        if (finalPass && lane == 0 && p + tailN <= E2_NYBCAP) {
+            int q0 = total;
+            for (int zz = zlast + 1; zz < nZ; zz++) {
+                int qi = zqi[zz], prev = (zz > 0) ? zqi[zz - 1] : -1;
+                if (qi != prev) {
+                    if (zz > 0) nyb[q0++] = 0xF;
+                    int sft = qi - 5;
+                    if (sft < 0xE) nyb[q0++] = (uint8_t)sft; else { nyb[q0++] = 0xE; nyb[q0++] = (uint8_t)(sft - 0xE); }
+                }
+            }
+            if (n > 4) {
+                if (prevQ != -1) nyb[p++] = 0xF;
+                if (nq) { nyb[p++] = 0xF; nyb[p++] = (uint8_t)(nq - 1); nyb[p++] = (uint8_t)((nd >> 4) & 0xF); nyb[p++] = (uint8_t)(nd & 0xF); }
+                else { nyb[p++] = 0xE; nyb[p++] = 0xF; }
+            } else if (n > 0) { nyb[p++] = 0x0; nyb[p++] = (uint8_t)(n - 1); }
+        }
+        total += qtail + tailN;
+        if (total > E2_NYBCAP) overflow = true;
+    }
+    if (overflow) {                                          // hand the whole block to the serial kernel
+        if (lane == 0) atomicOr(&c.slow[blk], 4);
+        return;
+    }
+    __syncthreads();
+    if (lane == 0) c.unitNyb[gid] = total;
+    if (!finalPass) return;
+    // I. nybbles -> bytes in the unit's staging row (same layout k_encode_units writes)
+    uint8_t *dst = c.unitBuf + (size_t)blk * c.C * c.unitCap + (size_t)ch * c.unitCap + 2 * off + 8 * j;
+    int nb = (total + 1) / 2;
+    for (int b = lane; b < nb; b += 64) {
+        unsigned lo4 = nyb[2 * b];
+        unsigned hi4 = (2 * b + 1 < total) ? nyb[2 * b + 1] : 0;
+        dst[b] = (uint8_t)(lo4 | (hi4 << 4));
+    }
+}
+
 // Encode.c:329-359: header nybble(s) + units in (channel, subblock) order, byte aligned.
 // One wave per block.
 __global__ __launch_bounds__(64) void k_pack(UlcxEncCtx c, int finalPass) {
     int blk = blockIdx.x, lane = threadIdx.x;
     if (!finalPass && c.cbrDone[blk]) return;
     if (c.useFused && !c.slow[blk]) return;
+    if (c.fbMode == 1 && c.isFb[blk]) return;
+    if (c.fbMode == 2 && !c.isFb[blk]) return;
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     int nU = c.C * 4;
@@ -1178,10 +1698,10 @@ size_t ulcx_enc_xf_lds_bytes(int BS) { return (size_t)BS * 18 + 16; }   // 2BS +
 const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES] = {
     "k_wc_energy", "k_wc_forward", "k_wc_backward", "k_wc_integrate", "k_wc_decide",
     "k_xf", "k_cplx", "k_nbark", "k_nline", "k_pbark", "k_keys",
-    "k_selenc", "k_heapsel", "k_encode_units(slow path)", "k_pack(slow path)", "cbr_probe_passes", "k_state_update",
+    "k_select", "k_heapsel", "k_gapsums+k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update",
 };
 
-int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev) {
+int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStream_t side, hipEvent_t evFork, hipEvent_t evJoin) {
     int NB = c.B * c.K;
     int stage = 0;
 #define MARK() do { if (ev) CK(hipEventRecord(ev[stage++], st)); } while (0)
@@ -1223,6 +1743,38 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev) {
     // ceil(log2(MaxCoef))+1 probes; every block runs its own search in lock step, then one final pass.
     int probes = 0;
     if (c.mode != ULCX_MODE_VBR) { probes = 2; int m = N; while (m > 1) { probes++; m >>= 1; } }
+    auto launch_select = [&](int fin) {
+        int R = N / 64;
+        if (c.useFused) return false;
+        switch (R) {
+            case 64: hipLaunchKernelGGL(k_select_wave<64>, dim3(NB), dim3(64), 0, st, c, fin); return true;
+            case 32: hipLaunchKernelGGL(k_select_wave<32>, dim3(NB), dim3(64), 0, st, c, fin); return true;
+            case 16: hipLaunchKernelGGL(k_select_wave<16>, dim3(NB), dim3(64), 0, st, c, fin); return true;
+            case 8:  hipLaunchKernelGGL(k_select_wave<8>,  dim3(NB), dim3(64), 0, st, c, fin); return true;
+            case 4:  hipLaunchKernelGGL(k_select_wave<4>,  dim3(NB), dim3(64), 0, st, c, fin); return true;
+            default: return false;
+        }
+    };
+    auto launch_encode = [&](UlcxEncCtx cc, hipStream_t s2, int fin, bool ev0) -> int {
+        if (cc.useWave && !cc.useFused) {
+            CK(hipMemsetAsync(cc.slow, 0, sizeof(int) * (size_t)NB, s2));
+            size_t lds = (size_t)cc.BS * 8 + cc.BS / 8 + E2_KCAP * 4 + E2_ZCAP * 8 + E2_KCAP * 4 + E2_ZCAP + E2_NYBCAP + 64;
+            hipLaunchKernelGGL(k_encode_wave, dim3(nUnits), dim3(64), lds, s2, cc, fin);
+        }
+        if (cc.useGapSums) {
+            size_t glds = (size_t)N * 4 + N / 8;
+            if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+            hipLaunchKernelGGL(k_gapsums, dim3(NB), dim3(WG), glds, s2, cc, fin);
+        }
+        hipLaunchKernelGGL(k_encode_units, dim3((nUnits + 63) / 64), dim3(64), 0, s2, cc, fin);
+        if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
+        hipLaunchKernelGGL(k_pack, dim3(NB), dim3(64), 0, s2, cc, fin);
+        if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
+        return ULCX_OK;
+    };
+    // Tie-straddle blocks (~4e-4 of all) need a ~7 ms single-lane heapsort replay; in VBR (one pass)
+    // it runs on a side stream next to the encode pass of all other blocks, then the streams join.
+    bool async_fb = (side != nullptr) && (c.mode == ULCX_MODE_VBR) && !c.useFused && !c.useWave;
     for (int p = 0; p <= probes; p++) {
         int fin = (p == probes) ? 1 : 0;
         bool ev0 = (p == 0);
@@ -1231,13 +1783,26 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev) {
             int stageBytes = 2048 * c.C;
             size_t lds = (size_t)N * 8 + N / 8 + stageBytes + 256 * 4 + c.C * 16 + 16;
             if (p == 0 && lds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_selenc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_selenc, dim3(NB), dim3(WG), lds, st, c, fin, stageBytes);                 if (ev0) MARK();
-        } else {
-            hipLaunchKernelGGL(k_select, dim3(NB), dim3(WG), 0, st, c, fin);                               if (ev0) MARK();
+            hipLaunchKernelGGL(k_selenc, dim3(NB), dim3(WG), lds, st, c, fin, stageBytes);
+        } else if (!launch_select(fin)) {
+            hipLaunchKernelGGL(k_select, dim3(NB), dim3(WG), 0, st, c, fin);
         }
-        hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, st, c, ldsEntries);                 if (ev0) MARK();
-        hipLaunchKernelGGL(k_encode_units, dim3((nUnits + 63) / 64), dim3(64), 0, st, c, fin);             if (ev0) MARK();
-        hipLaunchKernelGGL(k_pack, dim3(NB), dim3(64), 0, st, c, fin);                                     if (ev0) MARK();
+        if (ev0) MARK();
+        if (async_fb) {
+            CK(hipEventRecord(evFork, st));
+            CK(hipStreamWaitEvent(side, evFork, 0));
+            UlcxEncCtx cf = c; cf.fbMode = 2;
+            hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, side, cf, ldsEntries);
+            int rc = launch_encode(cf, side, fin, false); if (rc) return rc;
+            CK(hipEventRecord(evJoin, side));
+            if (ev0) MARK();                                   // (k_heapsel interval is empty on the main stream)
+            UlcxEncCtx cm = c; cm.fbMode = 1;
+            rc = launch_encode(cm, st, fin, ev0); if (rc) return rc;
+            CK(hipStreamWaitEvent(st, evJoin, 0));
+        } else {
+            hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, st, c, ldsEntries);             if (ev0) MARK();
+            int rc = launch_encode(c, st, fin, ev0); if (rc) return rc;
+        }
     }
     MARK();   // cbr_probe_passes (empty interval for VBR)
     hipLaunchKernelGGL(k_state_update, dim3(c.B), dim3(WG), 0, st, c);                                     MARK();

@@ -76,6 +76,12 @@ struct UlcxEncCtx {
     int    *cbrBudget;                   // [NB] bit budget (ulcEncoder.c:96)
     int    *slow;                        // [NB] 0 = done by the fused fast path, 1 = tie straddle, 2 = staging overflow
     int     useFused;                    // fused select+encode+pack kernel usable (LDS fits)
+    float2 *gapSum;                      // [NB][C*BS] {Sum, SumW} of the noise run in front of each kept coefficient (speculative)
+    float  *tailSum;                     // [NB][C*4][8] five HF-extension sums + start index of the tail they assume
+    int     useGapSums;
+    int    *isFb;                        // [NB] 1 = threshold tie group straddles the cut (needs k_heapsel)
+    int     fbMode;                      // 0 = all blocks, 1 = skip isFb blocks, 2 = only isFb blocks
+    int     useWave;                     // wave-per-unit encode pass (k_encode_wave); serial kernel only for overflow blocks
     void   *heapScratch;                 // [ULCX_HEAP_GRID][C*BS] {key,idx} heaps, only when C*BS*8 exceeds the LDS budget
 };
 
@@ -117,6 +123,6 @@ void ulcx_set_error(const char *fmt, ...);
 #define ULCX_ENC_STAGES 17
 extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES];
 #define ULCX_DEC_STAGES 4
-int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */);
+int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, hipStream_t side, hipEvent_t evFork, hipEvent_t evJoin);
 int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev);
 size_t ulcx_enc_xf_lds_bytes(int BS);
