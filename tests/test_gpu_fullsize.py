@@ -1,0 +1,141 @@
+"""BASELINE.json configurations at (or near) full size on the GPU, checked through
+size-independent properties (the oracle cannot encode 10^5 blocks in test time):
+determinism, call-splitting invariance, encode -> decode round trip (delay 2*BlockSize,
+codec-level SNR), decoder consumes exactly what the encoder wrote, CBR never over budget,
+window switching exercised, plus a seeded random sample of streams compared byte for byte
+with the oracle."""
+import os
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ulc-codec_amd"))
+from ulc_testlib import oracle_encode_debug
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_pcm(B, n, rate, seed, transient_rate=4.0):
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    bench.RATE = rate
+    return bench.make_pcm(torch, B, n, torch.device("cuda", 0), seed)
+
+
+def _run(B, K, bs, ch, rate, mode, p0, calls=1, seed=1):
+    import torch
+    import ulc_amd as amd
+    dev = torch.device("cuda", 0)
+    pcm = _torch_pcm(B, K * bs, rate, seed)
+    if ch == 1:
+        pcm = pcm[:, :, :1].contiguous()
+    enc = amd.BatchEncoder(B, ch, bs, rate, K)
+    dec = amd.BatchDecoder(B, ch, bs, K)
+    slot = enc.slot
+    out = torch.zeros(B, K, slot, dtype=torch.uint8, device=dev)
+    bits = torch.zeros(B, K, dtype=torch.int32, device=dev)
+    wc = torch.zeros(B, K, dtype=torch.int32, device=dev)
+    dpcm = torch.zeros(B, K * bs, ch, dtype=torch.float32, device=dev)
+    dbits = torch.zeros(B, K, dtype=torch.int32, device=dev)
+    if calls == 1:
+        enc.encode_dev(pcm.data_ptr(), K, out.data_ptr(), bits.data_ptr(), wc.data_ptr(), 0, mode=mode, p0=p0)
+    else:
+        kk = K // calls
+        for c in range(calls):
+            sub = pcm[:, c * kk * bs:(c + 1) * kk * bs].contiguous()
+            o = torch.zeros(B, kk, slot, dtype=torch.uint8, device=dev); b = torch.zeros(B, kk, dtype=torch.int32, device=dev)
+            w = torch.zeros(B, kk, dtype=torch.int32, device=dev)
+            enc.encode_dev(sub.data_ptr(), kk, o.data_ptr(), b.data_ptr(), w.data_ptr(), 0, mode=mode, p0=p0)
+            torch.cuda.synchronize()
+            out[:, c * kk:(c + 1) * kk] = o; bits[:, c * kk:(c + 1) * kk] = b; wc[:, c * kk:(c + 1) * kk] = w
+    dec.decode_dev(out.data_ptr(), slot, K, dpcm.data_ptr(), dbits.data_ptr())
+    torch.cuda.synchronize()
+    res = dict(pcm=pcm, out=out, bits=bits, wc=wc, dpcm=dpcm, dbits=dbits, slot=slot)
+    enc.close(); dec.close()
+    return res
+
+
+def _snr_db(x, y):
+    import torch
+    return float(10 * torch.log10((x ** 2).sum() / ((x - y) ** 2).sum()))
+
+
+def test_config2_vbr_batch4096_properties():
+    """configs[1]: Batch=4096 stereo 44.1 kHz streams, BlockSize=2048, VBR -50."""
+    import torch
+    B, K, bs, ch, rate = 4096, 8, 2048, 2, 44100
+    a = _run(B, K, bs, ch, rate, 0, 50.0)
+    b = _run(B, K, bs, ch, rate, 0, 50.0, calls=2)                 # same streams, two calls of 4 blocks
+    assert torch.equal(a["bits"], b["bits"]) and torch.equal(a["wc"], b["wc"]), "call splitting changed the result"
+    assert torch.equal(a["out"], b["out"]), "call splitting changed the bytes"
+    bits, dbits = a["bits"], a["dbits"]
+    assert int((bits % 8).abs().sum()) == 0 and int(bits.min()) >= 8
+    assert bool((dbits > 0).all()) and bool((dbits <= bits).all()) and bool((bits - dbits < 8).all()), "decoder did not consume exactly the encoder's nybbles"
+    d = 2 * bs
+    snr = _snr_db(a["pcm"][:, :-d], a["dpcm"][:, d:])
+    assert snr > 12.0, snr
+    codes = set(np.unique(a["wc"].cpu().numpy()).tolist())
+    assert 0x10 in codes and any(c >= 0x80 for c in codes), codes      # window switching occurred somewhere in the batch
+    # byte-for-byte against the oracle on a seeded sample of streams
+    pcm_h = a["pcm"].cpu().numpy(); out_h = a["out"].cpu().numpy(); bits_h = bits.cpu().numpy()
+    for s in np.random.default_rng(0).choice(B, 12, replace=False):
+        ref = oracle_encode_debug(pcm_h[s], bs, rate, 0, 50.0, slot=a["slot"])
+        assert np.array_equal(bits_h[s], ref["bits"])
+        for k in range(K):
+            nb = bits_h[s, k] // 8
+            assert np.array_equal(out_h[s, k, :nb], ref["out"][k, :nb]), (s, k)
+
+
+def test_config3_decode_65536_blocks_properties():
+    """configs[2]: 65536 .ulc blocks decode (2048 streams x 32 blocks)."""
+    import torch
+    B, K, bs, ch, rate = 2048, 32, 2048, 2, 44100
+    a = _run(B, K, bs, ch, rate, 0, 50.0, seed=3)
+    assert bool((a["dbits"] > 0).all()) and bool((a["bits"] - a["dbits"] < 8).all())
+    assert bool(torch.isfinite(a["dpcm"]).all())
+    d = 2 * bs
+    assert _snr_db(a["pcm"][:, :-d], a["dpcm"][:, d:]) > 12.0
+    # linearity of the decoder's transform stage is not observable through the API; determinism is:
+    b = _run(B, K, bs, ch, rate, 0, 50.0, seed=3)
+    assert torch.equal(a["dpcm"], b["dpcm"])
+
+
+def test_config4_cbr64_48k_never_over_budget():
+    """configs[3] shape: CBR 64 kbps, 48 kHz M/S stereo, BlockSize=2048 (one GPU's share: 4096 streams)."""
+    import torch
+    B, K, bs, ch, rate, kbps = 4096, 4, 2048, 2, 48000, 64.0
+    a = _run(B, K, bs, ch, rate, 1, kbps, seed=4)
+    budget = int((bs * kbps) * 1000.0 / rate)
+    bits = a["bits"]
+    assert int(bits.max()) <= budget + 7, (int(bits.max()), budget)
+    assert float(bits[:, 2:].float().mean()) > 0.9 * budget              # the search fills the budget
+    assert bool((a["dbits"] > 0).all())
+    pcm_h = a["pcm"].cpu().numpy(); out_h = a["out"].cpu().numpy(); bits_h = bits.cpu().numpy()
+    for s in np.random.default_rng(1).choice(B, 6, replace=False):
+        ref = oracle_encode_debug(pcm_h[s], bs, rate, 1, kbps, slot=a["slot"])
+        assert np.array_equal(bits_h[s], ref["bits"])
+        for k in range(K):
+            nb = bits_h[s, k] // 8
+            assert np.array_equal(out_h[s, k, :nb], ref["out"][k, :nb]), (s, k)
+
+
+def test_config5_window_switch_stress_bs4096():
+    """configs[4] shape: transient-heavy input, BlockSize=4096 (one GPU's share: 2048 streams)."""
+    B, K, bs, ch, rate = 2048, 8, 4096, 2, 44100
+    a = _run(B, K, bs, ch, rate, 0, 50.0, seed=5)
+    codes = np.unique(a["wc"].cpu().numpy())
+    dec_codes = sorted({int(c) >> 4 for c in codes if c >= 0x80})
+    assert len(dec_codes) >= 6, f"decimation positions seen: {dec_codes}"     # 1/8-decimation positions 8..15
+    assert any((int(c) & 7) >= 2 for c in codes if c >= 0x80)                 # overlap scaling beyond 1
+    d = 2 * bs
+    assert _snr_db(a["pcm"][:, :-d], a["dpcm"][:, d:]) > 12.0
+    pcm_h = a["pcm"].cpu().numpy(); out_h = a["out"].cpu().numpy(); bits_h = a["bits"].cpu().numpy(); wc_h = a["wc"].cpu().numpy()
+    sw = np.argsort(-(wc_h >= 0x80).sum(axis=1))[:6]                          # the most window-switched streams
+    for s in sw:
+        ref = oracle_encode_debug(pcm_h[s], bs, rate, 0, 50.0, slot=a["slot"])
+        assert np.array_equal(wc_h[s], ref["wc"]) and np.array_equal(bits_h[s], ref["bits"])
+        for k in range(K):
+            nb = bits_h[s, k] // 8
+            assert np.array_equal(out_h[s, k, :nb], ref["out"][k, :nb]), (s, k)
