@@ -252,25 +252,32 @@ __device__ __forceinline__ int first_overlap(int wc, int BS) {   // BlockTransfo
     return ov;
 }
 
+// window value of frame sample i (0 <= i < 2S) of a subblock with left overlap ovL (ramp
+// centred on the span start) and right overlap ov: closed form of the lapping FIFO
+// (BlockTransform.c:175-224) + sine window of the transform (oracle/orc_fourier.c)
+__device__ __forceinline__ float win_apply(float x, int i, int S, int aL, int ovL, int aR, int ov,
+                                           const float *__restrict__ rise, const float *__restrict__ fall) {
+    if (i < S) return (i < aL) ? 0.0f : (i < aL + ovL) ? x * rise[i - aL] : x;
+    int n = i - S;
+    return (n < aR) ? x : (n < aR + ov) ? x * fall[n - aR] : 0.0f;
+}
+
 __global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c) {
     extern __shared__ float lds[];
     const int BS = c.BS, C = c.C;
     int blk = blockIdx.x;
     int s = blk / c.K, k = blk % c.K;
     int tid = threadIdx.x;
-    float  *f    = lds;                               // 2*BS  windowed frame
-    float2 *zc   = (float2 *)(lds + 2 * BS);          // BS/2 complex
-    float2 *zs   = zc + BS / 2;                       // BS/2 complex
-    float  *amp2 = (float *)(zs + BS / 2);            // BS/2
-    int    &s_nnz = *(int *)(amp2 + BS / 2);          // (kept inside the dynamic region: no static LDS in front of it)
+    float2 *z    = (float2 *)lds;                     // 4 arrays of up to BS/2 complex: {MDCT, MDST} x {ch, ch+1}
+    float  *amp2 = lds + 4 * BS;                      // BS/2
+    int    &s_nnz = *(int *)(amp2 + BS / 2);          // (inside the dynamic region: no static LDS in front of it)
     if (tid == 0) s_nnz = 0;
     for (int i = tid; i < BS / 2; i += WG) amp2[i] = 0.0f;
 
     const int *wrow = c.wcArr + (size_t)s * (c.maxK + 2) + k;
     int wcPrev = wrow[0], wc = wrow[1], wcNext = wrow[2];
     int nextOv = first_overlap(wcNext, BS);
-    // right-edge overlap of the previous block's last subblock = left overlap of our first
-    int ovFirst;
+    int ovFirst;                                       // right overlap of the previous block's last subblock
     {
         unsigned pp = ulcx_pattern(wcPrev);
         int lastS = BS;
@@ -285,7 +292,8 @@ __global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c) {
     int nnz = 0;
     __syncthreads();
 
-    for (int ch = 0; ch < C; ch++) {
+    for (int ch0 = 0; ch0 < C; ch0 += 2) {             // one M/S pair (or a trailing single channel) at a time
+        const int nch = (ch0 + 1 < C) ? 2 : 1;
         unsigned pat = ulcx_pattern(wc);
         int off = 0, ovL = ovFirst;
         do {
@@ -297,48 +305,66 @@ __global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c) {
             else ov = nextOv;
             if (ov > S) ov = S;
             const int M = S >> 1;
-
-            // 1. windowed frame f[0..2S): closed form of the lapping FIFO (BlockTransform.c:175-224):
-            //    subblock span starts at b = (k-1.5)BS + off; frame = [b - S/2, b + 3S/2)
+            // subblock span starts at b = (k-1.5)BS + off; frame = [b - S/2, b + 3S/2)
             int t0 = (k - 1) * BS - BS / 2 + off - S / 2;
             int aL = (S - ovL) >> 1, aR = (S - ov) >> 1;
             const float *rise = c.T.winRise + ovL, *fall = c.T.winFall + ov;
-            for (int i = tid; i < 2 * S; i += WG) {
-                float x = ms_sample(smp_ptr(c, s, t0 + i), ch, C);
-                float v;
-                if (i < S) v = (i < aL) ? 0.0f : (i < aL + ovL) ? x * rise[i - aL] : x;
-                else { int n = i - S; v = (n < aR) ? x : (n < aR + ov) ? x * fall[n - aR] : 0.0f; }
-                f[i] = v;
-            }
-            __syncthreads();
-
-            // 2. TDAC fold + DCT-IV pre-twiddle (oracle/orc_fourier.c: v[], reversed w[])
             const float2 *pre = c.T.pre[d];
-            const float *Lp = f, *Rp = f + S;
+            float2 *zc0 = z, *zs0 = z + M, *zc1 = z + 2 * M, *zs1 = z + 3 * M;
+
+            // 1. TDAC fold + DCT-IV pre-twiddle straight from the input timeline
             for (int n = tid; n < M; n += WG) {
                 int m1 = 2 * n, m2 = S - 1 - 2 * n;
-                float v1, v2, w1, w2;                 // v[m1], v[m2], w[m1], w[m2]
-                if (m1 < M) {                         // m1 in first half, m2 in second half
-                    float ra = Rp[M - 1 - m1], rb = Rp[M + m1];
-                    v1 = ra + rb; w1 = ra - rb;
-                    float la = Lp[S - 1 - (m2 - M)], lb = Lp[m2 - M];
-                    v2 = la - lb; w2 = lb + la;
-                } else {
-                    float la = Lp[S - 1 - (m1 - M)], lb = Lp[m1 - M];
-                    v1 = la - lb; w1 = lb + la;
-                    float ra = Rp[M - 1 - m2], rb = Rp[M + m2];
-                    v2 = ra + rb; w2 = ra - rb;
+                bool lo = (m1 < M);
+                int mr = lo ? m1 : m2;                // index handled by the R (second-half) fold
+                int ml = lo ? m2 : m1;                // index handled by the L (first-half) fold
+                int iRa = S + (M - 1 - mr), iRb = S + (M + mr);
+                int iLa = S - 1 - (ml - M), iLb = ml - M;
+                float xa[2], xb[2], ya[2], yb[2];     // per channel: Ra, Rb, La, Lb (windowed)
+                {
+                    const float *pRa = smp_ptr(c, s, t0 + iRa), *pRb = smp_ptr(c, s, t0 + iRb);
+                    const float *pLa = smp_ptr(c, s, t0 + iLa), *pLb = smp_ptr(c, s, t0 + iLb);
+                    if (nch == 2) {
+                        float2 ra, rb, la, lb;
+                        if (C == 2) {                 // stereo: one 8-byte load per time position
+                            ra = *(const float2 *)pRa; rb = *(const float2 *)pRb; la = *(const float2 *)pLa; lb = *(const float2 *)pLb;
+                        } else {
+                            ra = make_float2(pRa[ch0], pRa[ch0 + 1]); rb = make_float2(pRb[ch0], pRb[ch0 + 1]);
+                            la = make_float2(pLa[ch0], pLa[ch0 + 1]); lb = make_float2(pLb[ch0], pLb[ch0 + 1]);
+                        }
+                        // M/S (BlockTransform.c:102-110)
+                        xa[0] = (ra.x + ra.y) * 0.5f; xa[1] = (ra.x - ra.y) * 0.5f;
+                        xb[0] = (rb.x + rb.y) * 0.5f; xb[1] = (rb.x - rb.y) * 0.5f;
+                        ya[0] = (la.x + la.y) * 0.5f; ya[1] = (la.x - la.y) * 0.5f;
+                        yb[0] = (lb.x + lb.y) * 0.5f; yb[1] = (lb.x - lb.y) * 0.5f;
+                    } else {
+                        xa[0] = pRa[ch0]; xb[0] = pRb[ch0]; ya[0] = pLa[ch0]; yb[0] = pLb[ch0];
+                        xa[1] = xb[1] = ya[1] = yb[1] = 0.0f;
+                    }
                 }
                 float2 P = pre[n];
-                zc[n] = cmulc(make_float2(v1, v2), P);        // u = v      : (u[2n], u[S-1-2n])
-                zs[n] = cmulc(make_float2(w2, w1), P);        // u = rev(w) : (w[S-1-2n], w[2n])
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    if (q >= nch) break;
+                    float ra = win_apply(xa[q], iRa, S, aL, ovL, aR, ov, rise, fall);
+                    float rb = win_apply(xb[q], iRb, S, aL, ovL, aR, ov, rise, fall);
+                    float la = win_apply(ya[q], iLa, S, aL, ovL, aR, ov, rise, fall);
+                    float lb = win_apply(yb[q], iLb, S, aL, ovL, aR, ov, rise, fall);
+                    float vr = ra + rb, wr = ra - rb;            // v[mr], w[mr]
+                    float vl = la - lb, wl = lb + la;            // v[ml], w[ml]
+                    float v1 = lo ? vr : vl, v2 = lo ? vl : vr;  // v[m1], v[m2]
+                    float w1 = lo ? wr : wl, w2 = lo ? wl : wr;  // w[m1], w[m2]
+                    float2 *zc = q ? zc1 : zc0, *zs = q ? zs1 : zs0;
+                    zc[n] = cmulc(make_float2(v1, v2), P);       // u = v      : (u[2n], u[S-1-2n])
+                    zs[n] = cmulc(make_float2(w2, w1), P);       // u = rev(w) : (w[S-1-2n], w[2n])
+                }
             }
             __syncthreads();
 
-            // 3. two M-point FFTs in LDS
-            fft2_dif(zc, zs, M, c.T.tw[d], tid);
+            // 2. 2*nch M-point FFTs in LDS
+            fftn_dif(z, 2 * nch, M, c.T.tw[d], tid);
 
-            // 4. post-twiddle + normalise + keys + per-line energies (BlockTransform.c:243-281)
+            // 3. post-twiddle + normalise + keys + per-line energies (BlockTransform.c:243-281)
             int bits = 31 - __clz(M);
             float norm = 2.0f / S;
             for (int kk = tid; kk < M / 2; kk += WG) {
@@ -346,30 +372,35 @@ __global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c) {
                 int r1 = (int)(__brev((unsigned)k1) >> (32 - bits));
                 int r2 = (int)(__brev((unsigned)k2) >> (32 - bits));
                 float2 P1 = pre[k1], P2 = pre[k2];
-                float2 yc1 = cmulc(zc[r1], P1), yc2 = cmulc(zc[r2], P2);
-                float2 ys1 = cmulc(zs[r1], P1), ys2 = cmulc(zs[r2], P2);
-                // pair j = k1: coefficients 2k1, 2k1+1 ; pair j = k2: coefficients 2k2, 2k2+1
-                float mdct[4] = { yc1.x, -yc2.y, yc2.x, -yc1.y };
-                float mdst[4] = { ys1.x,  ys2.y, ys2.x,  ys1.y };
-                int   jj[2]   = { k1, k2 };
+                float am1 = amp2[off / 2 + k1], am2 = amp2[off / 2 + k2];
 #pragma unroll
-                for (int p = 0; p < 2; p++) {
-                    float re0 = mdct[2*p] * norm,   im0 = mdst[2*p] * norm;
-                    float re1 = mdct[2*p+1] * norm, im1 = mdst[2*p+1] * norm;
-                    float re0s = re0 * re0, im0s = im0 * im0, re1s = re1 * re1, im1s = im1 * im1;
-                    float a0 = re0s + im0s, a1 = re1s + im1s;
-                    float k0v, k1v;
-                    if (fabsf(re0) < 0.5f * ULCX_COEF_EPS) k0v = __uint_as_float(0xff800000u); else { k0v = fastlog(re0s); nnz++; }
-                    if (fabsf(re1) < 0.5f * ULCX_COEF_EPS) k1v = __uint_as_float(0xff800000u); else { k1v = fastlog(re1s); nnz++; }
-                    int j = jj[p];
-                    size_t gi = (size_t)ch * BS + off + 2 * j;
-                    *(float2 *)(coefO + gi) = make_float2(re0, re1);
-                    *(float2 *)(keyO + gi)  = make_float2(k0v, k1v);
-                    nsumO[(size_t)ch * (BS / 2) + off / 2 + j] = a0 + a1;             // (0 + a0) + a1
-                    float am = amp2[off / 2 + j];
-                    am += a0; am += a1;                                            // channel order preserved
-                    amp2[off / 2 + j] = am;
+                for (int q = 0; q < 2; q++) {
+                    if (q >= nch) break;
+                    int ch = ch0 + q;
+                    float2 *zc = q ? zc1 : zc0, *zs = q ? zs1 : zs0;
+                    float2 yc1 = cmulc(zc[r1], P1), yc2 = cmulc(zc[r2], P2);
+                    float2 ys1 = cmulc(zs[r1], P1), ys2 = cmulc(zs[r2], P2);
+                    // pair j = k1: coefficients 2k1, 2k1+1 ; pair j = k2: coefficients 2k2, 2k2+1
+                    float mdct[4] = { yc1.x, -yc2.y, yc2.x, -yc1.y };
+                    float mdst[4] = { ys1.x,  ys2.y, ys2.x,  ys1.y };
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        float re0 = mdct[2*p] * norm,   im0 = mdst[2*p] * norm;
+                        float re1 = mdct[2*p+1] * norm, im1 = mdst[2*p+1] * norm;
+                        float re0s = re0 * re0, im0s = im0 * im0, re1s = re1 * re1, im1s = im1 * im1;
+                        float a0 = re0s + im0s, a1 = re1s + im1s;
+                        float k0v, k1v;
+                        if (fabsf(re0) < 0.5f * ULCX_COEF_EPS) k0v = __uint_as_float(0xff800000u); else { k0v = fastlog(re0s); nnz++; }
+                        if (fabsf(re1) < 0.5f * ULCX_COEF_EPS) k1v = __uint_as_float(0xff800000u); else { k1v = fastlog(re1s); nnz++; }
+                        int j = p ? k2 : k1;
+                        size_t gi = (size_t)ch * BS + off + 2 * j;
+                        *(float2 *)(coefO + gi) = make_float2(re0, re1);
+                        *(float2 *)(keyO + gi)  = make_float2(k0v, k1v);
+                        nsumO[(size_t)ch * (BS / 2) + off / 2 + j] = a0 + a1;          // (0 + a0) + a1
+                        if (p) { am2 += a0; am2 += a1; } else { am1 += a0; am1 += a1; } // channel order preserved
+                    }
                 }
+                amp2[off / 2 + k1] = am1; amp2[off / 2 + k2] = am2;
             }
             __syncthreads();
             off += S; ovL = ov;
@@ -761,6 +792,81 @@ __global__ __launch_bounds__(64) void k_heapsel(UlcxEncCtx c, int ldsEntries) {
     }
 }
 
+// Pipelined replay of the same heapsort, one wave per block, heap in LDS.
+//  * heapify: the reference sifts nodes N/2-1 .. 0; nodes of one tree level have disjoint
+//    subtrees, so a level is sifted in parallel (one lane per node), levels bottom-up.
+//  * pops: pop p moves the last heap element to the root and sifts it down.  A sift at level
+//    l only touches levels >= l, so pop p+1 may start once pop p is two levels down: up to
+//    ~6 pops are in flight, one lane each, every step advancing each by one level.  The only
+//    cross-pop hazard is the element pop p+1 lifts from the end of the heap: if an in-flight
+//    sift is still on the path to that leaf it could yet replace it, so the start waits.
+// Comparisons and tie behaviour are exactly those of heap_sift / BlockTransform.c:20-51.
+__global__ __launch_bounds__(64) void k_heapsel_pipe(UlcxEncCtx c) {
+    extern __shared__ HeapEnt hp[];
+    int count = *c.fbCount;
+    const int N = c.C * c.BS;
+    uint32_t *kb = (uint32_t *)(hp + N);
+    int lane = threadIdx.x;
+    for (int idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        int blk = c.fbList[idx];
+        int kSel = c.nout[blk];
+        const float *key = c.key + (size_t)blk * N;
+        uint32_t *keep = c.keep + (size_t)blk * (N / 32);
+        for (int i = lane; i < N; i += 64) { hp[i].v = key[i]; hp[i].i = i; }
+        for (int i = lane; i < N / 32; i += 64) kb[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        // ---- heapify, level by level
+        int top = 31 - __clz(N / 2);                      // level of node N/2-1 (root = level 0) for power-of-two N
+        for (int L = top; L >= 0; L--) {
+            int first = (1 << L) - 1, last = (2 << L) - 2;
+            if (last > N / 2 - 1) last = N / 2 - 1;
+            for (int n = first + lane; n <= last; n += 64) heap_sift(hp, n, N);
+            __syncthreads();
+        }
+        // ---- pipelined pops
+        int pops = N - kSel;
+        int P = 0, step = 0, lastStart = -2;
+        bool active = false; int pos = 0, size = 0; HeapEnt e; e.v = 0.0f; e.i = 0;
+        while (P < pops || __any(active)) {
+            if (P < pops && step - lastStart >= 2) {
+                int nl = N - 1 - P;                       // index of the element to lift = heap size after this pop
+                // is any in-flight sift on the path root -> nl ?
+                bool onPath = false;
+                if (active) {
+                    int a = pos + 1, b = nl + 1;          // 1-based heap numbering: a is ancestor-or-self of b iff b >> (depth diff) == a
+                    int da = 31 - __clz(a), db = 31 - __clz(b);
+                    onPath = (db >= da) && ((b >> (db - da)) == a);
+                }
+                int slot = P & 15;
+                bool slotBusy = __shfl((int)active, slot) != 0;
+                if (!__any(onPath) && !slotBusy) {
+                    HeapEnt g = hp[0];
+                    if (lane == slot) {
+                        kb[g.i >> 5] &= ~(1u << (g.i & 31));
+                        if (nl > 0) { e = hp[nl]; pos = 0; size = nl; active = true; }
+                    }
+                    P++; lastStart = step;
+                }
+            }
+            if (active) {
+                int c1 = 2 * pos + 1;
+                if (c1 >= size) { hp[pos] = e; active = false; }
+                else {
+                    HeapEnt cN = hp[c1];
+                    int ci = c1;
+                    if (c1 + 1 < size) { HeapEnt c2 = hp[c1 + 1]; if (c2.v < cN.v) { cN = c2; ci = c1 + 1; } }
+                    if (cN.v > e.v) { hp[pos] = e; active = false; }
+                    else { hp[pos] = cN; pos = ci; }
+                }
+            }
+            step++;
+        }
+        __syncthreads();
+        for (int i = lane; i < N / 32; i += 64) keep[i] = kb[i];
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Speculative, massively parallel evaluation of the ordered f32 sums the bitstream state
 // machine needs (NoiseFill.c:15-36, :41-62): for every kept coefficient the noise-run sums
@@ -826,7 +932,8 @@ __global__ __launch_bounds__(WG) void k_gapsums(UlcxEncCtx c, int finalPass) {
             for (int u = 0; u < 8; u++) { sum += p[u].y; sumw += p[u].x; }
         }
         for (; q < np; q++) { float2 p = d[q]; sum += p.y; sumw += p.x; }
-        gs[i] = make_float2(sum, sumw);
+        // NoiseFill.c:29-30: the amplitude does not depend on the quantizer, so finish it here
+        gs[i] = make_float2((sum == 0.0f) ? -1.0f : ulcx_expf(sum / sumw), 0.0f);
     }
     // tails: 8 threads per unit, 5 of them carry one chain each
     int nU = c.C * 4;
@@ -1022,7 +1129,7 @@ __device__ __forceinline__ int write_zone(NybWriter &w, int cur, int end, float 
             if (zr >= 16) {
                 v = zr - 16; if (v > 0x1FF) v = 0x1FF;
                 n = v + 16;
-                if (specOk) { float2 sw = gapSum[cur]; nq = noise_q_from_sums(sw.x, sw.y, quant); }
+                if (specOk) { float amp = gapSum[cur].x; nq = (amp < 0.0f) ? 0 : quant_coef_u(amp * quant, 8); }
                 else nq = get_noise_q(pairs, nextCoded, n, quant);
             }
             specOk = false;                                        // only the first run of a gap was speculated
@@ -1737,7 +1844,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
     int N = c.C * c.BS;
     int ldsEntries = ((size_t)N * 8 <= ULCX_HEAP_LDS_BYTES) ? N : 0;
     size_t heapLds = ldsEntries ? (size_t)N * 8 + (size_t)N / 8 : 0;
-    if (heapLds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_heapsel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heapLds));
+    if (heapLds > 48 * 1024) { CK(hipFuncSetAttribute((const void *)k_heapsel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heapLds)); CK(hipFuncSetAttribute((const void *)k_heapsel_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heapLds)); }
     int fbGrid = NB < ULCX_HEAP_GRID ? NB : ULCX_HEAP_GRID;
     // VBR: one pass.  CBR/ABR: the reference's binary search (ulcEncoder.c:98-110) needs at most
     // ceil(log2(MaxCoef))+1 probes; every block runs its own search in lock step, then one final pass.
@@ -1792,7 +1899,8 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
             CK(hipEventRecord(evFork, st));
             CK(hipStreamWaitEvent(side, evFork, 0));
             UlcxEncCtx cf = c; cf.fbMode = 2;
-            hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, side, cf, ldsEntries);
+            if (ldsEntries) hipLaunchKernelGGL(k_heapsel_pipe, dim3(fbGrid), dim3(64), heapLds, side, cf);
+            else hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, side, cf, ldsEntries);
             int rc = launch_encode(cf, side, fin, false); if (rc) return rc;
             CK(hipEventRecord(evJoin, side));
             if (ev0) MARK();                                   // (k_heapsel interval is empty on the main stream)
@@ -1800,7 +1908,9 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
             rc = launch_encode(cm, st, fin, ev0); if (rc) return rc;
             CK(hipStreamWaitEvent(st, evJoin, 0));
         } else {
-            hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, st, c, ldsEntries);             if (ev0) MARK();
+            if (ldsEntries) hipLaunchKernelGGL(k_heapsel_pipe, dim3(fbGrid), dim3(64), heapLds, st, c);
+            else hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, st, c, ldsEntries);
+            if (ev0) MARK();
             int rc = launch_encode(c, st, fin, ev0); if (rc) return rc;
         }
     }

@@ -95,3 +95,48 @@ __device__ void fft1_dif(float2 *z, int M, const float2 *__restrict__ tw, int ti
         __syncthreads();
     }
 }
+
+// nArr arrays of M points stored back to back (array a at z + a*M)
+__device__ void fftn_dif(float2 *z0, int nArr, int M, const float2 *__restrict__ tw, int tid) {
+    int h = M >> 1;
+    int quarter = M >> 2;
+    int qshift = 31 - __clz(quarter);
+    while (h >= 2) {
+        int q = h >> 1;
+        int stepA = M / (2 * h), stepB = stepA * 2;
+        for (int g = tid; g < nArr * quarter; g += WG) {
+            int a = g >> qshift;
+            int gg = g & (quarter - 1);
+            float2 *z = z0 + a * M;
+            int j = gg & (q - 1);
+            int p0 = (gg - j) * 4 + j;
+            int p1 = p0 + q, p2 = p0 + h, p3 = p2 + q;
+            float2 x0 = z[p0], x1 = z[p1], x2 = z[p2], x3 = z[p3];
+            float2 wA0 = tw[j * stepA], wA1 = tw[(j + q) * stepA], wB = tw[j * stepB];
+            float2 y0 = make_float2(x0.x + x2.x, x0.y + x2.y);
+            float2 y2 = cmulc(make_float2(x0.x - x2.x, x0.y - x2.y), wA0);
+            float2 y1 = make_float2(x1.x + x3.x, x1.y + x3.y);
+            float2 y3 = cmulc(make_float2(x1.x - x3.x, x1.y - x3.y), wA1);
+            z[p0] = make_float2(y0.x + y1.x, y0.y + y1.y);
+            z[p1] = cmulc(make_float2(y0.x - y1.x, y0.y - y1.y), wB);
+            z[p2] = make_float2(y2.x + y3.x, y2.y + y3.y);
+            z[p3] = cmulc(make_float2(y2.x - y3.x, y2.y - y3.y), wB);
+        }
+        __syncthreads();
+        h >>= 2;
+    }
+    if (h == 1) {
+        float2 w0 = tw[0];
+        int half = M >> 1;
+        int hshift = 31 - __clz(half);
+        for (int g = tid; g < nArr * half; g += WG) {
+            int a = g >> hshift;
+            int p = 2 * (g & (half - 1));
+            float2 *z = z0 + a * M;
+            float2 x = z[p], y = z[p + 1];
+            z[p] = make_float2(x.x + y.x, x.y + y.y);
+            z[p + 1] = cmulc(make_float2(x.x - y.x, x.y - y.y), w0);
+        }
+        __syncthreads();
+    }
+}
