@@ -155,3 +155,27 @@ def test_roundtrip_delay_and_snr_at_bench_shape():
     snr = 10 * np.log10((x ** 2).sum() / ((x - y) ** 2).sum())
     assert snr > 12.0, snr
     enc.close(); dec.close()
+
+
+def test_decode_corrupt_blocks_are_rejected_without_hanging():
+    """Corrupt input must come back as 'bits consumed = 0' (ulcDecoder.c:127,139,154) and kill
+    only its own stream; a stream of endless quantizer changes (no coefficient ever produced)
+    must not walk off the slot."""
+    amd = _amd()
+    bs, ch, rate, B, K = 2048, 2, 44100, 6, 4
+    pcm = _streams(B, K, bs, ch, rate, True, seed=8)
+    slot = 2 * ch * bs + 16
+    refs = [oracle_encode_debug(pcm[s], bs, rate, 0, 50.0, slot=slot) for s in range(B)]
+    blocks = np.stack([r["out"] for r in refs]).copy()
+    blocks[1, 2, :] = 0x0F                              # Fh,0h forever: quantizer changes only
+    blocks[3, 1, 2:40] = 0x11                           # long zero runs overrunning the subblock
+    blocks[4, 0, :] = 0xFF
+    dec = amd.BatchDecoder(B, ch, bs, K)
+    got, gbits = dec.decode(blocks)
+    assert (gbits[1, :2] > 0).all() and (gbits[1, 2:] == 0).all()
+    assert gbits[3, 0] > 0 and (gbits[3, 1:] == 0).all()
+    for s in (0, 2, 5):                                 # untouched streams are still bit-exact
+        rc, ref_pcm, ref_bits = oracle_decode_stream(refs[s]["out"], ch, bs)
+        assert np.array_equal(gbits[s], ref_bits) and np.array_equal(got[s], ref_pcm)
+    assert np.isfinite(got).all()
+    dec.close()

@@ -18,9 +18,13 @@
 #include "ulcx_fft.h"
 
 // ---------------------------------------------------------------------------
-struct NybReader {
-    const uint8_t *p; int size;
-    __device__ __forceinline__ unsigned get() {                   // ulcDecoder.c:82-88, low nybble first
+struct NybReader {                                                // ulcDecoder.c:82-88, low nybble first
+    const uint8_t *p; int size;                                   // size in bits, like the reference's counter
+    int limit;                                                    // a valid block never reaches the last 4 bytes of its slot;
+                                                                  // past that the block is corrupt (the reference would run off its buffer)
+    __device__ __forceinline__ void init(const uint8_t *base, int bitpos, int slotBytes) { p = base; size = bitpos; limit = slotBytes * 8 - 32; }
+    __device__ __forceinline__ bool overrun() const { return size > limit; }
+    __device__ __forceinline__ unsigned get() {
         unsigned x = p[size >> 3];
         unsigned n = (size & 4) ? (x >> 4) : (x & 0xF);
         size += 4;
@@ -43,14 +47,10 @@ __device__ __forceinline__ uint32_t xorshift32(uint32_t s) {      // ulcDecoder.
     s ^= s << 13; s ^= s >> 17; s ^= s << 5;
     return s;
 }
-struct CoefWriter {                                               // sequential float stream -> 16-byte stores
-    float *dst; int n; float4 buf;
-    __device__ __forceinline__ void put(float v) {
-        int l = n & 3;
-        if (l == 0) buf.x = v; else if (l == 1) buf.y = v; else if (l == 2) buf.z = v; else buf.w = v;
-        n++;
-        if ((n & 3) == 0) *(float4 *)(dst + n - 4) = buf;
-    }
+struct CoefWriter {                                               // the destination is pre-zeroed: zero runs just skip
+    float *dst; int n;
+    __device__ __forceinline__ void put(float v) { dst[n++] = v; }
+    __device__ __forceinline__ void skip(int k) { n += k; }
 };
 
 // ulcDecoder.c:99-197.  Returns 0 on a run that overruns the subblock (corrupt).
@@ -59,8 +59,9 @@ struct CoefWriter {                                               // sequential 
 template <bool GEN>
 __device__ int decode_subblock(CoefWriter &w, int N, NybReader &r, uint32_t &seed, int &draws) {
     int n, v;
+    bool bad = false;
     v = get_quantizer(r);
-    if (v == ESC_STOP) { if (GEN) { do w.put(0.0f); while (--N); } return 1; }
+    if (v == ESC_STOP) { if (GEN) w.skip(N); return 1; }
     float quant = expand_quantizer(v);
     for (;;) {
         v = (int)r.get();
@@ -77,7 +78,7 @@ __device__ int decode_subblock(CoefWriter &w, int N, NybReader &r, uint32_t &see
             n = (int)r.get() + 1;
             if (n > N) return 0;
             N -= n;
-            if (GEN) { do w.put(0.0f); while (--n); }
+            if (GEN) w.skip(n);
             if (N == 0) break;
             continue;
         }
@@ -87,7 +88,7 @@ __device__ int decode_subblock(CoefWriter &w, int N, NybReader &r, uint32_t &see
             n += 33;
             if (n > N) return 0;
             N -= n;
-            if (GEN) { do w.put(0.0f); while (--n); }
+            if (GEN) w.skip(n);
             if (N == 0) break;
             continue;
         }
@@ -113,6 +114,11 @@ __device__ int decode_subblock(CoefWriter &w, int N, NybReader &r, uint32_t &see
             continue;
         }
         v = get_quantizer(r);
+        // quantizer changes are the only codes that consume no coefficient: bound them by the slot so a
+        // corrupt stream cannot walk off the buffer (every other code shrinks N).  Branch-free on purpose:
+        // an extra early return here cost +80 % kernel time (control-flow restructuring).
+        bad |= (r.size > r.limit);
+        v = bad ? ESC_STOP : v;
         if (v >= 0) { quant = expand_quantizer(v); continue; }
         if (v == ESC_STOP_NOISE) {
             v = (int)r.get() + 1;
@@ -130,9 +136,9 @@ __device__ int decode_subblock(CoefWriter &w, int N, NybReader &r, uint32_t &see
             }
             break;
         }
-        if (v == ESC_STOP) { if (GEN) { do w.put(0.0f); while (--N); } break; }
+        if (v == ESC_STOP) { if (GEN) w.skip(N); break; }
     }
-    return 1;
+    return bad ? 0 : 1;
 }
 
 // Pass 1 — one lane per block: walk the syntax, record where each (channel, subblock)
@@ -140,7 +146,7 @@ __device__ int decode_subblock(CoefWriter &w, int N, NybReader &r, uint32_t &see
 __global__ __launch_bounds__(64) void k_dscan(UlcxDecCtx c) {
     int blk = blockIdx.x * 64 + threadIdx.x;
     if (blk >= c.B * c.K) return;
-    NybReader r; r.p = c.in + (size_t)blk * c.slot; r.size = 0;
+    NybReader r; r.init(c.in + (size_t)blk * c.slot, 0, c.slot);
     int wc = (int)r.get();                                         // ulcDecoder.c:211-216
     if (wc & 0x8) wc |= (int)r.get() << 4;
     else wc |= 1 << 4;
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(64) void k_dgen(UlcxDecCtx c) {
         pat >>= 4;
         if (!pat) return;
     }
-    NybReader r; r.p = c.in + (size_t)blk * c.slot; r.size = c.unitStart[(size_t)blk * c.C * 4 + ch * 4 + j];
+    NybReader r; r.init(c.in + (size_t)blk * c.slot, c.unitStart[(size_t)blk * c.C * 4 + ch * 4 + j], c.slot);
     uint32_t seed = rng_jump(c.jump, c.blockSeed[blk], (uint32_t)c.unitDraws[(size_t)blk * c.C * 4 + ch * 4 + j]);
     CoefWriter w; w.dst = c.coef + (size_t)blk * c.C * c.BS + (size_t)ch * c.BS + off; w.n = 0;
     int draws = 0;
@@ -356,6 +362,7 @@ int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev) {
     if (ev) CK(hipEventRecord(ev[stage++], st));
     hipLaunchKernelGGL(k_dseed, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
     if (ev) CK(hipEventRecord(ev[stage++], st));
+    CK(hipMemsetAsync(c.coef, 0, sizeof(float) * (size_t)NB * c.C * c.BS, st));     // zero runs are not written by k_dgen
     hipLaunchKernelGGL(k_dgen, dim3((NB * c.C * 4 + 63) / 64), dim3(64), 0, st, c);
     if (ev) CK(hipEventRecord(ev[stage++], st));
     size_t lds = ulcx_dec_lds_bytes(c.BS, c.C);

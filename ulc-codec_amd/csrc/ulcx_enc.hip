@@ -96,37 +96,38 @@ __global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c) {
 // WindowControl.c:72-88: forward one-pole smear, the only sample-rate recurrence that
 // crosses blocks.  One lane per stream (both filters), strictly sequential in time.
 __global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c) {
-    int s = blockIdx.x * 64 + threadIdx.x;
+    // lane = (stream, filter): 32 streams x {HP, BP} per wave; the two one-pole chains are independent
+    int gl = blockIdx.x * 64 + threadIdx.x;
+    int s = gl >> 1, f = gl & 1;
     bool live = s < c.B;
-    float2 *v = c.env + env_idx(c, s, 0);
-    float eh = live ? c.wcs[s].tf[0] : 0.0f, eb = live ? c.wcs[s].tf[1] : 0.0f;
+    float *v = (float *)(c.env + env_idx(c, live ? s : 0, 0)) + f;     // this lane's float inside each {hp,bp} pair
+    float env = live ? c.wcs[s].tf[f] : 0.0f;
+    float cc = f ? c.cBP : c.cHP;
     int n = c.K * c.BS;
     constexpr int U = 16, D = 4;          // D batches of U steps in flight: one wave per CU must cover HBM latency by itself
-    float2 x[D][U];
+    float x[D][U];
 #pragma unroll
-    for (int b = 0; b < D - 1; b++)
+    for (int b2 = 0; b2 < D - 1; b2++)
 #pragma unroll
-        for (int j = 0; j < U; j++) { int t = b * U + j; x[b][j] = v[(size_t)(t < n ? t : 0) * 64]; }
+        for (int j = 0; j < U; j++) { int t = b2 * U + j; x[b2][j] = v[(size_t)(t < n ? t : 0) * 128]; }
     for (int i = 0; i < n; i += D * U) {
 #pragma unroll
-        for (int b = 0; b < D; b++) {
-            int base = i + b * U;
+        for (int b2 = 0; b2 < D; b2++) {
+            int base = i + b2 * U;
             int pf = base + (D - 1) * U;            // batch to prefetch into the slot freed last
 #pragma unroll
-            for (int j = 0; j < U; j++) { int t = pf + j; x[(b + D - 1) % D][j] = v[(size_t)(t < n ? t : 0) * 64]; }
+            for (int j = 0; j < U; j++) { int t = pf + j; x[(b2 + D - 1) % D][j] = v[(size_t)(t < n ? t : 0) * 128]; }
             if (base < n) {
 #pragma unroll
-                for (int j = 0; j < U; j++) {
-                    float dh = x[b][j].x - eh; eh += dh * c.cHP;
-                    float db = x[b][j].y - eb; eb += db * c.cBP;
-                    x[b][j] = make_float2(eh, eb);
-                }
+                for (int j = 0; j < U; j++) { float d = x[b2][j] - env; env += d * cc; x[b2][j] = env; }
+                if (live) {
 #pragma unroll
-                for (int j = 0; j < U; j++) v[(size_t)(base + j) * 64] = x[b][j];
+                    for (int j = 0; j < U; j++) v[(size_t)(base + j) * 128] = x[b2][j];
+                }
             }
         }
     }
-    if (live) { c.wcs[s].tf[0] = eh; c.wcs[s].tf[1] = eb; }          // state for the next call
+    if (live) c.wcs[s].tf[f] = env;                                   // state for the next call
 }
 
 // WindowControl.c:90-104: backward sweep from each block's forward end state.
@@ -876,6 +877,7 @@ __global__ __launch_bounds__(64) void k_heapsel_pipe(UlcxEncCtx c) {
 // the serial kernel would compute; it checks the assumption and recomputes if it is off
 // (a kept coefficient collapsed, a noise run fell back to a zero run, ...).
 // ---------------------------------------------------------------------------
+#define E_GAPCAP 1024      // gaps >= 16 per block: at most N/17 of them; N <= 16384 here
 __global__ __launch_bounds__(WG) void k_gapsums(UlcxEncCtx c, int finalPass) {
     extern __shared__ uint32_t gsm[];
     int blk = blockIdx.x, tid = threadIdx.x;
@@ -895,9 +897,18 @@ __global__ __launch_bounds__(WG) void k_gapsums(UlcxEncCtx c, int finalPass) {
     }
     __syncthreads();
     float2 *gs = c.gapSum + (size_t)blk * N;
-    // gaps in front of kept coefficients
-    for (int i = tid; i < N; i += WG) {
-        if (!((kw[i >> 5] >> (i & 31)) & 1)) continue;
+    // gaps in front of kept coefficients.  Pass 1: every thread scans its slots and queues the
+    // kept coefficients whose gap is long enough for a noise run; pass 2: one queued gap per
+    // thread, so a wave's time is its longest gap once, not once per strided slot.
+    uint32_t *wl = kw + N / 32;                            // work list: (start << 16 | i - start) ... stored as two words
+    int *wcount = (int *)(wl + 2 * E_GAPCAP);
+    if (tid == 0) *wcount = 0;
+    __syncthreads();
+    for (int hw = tid; hw < N / 16; hw += WG) {              // 16 coefficient slots per step: only set bits are visited
+      uint32_t bitsHere = (kw[hw >> 1] >> (16 * (hw & 1))) & 0xFFFFu;
+      while (bitsHere) {
+        int i = hw * 16 + __ffs(bitsHere) - 1;
+        bitsHere &= bitsHere - 1;
         // start of the unit containing i
         int ch = i / c.BS, r = i - ch * c.BS;
         unsigned pat = ulcx_pattern(wc);
@@ -918,6 +929,16 @@ __global__ __launch_bounds__(WG) void k_gapsums(UlcxEncCtx c, int finalPass) {
         }
         int start = prev + 1, zr = i - start;
         if (zr < 16) continue;
+        int slot = atomicAdd(wcount, 1);
+        if (slot < E_GAPCAP) { wl[2 * slot] = (uint32_t)i; wl[2 * slot + 1] = (uint32_t)start; }
+        else gs[i] = make_float2(-2.0f, 0.0f);             // list full (cannot happen for N/16 <= cap): mark "not computed"
+      }
+    }
+    __syncthreads();
+    int nw = *wcount; if (nw > E_GAPCAP) nw = E_GAPCAP;
+    for (int t = tid; t < nw; t += WG) {
+        int i = (int)wl[2 * t], start = (int)wl[2 * t + 1];
+        int zr = i - start;
         int v = zr - 16; if (v > 0x1FF) v = 0x1FF;
         int n = v + 16;
         const float2 *d = (const float2 *)(pairs + (start / 2) * 2);
@@ -1129,7 +1150,8 @@ __device__ __forceinline__ int write_zone(NybWriter &w, int cur, int end, float 
             if (zr >= 16) {
                 v = zr - 16; if (v > 0x1FF) v = 0x1FF;
                 n = v + 16;
-                if (specOk) { float amp = gapSum[cur].x; nq = (amp < 0.0f) ? 0 : quant_coef_u(amp * quant, 8); }
+                float amp = specOk ? gapSum[cur].x : -2.0f;
+                if (amp > -1.5f) nq = (amp < 0.0f) ? 0 : quant_coef_u(amp * quant, 8);
                 else nq = get_noise_q(pairs, nextCoded, n, quant);
             }
             specOk = false;                                        // only the first run of a gap was speculated
@@ -1817,7 +1839,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
     {
         int SG = (c.B + 63) / 64;
         hipLaunchKernelGGL(k_wc_energy, dim3((unsigned)(SG * ((c.K * c.BS) / 64))), dim3(WG), 0, st, c);   MARK();
-        hipLaunchKernelGGL(k_wc_forward, dim3(SG), dim3(64), 0, st, c);                                    MARK();
+        hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, st, c);                                    MARK();
         hipLaunchKernelGGL(k_wc_backward, dim3(SG * c.K), dim3(64), 0, st, c);                             MARK();
         hipLaunchKernelGGL(k_wc_integrate, dim3((c.B + 63) / 64), dim3(64), 0, st, c);                     MARK();
         hipLaunchKernelGGL(k_wc_decide, dim3((NB + 63) / 64), dim3(64), 0, st, c);                         MARK();
@@ -1869,7 +1891,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
             hipLaunchKernelGGL(k_encode_wave, dim3(nUnits), dim3(64), lds, s2, cc, fin);
         }
         if (cc.useGapSums) {
-            size_t glds = (size_t)N * 4 + N / 8;
+            size_t glds = (size_t)N * 4 + N / 8 + 8 * E_GAPCAP + 16;
             if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
             hipLaunchKernelGGL(k_gapsums, dim3(NB), dim3(WG), glds, s2, cc, fin);
         }
