@@ -148,7 +148,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     // experimental fused select+encode+pack kernel (k_selenc): measured slower than the lane-per-unit
     // kernels on MI355X (profiles/r01 notes in DESIGN.md §6), so opt-in only.
     c.useFused = 0;
-    c.useWave = 0;        // k_encode_wave: correct but latency-bound; opt-in with ULCX_WAVE=1
+    c.useWave = 1;        // wave-per-unit encode pass fed by k_gapsums; ULCX_WAVE=0 selects the serial lane-per-unit kernel
     c.useGapSums = ((size_t)cb * 4 + cb / 8 + 8192 + 16 <= 150 * 1024 && cb <= 16384) ? 1 : 0;
     if (const char *ev = getenv("ULCX_GAPSUMS")) c.useGapSums = (ev[0] != '0');
     DA(c.gapSum, NB * cb, false);

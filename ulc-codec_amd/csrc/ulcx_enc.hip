@@ -683,9 +683,12 @@ __global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
 // One WAVE per block, keys held in registers (R = N/64 per lane): no workgroup barriers,
 // the 256-bin histogram of each radix pass lives in a private 1 KB LDS slice.
 template <int R>
-__global__ __launch_bounds__(64) void k_select_wave(UlcxEncCtx c, int finalPass) {
-    __shared__ int hist[256];
-    int blk = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass) {
+    __shared__ int histAll[4][256];
+    int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int *hist = histAll[wv];
+    int blk = blockIdx.x * 4 + wv;                        // 4 waves per workgroup: fewer, fatter dispatches
+    if (blk >= c.B * c.K) return;
     if (!finalPass && c.cbrDone[blk]) return;
     const int N = R * 64;
     int kSel = c.nout[blk];
@@ -1270,8 +1273,10 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
     return x - v;
 }
 
-// run codes of one gap (Encode.c:118-188); nybbles appended LSB-first to (lo,hi), count in cnt
-__device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const float *coefU, const float *pairL,
+// run codes of one gap (Encode.c:118-188); nybbles appended LSB-first to (lo,hi), count in cnt.
+// amp0 >= -1: noise amplitude of the gap's FIRST run already evaluated by k_gapsums (-1 = "Sum == 0");
+// anything else (and every later run of the gap) is summed here from the pairs in HBM.
+__device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const float *coefU, const float *pairU, float amp0,
                                           unsigned long long &lo, unsigned long long &hi, int &cnt) {
     auto put = [&](unsigned x) {
         x &= 0xF;
@@ -1295,8 +1300,10 @@ __device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const flo
         if (zr >= 16) {
             v = zr - 16; if (v > 0x1FF) v = 0x1FF;
             n = v + 16;
-            nq = get_noise_q(pairL, nc, n, quant);
+            if (amp0 > -1.5f) nq = (amp0 < 0.0f) ? 0 : quant_coef_u(amp0 * quant, 8);
+            else nq = get_noise_q(pairU, nc, n, quant);
         }
+        amp0 = -2.0f;
         if (nq) { put(0x8); put((unsigned)(v >> 5)); put((unsigned)(v >> 1)); put((unsigned)((v & 1) | ((nq - 1) << 1))); }
         else if (zr < 33) { v = zr - 1; if (v > 0xF) v = 0xF; n = v + 1; put(0x0); put((unsigned)v); }
         else { v = zr - 33; if (v > 0xFF) v = 0xFF; n = v + 33; put(0x1); put((unsigned)(v >> 4)); put((unsigned)v); }
@@ -1305,73 +1312,72 @@ __device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const flo
     }
 }
 
-__global__ __launch_bounds__(64) void k_encode_wave(UlcxEncCtx c, int finalPass) {
-    extern __shared__ float e2[];
-    int gid = blockIdx.x, lane = threadIdx.x;
-    int j = gid & 3, ch = (gid >> 2) % c.C, blk = gid / (4 * c.C);
-    if (!finalPass && c.cbrDone[blk]) return;
-    int s = blk / c.K, k = blk % c.K;
-    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+// wave-local ordering of LDS traffic (all 64 lanes run in lockstep; LDS ops of one wave complete in order)
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+__device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, int ch, int j, int wc, int lane, float *e2) {
+    int gid = (blk * c.C + ch) * 4 + j;
     int d, off, S;
     if (!unit_geom(wc, j, c.BS, d, off, S)) { if (lane == 0) c.unitNyb[gid] = 0; return; }
     const int N = c.C * c.BS;
     const int ubase = ch * c.BS + off;                       // unit offset inside the block arrays
     const float *coefU = c.coef + (size_t)blk * N + ubase;
-    const float *pairG = c.npair + (size_t)blk * N + ubase;
-    const uint32_t *keepB = c.keep + (size_t)blk * (N / 32);
+    const float *pairU = c.npair + (size_t)blk * N + ubase;
+    const float2 *gapU = c.gapSum + (size_t)blk * N + ubase;
+    const uint32_t *keepU = c.keep + (size_t)blk * (N / 32) + (ubase >> 5);
 
-    float    *pairL = e2;                                    // S floats
-    float    *kval  = pairL + S;                             // E2_KCAP  (later: quantised value bits)
+    float    *kval  = e2;                                    // E2_KCAP  (later: quantised value bits)
     float    *zmax  = kval + E2_KCAP;                        // E2_ZCAP
     int      *zpre  = (int *)(zmax + E2_ZCAP);               // E2_ZCAP  inclusive prefix of quantizer-code nybbles
-    uint16_t *kidx  = (uint16_t *)(zpre + E2_ZCAP);          // E2_KCAP
+    uint16_t *kidx  = (uint16_t *)(zpre + E2_ZCAP);          // E2_KCAP  (bit 15 later: "previous kept item was coded")
     uint16_t *kz    = kidx + E2_KCAP;                        // E2_KCAP
     int8_t   *zqi   = (int8_t *)(kz + E2_KCAP);              // E2_ZCAP
     uint8_t  *nyb   = (uint8_t *)(zqi + E2_ZCAP);            // E2_NYBCAP (one nybble per byte)
 
-    // A. noise pairs, coefficients and kept-set words of the unit -> LDS (coalesced, all loads in flight at once)
-    float    *coefL = (float *)(nyb + E2_NYBCAP);            // S floats
-    uint32_t *keepL = (uint32_t *)(coefL + S);               // S/32 + 1 words
-    for (int i = lane; i < S / 2; i += 64) ((float2 *)pairL)[i] = ((const float2 *)pairG)[i];
-    for (int i = lane; i < S / 4; i += 64) ((float4 *)coefL)[i] = ((const float4 *)coefU)[i];
-    for (int i = lane; i < S / 32; i += 64) keepL[i] = keepB[(ubase >> 5) + i];
-    __syncthreads();
-
-    // B. compact the kept coefficients (rank < nOutCoef)
+    // B. compact the kept coefficients (rank < nOutCoef); loads issued 8 chunks at a time
     int nK = 0;
-    for (int base = 0; base < S; base += 64) {
-        int i = base + lane;
-        bool kp = (keepL[i >> 5] >> (i & 31)) & 1;
-        float cv = coefL[i];
-        unsigned long long m = __ballot(kp);
-        int pos = nK + __popcll(m & ((1ull << lane) - 1));
-        if (kp && pos < E2_KCAP) { kidx[pos] = (uint16_t)i; kval[pos] = cv; }
-        nK += __popcll(m);
+    for (int base = 0; base < S; base += 512) {
+        float cv[8]; uint32_t kwv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            int i = base + u * 64 + lane;
+            bool in = i < S;
+            cv[u] = in ? coefU[i] : 0.0f;
+            kwv[u] = in ? keepU[i >> 5] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            int i = base + u * 64 + lane;
+            bool kp = (i < S) && ((kwv[u] >> (i & 31)) & 1);
+            unsigned long long m = __ballot(kp);
+            int pos = nK + __popcll(m & ((1ull << lane) - 1));
+            if (kp && pos < E2_KCAP) { kidx[pos] = (uint16_t)i; kval[pos] = cv[u]; }
+            nK += __popcll(m);
+        }
     }
     bool overflow = nK > E2_KCAP;
-    __syncthreads();
+    WAVE_SYNC();
 
     // C. zone segmentation: greedy scan (Encode.c:218-269), uniform across the wave
     int nZ = 0;
     if (!overflow) {
         float qmin = 1000.0f, qmax = -1000.0f;
-        int zstart = -1;
         for (int base = 0; base < nK; base += 64) {
             float mine = (base + lane < nK) ? kval[base + lane] : 0.0f;
             int cntc = (nK - base < 64) ? nK - base : 64;
+            int myz = 0;
             for (int t = 0; t < cntc; t++) {
                 float lvl = fabsf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mine), t)));
                 float nmin = (lvl < qmin) ? lvl : qmin;
                 float nmax = (lvl > qmax) ? lvl : qmax;
-                if (zstart == -1) zstart = base + t;
                 if (nmax > nmin * 4.0f) {
                     if (nZ < E2_ZCAP && lane == 0) zmax[nZ] = qmax;
                     nZ++;
-                    zstart = base + t;
                     qmin = qmax = lvl;
                 } else { qmin = nmin; qmax = nmax; }
-                if (lane == t) kz[base + t] = (uint16_t)nZ;
+                if (lane == t) myz = nZ;
             }
+            if (base + lane < nK) kz[base + lane] = (uint16_t)myz;
         }
         if (qmax > 0.0f * 4.0f) {                            // end sentinel: NewMin = 0 (Encode.c:226-238)
             if (nZ < E2_ZCAP && lane == 0) zmax[nZ] = qmax;
@@ -1379,7 +1385,7 @@ __global__ __launch_bounds__(64) void k_encode_wave(UlcxEncCtx c, int finalPass)
         }
         if (nZ > E2_ZCAP) overflow = true;
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     // D. quantizer per zone + nybbles of its change code (Encode.c:240-244, 32-45)
     if (!overflow) {
@@ -1388,7 +1394,7 @@ __global__ __launch_bounds__(64) void k_encode_wave(UlcxEncCtx c, int finalPass)
             int z = base + lane;
             int qn = 0;
             if (z < nZ) { int qi = build_quantizer(zmax[z]); zqi[z] = (int8_t)qi; }
-            __syncthreads();
+            WAVE_SYNC();
             if (z < nZ) {
                 int qi = zqi[z];
                 int prev = (z > 0) ? zqi[z - 1] : -1;
@@ -1399,11 +1405,14 @@ __global__ __launch_bounds__(64) void k_encode_wave(UlcxEncCtx c, int finalPass)
             run += tot;
         }
     }
-    __syncthreads();
+    WAVE_SYNC();
 
-    // E. quantise kept items, drop the ones that collapse (Encode.c:114), compact in place
+    // E. quantise kept items, drop the ones that collapse (Encode.c:114), compact in place.
+    //    Bit 15 of the compacted index records "the kept item right before me was coded too",
+    //    i.e. the gap in front of me is exactly the one k_gapsums speculated on.
     int nC = 0;
     if (!overflow) {
+        bool prevCodedCarry = true;                          // before the first kept item: gap starts at the unit start, as speculated
         for (int base = 0; base < nK; base += 64) {
             int kk = base + lane;
             bool coded = false; int qn = 0, idx = 0, z = 0;
@@ -1414,12 +1423,17 @@ __global__ __launch_bounds__(64) void k_encode_wave(UlcxEncCtx c, int finalPass)
                 qn = quant_coef(cq, 7);
             }
             unsigned long long m = __ballot(coded);
+            unsigned long long valid = __ballot(kk < nK);
+            // was the previous kept item (kk-1) coded?
+            bool prevCoded = (lane == 0) ? prevCodedCarry : (((m >> (lane - 1)) & 1) != 0);
             int pos = nC + __popcll(m & ((1ull << lane) - 1));
-            if (coded) { kidx[pos] = (uint16_t)idx; kz[pos] = (uint16_t)z; ((int *)kval)[pos] = qn; }
+            if (coded) { kidx[pos] = (uint16_t)(idx | (prevCoded ? 0x8000 : 0)); kz[pos] = (uint16_t)z; ((int *)kval)[pos] = qn; }
+            int lastValid = 63 - __clzll(valid);
+            prevCodedCarry = ((m >> lastValid) & 1) != 0;
             nC += __popcll(m);
         }
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     // F+H. gaps -> run codes; positions by prefix sum; emission
     int total = 0;
@@ -1428,12 +1442,16 @@ __global__ __launch_bounds__(64) void k_encode_wave(UlcxEncCtx c, int finalPass)
             int m = base + lane;
             unsigned long long lo = 0, hi = 0; int cnt = 0, pre = 0, z = 0, zp = -1, qn = 0;
             if (m < nC) {
-                int idx = kidx[m];
-                int start = (m > 0) ? kidx[m - 1] + 1 : 0;
+                int raw = kidx[m];
+                int idx = raw & 0x7FFF;
+                int start = (m > 0) ? (kidx[m - 1] & 0x7FFF) + 1 : 0;
                 z = kz[m]; zp = (m > 0) ? kz[m - 1] : -1;
                 qn = ((int *)kval)[m];
                 pre = zpre[z] - ((zp >= 0) ? zpre[zp] : 0);
-                gap_codes(start, idx - start, (float)(1u << zqi[z]), coefL, pairL, lo, hi, cnt);
+                int zr = idx - start;
+                float amp0 = -2.0f;
+                if (zr >= 16 && (raw & 0x8000) && c.useGapSums) amp0 = gapU[idx].x;
+                gap_codes(start, zr, (float)(1u << zqi[z]), coefU, pairU, amp0, lo, hi, cnt);
             }
             int mine = (m < nC) ? pre + cnt + 1 : 0;
             int tot, ex = wave_excl_scan(mine, lane, tot);
@@ -1459,51 +1477,34 @@ __global__ __launch_bounds__(64) void k_encode_wave(UlcxEncCtx c, int finalPass)
     // G. tail (Encode.c:271-312)
     if (!overflow) {
         int zlast = (nC > 0) ? kz[nC - 1] : -1;
-        int nextCoded = (nC > 0) ? kidx[nC - 1] + 1 : 0;
+        int nextCoded = (nC > 0) ? (kidx[nC - 1] & 0x7FFF) + 1 : 0;
         int n = S - nextCoded;
         int prevQ = (nZ > 0) ? zqi[nZ - 1] : -1;
         // quantizer codes of zones that closed after the last coded coefficient
         int qtail = ((nZ > 0) ? zpre[nZ - 1] : 0) - ((zlast >= 0) ? zpre[zlast] : 0);
         int nq = 0, nd = 0;
         if (n > 4 && prevQ != -1 && n >= 16) {
-            // NoiseFill.c:41-94: five ordered f32 sums, one per lane 0..4
-            const float2 *dd = (const float2 *)(pairL + (nextCoded / 2) * 2);
-            int np = (n + (nextCoded & 1) + 1) / 2;
-            float acc = 0.0f;
-            if (lane < 5) {
-                int i = 0;
-                for (; i + 8 <= np; i += 8) {
-                    float2 pv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) pv[u] = dd[i + u];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        float x = (i + u) * 2.0f;
-                        float wx = pv[u].x * x;
-                        float term = (lane == 0) ? wx : (lane == 1) ? wx * x : (lane == 2) ? x * pv[u].y : (lane == 3) ? pv[u].y : pv[u].x;
+            const float *ts = c.tailSum + (size_t)gid * 8;
+            float sx, sx2, sxy, sy, sw;
+            if (c.useGapSums && __float_as_int(ts[5]) == ubase + nextCoded) {
+                sx = ts[0]; sx2 = ts[1]; sxy = ts[2]; sy = ts[3]; sw = ts[4];
+            } else {
+                // NoiseFill.c:41-62: five ordered f32 sums, one per lane 0..4 (rare: the speculated tail start was off)
+                const float2 *dd = (const float2 *)(pairU + (nextCoded / 2) * 2);
+                int np = (n + (nextCoded & 1) + 1) / 2;
+                float acc = 0.0f;
+                if (lane < 5) {
+                    for (int i = 0; i < np; i++) {
+                        float2 pv = dd[i];
+                        float x = i * 2.0f;
+                        float wx = pv.x * x;
+                        float term = (lane == 0) ? wx : (lane == 1) ? wx * x : (lane == 2) ? x * pv.y : (lane == 3) ? pv.y : pv.x;
                         acc += term;
                     }
                 }
-                for (; i < np; i++) {
-                    float2 pv = dd[i];
-                    float x = i * 2.0f;
-                    float wx = pv.x * x;
-                    float term = (lane == 0) ? wx : (lane == 1) ? wx * x : (lane == 2) ? x * pv.y : (lane == 3) ? pv.y : pv.x;
-                    acc += term;
-                }
+                sx = __shfl(acc, 0); sx2 = __shfl(acc, 1); sxy = __shfl(acc, 2); sy = __shfl(acc, 3); sw = __shfl(acc, 4);
             }
-            float sx = __shfl(acc, 0), sx2 = __shfl(acc, 1), sxy = __shfl(acc, 2), sy = __shfl(acc, 3), sw = __shfl(acc, 4);
-            float q = (float)(1u << prevQ);
-            float det = sw * sx2 - sx * sx;
-            if (det != 0.0f) {
-                float amp = (sx2 * sy - sx * sxy) / det;
-                float dec = (sw * sxy - sx * sy) / det;
-                amp = ulcx_expf(amp);
-                dec = (dec < 0.0f) ? ulcx_expf(dec) : 1.0f;
-                int tq = quant_coef_u(amp * q * 4.0f, 16);
-                int td = quant_u((dec - 1.0f) * -0x1.0p19f);
-                if (td) { if (td > 0xFF) td = 0xFF; nq = tq; nd = td; }
-            }
+            hfext_from_sums(sx, sx2, sxy, sy, sw, (float)(1u << prevQ), nq, nd);
         }
         int tailN = 0;
         if (n > 4) tailN = ((prevQ != -1) ? 1 : 0) + (nq ? 4 : 2);
@@ -1532,7 +1533,7 @@ __global__ __launch_bounds__(64) void k_encode_wave(UlcxEncCtx c, int finalPass)
         if (lane == 0) atomicOr(&c.slow[blk], 4);
         return;
     }
-    __syncthreads();
+    WAVE_SYNC();
     if (lane == 0) c.unitNyb[gid] = total;
     if (!finalPass) return;
     // I. nybbles -> bytes in the unit's staging row (same layout k_encode_units writes)
@@ -1542,6 +1543,27 @@ __global__ __launch_bounds__(64) void k_encode_wave(UlcxEncCtx c, int finalPass)
         unsigned lo4 = nyb[2 * b];
         unsigned hi4 = (2 * b + 1 < total) ? nyb[2 * b + 1] : 0;
         dst[b] = (uint8_t)(lo4 | (hi4 << 4));
+    }
+}
+
+
+// 4 waves per workgroup (single-wave workgroups are dispatch-rate bound: ~12 ns each on MI355X),
+// one wave per (block, channel), looping over that channel's subblocks.
+__global__ __launch_bounds__(256) void k_encode_wave(UlcxEncCtx c, int finalPass, int ldsPerWave) {
+    extern __shared__ float e2all[];
+    int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int u = blockIdx.x * 4 + wv;                             // (block, channel) index
+    if (u >= c.B * c.K * c.C) return;
+    int blk = u / c.C, ch = u - blk * c.C;
+    if (!finalPass && c.cbrDone[blk]) return;
+    if (c.fbMode == 1 && c.isFb[blk]) return;
+    if (c.fbMode == 2 && !c.isFb[blk]) return;
+    int s = blk / c.K, k = blk % c.K;
+    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+    float *e2 = (float *)((char *)e2all + (size_t)wv * ldsPerWave);
+    for (int j = 0; j < 4; j++) {
+        encode_unit_wave(c, finalPass, blk, ch, j, wc, lane, e2);
+        WAVE_SYNC();
     }
 }
 
@@ -1876,24 +1898,24 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
         int R = N / 64;
         if (c.useFused) return false;
         switch (R) {
-            case 64: hipLaunchKernelGGL(k_select_wave<64>, dim3(NB), dim3(64), 0, st, c, fin); return true;
-            case 32: hipLaunchKernelGGL(k_select_wave<32>, dim3(NB), dim3(64), 0, st, c, fin); return true;
-            case 16: hipLaunchKernelGGL(k_select_wave<16>, dim3(NB), dim3(64), 0, st, c, fin); return true;
-            case 8:  hipLaunchKernelGGL(k_select_wave<8>,  dim3(NB), dim3(64), 0, st, c, fin); return true;
-            case 4:  hipLaunchKernelGGL(k_select_wave<4>,  dim3(NB), dim3(64), 0, st, c, fin); return true;
+            case 64: hipLaunchKernelGGL(k_select_wave<64>, dim3((NB + 3) / 4), dim3(256), 0, st, c, fin); return true;
+            case 32: hipLaunchKernelGGL(k_select_wave<32>, dim3((NB + 3) / 4), dim3(256), 0, st, c, fin); return true;
+            case 16: hipLaunchKernelGGL(k_select_wave<16>, dim3((NB + 3) / 4), dim3(256), 0, st, c, fin); return true;
+            case 8:  hipLaunchKernelGGL(k_select_wave<8>, dim3((NB + 3) / 4), dim3(256), 0, st, c, fin); return true;
+            case 4:  hipLaunchKernelGGL(k_select_wave<4>, dim3((NB + 3) / 4), dim3(256), 0, st, c, fin); return true;
             default: return false;
         }
     };
     auto launch_encode = [&](UlcxEncCtx cc, hipStream_t s2, int fin, bool ev0) -> int {
-        if (cc.useWave && !cc.useFused) {
-            CK(hipMemsetAsync(cc.slow, 0, sizeof(int) * (size_t)NB, s2));
-            size_t lds = (size_t)cc.BS * 8 + cc.BS / 8 + E2_KCAP * 4 + E2_ZCAP * 8 + E2_KCAP * 4 + E2_ZCAP + E2_NYBCAP + 64;
-            hipLaunchKernelGGL(k_encode_wave, dim3(nUnits), dim3(64), lds, s2, cc, fin);
-        }
         if (cc.useGapSums) {
             size_t glds = (size_t)N * 4 + N / 8 + 8 * E_GAPCAP + 16;
             if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
             hipLaunchKernelGGL(k_gapsums, dim3(NB), dim3(WG), glds, s2, cc, fin);
+        }
+        if (cc.useWave && !cc.useFused) {
+            int ldsW = E2_KCAP * 4 + E2_ZCAP * 8 + E2_KCAP * 4 + E2_ZCAP + E2_NYBCAP + 64;
+            int nBC = NB * cc.C;
+            hipLaunchKernelGGL(k_encode_wave, dim3((nBC + 3) / 4), dim3(256), (size_t)ldsW * 4, s2, cc, fin, ldsW);
         }
         hipLaunchKernelGGL(k_encode_units, dim3((nUnits + 63) / 64), dim3(64), 0, s2, cc, fin);
         if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
@@ -1903,11 +1925,12 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
     };
     // Tie-straddle blocks (~4e-4 of all) need a ~7 ms single-lane heapsort replay; in VBR (one pass)
     // it runs on a side stream next to the encode pass of all other blocks, then the streams join.
-    bool async_fb = (side != nullptr) && (c.mode == ULCX_MODE_VBR) && !c.useFused && !c.useWave;
+    bool async_fb = (side != nullptr) && (c.mode == ULCX_MODE_VBR) && !c.useFused;
     for (int p = 0; p <= probes; p++) {
         int fin = (p == probes) ? 1 : 0;
         bool ev0 = (p == 0);
         CK(hipMemsetAsync(c.fbCount, 0, sizeof(int), st));
+        if (c.useWave && !c.useFused) CK(hipMemsetAsync(c.slow, 0, sizeof(int) * (size_t)NB, st));   // before the streams fork
         if (c.useFused) {
             int stageBytes = 2048 * c.C;
             size_t lds = (size_t)N * 8 + N / 8 + stageBytes + 256 * 4 + c.C * 16 + 16;
