@@ -71,18 +71,29 @@ __global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c) {
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int r = tt * 64 + lane;                              // k*BS + n
     int t = r - c.BS / 2;                                // centre sample
+#pragma unroll 4
     for (int sl = wv; sl < 64; sl += 4) {
         int s = sg * 64 + sl;
         float2 v = make_float2(0.0f, 0.0f);
         if (s < c.B) {
             const float *p0 = smp_ptr(c, s, t - 1), *p1 = smp_ptr(c, s, t), *p2 = smp_ptr(c, s, t + 1);
             float ehp = 0.0f, ebp = 0.0f;
-            for (int ch = 0; ch < c.C; ch++) {
-                float t0 = ms_sample(p0, ch, c.C), t1 = ms_sample(p1, ch, c.C), t2 = ms_sample(p2, ch, c.C);
-                float hp = -t0 + 2 * t1 - t2;
-                float bp = -t0 + t2;
-                ehp += hp * hp;
-                ebp += bp * bp;
+            if (c.C == 2) {                                // stereo fast path: three 8-byte loads
+                float2 a = *(const float2 *)p0, b = *(const float2 *)p1, d = *(const float2 *)p2;
+                float m0 = (a.x + a.y) * 0.5f, m1 = (b.x + b.y) * 0.5f, m2 = (d.x + d.y) * 0.5f;
+                float s0 = (a.x - a.y) * 0.5f, s1 = (b.x - b.y) * 0.5f, s2 = (d.x - d.y) * 0.5f;
+                float hp = -m0 + 2 * m1 - m2, bp = -m0 + m2;
+                ehp += hp * hp; ebp += bp * bp;
+                hp = -s0 + 2 * s1 - s2; bp = -s0 + s2;
+                ehp += hp * hp; ebp += bp * bp;
+            } else {
+                for (int ch = 0; ch < c.C; ch++) {
+                    float t0 = ms_sample(p0, ch, c.C), t1 = ms_sample(p1, ch, c.C), t2 = ms_sample(p2, ch, c.C);
+                    float hp = -t0 + 2 * t1 - t2;
+                    float bp = -t0 + t2;
+                    ehp += hp * hp;
+                    ebp += bp * bp;
+                }
             }
             v = make_float2(sqrtf(ehp), sqrtf(ebp));
         }
@@ -425,12 +436,18 @@ __global__ __launch_bounds__(64) void k_cplx(UlcxEncCtx c) {
     int n = c.C * c.BS;
     const float4 *p = (const float4 *)(c.coef + (size_t)blk * n);
     float cx = 0.0f, cw = 0.0f;
-    for (int i = 0; i < n / 4; i++) {
-        float4 v = p[i];
-        cx += v.x * v.x; cw += fabsf(v.x);
-        cx += v.y * v.y; cw += fabsf(v.y);
-        cx += v.z * v.z; cw += fabsf(v.z);
-        cx += v.w * v.w; cw += fabsf(v.w);
+    for (int i = 0; i < n / 4; i += 4) {                  // n is a multiple of 256: 4 x 16-byte loads in flight per step
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) q[u] = p[i + u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float4 v = q[u];
+            cx += v.x * v.x; cw += fabsf(v.x);
+            cx += v.y * v.y; cw += fabsf(v.y);
+            cx += v.z * v.z; cw += fabsf(v.z);
+            cx += v.w * v.w; cw += fabsf(v.w);
+        }
     }
     if (cx != 0.0f) {
         cx = ulcx_logf((cw * cw) / cx) / c.cplxScale;
@@ -469,7 +486,21 @@ __global__ __launch_bounds__(64) void k_cplx(UlcxEncCtx c) {
 struct LineSum { int end; double fl, pk, pw; };
 __device__ __forceinline__ void linesum_advance(const float *src, LineSum &ls, int end) {
     double fl = ls.fl, pk = ls.pk, pw = ls.pw;
-    for (int l = ls.end; l < end; l++) {
+    int l = ls.end;
+    for (; l + 8 <= end; l += 8) {                        // loads issued 8 ahead; the three sums keep the reference's order
+        float vf[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) vf[u] = src[l + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            double v = (double)vf[u];
+            double vl = (double)fastlog(0x1.0p-126f + vf[u]);
+            fl += vl;
+            pk += vl * v;
+            pw += v;
+        }
+    }
+    for (; l < end; l++) {
         float vf = src[l];
         double v = (double)vf;
         double vl = (double)fastlog(0x1.0p-126f + vf);
@@ -684,10 +715,8 @@ __global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
 // the 256-bin histogram of each radix pass lives in a private 1 KB LDS slice.
 template <int R>
 __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass) {
-    __shared__ int histAll[4][256];
     int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int *hist = histAll[wv];
-    int blk = blockIdx.x * 4 + wv;                        // 4 waves per workgroup: fewer, fatter dispatches
+    int blk = blockIdx.x * 4 + wv;                        // 4 waves per workgroup, one block per wave
     if (blk >= c.B * c.K) return;
     if (!finalPass && c.cbrDone[blk]) return;
     const int N = R * 64;
@@ -702,39 +731,26 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
     uint32_t u[R];
 #pragma unroll
     for (int r = 0; r < R; r++) u[r] = key_ord(key[r * 64 + lane]);
-    uint32_t prefix = 0, pmask = 0;
-    int need = kSel, e = 0;
-    for (int pass = 0; pass < 4; pass++) {
-        int shift = 24 - 8 * pass;
-        hist[lane] = 0; hist[lane + 64] = 0; hist[lane + 128] = 0; hist[lane + 192] = 0;
-        __builtin_amdgcn_wave_barrier();
+    // T = kSel-th largest ordered key = the largest t with count(u >= t) >= kSel; found bit by bit
+    // (a histogram radix select serialises on LDS atomics here: log-domain keys share their top byte)
+    uint32_t T = 0;
+    for (int bit = 31; bit >= 0; bit--) {
+        uint32_t t = T | (1u << bit);
+        int cnt = 0;
 #pragma unroll
-        for (int r = 0; r < R; r++)
-            if ((u[r] & pmask) == prefix) atomicAdd(&hist[(u[r] >> shift) & 255], 1);
-        __builtin_amdgcn_wave_barrier();
-        int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
-        int tot = h0 + h1 + h2 + h3;
-        int suf = tot;
-        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_down(suf, o); if (lane + o < 64) suf += t; }
-        int above = suf - tot;
-        int a3 = above, a2 = above + h3, a1 = a2 + h2, a0 = a1 + h1;
-        int dsel = -1, acc = 0, hh = 0;
-        if (a3 < need && need <= a3 + h3) { dsel = 4 * lane + 3; acc = a3; hh = h3; }
-        else if (a2 < need && need <= a2 + h2) { dsel = 4 * lane + 2; acc = a2; hh = h2; }
-        else if (a1 < need && need <= a1 + h1) { dsel = 4 * lane + 1; acc = a1; hh = h1; }
-        else if (a0 < need && need <= a0 + h0) { dsel = 4 * lane + 0; acc = a0; hh = h0; }
-        unsigned long long who = __ballot(dsel >= 0);
-        int src = __ffsll((long long)who) - 1;
-        dsel = __shfl(dsel, src); acc = __shfl(acc, src); e = __shfl(hh, src);
-        prefix |= (uint32_t)dsel << shift;
-        need -= acc;
-        pmask |= 0xFFu << shift;
-        __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < R; r++) cnt += (u[r] >= t) ? 1 : 0;
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (cnt >= kSel) T = t;
     }
+    int g = 0, e = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) { g += (u[r] > T) ? 1 : 0; e += (u[r] == T) ? 1 : 0; }
+    for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o); e += __shfl_xor(e, o); }
+    int need = kSel - g;                                  // how many of the e keys tied at T belong to the kept set
     bool straddle = (need < e);
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        unsigned long long m = __ballot(u[r] >= prefix);
+        unsigned long long m = __ballot(u[r] >= T);
         if (lane == 0)  keep[2 * r] = (uint32_t)m;
         if (lane == 32) keep[2 * r + 1] = (uint32_t)(m >> 32);
     }
