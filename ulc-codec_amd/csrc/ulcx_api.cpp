@@ -21,7 +21,7 @@ struct ulcx_encoder {
     hipEvent_t ev[ULCX_ENC_STAGES + 1];
     bool evOk, evRecorded;
     int lastK;
-    hipStream_t side; hipEvent_t evFork, evJoin; bool sideOk;
+    hipStream_t side; hipEvent_t evFork, evJoin, evFork2; bool sideOk;
     // staging for the host-pointer API
     float *d_pcm; uint8_t *d_out; int32_t *d_bits, *d_wc; float *d_cplx;
 };
@@ -81,7 +81,7 @@ static void cleanup(ulcx_encoder *e) {
     for (void *p : e->allocs) hipFree(p);
     if (e->tables) hipFree(e->tables);
     if (e->evOk) for (auto &v : e->ev) hipEventDestroy(v);
-    if (e->sideOk) { hipStreamDestroy(e->side); hipEventDestroy(e->evFork); hipEventDestroy(e->evJoin); }
+    if (e->sideOk) { hipStreamDestroy(e->side); hipEventDestroy(e->evFork); hipEventDestroy(e->evJoin); hipEventDestroy(e->evFork2); }
     delete e;
 }
 
@@ -174,7 +174,8 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
         if (!(evs && evs[0] == '0')) {
             if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess &&
                 hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming) == hipSuccess) e->sideOk = true;
+                hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&e->evFork2, hipEventDisableTiming) == hipSuccess) e->sideOk = true;
         }
     }
     DA(c.isFb, NB, true);
@@ -197,7 +198,7 @@ extern "C" int ulcx_encode_dev(ulcx_encoder *e, int mode, float p0, float p1, co
     c.K = nBlocks; c.mode = mode; c.p0 = p0; c.p1 = p1;
     c.vbrTarget = (mode == ULCX_MODE_VBR) ? 0x1.E4EFB7p3f * logf(100.0f / p0) : 0.0f;     // ulcEncoder.c:144 (host libm, data independent)
     c.pcm = d_pcm; c.out = d_out; c.bits = d_bits; c.wcOut = d_wc; c.cplxOut = d_cplx;
-    int rc = ulcx_enc_launch(c, (hipStream_t)hipStream, e->ev, e->sideOk ? e->side : nullptr, e->evFork, e->evJoin);
+    int rc = ulcx_enc_launch(c, (hipStream_t)hipStream, e->ev, e->sideOk ? e->side : nullptr, e->evFork, e->evJoin, e->evFork2);
     e->evRecorded = (rc == ULCX_OK);
     e->lastK = nBlocks;
     return rc;

@@ -975,51 +975,68 @@ __global__ __launch_bounds__(WG) void k_gapsums(UlcxEncCtx c, int finalPass) {
         // NoiseFill.c:29-30: the amplitude does not depend on the quantizer, so finish it here
         gs[i] = make_float2((sum == 0.0f) ? -1.0f : ulcx_expf(sum / sumw), 0.0f);
     }
-    // tails: 8 threads per unit, 5 of them carry one chain each
-    int nU = c.C * 4;
-    for (int t = tid; t < nU * 8; t += WG) {
-        int u = t >> 3, chain = t & 7;
-        int ch = u >> 2, j = u & 3;
-        int d0, off, S;
-        float *ts = c.tailSum + ((size_t)blk * nU + u) * 8;
-        if (!unit_geom(wc, j, c.BS, d0, off, S)) continue;
-        int us = ch * c.BS + off, ue = us + S;
-        // last kept index in [us, ue)
-        int last = us - 1;
-        for (int w = (ue - 1) >> 5; (w << 5) + 31 >= us; w--) {
-            uint32_t m = kw[w];
-            if (m) { last = (w << 5) + 31 - __clz(m); break; }
-            if (w == 0) break;
-        }
-        if (last < us) last = us - 1;
-        int start = last + 1, n = ue - start;
-        if (chain == 5) ts[5] = __int_as_float(start);
-        if (n < 16 || chain >= 5) continue;
-        const float2 *d = (const float2 *)(pairs + (start / 2) * 2);
-        int np = (n + (start & 1) + 1) / 2;
-        float acc = 0.0f;
-        int q = 0;
-        for (; q + 8 <= np; q += 8) {
-            float2 pv[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) pv[e] = d[q + e];
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                float x = (q + e) * 2.0f;
-                float wx = pv[e].x * x;
-                float term = (chain == 0) ? wx : (chain == 1) ? wx * x : (chain == 2) ? x * pv[e].y : (chain == 3) ? pv[e].y : pv[e].x;
-                acc += term;
-            }
-        }
-        for (; q < np; q++) {
-            float2 pv = d[q];
-            float x = q * 2.0f;
-            float wx = pv.x * x;
-            float term = (chain == 0) ? wx : (chain == 1) ? wx * x : (chain == 2) ? x * pv.y : (chain == 3) ? pv.y : pv.x;
-            acc += term;
-        }
-        ts[chain] = acc;
+}
+
+// Tail HF-extension sums (NoiseFill.c:41-62) for the tail after each unit's last kept
+// coefficient: 8 lanes per unit, lanes 0..4 carry one ordered f32 chain each, lane 5 records
+// the start index the sums assume.  Pairs are read straight from HBM/L2 in batches of 8: the
+// chains are latency-bound, so they get their own launch with every unit of the batch in flight.
+__global__ __launch_bounds__(64) void k_tailsums(UlcxEncCtx c, int finalPass) {
+    int tid0 = blockIdx.x * 64 + threadIdx.x;
+    int chain = tid0 & 7;
+    int ui = tid0 >> 3;
+    int nBC = c.B * c.K * c.C;
+    if (ui >= nBC * 4) return;
+    int j = ui / nBC, rem = ui - j * nBC, blk = rem / c.C, ch = rem - blk * c.C;     // subblock index slowest
+    if (!finalPass && c.cbrDone[blk]) return;
+    if (c.fbMode == 1 && c.isFb[blk]) return;
+    if (c.fbMode == 2 && !c.isFb[blk]) return;
+    int s = blk / c.K, k = blk % c.K;
+    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+    int d0, off, S;
+    if (!unit_geom(wc, j, c.BS, d0, off, S)) return;
+    const int N = c.C * c.BS;
+    const uint32_t *kw = c.keep + (size_t)blk * (N / 32);
+    const float *pairs = c.npair + (size_t)blk * N;
+    float *ts = c.tailSum + ((size_t)(blk * c.C + ch) * 4 + j) * 8;
+    int us = ch * c.BS + off, ue = us + S;
+    int last = us - 1;                                       // last kept index in [us, ue) (unit bounds are multiples of 32)
+    for (int w = (ue - 1) >> 5; (w << 5) >= us; w--) {
+        uint32_t m = kw[w];
+        if (m) { last = (w << 5) + 31 - __clz(m); break; }
+        if (w == 0) break;
     }
+    int start = last + 1, n = ue - start;
+    if (chain == 5) ts[5] = __int_as_float(start);
+    if (n < 16 || chain >= 5) return;
+    const float2 *d = (const float2 *)(pairs + (start / 2) * 2);
+    int np = (n + (start & 1) + 1) / 2;
+    // term = (base * m1) * m2 with exact multiplications by 1.0f where a factor is absent:
+    //   SumX: w*x   SumX2: (w*x)*x   SumXY: x*wy   SumY: wy   SumW: w
+    bool useY = (chain == 2) || (chain == 3);
+    bool hasX1 = (chain <= 2), hasX2 = (chain == 1);
+    float acc = 0.0f;
+    int q = 0;
+    for (; q + 8 <= np; q += 8) {
+        float2 pv[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) pv[e] = d[q + e];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            float x = (q + e) * 2.0f;
+            float base = useY ? pv[e].y : pv[e].x;
+            float m1 = hasX1 ? x : 1.0f, m2 = hasX2 ? x : 1.0f;
+            acc += (base * m1) * m2;
+        }
+    }
+    for (; q < np; q++) {
+        float2 pv = d[q];
+        float x = q * 2.0f;
+        float base = useY ? pv.y : pv.x;
+        float m1 = hasX1 ? x : 1.0f, m2 = hasX2 ? x : 1.0f;
+        acc += (base * m1) * m2;
+    }
+    ts[chain] = acc;
 }
 
 // ---------------------------------------------------------------------------
@@ -1864,11 +1881,11 @@ size_t ulcx_enc_xf_lds_bytes(int BS) { return (size_t)BS * 18 + 16; }   // 2BS +
 // bench.py can price each one against the roofline live; ev holds ULCX_ENC_STAGES+1 events.
 const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES] = {
     "k_wc_energy", "k_wc_forward", "k_wc_backward", "k_wc_integrate", "k_wc_decide",
-    "k_xf", "k_cplx", "k_nbark", "k_nline", "k_pbark", "k_keys",
-    "k_select", "k_heapsel", "k_gapsums+k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update",
+    "k_xf", "k_cplx", "k_pbark", "k_keys",
+    "k_select", "k_nbark", "k_nline", "k_heapsel", "k_gapsums+k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update",
 };
 
-int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStream_t side, hipEvent_t evFork, hipEvent_t evJoin) {
+int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStream_t side, hipEvent_t evFork, hipEvent_t evJoin, hipEvent_t evFork2) {
     int NB = c.B * c.K;
     int stage = 0;
 #define MARK() do { if (ev) CK(hipEventRecord(ev[stage++], st)); } while (0)
@@ -1891,15 +1908,18 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
     hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c);                                  MARK();
     int nUnits = NB * c.C * 4;
     {
-        hipLaunchKernelGGL(k_nbark, dim3((nUnits + 63) / 64), dim3(64), 0, st, c);                         MARK();
-        size_t tot = (size_t)NB * c.C * (c.BS / 2);
-        hipLaunchKernelGGL(k_nline, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);            MARK();
-    }
-    {
         hipLaunchKernelGGL(k_pbark, dim3((NB * 4 + 63) / 64), dim3(64), 0, st, c);                         MARK();
         size_t tot = (size_t)NB * (c.BS / 2);
         hipLaunchKernelGGL(k_keys, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);             MARK();
     }
+    // (the noise log-spectrum does not feed the keys: it is launched after the selection so that the
+    //  main stream has work to run beside the side-stream heapsort of tie-straddle blocks)
+    auto launch_noise = [&](bool ev0) -> int {
+        hipLaunchKernelGGL(k_nbark, dim3((nUnits + 63) / 64), dim3(64), 0, st, c);                         if (ev0) MARK();
+        size_t tot = (size_t)NB * c.C * (c.BS / 2);
+        hipLaunchKernelGGL(k_nline, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);            if (ev0) MARK();
+        return ULCX_OK;
+    };
     // --- selection + encode pass(es)
     int N = c.C * c.BS;
     int ldsEntries = ((size_t)N * 8 <= ULCX_HEAP_LDS_BYTES) ? N : 0;
@@ -1927,6 +1947,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
             size_t glds = (size_t)N * 4 + N / 8 + 8 * E_GAPCAP + 16;
             if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
             hipLaunchKernelGGL(k_gapsums, dim3(NB), dim3(WG), glds, s2, cc, fin);
+            hipLaunchKernelGGL(k_tailsums, dim3((nUnits * 8 + 63) / 64), dim3(64), 0, s2, cc, fin);
         }
         if (cc.useWave && !cc.useFused) {
             int ldsW = E2_KCAP * 4 + E2_ZCAP * 8 + E2_KCAP * 4 + E2_ZCAP + E2_NYBCAP + 64;
@@ -1962,6 +1983,9 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
             UlcxEncCtx cf = c; cf.fbMode = 2;
             if (ldsEntries) hipLaunchKernelGGL(k_heapsel_pipe, dim3(fbGrid), dim3(64), heapLds, side, cf);
             else hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, side, cf, ldsEntries);
+            if (p == 0) { int rcn = launch_noise(ev0); if (rcn) return rcn; }
+            CK(hipEventRecord(evFork2, st));                    // the side stream's encode pass needs the noise pairs too
+            CK(hipStreamWaitEvent(side, evFork2, 0));
             int rc = launch_encode(cf, side, fin, false); if (rc) return rc;
             CK(hipEventRecord(evJoin, side));
             if (ev0) MARK();                                   // (k_heapsel interval is empty on the main stream)
@@ -1969,6 +1993,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
             rc = launch_encode(cm, st, fin, ev0); if (rc) return rc;
             CK(hipStreamWaitEvent(st, evJoin, 0));
         } else {
+            if (p == 0) { int rcn = launch_noise(ev0); if (rcn) return rcn; }
             if (ldsEntries) hipLaunchKernelGGL(k_heapsel_pipe, dim3(fbGrid), dim3(64), heapLds, st, c);
             else hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, st, c, ldsEntries);
             if (ev0) MARK();

@@ -123,6 +123,6 @@ void ulcx_set_error(const char *fmt, ...);
 #define ULCX_ENC_STAGES 17
 extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES];
 #define ULCX_DEC_STAGES 4
-int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, hipStream_t side, hipEvent_t evFork, hipEvent_t evJoin);
+int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, hipStream_t side, hipEvent_t evFork, hipEvent_t evJoin, hipEvent_t evFork2);
 int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev);
 size_t ulcx_enc_xf_lds_bytes(int BS);
