@@ -141,35 +141,95 @@ __device__ int decode_subblock(CoefWriter &w, int N, NybReader &r, uint32_t &see
     return bad ? 0 : 1;
 }
 
+// ---------------------------------------------------------------------------
+// Branch-free syntax walk for the scan pass.  The block syntax (FormatSpecs.md:57-141,
+// ulcDecoder.c:99-197) is a small finite-state machine over nybbles; written with selects
+// instead of a per-lane branch cascade, every lane of a wave executes the same instruction
+// stream per nybble whatever its own state.
+// ---------------------------------------------------------------------------
+enum { S_CODE = 0, S_Z0, S_Z1a, S_Z1b, S_N8a, S_N8b, S_N8c, S_QF, S_QFE, S_TN1, S_TN2, S_TN3, S_Q0, S_Q0E };
+struct ScanFsm {
+    int state, acc, N, draws;          // N = coefficients still to come in the current subblock
+    bool done, bad;
+    __device__ __forceinline__ void start(int n) { state = S_Q0; acc = 0; N = n; done = false; }
+    __device__ __forceinline__ void step(int v) {
+        const int st = state;
+        const bool plain = (v != 0x0) & (v != 0x1) & (v != 0x8) & (v != 0xF);      // +-2..+-7: one coefficient
+        // next state
+        int nxCode = plain ? S_CODE : (v == 0x0) ? S_Z0 : (v == 0x1) ? S_Z1a : (v == 0x8) ? S_N8a : S_QF;
+        int nxQF = (v == 0xF) ? S_TN1 : (v == 0xE) ? S_QFE : S_CODE;               // Fh,Fh.. / Fh,Eh.. / quantizer change
+        int nx = S_CODE;
+        nx = (st == S_CODE) ? nxCode : nx;
+        nx = (st == S_Z1a) ? S_Z1b : nx;
+        nx = (st == S_N8a) ? S_N8b : nx;
+        nx = (st == S_N8b) ? S_N8c : nx;
+        nx = (st == S_QF) ? nxQF : nx;
+        nx = (st == S_TN1) ? S_TN2 : nx;
+        nx = (st == S_TN2) ? S_TN3 : nx;
+        nx = (st == S_Q0 && v == 0xE) ? S_Q0E : nx;                                 // first quantizer, extended form
+        // effects of the code completed by this nybble
+        const int a2 = (acc << 4) | v;
+        int n = (st == S_CODE && plain) ? 1 : 0;
+        n = (st == S_Z0) ? v + 1 : n;                                               // 0h,X      : 1..16 zeros
+        n = (st == S_Z1b) ? a2 + 33 : n;                                            // 1h,Y,X    : 33..288 zeros
+        const int nn = ((acc << 1) | (v & 1)) + 16;                                 // 8h,Z,Y,X  : 16..527 noise coefficients
+        n = (st == S_N8c) ? nn : n;
+        int dr = (st == S_N8c) ? nn : 0;
+        const bool chk = (st == S_Z0) | (st == S_Z1b) | (st == S_N8c);
+        const bool stopZ = ((st == S_QFE) | (st == S_Q0E)) & (v == 0xF);            // [Fh,]Eh,Fh : zeros to the end
+        const bool stopN = (st == S_TN3);                                            // Fh,Fh,Z,Y,X: noise to the end
+        dr = stopN ? N : dr;
+        n = (stopZ | stopN) ? N : n;
+        const bool over = chk & (n > N);                                            // ulcDecoder.c:127,139,154
+        bad = bad | over;
+        N -= over ? 0 : n;
+        draws += over ? 0 : dr;
+        acc = ((st == S_Z1a) | (st == S_N8a)) ? v : (st == S_N8b) ? a2 : acc;
+        state = nx;
+        done = (N == 0) | over;
+    }
+};
+
 // Pass 1 — one lane per block: walk the syntax, record where each (channel, subblock)
 // unit starts (nybble offset) and how many RNG draws precede it inside the block.
 __global__ __launch_bounds__(64) void k_dscan(UlcxDecCtx c) {
     int blk = blockIdx.x * 64 + threadIdx.x;
     if (blk >= c.B * c.K) return;
-    NybReader r; r.init(c.in + (size_t)blk * c.slot, 0, c.slot);
-    int wc = (int)r.get();                                         // ulcDecoder.c:211-216
-    if (wc & 0x8) wc |= (int)r.get() << 4;
-    else wc |= 1 << 4;
-    CoefWriter w; w.dst = nullptr; w.n = 0;
-    uint32_t seed = 0;
-    int draws = 0, ok = 1;
+    const uint8_t *p = c.in + (size_t)blk * c.slot;
+    const int limit = c.slot * 8 - 32;
+    int pos = 0;
+    auto get = [&]() { unsigned x = p[pos >> 3]; int v = (pos & 4) ? (x >> 4) : (x & 0xF); pos += 4; return v; };
+    int wc = get();                                                 // ulcDecoder.c:211-216
+    { int v2 = (int)((p[pos >> 3] >> (pos & 4)) & 0xF); bool dec = (wc & 0x8) != 0; wc |= dec ? (v2 << 4) : (1 << 4); pos += dec ? 4 : 0; }
+    unsigned pat = ulcx_pattern(wc);                                // (code 0000 behaves as one plain N/1 block, as in the reference)
+    int nsub = 0; { unsigned q = pat; do nsub++; while (q >>= 4); }
+    if ((c.BS >> (pat & 7)) == c.BS) nsub = 1;                      // ulcDecoder.c:242-245
+    int total = c.C * nsub;
     int *ustart = c.unitStart + (size_t)blk * c.C * 4;
     int *udraw  = c.unitDraws + (size_t)blk * c.C * 4;
-    for (int ch = 0; ch < c.C && ok; ch++) {
-        unsigned pat = ulcx_pattern(wc);                            // (code 0000 behaves as one plain N/1 block, as in the reference)
-        int j = 0;
-        do {
-            int S = c.BS >> (pat & 7);
-            ustart[ch * 4 + j] = r.size;
-            udraw[ch * 4 + j] = draws;
-            if (!decode_subblock<false>(w, S, r, seed, draws)) { ok = 0; break; }
-            if (S == c.BS) break;                                   // ulcDecoder.c:242-245
-            j++;
-        } while (pat >>= 4);
+    ScanFsm f; f.draws = 0; f.bad = false;
+    int u = 0;
+    ustart[0] = pos; udraw[0] = 0;
+    f.start(c.BS >> (pat & 7));
+    bool fin = false;
+    while (!fin) {
+        int v = get();
+        f.step(v);
+        if (f.done) {
+            u++;
+            fin = f.bad | (u >= total);
+            if (!fin) {
+                int ch = u / nsub, j = u - ch * nsub;
+                ustart[ch * 4 + j] = pos; udraw[ch * 4 + j] = f.draws;
+                f.start(c.BS >> ((pat >> (4 * j)) & 7));
+            }
+        }
+        if (pos > limit) { f.bad = true; fin = true; }              // ran off the slot: corrupt (see NybReader::limit)
     }
-    c.bits[blk] = ok ? r.size : 0;
+    bool ok = !f.bad;
+    c.bits[blk] = ok ? pos : 0;
     c.wc[blk] = ok ? wc : 0;
-    c.draws[blk] = draws;
+    c.draws[blk] = f.draws;
 }
 
 // xorshift32 is linear over GF(2): state after n draws = T^n * state.  jump[i] holds the
