@@ -1882,7 +1882,7 @@ size_t ulcx_enc_xf_lds_bytes(int BS) { return (size_t)BS * 18 + 16; }   // 2BS +
 const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES] = {
     "k_wc_energy", "k_wc_forward", "k_wc_backward", "k_wc_integrate", "k_wc_decide",
     "k_xf", "k_cplx", "k_pbark", "k_keys",
-    "k_select", "k_nbark", "k_nline", "k_heapsel", "k_gapsums+k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update",
+    "k_select", "k_nbark", "k_nline", "k_heapsel", "k_gapsums", "k_tailsums", "k_encode_wave", "k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update",
 };
 
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStream_t side, hipEvent_t evFork, hipEvent_t evJoin, hipEvent_t evFork2) {
@@ -1947,13 +1947,16 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
             size_t glds = (size_t)N * 4 + N / 8 + 8 * E_GAPCAP + 16;
             if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
             hipLaunchKernelGGL(k_gapsums, dim3(NB), dim3(WG), glds, s2, cc, fin);
+            if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
             hipLaunchKernelGGL(k_tailsums, dim3((nUnits * 8 + 63) / 64), dim3(64), 0, s2, cc, fin);
-        }
+            if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
+        } else if (ev0 && ev) { CK(hipEventRecord(ev[stage++], s2)); CK(hipEventRecord(ev[stage++], s2)); }
         if (cc.useWave && !cc.useFused) {
             int ldsW = E2_KCAP * 4 + E2_ZCAP * 8 + E2_KCAP * 4 + E2_ZCAP + E2_NYBCAP + 64;
             int nBC = NB * cc.C;
             hipLaunchKernelGGL(k_encode_wave, dim3((nBC + 3) / 4), dim3(256), (size_t)ldsW * 4, s2, cc, fin, ldsW);
         }
+        if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
         hipLaunchKernelGGL(k_encode_units, dim3((nUnits + 63) / 64), dim3(64), 0, s2, cc, fin);
         if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
         hipLaunchKernelGGL(k_pack, dim3(NB), dim3(64), 0, s2, cc, fin);

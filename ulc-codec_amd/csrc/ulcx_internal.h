@@ -120,7 +120,7 @@ int  ulcx_tables_build(UlcxTables *devT, void **devBlob, int BS, int rateHz, boo
 void ulcx_set_error(const char *fmt, ...);
 
 // launchers (ulcx_enc.hip / ulcx_dec.hip)
-#define ULCX_ENC_STAGES 17
+#define ULCX_ENC_STAGES 20
 extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES];
 #define ULCX_DEC_STAGES 4
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, hipStream_t side, hipEvent_t evFork, hipEvent_t evJoin, hipEvent_t evFork2);
