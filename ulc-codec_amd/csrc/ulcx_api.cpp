@@ -22,6 +22,7 @@ struct ulcx_encoder {
     bool evOk, evRecorded;
     int lastK;
     hipStream_t side; hipEvent_t evFork, evJoin, evFork2; bool sideOk;
+    bool keysFinal;
     // staging for the host-pointer API
     float *d_pcm; uint8_t *d_out; int32_t *d_bits, *d_wc; float *d_cplx;
 };
@@ -110,7 +111,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     if (rc) return rc;
     ulcx_encoder *e = new ulcx_encoder();
     e->device = device; e->B = nStreams; e->C = nChan; e->BS = BlockSize; e->rate = RateHz; e->maxK = maxBlocksPerCall;
-    e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->lastK = 0; e->sideOk = false; e->side = nullptr;
+    e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->lastK = 0; e->sideOk = false; e->side = nullptr; e->keysFinal = false;
     e->d_pcm = nullptr; e->d_out = nullptr; e->d_bits = nullptr; e->d_wc = nullptr; e->d_cplx = nullptr;
     UlcxEncCtx &c = e->ctx;
     memset(&c, 0, sizeof(c));
@@ -201,6 +202,7 @@ extern "C" int ulcx_encode_dev(ulcx_encoder *e, int mode, float p0, float p1, co
     int rc = ulcx_enc_launch(c, (hipStream_t)hipStream, e->ev, e->sideOk ? e->side : nullptr, e->evFork, e->evJoin, e->evFork2);
     e->evRecorded = (rc == ULCX_OK);
     e->lastK = nBlocks;
+    e->keysFinal = false;
     return rc;
 }
 
@@ -237,7 +239,15 @@ extern "C" int ulcx_encoder_debug_fetch(ulcx_encoder *e, int nBlocks, float *h_c
     size_t NB = (size_t)e->B * nBlocks, cb = (size_t)e->C * e->BS;
     if (h_coef)  CKR(hipMemcpy(h_coef, e->ctx.coef, sizeof(float) * NB * cb, hipMemcpyDeviceToHost));
     if (h_noise) CKR(hipMemcpy(h_noise, e->ctx.npair, sizeof(float) * NB * cb, hipMemcpyDeviceToHost));
-    if (h_keys)  CKR(hipMemcpy(h_keys, e->ctx.key, sizeof(float) * NB * cb, hipMemcpyDeviceToHost));
+    if (h_keys) {
+        if (!e->keysFinal) {                       // the pipeline never writes final keys back; materialise them for the tap
+            UlcxEncCtx c2 = e->ctx; c2.K = nBlocks;
+            ulcx_enc_finalize_keys(c2, nullptr);
+            CKR(hipDeviceSynchronize());
+            e->keysFinal = true;
+        }
+        CKR(hipMemcpy(h_keys, e->ctx.key, sizeof(float) * NB * cb, hipMemcpyDeviceToHost));
+    }
     if (h_nout)  CKR(hipMemcpy(h_nout, e->ctx.nout, sizeof(int32_t) * NB, hipMemcpyDeviceToHost));
     if (h_keep) {
         std::vector<uint32_t> bits(NB * cb / 32);

@@ -612,8 +612,21 @@ __global__ __launch_bounds__(64) void k_pbark(UlcxEncCtx c) {
     }
 }
 
-// Psyopt.c:140-150 + BlockTransform.c:337-345
-__global__ __launch_bounds__(WG) void k_keys(UlcxEncCtx c) {
+// BlockTransform.c:337-345: key = 2*key0 + MaskingNp[n/2] + Log[0.5^2]*(Chan&1), formed where the
+// keys are consumed (selection kernels) instead of being written back to HBM.
+__device__ __forceinline__ float final_key(float v, float m, int ch) {
+    float t = 2 * v + m;
+    if (ch & 1) t = t + -0x1.62E430p0f;
+    return t;
+}
+// key of coefficient i of block blk (c.key holds key0 = FastLog(Re^2) or -inf, c.mask the masking level per line)
+__device__ __forceinline__ float load_final_key(const UlcxEncCtx &c, int blk, int i) {
+    int ch = i >> c.lgBS, n = i & (c.BS - 1);
+    return final_key(c.key[(size_t)blk * (c.C * c.BS) + i], c.mask[(size_t)blk * (c.BS / 2) + (n >> 1)], ch);
+}
+
+// Psyopt.c:140-150: masking level per line
+__global__ __launch_bounds__(WG) void k_mask(UlcxEncCtx c) {
     size_t gid = (size_t)blockIdx.x * WG + threadIdx.x;
     int half = c.BS / 2;
     size_t total = (size_t)c.B * c.K * half;
@@ -631,15 +644,21 @@ __global__ __launch_bounds__(WG) void k_keys(UlcxEncCtx c) {
     float fr = c.T.bandFrac[d][line];
     float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
     float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
-    float m = L * (1.0f - fr) + R * fr;
-    if (c.mask) c.mask[(size_t)blk * half + jp] = m;
-    float *key = c.key + (size_t)blk * (c.C * c.BS) + 2 * jp;
-    for (int ch = 0; ch < c.C; ch++) {
-        float2 v = *(float2 *)(key + (size_t)ch * c.BS);
-        float t0 = 2 * v.x + m, t1 = 2 * v.y + m;
-        if (ch & 1) { t0 = t0 + -0x1.62E430p0f; t1 = t1 + -0x1.62E430p0f; }
-        *(float2 *)(key + (size_t)ch * c.BS) = make_float2(t0, t1);
-    }
+    c.mask[(size_t)blk * half + jp] = L * (1.0f - fr) + R * fr;
+}
+
+// debug/parity tap only: materialise the final keys in c.key (ulcx_encoder_debug_fetch)
+__global__ __launch_bounds__(WG) void k_keys_finalize(UlcxEncCtx c) {
+    size_t gid = (size_t)blockIdx.x * WG + threadIdx.x;
+    size_t N = (size_t)c.C * c.BS;
+    if (gid >= (size_t)c.B * c.K * N) return;
+    int blk = (int)(gid / N), i = (int)(gid % N);
+    float v = load_final_key(c, blk, i);
+    c.key[gid] = v;
+}
+void ulcx_enc_finalize_keys(const UlcxEncCtx &c, hipStream_t st) {
+    size_t tot = (size_t)c.B * c.K * c.C * c.BS;
+    hipLaunchKernelGGL(k_keys_finalize, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);
 }
 
 // ---------------------------------------------------------------------------
@@ -678,7 +697,7 @@ __global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
         hist[tid] = 0;                   // WG == 256 bins
         __syncthreads();
         for (int i = tid; i < N; i += WG) {
-            uint32_t u = key_ord(key[i]);
+            uint32_t u = key_ord(load_final_key(c, blk, i));
             if ((u & pmask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
         }
         __syncthreads();
@@ -697,7 +716,7 @@ __global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
     int e = hist[prefix & 255];
     bool straddle = (need < e);
     for (int i = tid; i < N; i += WG) {
-        uint32_t u = key_ord(key[i]);
+        uint32_t u = key_ord(load_final_key(c, blk, i));
         bool kp = (u >= prefix);          // tie group fully in when not straddling
         unsigned long long m = __ballot(kp);
         int lane = tid & 63;
@@ -729,8 +748,14 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
         return;
     }
     uint32_t u[R];
+    {
+        const float *msk = c.mask + (size_t)blk * (c.BS / 2);
 #pragma unroll
-    for (int r = 0; r < R; r++) u[r] = key_ord(key[r * 64 + lane]);
+        for (int r = 0; r < R; r++) {
+            int i = r * 64 + lane;
+            u[r] = key_ord(final_key(key[i], msk[(i & (c.BS - 1)) >> 1], i >> c.lgBS));
+        }
+    }
     // T = kSel-th largest ordered key = the largest t with count(u >= t) >= kSel; found bit by bit
     // (a histogram radix select serialises on LDS atomics here: log-domain keys share their top byte)
     uint32_t T = 0;
@@ -793,7 +818,7 @@ __global__ __launch_bounds__(64) void k_heapsel(UlcxEncCtx c, int ldsEntries) {
         const float *key = c.key + (size_t)blk * N;
         uint32_t *keep = c.keep + (size_t)blk * (N / 32);
         uint32_t *kb = useLds ? (uint32_t *)(hl + N) : keep;        // kept-set bitmap (LDS copy when the heap is in LDS)
-        for (int i = threadIdx.x; i < N; i += 64) { h[i].v = key[i]; h[i].i = i; }
+        for (int i = threadIdx.x; i < N; i += 64) { h[i].v = load_final_key(c, blk, i); h[i].i = i; }
         for (int i = threadIdx.x; i < N / 32; i += 64) kb[i] = 0xFFFFFFFFu;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -832,7 +857,7 @@ __global__ __launch_bounds__(64) void k_heapsel_pipe(UlcxEncCtx c) {
         int kSel = c.nout[blk];
         const float *key = c.key + (size_t)blk * N;
         uint32_t *keep = c.keep + (size_t)blk * (N / 32);
-        for (int i = lane; i < N; i += 64) { hp[i].v = key[i]; hp[i].i = i; }
+        for (int i = lane; i < N; i += 64) { hp[i].v = load_final_key(c, blk, i); hp[i].i = i; }
         for (int i = lane; i < N / 32; i += 64) kb[i] = 0xFFFFFFFFu;
         __syncthreads();
         // ---- heapify, level by level
@@ -1682,7 +1707,7 @@ __global__ __launch_bounds__(WG) void k_selenc(UlcxEncCtx c, int finalPass, int 
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     int kSel = c.nout[blk];
     const float *keyG = c.key + (size_t)blk * N;
-    for (int i = tid; i < N; i += WG) ukey[i] = key_ord(keyG[i]);
+    for (int i = tid; i < N; i += WG) ukey[i] = key_ord(load_final_key(c, blk, i));
     if (tid == 0) misc[2] = 0;
     __syncthreads();
 
@@ -1881,7 +1906,7 @@ size_t ulcx_enc_xf_lds_bytes(int BS) { return (size_t)BS * 18 + 16; }   // 2BS +
 // bench.py can price each one against the roofline live; ev holds ULCX_ENC_STAGES+1 events.
 const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES] = {
     "k_wc_energy", "k_wc_forward", "k_wc_backward", "k_wc_integrate", "k_wc_decide",
-    "k_xf", "k_cplx", "k_pbark", "k_keys",
+    "k_xf", "k_cplx", "k_pbark", "k_mask",
     "k_select", "k_nbark", "k_nline", "k_heapsel", "k_gapsums", "k_tailsums", "k_encode_wave", "k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update",
 };
 
@@ -1910,7 +1935,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
     {
         hipLaunchKernelGGL(k_pbark, dim3((NB * 4 + 63) / 64), dim3(64), 0, st, c);                         MARK();
         size_t tot = (size_t)NB * (c.BS / 2);
-        hipLaunchKernelGGL(k_keys, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);             MARK();
+        hipLaunchKernelGGL(k_mask, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);             MARK();
     }
     // (the noise log-spectrum does not feed the keys: it is launched after the selection so that the
     //  main stream has work to run beside the side-stream heapsort of tie-straddle blocks)

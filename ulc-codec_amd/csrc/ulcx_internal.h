@@ -58,11 +58,11 @@ struct UlcxEncCtx {
     float  *bins;                        // [B][maxK+1][16] {Sum[8],SumW[8]}; row 0 = previous block
     int    *wcArr;                       // [B][maxK+2] WindowCtrl of blocks k0-1 .. k0+K
     float  *coef;                        // [NB][C*BS]   normalised MDCT (TransformBuffer)
-    float  *key;                         // [NB][C*BS]   importance keys
+    float  *key;                         // [NB][C*BS]   key0 = FastLog(Re^2) | -inf; final keys are formed on the fly (final_key)
     float  *nsum;                        // [NB][C*BS/2] per-line |X|^2 (noise input)
     float  *npair;                       // [NB][C*BS]   {w, w*log} pairs (TransformNoise)
     float  *amp2;                        // [NB][BS/2]
-    float  *mask;                        // [NB][BS/2]   (debug only; keys kernel recomputes)
+    float  *mask;                        // [NB][BS/2]   masking level per line (MaskingNp)
     float  *barkN;                       // [NB][C*4][25]
     float  *barkP;                       // [NB][4][25]
     int    *nnz;                         // [NB]
@@ -126,3 +126,4 @@ extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES];
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, hipStream_t side, hipEvent_t evFork, hipEvent_t evJoin, hipEvent_t evFork2);
 int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev);
 size_t ulcx_enc_xf_lds_bytes(int BS);
+void ulcx_enc_finalize_keys(const UlcxEncCtx &c, hipStream_t st);
