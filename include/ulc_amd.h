@@ -164,6 +164,42 @@ int  ulcx_decode_dev(ulcx_decoder *dec, const uint8_t *d_in, int slotBytes, int 
 int  ulcx_decode_host(ulcx_decoder *dec, const uint8_t *h_in, int slotBytes, int nBlocks,
                       float *h_pcm, int32_t *h_bits);
 
+/* ------------------------------------------------------------------------- */
+/* 3. `.ulc` container and packed streams               */
+/* ------------------------------------------------------------------------- */
+/* 24-byte little-endian file header, tools/ulc_Helper.h:10-20.  Blocks follow at
+ * StreamOffs, each rounded up to a whole byte, with NO per-block length
+ * (tools/ulcEncodeTool.c:160-169, tools/ulcDecodeTool.c:153-165). */
+#define ULCX_ULC_MAGIC 0x32434C55u            /* 'U' | 'L'<<8 | 'C'<<16 | '2'<<24 */
+typedef struct ulcx_file_header {
+    uint32_t Magic;
+    uint16_t BlockSize;
+    uint16_t MaxBlockSize;                     /* largest block in bytes (0 = unknown) */
+    uint32_t nBlocks;
+    uint32_t RateHz;
+    uint16_t nChan;
+    uint16_t RateKbps;                         /* lrint(total_bytes*8*RateHz/1000/(BlockSize*nBlocks)), ulcEncodeTool.c:173-190 */
+    uint32_t StreamOffs;
+} ulcx_file_header;
+void ulcx_ulc_header_pack(uint8_t dst[24], const ulcx_file_header *h);
+int  ulcx_ulc_header_parse(ulcx_file_header *h, const uint8_t *src, size_t len);   /* 0 ok, ULCX_ERR_ARG: short / bad magic */
+int  ulcx_ulc_rate_kbps(uint64_t totalBytes, uint32_t RateHz, uint32_t BlockSize, uint32_t nBlocks);
+
+/* Concatenate the per-block slots an encode call produced into one contiguous payload
+ * per stream (what the tool's fwrite loop produces).  Device pointers.
+ *   d_payload      [nStreams][payloadStride] bytes, stream s starts at s*payloadStride
+ *   d_payloadBytes [nStreams] bytes written;  d_maxBlock [nStreams] largest block (optional) */
+int  ulcx_pack_streams_dev(int device, int nStreams, int nBlocks, int slotBytes, const uint8_t *d_slots, const int32_t *d_bits,
+                           uint8_t *d_payload, long long payloadStride, int32_t *d_payloadBytes, int32_t *d_maxBlock, void *hipStream);
+
+/* Decode the next nBlocks blocks of every stream from packed payloads: block k+1 begins at the
+ * byte after block k ends, which only parsing reveals; the per-stream read position persists
+ * across calls (ulcx_decoder_reset rewinds it).  d_payloadBytes[s] = valid bytes of stream s. */
+int  ulcx_decode_packed_dev(ulcx_decoder *dec, const uint8_t *d_payload, long long payloadStride, const int32_t *d_payloadBytes,
+                            int nBlocks, float *d_pcm, int32_t *d_bits, void *hipStream);
+int  ulcx_decode_packed_host(ulcx_decoder *dec, const uint8_t *h_payload, long long payloadStride, const int32_t *h_payloadBytes,
+                             int nBlocks, float *h_pcm, int32_t *h_bits);
+
 /* Timing helper for bench.py: device time (ms, hipEvent) of the kernels the last
  * ulcx_*_dev call enqueued, per pipeline stage; returns number of stages written.
  * Only valid after the stream has been synchronised. */

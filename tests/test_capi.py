@@ -93,3 +93,23 @@ def test_reference_tools_link_unchanged(tool, lib, tmp_path):
     # runs far enough to print its usage text (no GPU needed for that)
     r = subprocess.run([str(exe)], capture_output=True, env=dict(os.environ, LD_LIBRARY_PATH=os.path.dirname(LIB) + ":/opt/rocm/lib"))
     assert b"sage" in r.stdout + r.stderr or r.returncode in (0, 1, 255)
+
+
+def test_ulc_container_header_roundtrip(lib):
+    """24-byte little-endian header, tools/ulc_Helper.h:10-20; RateKbps as ulcEncodeTool.c:173,190."""
+    import ulc_amd
+    ulc_amd.lib()
+    h = ulc_amd.FileHeader(0x32434C55, 2048, 395, 218, 44100, 2, 56, 24)
+    buf = (C.c_uint8 * 24)()
+    lib.ulcx_ulc_header_pack.argtypes = [C.POINTER(C.c_uint8), C.POINTER(ulc_amd.FileHeader)]
+    lib.ulcx_ulc_header_pack(buf, C.byref(h))
+    raw = bytes(buf)
+    assert raw[:4] == b"ULC2" and raw == bytes(h)                      # same layout as the C struct the tools fwrite
+    assert raw[4:8] == (2048).to_bytes(2, "little") + (395).to_bytes(2, "little") and raw[20:] == (24).to_bytes(4, "little")
+    g = ulc_amd.FileHeader()
+    lib.ulcx_ulc_header_parse.argtypes = [C.POINTER(ulc_amd.FileHeader), C.POINTER(C.c_uint8), C.c_size_t]
+    assert lib.ulcx_ulc_header_parse(C.byref(g), buf, 24) == 0 and bytes(g) == raw
+    bad = (C.c_uint8 * 24)(*b"RIFF" + bytes(20))
+    assert lib.ulcx_ulc_header_parse(C.byref(g), bad, 24) == -1 and lib.ulcx_ulc_header_parse(C.byref(g), buf, 23) == -1
+    lib.ulcx_ulc_rate_kbps.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+    assert lib.ulcx_ulc_rate_kbps(70632, 44100, 2048, 218) == round(70632 * 8 * 44100 / 1000 / (2048 * 218))

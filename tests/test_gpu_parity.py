@@ -179,3 +179,47 @@ def test_decode_corrupt_blocks_are_rejected_without_hanging():
         assert np.array_equal(gbits[s], ref_bits) and np.array_equal(got[s], ref_pcm)
     assert np.isfinite(got).all()
     dec.close()
+
+
+def test_packed_stream_pack_and_decode():
+    """.ulc payloads: blocks back to back, each rounded up to a byte, no lengths.
+    GPU pack == host concatenation; GPU packed decode (two calls, position carried) == oracle decode."""
+    import ctypes as C
+    import torch
+    amd = _amd()
+    bs, ch, rate, B, K = 1024, 2, 44100, 5, 8
+    pcm = _streams(B, K, bs, ch, rate, True, seed=12)
+    slot = 2 * ch * bs + 16
+    refs = [oracle_encode_debug(pcm[s], bs, rate, 0, 60.0, slot=slot) for s in range(B)]
+    payloads = [b"".join(r["out"][k, : (r["bits"][k] + 7) // 8].tobytes() for k in range(K)) for r in refs]
+    stride = max(len(p) for p in payloads) + 64
+    host = np.zeros((B, stride), np.uint8)
+    for s, p in enumerate(payloads):
+        host[s, : len(p)] = np.frombuffer(p, np.uint8)
+    nbytes = np.array([len(p) for p in payloads], np.int32)
+    # pack kernel
+    dev = torch.device("cuda", 0)
+    slots = torch.from_numpy(np.stack([r["out"] for r in refs])).to(dev)
+    bits = torch.from_numpy(np.stack([r["bits"] for r in refs])).to(dev)
+    pay = torch.zeros(B, stride, dtype=torch.uint8, device=dev); pb = torch.zeros(B, dtype=torch.int32, device=dev); mb = torch.zeros(B, dtype=torch.int32, device=dev)
+    rc = amd.lib().ulcx_pack_streams_dev(0, B, K, slot, slots.data_ptr(), bits.data_ptr(), pay.data_ptr(), stride, pb.data_ptr(), mb.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(pb.cpu().numpy(), nbytes) and np.array_equal(pay.cpu().numpy(), host)
+    assert np.array_equal(mb.cpu().numpy(), np.array([((r["bits"] + 7) // 8).max() for r in refs]))
+    # packed decode in two calls
+    dec = amd.BatchDecoder(B, ch, bs, K // 2)
+    p1, b1 = dec.decode_packed(host, nbytes, K // 2)
+    p2, b2 = dec.decode_packed(host, nbytes, K // 2)
+    got = np.concatenate([p1, p2], axis=1); gb = np.concatenate([b1, b2], axis=1)
+    for s in range(B):
+        rc2, ref_pcm, ref_bits = oracle_decode_stream(refs[s]["out"], ch, bs)
+        assert np.array_equal(gb[s], ref_bits) and np.array_equal(got[s], ref_pcm), s
+    # a truncated payload ends its stream there
+    dec.reset()
+    cut = nbytes.copy(); cut[2] = nbytes[2] // 2
+    p3, b3 = dec.decode_packed(host, cut, K // 2)
+    p4, b4 = dec.decode_packed(host, cut, K // 2)
+    b34 = np.concatenate([b3, b4], axis=1)
+    assert (b34[2] == 0).any() and (b34[[0, 1, 3, 4]] > 0).all()
+    dec.close()

@@ -292,6 +292,7 @@ static int dec_reset_state(ulcx_decoder *e) {
     CKR(hipMemset(c.lap, 0, sizeof(float) * (size_t)e->B * e->C * (e->BS / 2)));     // ulcDecoder.c:56
     CKR(hipMemset(c.lastSub, 0, sizeof(int) * (size_t)e->B));                          // ulcDecoder.c:52
     CKR(hipMemset(c.dead, 0, sizeof(int) * (size_t)e->B));
+    CKR(hipMemset(c.packOff, 0, sizeof(int) * (size_t)e->B));
     std::vector<uint32_t> seed((size_t)e->B, 1234567u);                                // ulcDecoder.c:76, one RNG per stream
     CKR(hipMemcpy(c.seed, seed.data(), sizeof(uint32_t) * seed.size(), hipMemcpyHostToDevice));
     return ULCX_OK;
@@ -323,6 +324,8 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     DA(c.wc, NB, true);
     DA(c.draws, NB, true);
     DA(c.blockSeed, NB, true);
+    DA(c.packOff, B, true);
+    DA(c.blkOff, NB, true);
     DA(c.unitStart, NB * nChan * 4, true);
     DA(c.unitDraws, NB * nChan * 4, true);
     {
@@ -383,6 +386,70 @@ extern "C" int ulcx_decode_host(ulcx_decoder *e, const uint8_t *h_in, int slotBy
     CKR(hipMemcpy(h_bits, e->d_bits, sizeof(int32_t) * NB, hipMemcpyDeviceToHost));
     return ULCX_OK;
 }
+// ---------------------------------------------------------------------------
+// .ulc container + packed streams (tools/ulc_Helper.h:10-20, ulcEncodeTool.c:92-100,160-195, ulcDecodeTool.c:73-80,123-166)
+// ---------------------------------------------------------------------------
+static void put16(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+static void put32(uint8_t *p, uint32_t v) { put16(p, v); put16(p + 2, v >> 16); }
+static uint32_t get16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+static uint32_t get32(const uint8_t *p) { return get16(p) | (get16(p + 2) << 16); }
+extern "C" void ulcx_ulc_header_pack(uint8_t dst[24], const ulcx_file_header *h) {
+    put32(dst + 0x00, h->Magic); put16(dst + 0x04, h->BlockSize); put16(dst + 0x06, h->MaxBlockSize);
+    put32(dst + 0x08, h->nBlocks); put32(dst + 0x0C, h->RateHz); put16(dst + 0x10, h->nChan);
+    put16(dst + 0x12, h->RateKbps); put32(dst + 0x14, h->StreamOffs);
+}
+extern "C" int ulcx_ulc_header_parse(ulcx_file_header *h, const uint8_t *src, size_t len) {
+    if (!h || !src || len < 24) { ulcx_set_error("ulc header: need 24 bytes"); return ULCX_ERR_ARG; }
+    h->Magic = get32(src); h->BlockSize = (uint16_t)get16(src + 4); h->MaxBlockSize = (uint16_t)get16(src + 6);
+    h->nBlocks = get32(src + 8); h->RateHz = get32(src + 12); h->nChan = (uint16_t)get16(src + 16);
+    h->RateKbps = (uint16_t)get16(src + 18); h->StreamOffs = get32(src + 20);
+    if (h->Magic != ULCX_ULC_MAGIC) { ulcx_set_error("not a ULC2 container"); return ULCX_ERR_ARG; }   /* ulcDecodeTool.c:77-80 */
+    return ULCX_OK;
+}
+extern "C" int ulcx_ulc_rate_kbps(uint64_t totalBytes, uint32_t RateHz, uint32_t BlockSize, uint32_t nBlocks) {
+    double avg = (double)totalBytes * 8.0 * RateHz / 1000.0 / ((double)BlockSize * nBlocks);          /* ulcEncodeTool.c:173,190 */
+    return (int)lrint(avg);
+}
+extern "C" int ulcx_pack_streams_dev(int device, int nStreams, int nBlocks, int slotBytes, const uint8_t *d_slots, const int32_t *d_bits,
+                                     uint8_t *d_payload, long long payloadStride, int32_t *d_payloadBytes, int32_t *d_maxBlock, void *hipStream) {
+    if (nStreams < 1 || nBlocks < 1 || slotBytes < 1 || !d_slots || !d_bits || !d_payload || !d_payloadBytes || payloadStride < 1) { ulcx_set_error("ulcx_pack_streams_dev: bad argument"); return ULCX_ERR_ARG; }
+    int rc = select_device(device);
+    if (rc) return rc;
+    return ulcx_pack_launch(nStreams, nBlocks, slotBytes, d_slots, d_bits, d_payload, payloadStride, d_payloadBytes, d_maxBlock, (hipStream_t)hipStream);
+}
+extern "C" int ulcx_decode_packed_dev(ulcx_decoder *e, const uint8_t *d_payload, long long payloadStride, const int32_t *d_payloadBytes,
+                                      int nBlocks, float *d_pcm, int32_t *d_bits, void *hipStream) {
+    if (!e || !d_payload || !d_payloadBytes || !d_pcm || !d_bits || payloadStride < 1 || nBlocks < 1 || nBlocks > e->maxK) { ulcx_set_error("ulcx_decode_packed_dev: bad argument"); return ULCX_ERR_ARG; }
+    CKR(hipSetDevice(e->device));
+    UlcxDecCtx c = e->ctx;
+    c.K = nBlocks; c.slot = 0; c.in = d_payload; c.pcm = d_pcm; c.bits = d_bits;
+    c.packed = 1; c.payStride = payloadStride; c.payBytes = d_payloadBytes;
+    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->ev);
+    e->evRecorded = (rc == ULCX_OK);
+    return rc;
+}
+extern "C" int ulcx_decode_packed_host(ulcx_decoder *e, const uint8_t *h_payload, long long payloadStride, const int32_t *h_payloadBytes,
+                                       int nBlocks, float *h_pcm, int32_t *h_bits) {
+    if (!e || !h_payload || !h_payloadBytes || !h_pcm || !h_bits || nBlocks < 1 || nBlocks > e->maxK || payloadStride < 1) return ULCX_ERR_ARG;
+    CKR(hipSetDevice(e->device));
+    size_t cb = (size_t)e->C * e->BS, NB = (size_t)e->B * nBlocks;
+    uint8_t *dp = nullptr; int32_t *dn = nullptr; float *dpcm = nullptr; int32_t *dbits = nullptr;
+    size_t payBytes = (size_t)e->B * (size_t)payloadStride + 16;
+    CKR(hipMalloc((void **)&dp, payBytes)); CKR(hipMalloc((void **)&dn, sizeof(int32_t) * e->B));
+    CKR(hipMalloc((void **)&dpcm, sizeof(float) * NB * cb)); CKR(hipMalloc((void **)&dbits, sizeof(int32_t) * NB));
+    CKR(hipMemset(dp, 0, payBytes));
+    CKR(hipMemcpy(dp, h_payload, (size_t)e->B * (size_t)payloadStride, hipMemcpyHostToDevice));
+    CKR(hipMemcpy(dn, h_payloadBytes, sizeof(int32_t) * e->B, hipMemcpyHostToDevice));
+    int rc = ulcx_decode_packed_dev(e, dp, payloadStride, dn, nBlocks, dpcm, dbits, nullptr);
+    if (rc == ULCX_OK) {
+        CKR(hipDeviceSynchronize());
+        CKR(hipMemcpy(h_pcm, dpcm, sizeof(float) * NB * cb, hipMemcpyDeviceToHost));
+        CKR(hipMemcpy(h_bits, dbits, sizeof(int32_t) * NB, hipMemcpyDeviceToHost));
+    }
+    hipFree(dp); hipFree(dn); hipFree(dpcm); hipFree(dbits);
+    return rc;
+}
+
 static const char *kDecStage[ULCX_DEC_STAGES] = { "k_dscan", "k_dseed", "k_dgen", "k_dimdct" };
 extern "C" const char *ulcx_decoder_stage_name(int i) { return (i >= 0 && i < ULCX_DEC_STAGES) ? kDecStage[i] : ""; }
 extern "C" int ulcx_decoder_stage_ms(ulcx_decoder *e, float *ms, int maxStages) {

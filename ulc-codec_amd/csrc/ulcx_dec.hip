@@ -190,17 +190,20 @@ struct ScanFsm {
     }
 };
 
-// Pass 1 — one lane per block: walk the syntax, record where each (channel, subblock)
-// unit starts (nybble offset) and how many RNG draws precede it inside the block.
-__global__ __launch_bounds__(64) void k_dscan(UlcxDecCtx c) {
-    int blk = blockIdx.x * 64 + threadIdx.x;
-    if (blk >= c.B * c.K) return;
-    const uint8_t *p = c.in + (size_t)blk * c.slot;
-    const int limit = c.slot * 8 - 32;
+// base pointer of block blk's bytes: its slot, or (packed mode) its parsed offset inside the stream payload
+__device__ __forceinline__ const uint8_t *block_ptr(const UlcxDecCtx &c, int blk) {
+    if (!c.packed) return c.in + (size_t)blk * c.slot;
+    return c.in + (size_t)(blk / c.K) * c.payStride + c.blkOff[blk];
+}
+
+// Syntax walk of one block starting at p (limitBits readable): records unit starts / draw counts.
+// Returns bits consumed (0 = corrupt).
+__device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const uint8_t *p, int limit) {
     int pos = 0;
-    auto get = [&]() { unsigned x = p[pos >> 3]; int v = (pos & 4) ? (x >> 4) : (x & 0xF); pos += 4; return v; };
+    // never reads at or past `limit` bits (a clamped read of byte 0 instead): running past it marks the block corrupt below
+    auto get = [&]() { unsigned x = p[(pos < limit ? pos : 0) >> 3]; int v = (pos & 4) ? (x >> 4) : (x & 0xF); pos += 4; return v; };
     int wc = get();                                                 // ulcDecoder.c:211-216
-    { int v2 = (int)((p[pos >> 3] >> (pos & 4)) & 0xF); bool dec = (wc & 0x8) != 0; wc |= dec ? (v2 << 4) : (1 << 4); pos += dec ? 4 : 0; }
+    { int v2 = (int)((p[(pos < limit ? pos : 0) >> 3] >> (pos & 4)) & 0xF); bool dec = (wc & 0x8) != 0; wc |= dec ? (v2 << 4) : (1 << 4); pos += dec ? 4 : 0; }
     unsigned pat = ulcx_pattern(wc);                                // (code 0000 behaves as one plain N/1 block, as in the reference)
     int nsub = 0; { unsigned q = pat; do nsub++; while (q >>= 4); }
     if ((c.BS >> (pat & 7)) == c.BS) nsub = 1;                      // ulcDecoder.c:242-245
@@ -211,7 +214,8 @@ __global__ __launch_bounds__(64) void k_dscan(UlcxDecCtx c) {
     int u = 0;
     ustart[0] = pos; udraw[0] = 0;
     f.start(c.BS >> (pat & 7));
-    bool fin = false;
+    bool fin = (limit < 16);
+    f.bad = fin;
     while (!fin) {
         int v = get();
         f.step(v);
@@ -224,12 +228,42 @@ __global__ __launch_bounds__(64) void k_dscan(UlcxDecCtx c) {
                 f.start(c.BS >> ((pat >> (4 * j)) & 7));
             }
         }
-        if (pos > limit) { f.bad = true; fin = true; }              // ran off the slot: corrupt (see NybReader::limit)
+        if (pos > limit) { f.bad = true; fin = true; }              // ran off the readable bytes: corrupt
     }
     bool ok = !f.bad;
     c.bits[blk] = ok ? pos : 0;
     c.wc[blk] = ok ? wc : 0;
     c.draws[blk] = f.draws;
+    return ok ? pos : 0;
+}
+
+// Pass 1 — one lane per block: walk the syntax, record where each (channel, subblock)
+// unit starts (nybble offset) and how many RNG draws precede it inside the block.
+__global__ __launch_bounds__(64) void k_dscan(UlcxDecCtx c) {
+    int blk = blockIdx.x * 64 + threadIdx.x;
+    if (blk >= c.B * c.K) return;
+    scan_block(c, blk, c.in + (size_t)blk * c.slot, c.slot * 8 - 32);
+}
+
+// Pass 1, packed payloads — one lane per stream: a block's start is only known once the previous
+// block has been parsed (the container stores no block lengths, tools/ulcDecodeTool.c:153-165).
+__global__ __launch_bounds__(64) void k_dscan_packed(UlcxDecCtx c) {
+    int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= c.B) return;
+    int off = c.packOff[s];
+    int avail = c.payBytes[s];
+    const uint8_t *base = c.in + (size_t)s * c.payStride;
+    bool dead = false;
+    for (int k = 0; k < c.K; k++) {
+        int blk = s * c.K + k;
+        c.blkOff[blk] = off;
+        int bits = 0;
+        if (!dead && off < avail) bits = scan_block(c, blk, base + off, (avail - off) * 8);
+        else { c.bits[blk] = 0; c.wc[blk] = 0; c.draws[blk] = 0; }
+        if (!bits) dead = true;
+        off += (bits + 7) >> 3;                                     // the tool rounds every block up to a byte
+    }
+    c.packOff[s] = off;
 }
 
 // xorshift32 is linear over GF(2): state after n draws = T^n * state.  jump[i] holds the
@@ -283,7 +317,7 @@ __global__ __launch_bounds__(64) void k_dgen(UlcxDecCtx c) {
         pat >>= 4;
         if (!pat) return;
     }
-    NybReader r; r.init(c.in + (size_t)blk * c.slot, c.unitStart[(size_t)blk * c.C * 4 + ch * 4 + j], c.slot);
+    NybReader r; r.init(block_ptr(c, blk), c.unitStart[(size_t)blk * c.C * 4 + ch * 4 + j], c.packed ? (1 << 24) : c.slot);
     uint32_t seed = rng_jump(c.jump, c.blockSeed[blk], (uint32_t)c.unitDraws[(size_t)blk * c.C * 4 + ch * 4 + j]);
     CoefWriter w; w.dst = c.coef + (size_t)blk * c.C * c.BS + (size_t)ch * c.BS + off; w.n = 0;
     int draws = 0;
@@ -418,7 +452,8 @@ int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev) {
     int stage = 0;
     if (ev) CK(hipEventRecord(ev[stage++], st));
     int NB = c.B * c.K;
-    hipLaunchKernelGGL(k_dscan, dim3((NB + 63) / 64), dim3(64), 0, st, c);
+    if (c.packed) hipLaunchKernelGGL(k_dscan_packed, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
+    else hipLaunchKernelGGL(k_dscan, dim3((NB + 63) / 64), dim3(64), 0, st, c);
     if (ev) CK(hipEventRecord(ev[stage++], st));
     hipLaunchKernelGGL(k_dseed, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
     if (ev) CK(hipEventRecord(ev[stage++], st));
@@ -429,6 +464,32 @@ int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev) {
     if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_dimdct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_dimdct, dim3(c.B), dim3(WG), lds, st, c);
     if (ev) CK(hipEventRecord(ev[stage++], st));
+    CK(hipGetLastError());
+    return ULCX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Slots -> contiguous per-stream payloads (tools/ulcEncodeTool.c:160-169)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_streams(int nBlocks, int slotBytes, const uint8_t *slots, const int32_t *bits,
+                                                       uint8_t *payload, long long stride, int32_t *payloadBytes, int32_t *maxBlock) {
+    __shared__ int s_off, s_len;
+    int s = blockIdx.x, tid = threadIdx.x;
+    uint8_t *dst = payload + (size_t)s * stride;
+    int off = 0, mx = 0;
+    for (int k = 0; k < nBlocks; k++) {
+        int n = (bits[(size_t)s * nBlocks + k] + 7) >> 3;
+        const uint8_t *src = slots + ((size_t)s * nBlocks + k) * slotBytes;
+        if ((size_t)off + n <= (size_t)stride) for (int i = tid; i < n; i += 256) dst[off + i] = src[i];
+        off += n;
+        mx = n > mx ? n : mx;
+    }
+    (void)s_off; (void)s_len;
+    if (tid == 0) { payloadBytes[s] = off; if (maxBlock) maxBlock[s] = mx; }
+}
+int ulcx_pack_launch(int nStreams, int nBlocks, int slotBytes, const uint8_t *d_slots, const int32_t *d_bits, uint8_t *d_payload,
+                     long long stride, int32_t *d_payloadBytes, int32_t *d_maxBlock, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_streams, dim3(nStreams), dim3(256), 0, st, nBlocks, slotBytes, d_slots, d_bits, d_payload, stride, d_payloadBytes, d_maxBlock);
     CK(hipGetLastError());
     return ULCX_OK;
 }

@@ -102,6 +102,12 @@ struct UlcxDecCtx {
     uint32_t *blockSeed;                 // [NB] RNG state at the start of the block
     int   *unitStart, *unitDraws;        // [NB][C*4] nybble offset / draws before each (chan,subblock) unit
     const uint32_t *jump;                // [32][32] columns of T^(2^i), T = one xorshift32 step
+    // packed-stream mode (.ulc payloads): blocks are located by parsing, not by slot
+    int   packed;
+    long long payStride;                 // bytes between stream payloads
+    const int32_t *payBytes;             // [B] valid bytes per stream
+    int  *packOff;                       // [B] persistent read position of each stream
+    int  *blkOff;                        // [NB] byte offset of each block inside its stream payload
 };
 
 // ulcHelper.h:24-46
@@ -125,5 +131,7 @@ extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES];
 #define ULCX_DEC_STAGES 4
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, hipStream_t side, hipEvent_t evFork, hipEvent_t evJoin, hipEvent_t evFork2);
 int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev);
+int ulcx_pack_launch(int nStreams, int nBlocks, int slotBytes, const uint8_t *d_slots, const int32_t *d_bits, uint8_t *d_payload,
+                     long long stride, int32_t *d_payloadBytes, int32_t *d_maxBlock, hipStream_t st);
 size_t ulcx_enc_xf_lds_bytes(int BS);
 void ulcx_enc_finalize_keys(const UlcxEncCtx &c, hipStream_t st);

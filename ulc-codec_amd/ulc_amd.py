@@ -19,8 +19,17 @@ EXPORTS = [
     "ulcx_last_error", "ulcx_device_count", "ulcx_encoder_create", "ulcx_encoder_destroy", "ulcx_encoder_reset",
     "ulcx_encoder_slot_bytes", "ulcx_encode_dev", "ulcx_encode_host", "ulcx_encoder_debug_fetch",
     "ulcx_decoder_create", "ulcx_decoder_destroy", "ulcx_decoder_reset", "ulcx_decode_dev", "ulcx_decode_host",
-    "ulcx_encoder_last_fallbacks", "ulcx_encoder_stage_ms", "ulcx_encoder_stage_name", "ulcx_decoder_stage_ms", "ulcx_decoder_stage_name",
+    "ulcx_encoder_last_fallbacks", "ulcx_ulc_header_pack", "ulcx_ulc_header_parse", "ulcx_ulc_rate_kbps",
+    "ulcx_pack_streams_dev", "ulcx_decode_packed_dev", "ulcx_decode_packed_host", "ulcx_encoder_stage_ms", "ulcx_encoder_stage_name", "ulcx_decoder_stage_ms", "ulcx_decoder_stage_name",
 ]
+
+
+
+class FileHeader(C.Structure):
+    """tools/ulc_Helper.h:10-20 (24 bytes)."""
+    _fields_ = [("Magic", C.c_uint32), ("BlockSize", C.c_uint16), ("MaxBlockSize", C.c_uint16), ("nBlocks", C.c_uint32),
+                ("RateHz", C.c_uint32), ("nChan", C.c_uint16), ("RateKbps", C.c_uint16), ("StreamOffs", C.c_uint32)]
+
 
 _lib = None
 
@@ -46,6 +55,13 @@ def lib():
         l.ulcx_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         l.ulcx_decode_host.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, _f32p, _i32p]
         l.ulcx_encoder_last_fallbacks.argtypes = [C.c_void_p]
+        l.ulcx_decode_packed_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.ulcx_decode_packed_host.argtypes = [C.c_void_p, _u8p, C.c_longlong, _i32p, C.c_int, _f32p, _i32p]
+        l.ulcx_pack_streams_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
+        l.ulcx_ulc_header_pack.argtypes = [_u8p, C.POINTER(FileHeader)]
+        l.ulcx_ulc_header_parse.argtypes = [C.POINTER(FileHeader), _u8p, C.c_size_t]
+        l.ulcx_ulc_rate_kbps.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         l.ulcx_encoder_stage_ms.argtypes = [C.c_void_p, _f32p, C.c_int]
         l.ulcx_decoder_stage_ms.argtypes = [C.c_void_p, _f32p, C.c_int]
         l.ulcx_encoder_stage_name.restype = C.c_char_p
@@ -162,6 +178,18 @@ class BatchDecoder:
         pcm = np.zeros((B, K * self.BS, self.C), np.float32)
         bits = np.zeros((B, K), np.int32)
         _check(lib().ulcx_decode_host(self.h, _p(blocks, _u8p), slot, K, _p(pcm, _f32p), _p(bits, _i32p)), "ulcx_decode_host")
+        return pcm, bits
+
+    def decode_packed(self, payload, payload_bytes, n_blocks):
+        """payload: uint8 [B][stride] contiguous blocks per stream (a .ulc file's data section each);
+        continues from where the previous call stopped."""
+        payload = np.ascontiguousarray(payload, dtype=np.uint8)
+        nbytes = np.ascontiguousarray(payload_bytes, dtype=np.int32)
+        B, stride = payload.shape
+        pcm = np.zeros((B, n_blocks * self.BS, self.C), np.float32)
+        bits = np.zeros((B, n_blocks), np.int32)
+        _check(lib().ulcx_decode_packed_host(self.h, _p(payload, _u8p), stride, _p(nbytes, _i32p), n_blocks, _p(pcm, _f32p), _p(bits, _i32p)),
+               "ulcx_decode_packed_host")
         return pcm, bits
 
     def decode_dev(self, d_in, slot, n_blocks, d_pcm, d_bits, stream=0):
