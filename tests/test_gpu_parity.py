@@ -223,3 +223,35 @@ def test_packed_stream_pack_and_decode():
     b34 = np.concatenate([b3, b4], axis=1)
     assert (b34[2] == 0).any() and (b34[[0, 1, 3, 4]] > 0).all()
     dec.close()
+
+
+@pytest.mark.parametrize("bs,ch,rate,B,K,calls,q", [
+    (8192, 2, 48000, 2, 3, 1, 40.0),     # largest block size built for the device
+    (2048, 6, 48000, 2, 4, 1, 50.0),     # 5.1-style: three M/S pairs
+    (1024, 5, 44100, 3, 4, 1, 70.0),     # odd channel count > 2
+    (2048, 2, 44100, 1, 1, 6, 50.0),     # one stream, one block per call: the drop-in shim's shape
+    (256, 2, 8000, 3, 9, 3, 95.0),       # smallest block, low rate, high quality (dense coding)
+])
+def test_encode_decode_unusual_geometries(bs, ch, rate, B, K, calls, q):
+    amd = _amd()
+    pcm = _streams(B, K * calls, bs, ch, rate, True, seed=bs + 7 * ch)
+    enc = amd.BatchEncoder(B, ch, bs, rate, K)
+    refs = [oracle_encode_debug(pcm[s], bs, rate, 0, q, slot=enc.slot) for s in range(B)]
+    outs = []
+    for c in range(calls):
+        res = enc.encode(pcm[:, c * K * bs:(c + 1) * K * bs], amd.MODE_VBR, q)
+        for s in range(B):
+            _compare_encode(res, refs[s], s, c * K, K, None, f"geom bs={bs} ch={ch}")
+        outs.append(res[0])
+    enc.close()
+    blocks = np.concatenate(outs, axis=1)
+    try:
+        dec = amd.BatchDecoder(B, ch, bs, K)
+    except amd.UlcError as e:
+        assert "LDS" in str(e) or "not built" in str(e), e          # documented limit
+        return
+    got = np.concatenate([dec.decode(blocks[:, c * K:(c + 1) * K])[0] for c in range(calls)], axis=1)
+    for s in range(B):
+        rc, ref_pcm, _ = oracle_decode_stream(refs[s]["out"], ch, bs)
+        assert rc == 0 and np.array_equal(got[s], ref_pcm), f"geom bs={bs} ch={ch} stream {s}"
+    dec.close()
