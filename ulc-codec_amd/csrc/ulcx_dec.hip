@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64) void k_dgen(UlcxDecCtx c) {
 }
 
 // ---------------------------------------------------------------------------
-// IMDCT + overlap-add.  LDS carve (floats): lap [C][BS/2] | z [BS] (BS/2 complex) |
+// IMDCT + overlap-add.  LDS carve (floats): lap [C][BS/2] | z [2*BS] (two arrays of BS/2 complex) |
 // dec [BS] | tmpq [BS/2] | stage [2][BS]
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
     int s = blockIdx.x, tid = threadIdx.x;
     float  *lap   = lds;
     float2 *z     = (float2 *)(lap + (size_t)C * H2);
-    float  *dec   = (float *)(z + H2);
+    float  *dec   = (float *)(z + 2 * H2);
     float  *tmpq  = dec + BS;
     float  *stage = tmpq + H2;
     float *glap = c.lap + (size_t)s * C * H2;
@@ -352,6 +352,62 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
         }
         const float *coefB = c.coef + (size_t)blk * C * BS;
         int newLast = lastSub;
+        // ---- stereo, un-decimated block (the common case): both channels at once, inverse M/S in
+        //      registers, interleaved stores; no staging through LDS
+        if (C == 2 && (BS >> (ulcx_pattern(wc) & 7)) == BS) {
+            const int S = BS, M = BS >> 1;
+            unsigned pat0 = ulcx_pattern(wc);
+            int ov = S;                                             // ulcDecoder.c:234-239
+            if (pat0 & 8) ov >>= (wc & 7);
+            if (ov > lastSub) ov = lastSub;
+            const float2 *pre = c.T.pre[0];
+            float2 *z0 = z, *z1 = z + M;
+            const float *X0 = coefB, *X1 = coefB + BS;
+            for (int n = tid; n < M; n += WG) {
+                float2 P = pre[n];
+                z0[n] = cmulc(make_float2(X0[2 * n], X0[S - 1 - 2 * n]), P);
+                z1[n] = cmulc(make_float2(X1[2 * n], X1[S - 1 - 2 * n]), P);
+            }
+            __syncthreads();
+            fftn_dif(z, 2, M, c.T.tw[0], tid);
+            int a = (S - ov) >> 1;
+            const float *fall = c.T.winFall + ov, *rise = c.T.winRise + ov;
+            int bits = 31 - __clz(M);
+            float *L0 = lap, *L1 = lap + H2;
+            for (int kk = tid; kk < M / 2; kk += WG) {
+                int k1 = kk, k2 = M - 1 - kk;
+                int r1 = (int)(__brev((unsigned)k1) >> (32 - bits));
+                int r2 = (int)(__brev((unsigned)k2) >> (32 - bits));
+                float2 P1 = pre[k1], P2 = pre[k2];
+                float2 ya1 = cmulc(z0[r1], P1), ya2 = cmulc(z0[r2], P2);     // channel 0 (M)
+                float2 yb1 = cmulc(z1[r1], P1), yb2 = cmulc(z1[r2], P2);     // channel 1 (S)
+                float A0m = L0[2 * k1], A1m = L0[2 * k1 + 1], A0s = L1[2 * k1], A1s = L1[2 * k1 + 1];
+                float Bm[2] = { -ya1.y, ya2.x }, Bs[2] = { -yb1.y, yb2.x };
+                float Am[2] = { A0m, A1m }, As[2] = { A0s, A1s };
+                int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    int p = pv[q];
+                    float mLo, mHi, sLo, sHi;                                  // outputs at positions p and S-1-p
+                    if (p < a) { mLo = Am[q]; mHi = Bm[q]; sLo = As[q]; sHi = Bs[q]; }
+                    else {
+                        float cw = fall[p - a], sw = rise[p - a];
+                        float m0 = cw * Am[q], m1 = sw * Bm[q], m2 = sw * Am[q], m3 = cw * Bm[q];
+                        mLo = m0 - m1; mHi = m2 + m3;
+                        float s0 = cw * As[q], s1 = sw * Bs[q], s2 = sw * As[q], s3 = cw * Bs[q];
+                        sLo = s0 - s1; sHi = s2 + s3;
+                    }
+                    // inverse M/S (ulcDecoder.c:281-289) + interleave (:292-297)
+                    *(float2 *)(outp + 2 * p) = make_float2(mLo + sLo, mLo - sLo);
+                    *(float2 *)(outp + 2 * (S - 1 - p)) = make_float2(mHi + sHi, mHi - sHi);
+                }
+                L0[2 * k1] = ya1.x; L0[2 * k1 + 1] = -ya2.y;
+                L1[2 * k1] = yb1.x; L1[2 * k1 + 1] = -yb2.y;
+            }
+            __syncthreads();
+            lastSub = S;
+            continue;
+        }
         for (int ch = 0; ch < C; ch++) {
             int last = lastSub;                                     // ulcDecoder.c:219
             float *dst = stage + (size_t)(ch & 1) * BS;
@@ -443,7 +499,7 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
 }
 
 size_t ulcx_dec_lds_bytes(int BS, int C) {
-    return sizeof(float) * ((size_t)C * (BS / 2) + BS + BS + BS / 2 + 2 * (size_t)BS);
+    return sizeof(float) * ((size_t)C * (BS / 2) + 2 * (size_t)BS + BS + BS / 2 + 2 * (size_t)BS);
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)
