@@ -874,41 +874,55 @@ __global__ __launch_bounds__(64) void k_heapsel_pipe(UlcxEncCtx c) {
             for (int n = first + lane; n <= last; n += 64) heap_sift(hp, n, N);
             __syncthreads();
         }
-        // ---- pipelined pops
+        // ---- pipelined pops.  Every step issues all of its LDS reads first (root, the leaf the next
+        //      pop lifts, the root's children, each in-flight sift's children): one round trip per step.
         int pops = N - kSel;
         int P = 0, step = 0, lastStart = -2;
         bool active = false; int pos = 0, size = 0; HeapEnt e; e.v = 0.0f; e.i = 0;
         while (P < pops || __any(active)) {
-            if (P < pops && step - lastStart >= 2) {
-                int nl = N - 1 - P;                       // index of the element to lift = heap size after this pop
-                // is any in-flight sift on the path root -> nl ?
-                bool onPath = false;
-                if (active) {
-                    int a = pos + 1, b = nl + 1;          // 1-based heap numbering: a is ancestor-or-self of b iff b >> (depth diff) == a
-                    int da = 31 - __clz(a), db = 31 - __clz(b);
-                    onPath = (db >= da) && ((b >> (db - da)) == a);
-                }
-                int slot = P & 15;
-                bool slotBusy = __shfl((int)active, slot) != 0;
-                if (!__any(onPath) && !slotBusy) {
-                    HeapEnt g = hp[0];
-                    if (lane == slot) {
-                        kb[g.i >> 5] &= ~(1u << (g.i & 31));
-                        if (nl > 0) { e = hp[nl]; pos = 0; size = nl; active = true; }
-                    }
-                    P++; lastStart = step;
-                }
-            }
+            // -- may pop P start now?
+            int nl = N - 1 - P;                           // index of the element to lift = heap size after this pop
+            bool want = (P < pops) && (step - lastStart >= 2);
+            bool onPath = false;
             if (active) {
-                int c1 = 2 * pos + 1;
-                if (c1 >= size) { hp[pos] = e; active = false; }
+                int a1 = pos + 1, b1 = nl + 1;            // 1-based: a1 is ancestor-or-self of b1 iff b1 >> (depth diff) == a1
+                int da = 31 - __clz(a1), db = 31 - __clz(b1);
+                onPath = (db >= da) && ((b1 >> (db - da)) == a1);
+            }
+            int slot = P & 15;
+            bool slotBusy = __shfl((int)active, slot) != 0;
+            bool start = want && !__any(onPath) && !slotBusy;
+            // -- issue every read of this step
+            int c1 = 2 * pos + 1;
+            bool sift = active && (c1 < size);
+            HeapEnt g = hp[0], el = hp[nl > 0 ? nl : 0], r1 = hp[1], r2 = hp[2];
+            HeapEnt cL = hp[sift ? c1 : 0], cR = hp[(sift && c1 + 1 < size) ? c1 + 1 : 0];
+            // -- in-flight sifts advance one level
+            if (active) {
+                if (!sift) { hp[pos] = e; active = false; }
                 else {
-                    HeapEnt cN = hp[c1];
-                    int ci = c1;
-                    if (c1 + 1 < size) { HeapEnt c2 = hp[c1 + 1]; if (c2.v < cN.v) { cN = c2; ci = c1 + 1; } }
+                    HeapEnt cN = cL; int ci = c1;
+                    if (c1 + 1 < size && cR.v < cN.v) { cN = cR; ci = c1 + 1; }
                     if (cN.v > e.v) { hp[pos] = e; active = false; }
                     else { hp[pos] = cN; pos = ci; }
                 }
+            }
+            // -- the new pop: discard the root, lift the last element, and do its level-0 step right away
+            if (start) {
+                if (lane == slot) {
+                    atomicAnd(&kb[g.i >> 5], ~(1u << (g.i & 31)));
+                    if (nl > 0) {
+                        e = el; size = nl; pos = 0; active = true;
+                        if (1 >= size) { hp[0] = e; active = false; }
+                        else {
+                            HeapEnt cN = r1; int ci = 1;
+                            if (2 < size && r2.v < cN.v) { cN = r2; ci = 2; }
+                            if (cN.v > e.v) { hp[0] = e; active = false; }
+                            else { hp[0] = cN; pos = ci; }
+                        }
+                    }
+                }
+                P++; lastStart = step;
             }
             step++;
         }
@@ -1326,9 +1340,9 @@ __global__ __launch_bounds__(64) void k_encode_units(UlcxEncCtx c, int finalPass
 // Every float operation keeps the reference's order, so the nybbles are identical.
 // Units that exceed the LDS capacities below fall back to k_encode_units (c.slow).
 // ---------------------------------------------------------------------------
-#define E2_KCAP   768      // kept coefficients per unit
-#define E2_ZCAP   256      // quantizer zones per unit
-#define E2_NYBCAP 3072     // nybbles per unit
+#define E2_KCAP   512      // kept coefficients per unit
+#define E2_ZCAP   128      // quantizer zones per unit
+#define E2_NYBCAP 2048     // nybbles per unit
 
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
     int x = v;
