@@ -180,6 +180,15 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
         }
     }
     DA(c.isFb, NB, true);
+    DA(c.ownSlot, NB, true);
+    {
+        size_t slots = NB;
+        size_t maxSlots = ((size_t)1 << 30) / (cb * 4);          // at most 1 GiB of resident rankings
+        if (maxSlots < 1) maxSlots = 1;
+        if (slots > maxSlots) slots = maxSlots;
+        c.rankSlots = (int)slots;
+        DA(c.rankBuf, slots * cb, false);
+    }
     rc = enc_reset_state(e);
     if (rc) { cleanup(e); return rc; }
     *out = e;

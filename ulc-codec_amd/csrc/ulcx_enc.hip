@@ -667,6 +667,17 @@ void ulcx_enc_finalize_keys(const UlcxEncCtx &c, hipStream_t st) {
     hipLaunchKernelGGL(k_keys_finalize, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);
 }
 
+// Which blocks a launch of the select/encode kernels works on:
+//   probe passes skip blocks whose rate search has converged; fbMode 1 skips blocks that left the lock-step
+//   path because a threshold tie group straddled the cut (c.isFb, set once per call); fbMode 2 processes
+//   only those, restricted to the slots [fbLo, fbHi) of the fallback list whose ranks are resident.
+__device__ __forceinline__ bool skip_block(const UlcxEncCtx &c, int blk, int finalPass) {
+    if (!finalPass && c.cbrDone[blk]) return true;
+    if (c.fbMode == 1) return c.isFb[blk] != 0;
+    if (c.fbMode == 2) { if (!c.isFb[blk]) return true; int sl = c.ownSlot[blk]; return sl < c.fbLo || sl >= c.fbHi; }
+    return false;
+}
+
 // ---------------------------------------------------------------------------
 // Selection of the nOutCoef most important coefficients.
 // The reference heapsorts all keys into ranks (BlockTransform.c:20-77) but ranks are
@@ -687,13 +698,13 @@ __global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
     __shared__ int s_need;
     int blk = blockIdx.x, tid = threadIdx.x;
     if (!finalPass && c.cbrDone[blk]) return;        // rate search already converged: wait for the final pass
+    if (c.isFb[blk]) return;
     int N = c.C * c.BS;
     int kSel = c.nout[blk];
     const float *key = c.key + (size_t)blk * N;
     uint32_t *keep = c.keep + (size_t)blk * (N / 32);
     if (kSel <= 0) {
         for (int i = tid; i < N / 32; i += WG) keep[i] = 0;
-        if (tid == 0) c.isFb[blk] = 0;
         return;
     }
     uint32_t prefix = 0, pmask = 0;
@@ -729,10 +740,11 @@ __global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
         if (lane == 0)  keep[i >> 5] = (uint32_t)m;
         if (lane == 32) keep[i >> 5] = (uint32_t)(m >> 32);
     }
-    if (tid == 0) c.isFb[blk] = straddle ? 1 : 0;
     if (straddle && tid == 0) {
         int slot = atomicAdd(c.fbCount, 1);
         c.fbList[slot] = blk;
+        c.ownSlot[blk] = slot;
+        c.isFb[blk] = 1;
     }
 }
 
@@ -744,11 +756,11 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
     int blk = blockIdx.x * 4 + wv;                        // 4 waves per workgroup, one block per wave
     if (blk >= c.B * c.K) return;
     if (!finalPass && c.cbrDone[blk]) return;
+    if (c.isFb[blk]) return;                              // already handed to the exact (heapsort-rank) path this call
     const int N = R * 64;
     int kSel = c.nout[blk];
     const float *key = c.key + (size_t)blk * N;
     uint32_t *keep = c.keep + (size_t)blk * (N / 32);
-    if (lane == 0) c.isFb[blk] = 0;
     if (kSel <= 0) {
         for (int i = lane; i < N / 32; i += 64) keep[i] = 0;
         return;
@@ -788,6 +800,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
     if (straddle && lane == 0) {
         int slot = atomicAdd(c.fbCount, 1);
         c.fbList[slot] = blk;
+        c.ownSlot[blk] = slot;
         c.isFb[blk] = 1;
     }
 }
@@ -814,31 +827,23 @@ __device__ void heap_sift(P h, int root, int n) {
 }
 __global__ __launch_bounds__(64) void k_heapsel(UlcxEncCtx c, int ldsEntries) {
     extern __shared__ HeapEnt hl[];
-    int count = *c.fbCount;
+    int count = *c.fbCount; if (count > c.fbHi) count = c.fbHi;
     int N = c.C * c.BS;
     bool useLds = (N <= ldsEntries);
     HeapEnt *h = useLds ? hl : (HeapEnt *)c.heapScratch + (size_t)blockIdx.x * N;
-    for (int idx = blockIdx.x; idx < count; idx += gridDim.x) {
+    for (int idx = c.fbLo + blockIdx.x; idx < count; idx += gridDim.x) {
         int blk = c.fbList[idx];
-        int kSel = c.nout[blk];
-        const float *key = c.key + (size_t)blk * N;
-        uint32_t *keep = c.keep + (size_t)blk * (N / 32);
-        uint32_t *kb = useLds ? (uint32_t *)(hl + N) : keep;        // kept-set bitmap (LDS copy when the heap is in LDS)
+        int *rank = c.rankBuf + (size_t)(idx - c.fbLo) * N;
         for (int i = threadIdx.x; i < N; i += 64) { h[i].v = load_final_key(c, blk, i); h[i].i = i; }
-        for (int i = threadIdx.x; i < N / 32; i += 64) kb[i] = 0xFFFFFFFFu;
         __syncthreads();
         if (threadIdx.x == 0) {
             for (int n = N / 2 - 1; n >= 0; n--) heap_sift(h, n, N);
-            int pops = N - kSel;
-            int n = N - 1;
-            for (int p = 0; p < pops; p++, n--) {
-                int gone = h[0].i;
-                kb[gone >> 5] &= ~(1u << (gone & 31));
-                if (n > 0) { h[0] = h[n]; heap_sift(h, 0, n); }
+            for (int n = N - 1; n > 0; n--) {             // BlockTransform.c:66-76: ranks N-1 .. 1 in pop order
+                rank[h[0].i] = n;
+                h[0] = h[n]; heap_sift(h, 0, n);
             }
+            rank[h[0].i] = 0;
         }
-        __syncthreads();
-        if (useLds) for (int i = threadIdx.x; i < N / 32; i += 64) keep[i] = kb[i];
         __syncthreads();
     }
 }
@@ -854,17 +859,13 @@ __global__ __launch_bounds__(64) void k_heapsel(UlcxEncCtx c, int ldsEntries) {
 // Comparisons and tie behaviour are exactly those of heap_sift / BlockTransform.c:20-51.
 __global__ __launch_bounds__(64) void k_heapsel_pipe(UlcxEncCtx c) {
     extern __shared__ HeapEnt hp[];
-    int count = *c.fbCount;
+    int count = *c.fbCount; if (count > c.fbHi) count = c.fbHi;
     const int N = c.C * c.BS;
-    uint32_t *kb = (uint32_t *)(hp + N);
     int lane = threadIdx.x;
-    for (int idx = blockIdx.x; idx < count; idx += gridDim.x) {
+    for (int idx = c.fbLo + blockIdx.x; idx < count; idx += gridDim.x) {
         int blk = c.fbList[idx];
-        int kSel = c.nout[blk];
-        const float *key = c.key + (size_t)blk * N;
-        uint32_t *keep = c.keep + (size_t)blk * (N / 32);
+        int *rank = c.rankBuf + (size_t)(idx - c.fbLo) * N;      // full ranking, so every later nOutCoef of this block is a lookup
         for (int i = lane; i < N; i += 64) { hp[i].v = load_final_key(c, blk, i); hp[i].i = i; }
-        for (int i = lane; i < N / 32; i += 64) kb[i] = 0xFFFFFFFFu;
         __syncthreads();
         // ---- heapify, level by level
         int top = 31 - __clz(N / 2);                      // level of node N/2-1 (root = level 0) for power-of-two N
@@ -876,7 +877,7 @@ __global__ __launch_bounds__(64) void k_heapsel_pipe(UlcxEncCtx c) {
         }
         // ---- pipelined pops.  Every step issues all of its LDS reads first (root, the leaf the next
         //      pop lifts, the root's children, each in-flight sift's children): one round trip per step.
-        int pops = N - kSel;
+        int pops = N;                                     // pop p gets rank N-1-p (BlockTransform.c:66-76)
         int P = 0, step = 0, lastStart = -2;
         bool active = false; int pos = 0, size = 0; HeapEnt e; e.v = 0.0f; e.i = 0;
         while (P < pops || __any(active)) {
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(64) void k_heapsel_pipe(UlcxEncCtx c) {
             // -- the new pop: discard the root, lift the last element, and do its level-0 step right away
             if (start) {
                 if (lane == slot) {
-                    atomicAnd(&kb[g.i >> 5], ~(1u << (g.i & 31)));
+                    rank[g.i] = nl;
                     if (nl > 0) {
                         e = el; size = nl; pos = 0; active = true;
                         if (1 >= size) { hp[0] = e; active = false; }
@@ -927,8 +928,25 @@ __global__ __launch_bounds__(64) void k_heapsel_pipe(UlcxEncCtx c) {
             step++;
         }
         __syncthreads();
-        for (int i = lane; i < N / 32; i += 64) keep[i] = kb[i];
-        __syncthreads();
+    }
+}
+
+// kept set of the exact-path blocks from their ranking: rank < nOutCoef (Encode.c:108,220)
+__global__ __launch_bounds__(WG) void k_keep_ranks(UlcxEncCtx c, int finalPass) {
+    int count = *c.fbCount; if (count > c.fbHi) count = c.fbHi;
+    const int N = c.C * c.BS;
+    for (int idx = c.fbLo + blockIdx.x; idx < count; idx += gridDim.x) {
+        int blk = c.fbList[idx];
+        if (!finalPass && c.cbrDone[blk]) continue;
+        const int *rank = c.rankBuf + (size_t)(idx - c.fbLo) * N;
+        uint32_t *keep = c.keep + (size_t)blk * (N / 32);
+        int kSel = c.nout[blk];
+        for (int i = threadIdx.x; i < N; i += WG) {
+            unsigned long long m = __ballot(rank[i] < kSel);
+            int lane = threadIdx.x & 63;
+            if (lane == 0)  keep[i >> 5] = (uint32_t)m;
+            if (lane == 32) keep[i >> 5] = (uint32_t)(m >> 32);
+        }
     }
 }
 
@@ -945,9 +963,7 @@ __global__ __launch_bounds__(64) void k_heapsel_pipe(UlcxEncCtx c) {
 __global__ __launch_bounds__(WG) void k_gapsums(UlcxEncCtx c, int finalPass) {
     extern __shared__ uint32_t gsm[];
     int blk = blockIdx.x, tid = threadIdx.x;
-    if (!finalPass && c.cbrDone[blk]) return;
-    if (c.fbMode == 1 && c.isFb[blk]) return;
-    if (c.fbMode == 2 && !c.isFb[blk]) return;
+    if (skip_block(c, blk, finalPass)) return;
     const int N = c.C * c.BS;
     float *pairs = (float *)gsm;                           // N floats: the block's {w, w*log} pairs
     uint32_t *kw = gsm + N;                                // keep words of the block
@@ -1033,9 +1049,7 @@ __global__ __launch_bounds__(64) void k_tailsums(UlcxEncCtx c, int finalPass) {
     int nBC = c.B * c.K * c.C;
     if (ui >= nBC * 4) return;
     int j = ui / nBC, rem = ui - j * nBC, blk = rem / c.C, ch = rem - blk * c.C;     // subblock index slowest
-    if (!finalPass && c.cbrDone[blk]) return;
-    if (c.fbMode == 1 && c.isFb[blk]) return;
-    if (c.fbMode == 2 && !c.isFb[blk]) return;
+    if (skip_block(c, blk, finalPass)) return;
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     int d0, off, S;
@@ -1265,10 +1279,9 @@ __global__ __launch_bounds__(64) void k_encode_units(UlcxEncCtx c, int finalPass
     // (subblock index fastest on purpose: the state machine diverges per lane, so sparse waves -
     //  4x more of them in flight - hide its latency better than dense ones; measured 7.1 vs 9.6 ms)
     int j = gid & 3, ch = (gid >> 2) % c.C, blk = gid / (4 * c.C);
-    if (!finalPass && c.cbrDone[blk]) return;
-    if ((c.useFused || c.useWave) && !c.slow[blk]) return;
-    if (c.fbMode == 1 && c.isFb[blk]) return;            // tie-straddle blocks are encoded on the side stream
-    if (c.fbMode == 2 && !c.isFb[blk]) return;
+    if (skip_block(c, blk, finalPass)) return;
+    if (c.useFused && !c.slow[blk]) return;
+    if (c.useWave && !c.useFused && !(c.slow[blk] & 2)) return;      // only what both wave-kernel attempts could not hold
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     int d, off, S;
@@ -1340,9 +1353,12 @@ __global__ __launch_bounds__(64) void k_encode_units(UlcxEncCtx c, int finalPass
 // Every float operation keeps the reference's order, so the nybbles are identical.
 // Units that exceed the LDS capacities below fall back to k_encode_units (c.slow).
 // ---------------------------------------------------------------------------
-#define E2_KCAP   512      // kept coefficients per unit
-#define E2_ZCAP   128      // quantizer zones per unit
-#define E2_NYBCAP 2048     // nybbles per unit
+// LDS capacities of one wave (kept coefficients / quantizer zones / nybbles per unit) are launch
+// parameters: a first launch with small caps (high occupancy) covers ordinary blocks, units that
+// overflow are retried by a second launch with caps that hold any unit of this block size, and only
+// what still does not fit goes to the serial kernel.
+struct WaveCaps { int k, z, nyb; };
+__host__ __device__ static inline int wavecaps_lds(const WaveCaps &w) { return w.k * 4 + w.z * 8 + w.k * 4 + w.z + w.nyb + 64; }
 
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
     int x = v;
@@ -1393,7 +1409,8 @@ __device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const flo
 // wave-local ordering of LDS traffic (all 64 lanes run in lockstep; LDS ops of one wave complete in order)
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-__device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, int ch, int j, int wc, int lane, float *e2) {
+__device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, int ch, int j, int wc, int lane, float *e2, const WaveCaps caps, int failBit) {
+    const int E2_KCAP = caps.k, E2_ZCAP = caps.z, E2_NYBCAP = caps.nyb;
     int gid = (blk * c.C + ch) * 4 + j;
     int d, off, S;
     if (!unit_geom(wc, j, c.BS, d, off, S)) { if (lane == 0) c.unitNyb[gid] = 0; return; }
@@ -1608,7 +1625,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
         if (total > E2_NYBCAP) overflow = true;
     }
     if (overflow) {                                          // hand the whole block to the serial kernel
-        if (lane == 0) atomicOr(&c.slow[blk], 4);
+        if (lane == 0) atomicOr(&c.slow[blk], failBit);
         return;
     }
     WAVE_SYNC();
@@ -1627,20 +1644,22 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
 
 // 4 waves per workgroup (single-wave workgroups are dispatch-rate bound: ~12 ns each on MI355X),
 // one wave per (block, channel), looping over that channel's subblocks.
-__global__ __launch_bounds__(256) void k_encode_wave(UlcxEncCtx c, int finalPass, int ldsPerWave) {
+__global__ __launch_bounds__(256) void k_encode_wave(UlcxEncCtx c, int finalPass, WaveCaps caps, int phase) {
     extern __shared__ float e2all[];
     int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int u = blockIdx.x * 4 + wv;                             // (block, channel) index
     if (u >= c.B * c.K * c.C) return;
     int blk = u / c.C, ch = u - blk * c.C;
-    if (!finalPass && c.cbrDone[blk]) return;
-    if (c.fbMode == 1 && c.isFb[blk]) return;
-    if (c.fbMode == 2 && !c.isFb[blk]) return;
+    if (skip_block(c, blk, finalPass)) return;
+    // phase 0: small caps, a retry follows (failures set bit 0); 1: the retry, only blocks phase 0 gave up on;
+    // 2: single launch.  Failures of 1 and 2 set bit 1 = left to k_encode_units.
+    if (phase == 1 && !(c.slow[blk] & 1)) return;
+    const int ldsPerWave = wavecaps_lds(caps);
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     float *e2 = (float *)((char *)e2all + (size_t)wv * ldsPerWave);
     for (int j = 0; j < 4; j++) {
-        encode_unit_wave(c, finalPass, blk, ch, j, wc, lane, e2);
+        encode_unit_wave(c, finalPass, blk, ch, j, wc, lane, e2, caps, phase ? 2 : 1);
         WAVE_SYNC();
     }
 }
@@ -1649,10 +1668,8 @@ __global__ __launch_bounds__(256) void k_encode_wave(UlcxEncCtx c, int finalPass
 // One wave per block.
 __global__ __launch_bounds__(64) void k_pack(UlcxEncCtx c, int finalPass) {
     int blk = blockIdx.x, lane = threadIdx.x;
-    if (!finalPass && c.cbrDone[blk]) return;
+    if (skip_block(c, blk, finalPass)) return;
     if (c.useFused && !c.slow[blk]) return;
-    if (c.fbMode == 1 && c.isFb[blk]) return;
-    if (c.fbMode == 2 && !c.isFb[blk]) return;
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     int nU = c.C * 4;
@@ -1987,7 +2004,15 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
             default: return false;
         }
     };
-    auto launch_encode = [&](UlcxEncCtx cc, hipStream_t s2, int fin, bool ev0) -> int {
+    // wave-kernel capacities: small (ordinary blocks, high occupancy) and full (any unit of this block size)
+    WaveCaps capS = { 512, 128, 2048 };
+    WaveCaps capF = { (c.BS + 63) & ~63, ((c.BS / 2) + 63) & ~63, 4 * c.BS + 64 };
+    while ((size_t)wavecaps_lds(capF) * 4 > 150 * 1024) {       // largest that 4 waves fit in LDS; beyond it k_encode_units
+        capF.k = (capF.k / 2 + 63) & ~63; capF.z = (capF.z / 2 + 63) & ~63; capF.nyb = capF.nyb / 2 + 32;
+    }
+    bool haveFull = capF.k > capS.k;
+    if (haveFull && (size_t)wavecaps_lds(capF) * 4 > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_encode_wave, hipFuncAttributeMaxDynamicSharedMemorySize, wavecaps_lds(capF) * 4));
+    auto launch_encode = [&](UlcxEncCtx cc, hipStream_t s2, int fin, bool ev0, bool bigFirst) -> int {
         if (cc.useGapSums) {
             size_t glds = (size_t)N * 4 + N / 8 + 8 * E_GAPCAP + 16;
             if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
@@ -1997,9 +2022,13 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
             if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
         } else if (ev0 && ev) { CK(hipEventRecord(ev[stage++], s2)); CK(hipEventRecord(ev[stage++], s2)); }
         if (cc.useWave && !cc.useFused) {
-            int ldsW = E2_KCAP * 4 + E2_ZCAP * 8 + E2_KCAP * 4 + E2_ZCAP + E2_NYBCAP + 64;
             int nBC = NB * cc.C;
-            hipLaunchKernelGGL(k_encode_wave, dim3((nBC + 3) / 4), dim3(256), (size_t)ldsW * 4, s2, cc, fin, ldsW);
+            // early CBR probes keep ~N/2 coefficients per block: go straight to the full-size caps there
+            WaveCaps first = (bigFirst && haveFull) ? capF : capS;
+            bool twoPhase = haveFull && !bigFirst;
+            hipLaunchKernelGGL(k_encode_wave, dim3((nBC + 3) / 4), dim3(256), (size_t)wavecaps_lds(first) * 4, s2, cc, fin, first, twoPhase ? 0 : 2);
+            if (twoPhase)
+                hipLaunchKernelGGL(k_encode_wave, dim3((nBC + 3) / 4), dim3(256), (size_t)wavecaps_lds(capF) * 4, s2, cc, fin, capF, 1);
         }
         if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
         hipLaunchKernelGGL(k_encode_units, dim3((nUnits + 63) / 64), dim3(64), 0, s2, cc, fin);
@@ -2008,14 +2037,33 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
         if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
         return ULCX_OK;
     };
-    // Tie-straddle blocks (~4e-4 of all) need a ~7 ms single-lane heapsort replay; in VBR (one pass)
-    // it runs on a side stream next to the encode pass of all other blocks, then the streams join.
+    // Exact path for tie-straddle blocks (~4e-4 of all): ONE heapsort per block and call gives the full
+    // ranking, from which the block finishes its own rate search / final pass by lookup.
+    auto exact_sort = [&](hipStream_t s2, int lo) -> int {
+        UlcxEncCtx cf = c; cf.fbMode = 2; cf.fbLo = lo; cf.fbHi = lo + c.rankSlots;
+        if (ldsEntries) hipLaunchKernelGGL(k_heapsel_pipe, dim3(fbGrid), dim3(64), heapLds, s2, cf);
+        else hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, s2, cf, ldsEntries);
+        return ULCX_OK;
+    };
+    auto exact_passes = [&](hipStream_t s2, int lo, bool resetSlow) -> int {
+        UlcxEncCtx cf = c; cf.fbMode = 2; cf.fbLo = lo; cf.fbHi = lo + c.rankSlots;
+        for (int p = 0; p <= probes; p++) {
+            int fin = (p == probes) ? 1 : 0;
+            hipLaunchKernelGGL(k_keep_ranks, dim3(fbGrid), dim3(WG), 0, s2, cf, fin);
+            if (resetSlow && cf.useWave) CK(hipMemsetAsync(cf.slow, 0, sizeof(int) * (size_t)NB, s2));
+            int rc = launch_encode(cf, s2, fin, false, p < 3 && probes > 0); if (rc) return rc;
+        }
+        return ULCX_OK;
+    };
+    CK(hipMemsetAsync(c.fbCount, 0, sizeof(int), st));
+    CK(hipMemsetAsync(c.isFb, 0, sizeof(int) * (size_t)NB, st));
+    // VBR (one pass): the exact path runs on a side stream next to the encode pass of all other blocks.
+    // CBR/ABR: it runs after the lock-step passes (a block joins it at whatever pass it first straddles).
     bool async_fb = (side != nullptr) && (c.mode == ULCX_MODE_VBR) && !c.useFused;
     for (int p = 0; p <= probes; p++) {
         int fin = (p == probes) ? 1 : 0;
         bool ev0 = (p == 0);
-        CK(hipMemsetAsync(c.fbCount, 0, sizeof(int), st));
-        if (c.useWave && !c.useFused) CK(hipMemsetAsync(c.slow, 0, sizeof(int) * (size_t)NB, st));   // before the streams fork
+        if (c.useWave && !c.useFused) CK(hipMemsetAsync(c.slow, 0, sizeof(int) * (size_t)NB, st));
         if (c.useFused) {
             int stageBytes = 2048 * c.C;
             size_t lds = (size_t)N * 8 + N / 8 + stageBytes + 256 * 4 + c.C * 16 + 16;
@@ -2028,24 +2076,28 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
         if (async_fb) {
             CK(hipEventRecord(evFork, st));
             CK(hipStreamWaitEvent(side, evFork, 0));
-            UlcxEncCtx cf = c; cf.fbMode = 2;
-            if (ldsEntries) hipLaunchKernelGGL(k_heapsel_pipe, dim3(fbGrid), dim3(64), heapLds, side, cf);
-            else hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, side, cf, ldsEntries);
-            if (p == 0) { int rcn = launch_noise(ev0); if (rcn) return rcn; }
-            CK(hipEventRecord(evFork2, st));                    // the side stream's encode pass needs the noise pairs too
+            int rc = exact_sort(side, 0); if (rc) return rc;   // needs only the keys: starts right behind the select
+        }
+        if (p == 0) { int rcn = launch_noise(ev0); if (rcn) return rcn; }
+        if (async_fb) {
+            CK(hipEventRecord(evFork2, st));                    // the exact path's encode pass needs the noise pairs too
             CK(hipStreamWaitEvent(side, evFork2, 0));
-            int rc = launch_encode(cf, side, fin, false); if (rc) return rc;
+            int rc = exact_passes(side, 0, false); if (rc) return rc;
+            for (int lo = c.rankSlots; lo < NB; lo += c.rankSlots) {
+                rc = exact_sort(side, lo); if (rc) return rc;
+                rc = exact_passes(side, lo, false); if (rc) return rc;
+            }
             CK(hipEventRecord(evJoin, side));
-            if (ev0) MARK();                                   // (k_heapsel interval is empty on the main stream)
-            UlcxEncCtx cm = c; cm.fbMode = 1;
-            rc = launch_encode(cm, st, fin, ev0); if (rc) return rc;
-            CK(hipStreamWaitEvent(st, evJoin, 0));
-        } else {
-            if (p == 0) { int rcn = launch_noise(ev0); if (rcn) return rcn; }
-            if (ldsEntries) hipLaunchKernelGGL(k_heapsel_pipe, dim3(fbGrid), dim3(64), heapLds, st, c);
-            else hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, st, c, ldsEntries);
-            if (ev0) MARK();
-            int rc = launch_encode(c, st, fin, ev0); if (rc) return rc;
+        }
+        if (ev0) MARK();                                       // ("k_heapsel": empty interval on the main stream)
+        UlcxEncCtx cm = c; cm.fbMode = c.useFused ? 0 : 1;
+        int rc = launch_encode(cm, st, fin, ev0, probes > 0 && p < 3); if (rc) return rc;
+        if (async_fb) CK(hipStreamWaitEvent(st, evJoin, 0));
+    }
+    if (!async_fb && !c.useFused) {
+        for (int lo = 0; lo < NB; lo += c.rankSlots) {
+            int rc = exact_sort(st, lo); if (rc) return rc;
+            rc = exact_passes(st, lo, true); if (rc) return rc;
         }
     }
     MARK();   // cbr_probe_passes (empty interval for VBR)

@@ -79,7 +79,10 @@ struct UlcxEncCtx {
     float2 *gapSum;                      // [NB][C*BS] {Sum, SumW} of the noise run in front of each kept coefficient (speculative)
     float  *tailSum;                     // [NB][C*4][8] five HF-extension sums + start index of the tail they assume
     int     useGapSums;
-    int    *isFb;                        // [NB] 1 = threshold tie group straddles the cut (needs k_heapsel)
+    int    *isFb;                        // [NB] 1 = a threshold tie group straddled the cut this call: block is on the exact (rank) path
+    int    *ownSlot;                     // [NB] its slot in fbList
+    int    *rankBuf;                     // [rankSlots][C*BS] full heapsort ranking of exact-path blocks
+    int     rankSlots, fbLo, fbHi;       // resident rank slots; slot window of the current exact-path launch
     int     fbMode;                      // 0 = all blocks, 1 = skip isFb blocks, 2 = only isFb blocks
     int     useWave;                     // wave-per-unit encode pass (k_encode_wave); serial kernel only for overflow blocks
     void   *heapScratch;                 // [ULCX_HEAP_GRID][C*BS] {key,idx} heaps, only when C*BS*8 exceeds the LDS budget
