@@ -145,7 +145,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.nnz, NB, true);
     DA(c.cplx, NB, true);
     DA(c.nout, NB, true);
-    DA(c.slow, NB, true);
+    DA(c.slow, 3 * NB + 2, true);                      // flags [NB], retry-queue counters [2], retry queues [2][NB]
     // experimental fused select+encode+pack kernel (k_selenc): measured slower than the lane-per-unit
     // kernels on MI355X (profiles/r01 notes in DESIGN.md §6), so opt-in only.
     c.useFused = 0;

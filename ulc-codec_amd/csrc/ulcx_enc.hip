@@ -674,8 +674,12 @@ void ulcx_enc_finalize_keys(const UlcxEncCtx &c, hipStream_t st) {
 __device__ __forceinline__ bool skip_block(const UlcxEncCtx &c, int blk, int finalPass) {
     if (!finalPass && c.cbrDone[blk]) return true;
     if (c.fbMode == 1) return c.isFb[blk] != 0;
-    if (c.fbMode == 2) { if (!c.isFb[blk]) return true; int sl = c.ownSlot[blk]; return sl < c.fbLo || sl >= c.fbHi; }
-    return false;
+    return false;                                            // fbMode 2: the launch enumerates the owned blocks itself (fb_count / fbList)
+}
+// fbMode 2 launches are small fixed grids that walk the exact-path list: n = resident entries of it
+__device__ __forceinline__ int fb_count(const UlcxEncCtx &c) {
+    int n = *c.fbCount; if (n > c.fbHi) n = c.fbHi;
+    n -= c.fbLo; return n > 0 ? n : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -857,15 +861,19 @@ __global__ __launch_bounds__(64) void k_heapsel(UlcxEncCtx c, int ldsEntries) {
 //    cross-pop hazard is the element pop p+1 lifts from the end of the heap: if an in-flight
 //    sift is still on the path to that leaf it could yet replace it, so the start waits.
 // Comparisons and tie behaviour are exactly those of heap_sift / BlockTransform.c:20-51.
-__global__ __launch_bounds__(64) void k_heapsel_pipe(UlcxEncCtx c) {
-    extern __shared__ HeapEnt hp[];
+__global__ __launch_bounds__(64) void k_heapsel_pipe(UlcxEncCtx c, int fullRanking) {
+    extern __shared__ __align__(16) int4 hraw4[];
+    HeapEnt *hp = (HeapEnt *)hraw4 + 1;                       // node n at slot n+1: a node's two children share one aligned 16 B pair
+    int2 *slots = (int2 *)hraw4;
+    const int4 *pairs = hraw4;                                // pairs[pos+1] = {child 2pos+1, child 2pos+2}
     int count = *c.fbCount; if (count > c.fbHi) count = c.fbHi;
     const int N = c.C * c.BS;
     int lane = threadIdx.x;
     for (int idx = c.fbLo + blockIdx.x; idx < count; idx += gridDim.x) {
         int blk = c.fbList[idx];
         int *rank = c.rankBuf + (size_t)(idx - c.fbLo) * N;      // full ranking, so every later nOutCoef of this block is a lookup
-        for (int i = lane; i < N; i += 64) { hp[i].v = load_final_key(c, blk, i); hp[i].i = i; }
+        for (int i = lane; i < N; i += 64) { hp[i].v = load_final_key(c, blk, i); hp[i].i = i; rank[i] = 0; }
+        if (lane == 0) { hp[N].v = 0.0f; hp[N].i = 0; }
         __syncthreads();
         // ---- heapify, level by level
         int top = 31 - __clz(N / 2);                      // level of node N/2-1 (root = level 0) for power-of-two N
@@ -875,58 +883,50 @@ __global__ __launch_bounds__(64) void k_heapsel_pipe(UlcxEncCtx c) {
             for (int n = first + lane; n <= last; n += 64) heap_sift(hp, n, N);
             __syncthreads();
         }
-        // ---- pipelined pops.  Every step issues all of its LDS reads first (root, the leaf the next
-        //      pop lifts, the root's children, each in-flight sift's children): one round trip per step.
-        int pops = N;                                     // pop p gets rank N-1-p (BlockTransform.c:66-76)
-        int P = 0, step = 0, lastStart = -2;
-        bool active = false; int pos = 0, size = 0; HeapEnt e; e.v = 0.0f; e.i = 0;
-        while (P < pops || __any(active)) {
-            // -- may pop P start now?
-            int nl = N - 1 - P;                           // index of the element to lift = heap size after this pop
-            bool want = (P < pops) && (step - lastStart >= 2);
-            bool onPath = false;
-            if (active) {
-                int a1 = pos + 1, b1 = nl + 1;            // 1-based: a1 is ancestor-or-self of b1 iff b1 >> (depth diff) == a1
-                int da = 31 - __clz(a1), db = 31 - __clz(b1);
-                onPath = (db >= da) && ((b1 >> (db - da)) == a1);
-            }
-            int slot = P & 15;
-            bool slotBusy = __shfl((int)active, slot) != 0;
-            bool start = want && !__any(onPath) && !slotBusy;
-            // -- issue every read of this step
-            int c1 = 2 * pos + 1;
-            bool sift = active && (c1 < size);
-            HeapEnt g = hp[0], el = hp[nl > 0 ? nl : 0], r1 = hp[1], r2 = hp[2];
-            HeapEnt cL = hp[sift ? c1 : 0], cR = hp[(sift && c1 + 1 < size) ? c1 + 1 : 0];
-            // -- in-flight sifts advance one level
-            if (active) {
-                if (!sift) { hp[pos] = e; active = false; }
-                else {
-                    HeapEnt cN = cL; int ci = c1;
-                    if (c1 + 1 < size && cR.v < cN.v) { cN = cR; ci = c1 + 1; }
-                    if (cN.v > e.v) { hp[pos] = e; active = false; }
-                    else { hp[pos] = cN; pos = ci; }
-                }
-            }
-            // -- the new pop: discard the root, lift the last element, and do its level-0 step right away
-            if (start) {
-                if (lane == slot) {
-                    rank[g.i] = nl;
-                    if (nl > 0) {
-                        e = el; size = nl; pos = 0; active = true;
-                        if (1 >= size) { hp[0] = e; active = false; }
-                        else {
-                            HeapEnt cN = r1; int ci = 1;
-                            if (2 < size && r2.v < cN.v) { cN = r2; ci = 2; }
-                            if (cN.v > e.v) { hp[0] = e; active = false; }
-                            else { hp[0] = cN; pos = ci; }
-                        }
-                    }
-                }
-                P++; lastStart = step;
-            }
-            step++;
+        // ---- pipelined pops.  A step = one LDS round trip: every in-flight sift reads its child pair
+        //      and moves one level.  Pop P starts (takes the root's rank, lifts the last leaf into a
+        //      register) in the first half of an iteration and does its level-l compare l+1 steps later;
+        //      one iteration = two steps, so the next pop finds the root already rewritten.
+        //      An idle lane has pos = N+1: no children, and its store lands in a dummy slot.
+        //      A one-pass (VBR) call only needs the kept set: stop after N-nOutCoef pops; rank 0 (also
+        //      the last pop's rank) is what rankBuf was initialised to.
+        int kSel = c.nout[blk];
+        int pops = fullRanking ? N : N - (kSel > 0 ? kSel : 0);
+        if (pops > N - 1) pops = N - 1;
+        const int IDLE = N + 1;
+        int pos = IDLE, lev = 0, size = 0; float ev = 0.0f; int ei = 0;
+#define HEAP_SIFT_STEP()                                                                          \
+        {                                                                                         \
+            int c1 = 2 * pos + 1;                                                                 \
+            int pi = pos + 1 < N / 2 ? pos + 1 : N / 2;                                           \
+            int4 ch = pairs[pi];                                                                  \
+            float vL = __int_as_float(ch.x), vR = __int_as_float(ch.z);                           \
+            bool pickR = (c1 + 1 < size) && (vR < vL);                                            \
+            float vN = pickR ? vR : vL; int iN = pickR ? ch.w : ch.y;                             \
+            bool stop = !(c1 < size) || (vN > ev);                                                \
+            slots[pos + 1] = make_int2(__float_as_int(stop ? ev : vN), stop ? ei : iN);           \
+            pos = stop ? IDLE : c1 + (pickR ? 1 : 0);                                             \
+            lev = stop ? 0 : lev + 1;                                                             \
         }
+        for (int P = 0; P < pops; ) {
+            int nl = N - 1 - P;                           // index of the element to lift = heap size after this pop (>= 1)
+            int b1 = nl + 1, db = 31 - __clz(b1);
+            // an in-flight sift still above the leaf on its root path could yet replace it: wait
+            int sh = db - lev; sh = sh > 0 ? sh : 0;
+            bool start = !__ballot((b1 >> sh) == pos + 1);
+            int2 g = slots[1], el = slots[nl + 1];
+            HEAP_SIFT_STEP();
+            if (start) {
+                if (lane == (P & 15)) {                   // <= 7 sifts in flight, each <= 14 steps: slot P&15 is idle again
+                    rank[g.y] = nl;                       // pop p gets rank N-1-p (BlockTransform.c:66-76)
+                    ev = __int_as_float(el.x); ei = el.y; size = nl; pos = 0; lev = 0;
+                }
+                P++;
+            }
+            HEAP_SIFT_STEP();
+        }
+        while (__ballot(pos != IDLE)) HEAP_SIFT_STEP();
+#undef HEAP_SIFT_STEP
         __syncthreads();
     }
 }
@@ -960,9 +960,9 @@ __global__ __launch_bounds__(WG) void k_keep_ranks(UlcxEncCtx c, int finalPass) 
 // (a kept coefficient collapsed, a noise run fell back to a zero run, ...).
 // ---------------------------------------------------------------------------
 #define E_GAPCAP 1024      // gaps >= 16 per block: at most N/17 of them; N <= 16384 here
-__global__ __launch_bounds__(WG) void k_gapsums(UlcxEncCtx c, int finalPass) {
+__device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
     extern __shared__ uint32_t gsm[];
-    int blk = blockIdx.x, tid = threadIdx.x;
+    int tid = threadIdx.x;
     if (skip_block(c, blk, finalPass)) return;
     const int N = c.C * c.BS;
     float *pairs = (float *)gsm;                           // N floats: the block's {w, w*log} pairs
@@ -1037,18 +1037,23 @@ __global__ __launch_bounds__(WG) void k_gapsums(UlcxEncCtx c, int finalPass) {
         gs[i] = make_float2((sum == 0.0f) ? -1.0f : ulcx_expf(sum / sumw), 0.0f);
     }
 }
+__global__ __launch_bounds__(WG) void k_gapsums(UlcxEncCtx c, int finalPass) {
+    if (c.fbMode != 2) { gapsums_block(c, finalPass, blockIdx.x); return; }
+    int n = fb_count(c);
+    for (int v = blockIdx.x; v < n; v += gridDim.x) { gapsums_block(c, finalPass, c.fbList[c.fbLo + v]); __syncthreads(); }
+}
 
 // Tail HF-extension sums (NoiseFill.c:41-62) for the tail after each unit's last kept
 // coefficient: 8 lanes per unit, lanes 0..4 carry one ordered f32 chain each, lane 5 records
 // the start index the sums assume.  Pairs are read straight from HBM/L2 in batches of 8: the
 // chains are latency-bound, so they get their own launch with every unit of the batch in flight.
-__global__ __launch_bounds__(64) void k_tailsums(UlcxEncCtx c, int finalPass) {
-    int tid0 = blockIdx.x * 64 + threadIdx.x;
+__device__ void tailsums_lane(const UlcxEncCtx &c, int finalPass, int tid0, int nBlk) {
     int chain = tid0 & 7;
     int ui = tid0 >> 3;
-    int nBC = c.B * c.K * c.C;
+    int nBC = nBlk * c.C;
     if (ui >= nBC * 4) return;
     int j = ui / nBC, rem = ui - j * nBC, blk = rem / c.C, ch = rem - blk * c.C;     // subblock index slowest
+    if (c.fbMode == 2) blk = c.fbList[c.fbLo + blk];
     if (skip_block(c, blk, finalPass)) return;
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
@@ -1096,6 +1101,11 @@ __global__ __launch_bounds__(64) void k_tailsums(UlcxEncCtx c, int finalPass) {
         acc += (base * m1) * m2;
     }
     ts[chain] = acc;
+}
+__global__ __launch_bounds__(64) void k_tailsums(UlcxEncCtx c, int finalPass) {
+    if (c.fbMode != 2) { tailsums_lane(c, finalPass, blockIdx.x * 64 + threadIdx.x, c.B * c.K); return; }
+    int n = fb_count(c), total = n * c.C * 32;
+    for (int t = blockIdx.x * 64; t < total; t += gridDim.x * 64) tailsums_lane(c, finalPass, t + threadIdx.x, n);
 }
 
 // ---------------------------------------------------------------------------
@@ -1272,13 +1282,13 @@ __device__ __forceinline__ int write_zone(NybWriter &w, int cur, int end, float 
 }
 
 // Encode.c:200-313
-__global__ __launch_bounds__(64) void k_encode_units(UlcxEncCtx c, int finalPass) {
-    int gid = blockIdx.x * 64 + threadIdx.x;
-    int nUnits = c.B * c.K * c.C * 4;
+__device__ void encode_units_lane(const UlcxEncCtx &c, int finalPass, int gid, int nBlk) {
+    int nUnits = nBlk * c.C * 4;
     if (gid >= nUnits) return;
     // (subblock index fastest on purpose: the state machine diverges per lane, so sparse waves -
     //  4x more of them in flight - hide its latency better than dense ones; measured 7.1 vs 9.6 ms)
     int j = gid & 3, ch = (gid >> 2) % c.C, blk = gid / (4 * c.C);
+    if (c.fbMode == 2) { blk = c.fbList[c.fbLo + blk]; gid = (blk * c.C + ch) * 4 + j; }
     if (skip_block(c, blk, finalPass)) return;
     if (c.useFused && !c.slow[blk]) return;
     if (c.useWave && !c.useFused && !(c.slow[blk] & 2)) return;      // only what both wave-kernel attempts could not hold
@@ -1337,6 +1347,11 @@ __global__ __launch_bounds__(64) void k_encode_units(UlcxEncCtx c, int finalPass
     w.flush();
     c.unitNyb[gid] = w.n;
 }
+__global__ __launch_bounds__(64) void k_encode_units(UlcxEncCtx c, int finalPass) {
+    if (c.fbMode != 2) { encode_units_lane(c, finalPass, blockIdx.x * 64 + threadIdx.x, c.B * c.K); return; }
+    int n = fb_count(c), total = n * c.C * 4;
+    for (int t = blockIdx.x * 64; t < total; t += gridDim.x * 64) encode_units_lane(c, finalPass, t + threadIdx.x, n);
+}
 
 // ---------------------------------------------------------------------------
 // Fast encode pass: ONE WAVE per (block, channel, subblock) unit.
@@ -1358,6 +1373,9 @@ __global__ __launch_bounds__(64) void k_encode_units(UlcxEncCtx c, int finalPass
 // overflow are retried by a second launch with caps that hold any unit of this block size, and only
 // what still does not fit goes to the serial kernel.
 struct WaveCaps { int k, z, nyb; };
+#define WAVE_SK 512
+#define WAVE_SZ 128
+#define WAVE_SN 2048
 __host__ __device__ static inline int wavecaps_lds(const WaveCaps &w) { return w.k * 4 + w.z * 8 + w.k * 4 + w.z + w.nyb + 64; }
 
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
@@ -1409,8 +1427,10 @@ __device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const flo
 // wave-local ordering of LDS traffic (all 64 lanes run in lockstep; LDS ops of one wave complete in order)
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
+template <bool SMALL>
 __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, int ch, int j, int wc, int lane, float *e2, const WaveCaps caps, int failBit) {
-    const int E2_KCAP = caps.k, E2_ZCAP = caps.z, E2_NYBCAP = caps.nyb;
+    // SMALL: the ordinary-block capacities as compile-time constants (constant LDS offsets); else the launch's
+    const int E2_KCAP = SMALL ? WAVE_SK : caps.k, E2_ZCAP = SMALL ? WAVE_SZ : caps.z, E2_NYBCAP = SMALL ? WAVE_SN : caps.nyb;
     int gid = (blk * c.C + ch) * 4 + j;
     int d, off, S;
     if (!unit_geom(wc, j, c.BS, d, off, S)) { if (lane == 0) c.unitNyb[gid] = 0; return; }
@@ -1625,7 +1645,14 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
         if (total > E2_NYBCAP) overflow = true;
     }
     if (overflow) {                                          // hand the whole block to the serial kernel
-        if (lane == 0) atomicOr(&c.slow[blk], failBit);
+        if (lane == 0) {
+            int old = atomicOr(&c.slow[blk], failBit);
+            if (failBit == 1 && !(old & 1)) {              // first failure of this block: queue it for the full-capacity retry launch
+                const int NBq = c.B * c.K, which = (c.fbMode == 2) ? 1 : 0;
+                int q = atomicAdd(&c.slow[NBq + which], 1);
+                c.slow[NBq + 2 + which * NBq + q] = blk;
+            }
+        }
         return;
     }
     WAVE_SYNC();
@@ -1644,30 +1671,38 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
 
 // 4 waves per workgroup (single-wave workgroups are dispatch-rate bound: ~12 ns each on MI355X),
 // one wave per (block, channel), looping over that channel's subblocks.
+template <bool SMALL>
 __global__ __launch_bounds__(256) void k_encode_wave(UlcxEncCtx c, int finalPass, WaveCaps caps, int phase) {
     extern __shared__ float e2all[];
     int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int u = blockIdx.x * 4 + wv;                             // (block, channel) index
-    if (u >= c.B * c.K * c.C) return;
-    int blk = u / c.C, ch = u - blk * c.C;
-    if (skip_block(c, blk, finalPass)) return;
-    // phase 0: small caps, a retry follows (failures set bit 0); 1: the retry, only blocks phase 0 gave up on;
-    // 2: single launch.  Failures of 1 and 2 set bit 1 = left to k_encode_units.
-    if (phase == 1 && !(c.slow[blk] & 1)) return;
-    const int ldsPerWave = wavecaps_lds(caps);
-    int s = blk / c.K, k = blk % c.K;
-    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+    const WaveCaps capS = { WAVE_SK, WAVE_SZ, WAVE_SN };
+    const int ldsPerWave = SMALL ? wavecaps_lds(capS) : wavecaps_lds(caps);
     float *e2 = (float *)((char *)e2all + (size_t)wv * ldsPerWave);
-    for (int j = 0; j < 4; j++) {
-        encode_unit_wave(c, finalPass, blk, ch, j, wc, lane, e2, caps, phase ? 2 : 1);
-        WAVE_SYNC();
+    // phase 0: small caps, a retry follows (a failing block is queued); 1: the retry, walks that queue;
+    // 2: single launch.  Failures of 1 and 2 set bit 1 = left to k_encode_units.
+    const int NBq = c.B * c.K, which = (c.fbMode == 2) ? 1 : 0;
+    const int *queue = c.slow + NBq + 2 + which * NBq;
+    int nBlk = (phase == 1) ? c.slow[NBq + which] : (c.fbMode == 2) ? fb_count(c) : NBq;
+    for (int u = blockIdx.x * 4 + wv; u < nBlk * c.C; u += gridDim.x * 4) {      // (block, channel) index; one trip for the full-batch launch
+        int blk = u / c.C, ch = u - blk * c.C;
+        if (phase == 1) blk = queue[blk];
+        else {
+            if (c.fbMode == 2) blk = c.fbList[c.fbLo + blk];
+            if (skip_block(c, blk, finalPass)) continue;
+        }
+        int s = blk / c.K, k = blk % c.K;
+        int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+        for (int j = 0; j < 4; j++) {
+            encode_unit_wave<SMALL>(c, finalPass, blk, ch, j, wc, lane, e2, caps, phase ? 2 : 1);
+            WAVE_SYNC();
+        }
     }
 }
 
 // Encode.c:329-359: header nybble(s) + units in (channel, subblock) order, byte aligned.
 // One wave per block.
-__global__ __launch_bounds__(64) void k_pack(UlcxEncCtx c, int finalPass) {
-    int blk = blockIdx.x, lane = threadIdx.x;
+__device__ void pack_block(const UlcxEncCtx &c, int finalPass, int blk) {
+    int lane = threadIdx.x;
     if (skip_block(c, blk, finalPass)) return;
     if (c.useFused && !c.slow[blk]) return;
     int s = blk / c.K, k = blk % c.K;
@@ -1718,6 +1753,11 @@ __global__ __launch_bounds__(64) void k_pack(UlcxEncCtx c, int finalPass) {
         if (b < c.slot) out[b] = (uint8_t)byte;
     }
     if (lane == 0) c.bits[blk] = bitsTot;
+}
+__global__ __launch_bounds__(64) void k_pack(UlcxEncCtx c, int finalPass) {
+    if (c.fbMode != 2) { pack_block(c, finalPass, blockIdx.x); return; }
+    int n = fb_count(c);
+    for (int v = blockIdx.x; v < n; v += gridDim.x) pack_block(c, finalPass, c.fbList[c.fbLo + v]);
 }
 
 // ---------------------------------------------------------------------------
@@ -2005,20 +2045,22 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
         }
     };
     // wave-kernel capacities: small (ordinary blocks, high occupancy) and full (any unit of this block size)
-    WaveCaps capS = { 512, 128, 2048 };
+    WaveCaps capS = { WAVE_SK, WAVE_SZ, WAVE_SN };
     WaveCaps capF = { (c.BS + 63) & ~63, ((c.BS / 2) + 63) & ~63, 4 * c.BS + 64 };
     while ((size_t)wavecaps_lds(capF) * 4 > 150 * 1024) {       // largest that 4 waves fit in LDS; beyond it k_encode_units
         capF.k = (capF.k / 2 + 63) & ~63; capF.z = (capF.z / 2 + 63) & ~63; capF.nyb = capF.nyb / 2 + 32;
     }
     bool haveFull = capF.k > capS.k;
-    if (haveFull && (size_t)wavecaps_lds(capF) * 4 > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_encode_wave, hipFuncAttributeMaxDynamicSharedMemorySize, wavecaps_lds(capF) * 4));
+    if (haveFull && (size_t)wavecaps_lds(capF) * 4 > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_encode_wave<false>, hipFuncAttributeMaxDynamicSharedMemorySize, wavecaps_lds(capF) * 4));
     auto launch_encode = [&](UlcxEncCtx cc, hipStream_t s2, int fin, bool ev0, bool bigFirst) -> int {
+        const bool fb2 = (cc.fbMode == 2);                 // exact path: small grids that walk the list of owned blocks
+        const int fbW = NB < 128 ? NB : 128;
         if (cc.useGapSums) {
             size_t glds = (size_t)N * 4 + N / 8 + 8 * E_GAPCAP + 16;
             if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
-            hipLaunchKernelGGL(k_gapsums, dim3(NB), dim3(WG), glds, s2, cc, fin);
+            hipLaunchKernelGGL(k_gapsums, dim3(fb2 ? fbW : NB), dim3(WG), glds, s2, cc, fin);
             if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
-            hipLaunchKernelGGL(k_tailsums, dim3((nUnits * 8 + 63) / 64), dim3(64), 0, s2, cc, fin);
+            hipLaunchKernelGGL(k_tailsums, dim3(fb2 ? fbW : (nUnits * 8 + 63) / 64), dim3(64), 0, s2, cc, fin);
             if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
         } else if (ev0 && ev) { CK(hipEventRecord(ev[stage++], s2)); CK(hipEventRecord(ev[stage++], s2)); }
         if (cc.useWave && !cc.useFused) {
@@ -2026,14 +2068,15 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
             // early CBR probes keep ~N/2 coefficients per block: go straight to the full-size caps there
             WaveCaps first = (bigFirst && haveFull) ? capF : capS;
             bool twoPhase = haveFull && !bigFirst;
-            hipLaunchKernelGGL(k_encode_wave, dim3((nBC + 3) / 4), dim3(256), (size_t)wavecaps_lds(first) * 4, s2, cc, fin, first, twoPhase ? 0 : 2);
+            if (bigFirst && haveFull) hipLaunchKernelGGL(k_encode_wave<false>, dim3(fb2 ? fbW : (nBC + 3) / 4), dim3(256), (size_t)wavecaps_lds(first) * 4, s2, cc, fin, first, 2);
+            else hipLaunchKernelGGL(k_encode_wave<true>, dim3(fb2 ? fbW : (nBC + 3) / 4), dim3(256), (size_t)wavecaps_lds(first) * 4, s2, cc, fin, first, twoPhase ? 0 : 2);
             if (twoPhase)
-                hipLaunchKernelGGL(k_encode_wave, dim3((nBC + 3) / 4), dim3(256), (size_t)wavecaps_lds(capF) * 4, s2, cc, fin, capF, 1);
+                hipLaunchKernelGGL(k_encode_wave<false>, dim3(fb2 ? fbW : ((nBC + 3) / 4 < 512 ? (nBC + 3) / 4 : 512)), dim3(256), (size_t)wavecaps_lds(capF) * 4, s2, cc, fin, capF, 1);
         }
         if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
-        hipLaunchKernelGGL(k_encode_units, dim3((nUnits + 63) / 64), dim3(64), 0, s2, cc, fin);
+        hipLaunchKernelGGL(k_encode_units, dim3(fb2 ? fbW : (nUnits + 63) / 64), dim3(64), 0, s2, cc, fin);
         if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
-        hipLaunchKernelGGL(k_pack, dim3(NB), dim3(64), 0, s2, cc, fin);
+        hipLaunchKernelGGL(k_pack, dim3(fb2 ? fbW : NB), dim3(64), 0, s2, cc, fin);
         if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
         return ULCX_OK;
     };
@@ -2041,7 +2084,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
     // ranking, from which the block finishes its own rate search / final pass by lookup.
     auto exact_sort = [&](hipStream_t s2, int lo) -> int {
         UlcxEncCtx cf = c; cf.fbMode = 2; cf.fbLo = lo; cf.fbHi = lo + c.rankSlots;
-        if (ldsEntries) hipLaunchKernelGGL(k_heapsel_pipe, dim3(fbGrid), dim3(64), heapLds, s2, cf);
+        if (ldsEntries) hipLaunchKernelGGL(k_heapsel_pipe, dim3(fbGrid), dim3(64), heapLds, s2, cf, probes > 0 ? 1 : 0);
         else hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, s2, cf, ldsEntries);
         return ULCX_OK;
     };
@@ -2050,7 +2093,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
         for (int p = 0; p <= probes; p++) {
             int fin = (p == probes) ? 1 : 0;
             hipLaunchKernelGGL(k_keep_ranks, dim3(fbGrid), dim3(WG), 0, s2, cf, fin);
-            if (resetSlow && cf.useWave) CK(hipMemsetAsync(cf.slow, 0, sizeof(int) * (size_t)NB, s2));
+            if (resetSlow && cf.useWave) CK(hipMemsetAsync(cf.slow, 0, sizeof(int) * ((size_t)NB + 2), s2));
             int rc = launch_encode(cf, s2, fin, false, p < 3 && probes > 0); if (rc) return rc;
         }
         return ULCX_OK;
@@ -2063,7 +2106,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
     for (int p = 0; p <= probes; p++) {
         int fin = (p == probes) ? 1 : 0;
         bool ev0 = (p == 0);
-        if (c.useWave && !c.useFused) CK(hipMemsetAsync(c.slow, 0, sizeof(int) * (size_t)NB, st));
+        if (c.useWave && !c.useFused) CK(hipMemsetAsync(c.slow, 0, sizeof(int) * ((size_t)NB + 2), st));
         if (c.useFused) {
             int stageBytes = 2048 * c.C;
             size_t lds = (size_t)N * 8 + N / 8 + stageBytes + 256 * 4 + c.C * 16 + 16;
