@@ -174,7 +174,7 @@ def main():
     # ---- roofline of the dominant kernel (algorithmic bytes: SURVEY.md §8d / BASELINE.md §4)
     mean_bytes = float(bits_host.mean()) / 8.0
     alg_bytes_block = 4 * CH * BS + mean_bytes + 8          # f32 in (or out) + stream bytes + size/WindowCtrl metadata
-    pseudo = ("cbr_probe_passes", "k_heapsel")      # intervals, not single kernels (join wait / side-stream launch)
+    pseudo = ("cbr_probe_passes", "k_heapsel", "wc_pipeline_exposed")   # intervals, not kernels (join wait / side-stream launches)
     allk = {**{("enc", k_): v for k_, v in acc_enc.items() if k_ not in pseudo}, **{("dec", k_): v for k_, v in acc_dec.items()}}
     (side, kname), kms = max(allk.items(), key=lambda kv: kv[1])
     launch_bytes = alg_bytes_block * B * K

@@ -64,10 +64,13 @@ __device__ __forceinline__ size_t env_idx(const UlcxEncCtx &c, int s, int t) {
 // Old/New boundary; then the sqrt of :80-81 (parallel part of the recurrence).
 // One workgroup = 64 streams x 64 time steps; input rows are read along time
 // (coalesced), transposed through LDS, written stream-minor.
-__global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c) {
+// All window-control kernels (and k_xf) take a block range [k0, k1) of the call so the host can
+// pipeline chunks of blocks: the stream-sequential recurrences of later chunks run beside the
+// transform of earlier ones.
+__global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c, int k0, int k1) {
     __shared__ float2 tile[64][65];
-    int tiles_t = (c.K * c.BS) / 64;
-    int sg = blockIdx.x / tiles_t, tt = blockIdx.x % tiles_t;
+    int tiles_t = ((k1 - k0) * c.BS) / 64;
+    int sg = blockIdx.x / tiles_t, tt = blockIdx.x % tiles_t + (k0 * c.BS) / 64;
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int r = tt * 64 + lane;                              // k*BS + n
     int t = r - c.BS / 2;                                // centre sample
@@ -106,15 +109,16 @@ __global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c) {
 
 // WindowControl.c:72-88: forward one-pole smear, the only sample-rate recurrence that
 // crosses blocks.  One lane per stream (both filters), strictly sequential in time.
-__global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c) {
+__global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c, int k0, int k1) {
     // lane = (stream, filter): 32 streams x {HP, BP} per wave; the two one-pole chains are independent
+    __builtin_amdgcn_s_setprio(3);                       // a serial chain: let it issue ahead of co-resident throughput kernels
     int gl = blockIdx.x * 64 + threadIdx.x;
     int s = gl >> 1, f = gl & 1;
     bool live = s < c.B;
-    float *v = (float *)(c.env + env_idx(c, live ? s : 0, 0)) + f;     // this lane's float inside each {hp,bp} pair
+    float *v = (float *)(c.env + env_idx(c, live ? s : 0, k0 * c.BS)) + f;     // this lane's float inside each {hp,bp} pair
     float env = live ? c.wcs[s].tf[f] : 0.0f;
     float cc = f ? c.cBP : c.cHP;
-    int n = c.K * c.BS;
+    int n = (k1 - k0) * c.BS;
     constexpr int U = 16, D = 4;          // D batches of U steps in flight: one wave per CU must cover HBM latency by itself
     float x[D][U];
 #pragma unroll
@@ -142,40 +146,56 @@ __global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c) {
 }
 
 // WindowControl.c:90-104: backward sweep from each block's forward end state.
-__global__ __launch_bounds__(64) void k_wc_backward(UlcxEncCtx c) {
+__global__ __launch_bounds__(64) void k_wc_backward(UlcxEncCtx c, int k0, int k1) {
+    __builtin_amdgcn_s_setprio(3);                       // a serial chain: let it issue ahead of co-resident throughput kernels
     int sl = threadIdx.x;
-    int k = blockIdx.x % c.K, sg = blockIdx.x / c.K;
+    int k = k0 + blockIdx.x % (k1 - k0), sg = blockIdx.x / (k1 - k0);
     float2 *e = c.env + ((size_t)sg * c.maxK * c.BS + (size_t)k * c.BS) * 64 + sl;
     float2 last = e[(size_t)(c.BS - 1) * 64];
     float pHP = last.x, pBP = last.y;
-    for (int n = c.BS - 1; n >= 0; n -= 4) {
-        float2 x[4];
+    // walk the block backwards, step r = 0 is sample BS-1; D batches of U steps in flight (BS is a multiple of D*U)
+    constexpr int U = 16, D = 4;
+    const int n = c.BS;
+    float2 x[D][U];
 #pragma unroll
-        for (int j = 0; j < 4; j++) x[j] = e[(size_t)(n - j) * 64];
+    for (int b2 = 0; b2 < D - 1; b2++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float dHP = x[j].x - pHP, dBP = x[j].y - pBP;
-            pHP += dHP * c.qHP;
-            pBP += dBP * c.qBP;
-            float a = dHP * pBP, b = dBP * pHP;
-            x[j].x = a * a + b * b;
+        for (int j = 0; j < U; j++) { int r = b2 * U + j; x[b2][j] = e[(size_t)(n - 1 - (r < n ? r : 0)) * 64]; }
+    for (int i = 0; i < n; i += D * U) {
+#pragma unroll
+        for (int b2 = 0; b2 < D; b2++) {
+            int base = i + b2 * U;
+            int pf = base + (D - 1) * U;
+#pragma unroll
+            for (int j = 0; j < U; j++) { int r = pf + j; x[(b2 + D - 1) % D][j] = e[(size_t)(n - 1 - (r < n ? r : 0)) * 64]; }
+            if (base < n) {
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    float dHP = x[b2][j].x - pHP, dBP = x[b2][j].y - pBP;
+                    pHP += dHP * c.qHP;
+                    pBP += dBP * c.qBP;
+                    float a = dHP * pBP, bb = dBP * pHP;
+                    x[b2][j].x = a * a + bb * bb;
+                }
+#pragma unroll
+                for (int j = 0; j < U; j++) e[(size_t)(n - 1 - (base + j)) * 64].x = x[b2][j].x;
+            }
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++) e[(size_t)(n - j) * 64].x = x[j].x;
     }
 }
 
 // WindowControl.c:106-134: 8 bins per block, smoothing state carried across blocks.
-__global__ __launch_bounds__(64) void k_wc_integrate(UlcxEncCtx c) {
+__global__ __launch_bounds__(64) void k_wc_integrate(UlcxEncCtx c, int k0, int k1) {
+    __builtin_amdgcn_s_setprio(3);
     int s = blockIdx.x * 64 + threadIdx.x;
     bool live = s < c.B;
     int sc = live ? s : 0;
     float env = c.wcs[sc].tf[2];
     float *bins = c.bins + (size_t)sc * (c.maxK + 1) * 16;
-    if (live) for (int i = 0; i < 8; i++) { bins[i] = c.wcs[s].binSum[i]; bins[8 + i] = c.wcs[s].binW[i]; }
-    const float2 *e = c.env + env_idx(c, s, 0);
+    if (live && k0 == 0) for (int i = 0; i < 8; i++) { bins[i] = c.wcs[s].binSum[i]; bins[8 + i] = c.wcs[s].binW[i]; }
+    const float2 *e = c.env + env_idx(c, s, k0 * c.BS);
     int bin = c.BS / 8;                   // >= 32, multiple of U
-    int n = c.K * c.BS;
+    int n = (k1 - k0) * c.BS;
     constexpr int U = 16, D = 4;
     float x[D][U];
 #pragma unroll
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(64) void k_wc_integrate(UlcxEncCtx c) {
             for (int j = 0; j < U; j++) { float d = x[b][j] - env; env += d * c.cBlk; sum += env; sw += 1; }
             int done = base + U;
             if (done % bin == 0) {        // bin boundary (bins never straddle a batch)
-                int gbin = done / bin - 1;            // global bin index = k*8 + i
+                int gbin = done / bin - 1 + k0 * 8;   // global bin index = k*8 + i
                 if (live) { float *o = bins + (size_t)(gbin / 8 + 1) * 16; o[gbin & 7] = sum; o[8 + (gbin & 7)] = sw; }
                 sum = 0.0f; sw = 0.0f;
             }
@@ -204,10 +224,10 @@ __global__ __launch_bounds__(64) void k_wc_integrate(UlcxEncCtx c) {
 }
 
 // WindowControl.c:156-238: decision from the bins of block k (R) and k-1 (L).
-__global__ __launch_bounds__(64) void k_wc_decide(UlcxEncCtx c) {
+__global__ __launch_bounds__(64) void k_wc_decide(UlcxEncCtx c, int k0, int k1) {
     int gid = blockIdx.x * 64 + threadIdx.x;
-    if (gid >= c.B * c.K) return;
-    int s = gid / c.K, k = gid % c.K;
+    if (gid >= c.B * (k1 - k0)) return;
+    int s = gid / (k1 - k0), k = k0 + gid % (k1 - k0);
     const float *L = c.bins + ((size_t)s * (c.maxK + 1) + k) * 16;
     const float *R = L + 16;
     int log2sub = c.lgBS - 3;
@@ -274,20 +294,22 @@ __device__ __forceinline__ float win_apply(float x, int i, int S, int aL, int ov
     return (n < aR) ? x : (n < aR + ov) ? x * fall[n - aR] : 0.0f;
 }
 
-__global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c) {
+__global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c, int k0, int k1) {
     extern __shared__ float lds[];
     const int BS = c.BS, C = c.C;
     // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its own L2).
     // Consecutive blocks of a stream read overlapping input (each frame spans two blocks), so give an
     // XCD a contiguous run of blocks: block = (b % 8) * ceil(NB/8) + b / 8.  Speed only, never correctness.
-    int NBk = c.B * c.K;
+    const int kc = k1 - k0;
+    int NBk = c.B * kc;
     int per = (NBk + 7) / 8;
-    int blk = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
-    if (blk >= NBk) return;
-    int s = blk / c.K, k = blk % c.K;
+    int vb = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+    if (vb >= NBk) return;
+    int s = vb / kc, k = k0 + vb % kc;
+    int blk = s * c.K + k;
     int tid = threadIdx.x;
     float2 *z    = (float2 *)lds;                     // 4 arrays of up to BS/2 complex: {MDCT, MDST} x {ch, ch+1}
-    float  *amp2 = lds + 4 * BS;                      // BS/2
+    float  *amp2 = lds + 4 * FFT_PADDED(BS);          // BS/2
     int    &s_nnz = *(int *)(amp2 + BS / 2);          // (inside the dynamic region: no static LDS in front of it)
     if (tid == 0) s_nnz = 0;
     for (int i = tid; i < BS / 2; i += WG) amp2[i] = 0.0f;
@@ -328,64 +350,88 @@ __global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c) {
             int aL = (S - ovL) >> 1, aR = (S - ov) >> 1;
             const float *rise = c.T.winRise + ovL, *fall = c.T.winFall + ov;
             const float2 *pre = c.T.pre[d];
-            float2 *zc0 = z, *zs0 = z + M, *zc1 = z + 2 * M, *zs1 = z + 3 * M;
+            const int Mp = FFT_PADDED(M);                // arrays are stored padded (ulcx_fft.h)
+            float2 *zc0 = z, *zs0 = z + Mp, *zc1 = z + 2 * Mp, *zs1 = z + 3 * Mp;
 
-            // 1. TDAC fold + DCT-IV pre-twiddle straight from the input timeline
-            for (int n = tid; n < M; n += WG) {
-                int m1 = 2 * n, m2 = S - 1 - 2 * n;
-                bool lo = (m1 < M);
-                int mr = lo ? m1 : m2;                // index handled by the R (second-half) fold
-                int ml = lo ? m2 : m1;                // index handled by the L (first-half) fold
-                int iRa = S + (M - 1 - mr), iRb = S + (M + mr);
-                int iLa = S - 1 - (ml - M), iLb = ml - M;
-                float xa[2], xb[2], ya[2], yb[2];     // per channel: Ra, Rb, La, Lb (windowed)
+            // 1. TDAC fold + DCT-IV pre-twiddle straight from the input timeline.
+            //    Fold index n uses frame positions {M-1-2n, M+2n, S+M-1-2n, S+M+2n} (n < M/2) or their
+            //    mirror images (n >= M/2); n = M/2-1-j and n = M/2+j use ADJACENT positions in all four
+            //    quarters of the frame, so one lane takes both: four 16-byte loads per lane, each wave
+            //    reading four contiguous 1 KB runs.
+            if (!(c.dbgSkip & 2)) for (int jj = tid; jj < M / 2; jj += WG) {
+                const int iA = 2 * jj, iB = S - 2 - 2 * jj, iC = S + 2 * jj, iD = 2 * S - 2 - 2 * jj;
+                float2 xs[8];                           // (ch0, ch0+1) after M/S at iA, iA+1, iB, iB+1, iC, iC+1, iD, iD+1
                 {
-                    const float *pRa = smp_ptr(c, s, t0 + iRa), *pRb = smp_ptr(c, s, t0 + iRb);
-                    const float *pLa = smp_ptr(c, s, t0 + iLa), *pLb = smp_ptr(c, s, t0 + iLb);
-                    if (nch == 2) {
-                        float2 ra, rb, la, lb;
-                        if (C == 2) {                 // stereo: one 8-byte load per time position
-                            ra = *(const float2 *)pRa; rb = *(const float2 *)pRb; la = *(const float2 *)pLa; lb = *(const float2 *)pLb;
+                    const int ip[4] = { iA, iB, iC, iD };
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float *p = smp_ptr(c, s, t0 + ip[r]);
+                        float2 e0, e1;
+                        if (nch == 2) {
+                            if (c.dbgSkip & 8) { e0 = make_float2(1.0f * jj, 2.0f); e1 = make_float2(3.0f, 0.5f * jj); }
+                            else if (C == 2) { float4 v = *(const float4 *)p; e0 = make_float2(v.x, v.y); e1 = make_float2(v.z, v.w); }
+                            else { e0 = make_float2(p[ch0], p[ch0 + 1]); e1 = make_float2(p[C + ch0], p[C + ch0 + 1]); }
+                            // M/S (BlockTransform.c:102-110)
+                            xs[2 * r]     = make_float2((e0.x + e0.y) * 0.5f, (e0.x - e0.y) * 0.5f);
+                            xs[2 * r + 1] = make_float2((e1.x + e1.y) * 0.5f, (e1.x - e1.y) * 0.5f);
                         } else {
-                            ra = make_float2(pRa[ch0], pRa[ch0 + 1]); rb = make_float2(pRb[ch0], pRb[ch0 + 1]);
-                            la = make_float2(pLa[ch0], pLa[ch0 + 1]); lb = make_float2(pLb[ch0], pLb[ch0 + 1]);
+                            xs[2 * r] = make_float2(p[ch0], 0.0f); xs[2 * r + 1] = make_float2(p[C + ch0], 0.0f);
                         }
-                        // M/S (BlockTransform.c:102-110)
-                        xa[0] = (ra.x + ra.y) * 0.5f; xa[1] = (ra.x - ra.y) * 0.5f;
-                        xb[0] = (rb.x + rb.y) * 0.5f; xb[1] = (rb.x - rb.y) * 0.5f;
-                        ya[0] = (la.x + la.y) * 0.5f; ya[1] = (la.x - la.y) * 0.5f;
-                        yb[0] = (lb.x + lb.y) * 0.5f; yb[1] = (lb.x - lb.y) * 0.5f;
-                    } else {
-                        xa[0] = pRa[ch0]; xb[0] = pRb[ch0]; ya[0] = pLa[ch0]; yb[0] = pLb[ch0];
-                        xa[1] = xb[1] = ya[1] = yb[1] = 0.0f;
                     }
                 }
-                float2 P = pre[n];
+                // window, branch-free (same factor for every channel).  Rising half (iA.., iB..): 0 below the ramp,
+                // rise[] on it, x itself above (x * 1.0f is x); falling half (iC.., iD..) mirrored.  win_apply() is the
+                // readable form of the same thing.
+                const int ipos[8] = { iA, iA + 1, iB, iB + 1, iC, iC + 1, iD, iD + 1 };
 #pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    if (q >= nch) break;
-                    float ra = win_apply(xa[q], iRa, S, aL, ovL, aR, ov, rise, fall);
-                    float rb = win_apply(xb[q], iRb, S, aL, ovL, aR, ov, rise, fall);
-                    float la = win_apply(ya[q], iLa, S, aL, ovL, aR, ov, rise, fall);
-                    float lb = win_apply(yb[q], iLb, S, aL, ovL, aR, ov, rise, fall);
-                    float vr = ra + rb, wr = ra - rb;            // v[mr], w[mr]
-                    float vl = la - lb, wl = lb + la;            // v[ml], w[ml]
-                    float v1 = lo ? vr : vl, v2 = lo ? vl : vr;  // v[m1], v[m2]
-                    float w1 = lo ? wr : wl, w2 = lo ? wl : wr;  // w[m1], w[m2]
-                    float2 *zc = q ? zc1 : zc0, *zs = q ? zs1 : zs0;
-                    zc[n] = cmulc(make_float2(v1, v2), P);       // u = v      : (u[2n], u[S-1-2n])
-                    zs[n] = cmulc(make_float2(w2, w1), P);       // u = rev(w) : (w[S-1-2n], w[2n])
+                for (int r = 0; r < 8; r++) {
+                    float f; bool zero;
+                    if (r < 4) {
+                        int idx = ipos[r] - aL;
+                        int ci = idx < 0 ? 0 : (idx < ovL ? idx : 0);
+                        float tv = (c.dbgSkip & 16) ? 0.5f : rise[ci];                     // rise[0] exists for ovL = 0 too (table row of the zero overlap)
+                        f = (idx < ovL) ? tv : 1.0f; zero = idx < 0;
+                    } else {
+                        int idx = ipos[r] - S - aR;
+                        int ci = idx < 0 ? 0 : (idx < ov ? idx : 0);
+                        float tv = (c.dbgSkip & 16) ? 0.5f : fall[ci];
+                        f = (idx < 0) ? 1.0f : tv; zero = idx >= ov;
+                    }
+                    float wx = xs[r].x * f, wy = xs[r].y * f;
+                    xs[r].x = zero ? 0.0f : wx;
+                    xs[r].y = zero ? 0.0f : wy;
+                }
+#pragma unroll
+                for (int hsel = 0; hsel < 2; hsel++) {
+                    // hsel 0: n = M/2-1-jj (Lb = iA+1, La = iB, Ra = iC+1, Rb = iD);  hsel 1: n = M/2+jj (Lb = iA, La = iB+1, Ra = iC, Rb = iD+1)
+                    const int n = hsel ? M / 2 + jj : M / 2 - 1 - jj;
+                    const float2 lbv = hsel ? xs[0] : xs[1], lav = hsel ? xs[3] : xs[2];
+                    const float2 rav = hsel ? xs[4] : xs[5], rbv = hsel ? xs[7] : xs[6];
+                    float2 P = (c.dbgSkip & 32) ? make_float2(0.5f, 0.25f) : pre[n];
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        if (q >= nch) break;
+                        float ra = q ? rav.y : rav.x, rb = q ? rbv.y : rbv.x, la = q ? lav.y : lav.x, lb = q ? lbv.y : lbv.x;
+                        float vr = ra + rb, wr = ra - rb;            // v[mr], w[mr]
+                        float vl = la - lb, wl = lb + la;            // v[ml], w[ml]
+                        float v1 = hsel ? vl : vr, v2 = hsel ? vr : vl;  // v[2n], v[S-1-2n]
+                        float w1 = hsel ? wl : wr, w2 = hsel ? wr : wl;  // w[2n], w[S-1-2n]
+                        float2 *zc = q ? zc1 : zc0, *zs = q ? zs1 : zs0;
+                        zc[FFT_PAD(n)] = cmulc(make_float2(v1, v2), P);       // u = v      : (u[2n], u[S-1-2n])
+                        zs[FFT_PAD(n)] = cmulc(make_float2(w2, w1), P);       // u = rev(w) : (w[S-1-2n], w[2n])
+                    }
                 }
             }
             __syncthreads();
 
-            // 2. 2*nch M-point FFTs in LDS
-            fftn_dif(z, 2 * nch, M, c.T.tw[d], tid);
+            // 2. 2*nch M-point FFTs in LDS, one wave per array, no barriers in between
+            if (!(c.dbgSkip & 1)) for (int a = tid >> 6; a < 2 * nch; a += WG / 64) fft_wave_dif(z + a * Mp, M, c.T.tw[d], tid & 63);
+            __syncthreads();
 
             // 3. post-twiddle + normalise + keys + per-line energies (BlockTransform.c:243-281)
             int bits = 31 - __clz(M);
             float norm = 2.0f / S;
-            for (int kk = tid; kk < M / 2; kk += WG) {
+            if (!(c.dbgSkip & 4)) for (int kk = tid; kk < M / 2; kk += WG) {
                 int k1 = kk, k2 = M - 1 - kk;
                 int r1 = (int)(__brev((unsigned)k1) >> (32 - bits));
                 int r2 = (int)(__brev((unsigned)k2) >> (32 - bits));
@@ -396,8 +442,8 @@ __global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c) {
                     if (q >= nch) break;
                     int ch = ch0 + q;
                     float2 *zc = q ? zc1 : zc0, *zs = q ? zs1 : zs0;
-                    float2 yc1 = cmulc(zc[r1], P1), yc2 = cmulc(zc[r2], P2);
-                    float2 ys1 = cmulc(zs[r1], P1), ys2 = cmulc(zs[r2], P2);
+                    float2 yc1 = cmulc(zc[FFT_PAD(r1)], P1), yc2 = cmulc(zc[FFT_PAD(r2)], P2);
+                    float2 ys1 = cmulc(zs[FFT_PAD(r1)], P1), ys2 = cmulc(zs[FFT_PAD(r2)], P2);
                     // pair j = k1: coefficients 2k1, 2k1+1 ; pair j = k2: coefficients 2k2, 2k2+1
                     float mdct[4] = { yc1.x, -yc2.y, yc2.x, -yc1.y };
                     float mdst[4] = { ys1.x,  ys2.y, ys2.x,  ys1.y };
@@ -1975,19 +2021,23 @@ __global__ __launch_bounds__(WG) void k_state_update(UlcxEncCtx c) {
 // ---------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------
-size_t ulcx_enc_xf_lds_bytes(int BS) { return (size_t)BS * 18 + 16; }   // 2BS + BS + BS + BS/2 floats + counter
+size_t ulcx_enc_xf_lds_bytes(int BS) { return (size_t)BS * 19 + 16; }   // 4 padded arrays of BS/2 complex + BS/2 floats + counter
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)
 
 // Per-kernel hipEvents (on the launch stream) bracket every kernel of the first pass so
 // bench.py can price each one against the roofline live; ev holds ULCX_ENC_STAGES+1 events.
-const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES] = {
+const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES_REPORTED] = {
     "k_wc_energy", "k_wc_forward", "k_wc_backward", "k_wc_integrate", "k_wc_decide",
     "k_xf", "k_cplx", "k_pbark", "k_mask",
-    "k_select", "k_nbark", "k_nline", "k_heapsel", "k_gapsums", "k_tailsums", "k_encode_wave", "k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update",
+    "k_select", "k_nbark", "k_nline", "k_heapsel", "k_gapsums", "k_tailsums", "k_encode_wave", "k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update", "wc_pipeline_exposed",
 };
 
-int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStream_t side, hipEvent_t evFork, hipEvent_t evJoin, hipEvent_t evFork2) {
+int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const UlcxEncAux &aux) {
+    hipStream_t side = aux.side, side2 = aux.side2, side3 = aux.side3;
+    hipEvent_t evFork = aux.evFork, evJoin = aux.evJoin, evFork2 = aux.evFork2, *evWC = aux.evWC;
+    const int wcPipe = (side && side2 && side3) ? aux.wcPipe : 1;
+    if (aux.nXf) *aux.nXf = 0;
     int NB = c.B * c.K;
     int stage = 0;
 #define MARK() do { if (ev) CK(hipEventRecord(ev[stage++], st)); } while (0)
@@ -1995,17 +2045,59 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
     // --- window control
     {
         int SG = (c.B + 63) / 64;
-        hipLaunchKernelGGL(k_wc_energy, dim3((unsigned)(SG * ((c.K * c.BS) / 64))), dim3(WG), 0, st, c);   MARK();
-        hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, st, c);                                    MARK();
-        hipLaunchKernelGGL(k_wc_backward, dim3(SG * c.K), dim3(64), 0, st, c);                             MARK();
-        hipLaunchKernelGGL(k_wc_integrate, dim3((c.B + 63) / 64), dim3(64), 0, st, c);                     MARK();
-        hipLaunchKernelGGL(k_wc_decide, dim3((NB + 63) / 64), dim3(64), 0, st, c);                         MARK();
-    }
-    // --- transform
-    {
+        // Chunks of blocks: the window-control kernels of chunk j+1.. (two stream-long serial recurrences, a few
+        // hundred waves: latency-bound, nearly no machine resources) run on the side stream beside the
+        // transform of chunk j on the main stream.  wcPipe = 1 keeps everything on the main stream.
+        const int nCh = wcPipe;
         size_t lds = ulcx_enc_xf_lds_bytes(c.BS);
         if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_xf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_xf, dim3(((NB + 7) / 8) * 8), dim3(WG), lds, st, c);                                          MARK();
+        auto launch_wc = [&](hipStream_t s2, int k0, int k1, bool marks) -> int {
+            int kc = k1 - k0;
+            hipLaunchKernelGGL(k_wc_energy, dim3((unsigned)(SG * ((kc * c.BS) / 64))), dim3(WG), 0, s2, c, k0, k1);   if (marks) MARK();
+            hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, s2, c, k0, k1);                  if (marks) MARK();
+            hipLaunchKernelGGL(k_wc_backward, dim3(SG * kc), dim3(64), 0, s2, c, k0, k1);                             if (marks) MARK();
+            hipLaunchKernelGGL(k_wc_integrate, dim3((c.B + 63) / 64), dim3(64), 0, s2, c, k0, k1);                    if (marks) MARK();
+            hipLaunchKernelGGL(k_wc_decide, dim3((c.B * kc + 63) / 64), dim3(64), 0, s2, c, k0, k1);                  if (marks) MARK();
+            return ULCX_OK;
+        };
+        if (nCh <= 1) {
+            int rc = launch_wc(st, 0, c.K, true); if (rc) return rc;
+            hipLaunchKernelGGL(k_xf, dim3(((NB + 7) / 8) * 8), dim3(WG), lds, st, c, 0, c.K);                            MARK();
+        } else {
+            for (int i = 0; i < 5; i++) MARK();                    // (window-control stages: hidden in the k_xf interval in this mode)
+            // side: energy_j, forward_j (the sample-rate chain, back to back over the chunks);
+            // side2: backward_j behind forward_j;  side3: integrate_j, decide_j behind backward_j;
+            // main: xf_j behind decide_j.  The first chunk is a single block so the transform starts early.
+            hipEvent_t ev0 = evWC[0], *evF = evWC + 1, *evB = evWC + 1 + ULCX_WC_MAXCH, *evD = evWC + 1 + 2 * ULCX_WC_MAXCH;
+            int cut[ULCX_WC_MAXCH + 1];
+            cut[0] = 0; cut[1] = 1;
+            for (int j = 2; j <= nCh; j++) cut[j] = 1 + (c.K - 1) * (j - 1) / (nCh - 1);
+            CK(hipEventRecord(ev0, st));
+            CK(hipStreamWaitEvent(side, ev0, 0));
+            for (int j = 0; j < nCh; j++) {
+                int k0 = cut[j], k1 = cut[j + 1], kc = k1 - k0;
+                hipLaunchKernelGGL(k_wc_energy, dim3((unsigned)(SG * ((kc * c.BS) / 64))), dim3(WG), 0, side, c, k0, k1);
+                hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, side, c, k0, k1);
+                CK(hipEventRecord(evF[j], side));
+                CK(hipStreamWaitEvent(side2, evF[j], 0));
+                hipLaunchKernelGGL(k_wc_backward, dim3(SG * kc), dim3(64), 0, side2, c, k0, k1);
+                CK(hipEventRecord(evB[j], side2));
+                CK(hipStreamWaitEvent(side3, evB[j], 0));
+                hipLaunchKernelGGL(k_wc_integrate, dim3((c.B + 63) / 64), dim3(64), 0, side3, c, k0, k1);
+                hipLaunchKernelGGL(k_wc_decide, dim3((c.B * kc + 63) / 64), dim3(64), 0, side3, c, k0, k1);
+                CK(hipEventRecord(evD[j], side3));
+            }
+            for (int j = 0; j < nCh; j++) {
+                int k0 = cut[j], k1 = cut[j + 1];
+                int nbk = c.B * (k1 - k0);
+                CK(hipStreamWaitEvent(st, evD[j], 0));
+                if (ev) CK(hipEventRecord(aux.evXf[2 * j], st));
+                hipLaunchKernelGGL(k_xf, dim3(((nbk + 7) / 8) * 8), dim3(WG), lds, st, c, k0, k1);
+                if (ev) CK(hipEventRecord(aux.evXf[2 * j + 1], st));
+            }
+            if (aux.nXf) *aux.nXf = nCh;
+            MARK();
+        }
     }
     hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c);                                  MARK();
     int nUnits = NB * c.C * 4;

@@ -140,3 +140,62 @@ __device__ void fftn_dif(float2 *z0, int nArr, int M, const float2 *__restrict__
         __syncthreads();
     }
 }
+
+// ---------------------------------------------------------------------------
+// Wave-per-array form of the same transform.  One wavefront owns one M-point array and
+// carries 2^R points per lane through R consecutive radix-2 DIF stages in registers
+// (R <= 4: 16 points, <= 3 LDS round trips for M <= 4096), so no workgroup barrier is
+// needed between passes: LDS operations of one wave execute in order.  Stage by stage
+// the butterflies, twiddle values and rounding are exactly those of fftn_dif.
+// Arrays are stored padded (one complex of padding after every 16) so that the late
+// passes, where a lane's points are adjacent, do not pile onto the same LDS banks.
+// ---------------------------------------------------------------------------
+#define FFT_PAD(p) ((p) + ((p) >> 4))
+#define FFT_PADDED(M) ((M) + ((M) >> 4))
+
+template <int R>
+__device__ __forceinline__ void fft_wave_pass(float2 *z, int M, int h, const float2 *__restrict__ tw, int lane) {
+    constexpr int NP = 1 << R;
+    const int q = h >> (R - 1);                    // spacing of one lane's points
+    const int stepA = M / (2 * h);
+    for (int gg = lane; gg < (M >> R); gg += 64) {
+        int j = gg & (q - 1);
+        int p0 = ((gg - j) << R) + j;
+        float2 x[NP];
+#pragma unroll
+        for (int m = 0; m < NP; m++) x[m] = z[FFT_PAD(p0 + m * q)];
+#pragma unroll
+        for (int s = 0; s < R; s++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int half = NP >> (s + 1);
+#pragma unroll
+            for (int m = 0; m < NP; m++) {
+                if (m & half) continue;
+                int t = m & (half - 1);
+                float2 w = tw[(j + t * q) * (stepA << s)];
+                float2 a = x[m], b = x[m + half];
+                x[m] = make_float2(a.x + b.x, a.y + b.y);
+                x[m + half] = cmulc(make_float2(a.x - b.x, a.y - b.y), w);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NP; m++) z[FFT_PAD(p0 + m * q)] = x[m];
+    }
+}
+
+// whole M-point transform of one padded array by one wave (M = 16 .. 4096)
+__device__ __forceinline__ void fft_wave_dif(float2 *z, int M, const float2 *__restrict__ tw, int lane) {
+    int rem = 31 - __clz(M);
+    int h = M >> 1;
+    while (rem > 0) {
+        int passes = (rem + 3) >> 2;
+        int r = (rem + passes - 1) / passes;       // 10 -> 4,3,3   9 -> 3,3,3   8 -> 4,4   5 -> 3,2
+        switch (r) {
+            case 4: fft_wave_pass<4>(z, M, h, tw, lane); break;
+            case 3: fft_wave_pass<3>(z, M, h, tw, lane); break;
+            case 2: fft_wave_pass<2>(z, M, h, tw, lane); break;
+            default: fft_wave_pass<1>(z, M, h, tw, lane); break;
+        }
+        h >>= r; rem -= r;
+    }
+}

@@ -82,6 +82,7 @@ struct UlcxEncCtx {
     int    *isFb;                        // [NB] 1 = a threshold tie group straddled the cut this call: block is on the exact (rank) path
     int    *ownSlot;                     // [NB] its slot in fbList
     int    *rankBuf;                     // [rankSlots][C*BS] full heapsort ranking of exact-path blocks
+    int     dbgSkip;
     int     rankSlots, fbLo, fbHi;       // resident rank slots; slot window of the current exact-path launch
     int     fbMode;                      // 0 = all blocks, 1 = skip isFb blocks, 2 = only isFb blocks
     int     useWave;                     // wave-per-unit encode pass (k_encode_wave); serial kernel only for overflow blocks
@@ -130,9 +131,20 @@ void ulcx_set_error(const char *fmt, ...);
 
 // launchers (ulcx_enc.hip / ulcx_dec.hip)
 #define ULCX_ENC_STAGES 20
-extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES];
+#define ULCX_ENC_STAGES_REPORTED (ULCX_ENC_STAGES + 1)   // + "wc_pipeline_exposed" (computed, not an event interval)
+extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES_REPORTED];
 #define ULCX_DEC_STAGES 4
-int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, hipStream_t side, hipEvent_t evFork, hipEvent_t evJoin, hipEvent_t evFork2);
+#define ULCX_WC_MAXCH 8
+// streams and events the encoder launch uses beside the caller's stream
+struct UlcxEncAux {
+    hipStream_t side, side2, side3;      // NULL: everything on the caller's stream
+    hipEvent_t evFork, evJoin, evFork2;  // exact-path fork/join
+    hipEvent_t *evWC;                    // [1 + 3*ULCX_WC_MAXCH] window-control pipeline
+    hipEvent_t *evXf;                    // [2*ULCX_WC_MAXCH] timing pairs around each transform chunk (used when ev != NULL)
+    int wcPipe;                          // chunks of blocks pipelined between window control and transform; 1 = off
+    int *nXf;                            // out: transform chunk launches this call
+};
+int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, const UlcxEncAux &aux);
 int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev);
 int ulcx_pack_launch(int nStreams, int nBlocks, int slotBytes, const uint8_t *d_slots, const int32_t *d_bits, uint8_t *d_payload,
                      long long stride, int32_t *d_payloadBytes, int32_t *d_maxBlock, hipStream_t st);
