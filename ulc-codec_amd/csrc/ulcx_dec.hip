@@ -317,11 +317,74 @@ __global__ __launch_bounds__(64) void k_dgen(UlcxDecCtx c) {
         pat >>= 4;
         if (!pat) return;
     }
-    NybReader r; r.init(block_ptr(c, blk), c.unitStart[(size_t)blk * c.C * 4 + ch * 4 + j], c.packed ? (1 << 24) : c.slot);
+    // Only blocks the scan pass found well-formed get here (wc != 0), so the walk below follows a valid syntax.
+    // ONE flat loop, no inner loops: an iteration either decodes one whole code (1-5 nybbles, read as one
+    // 32-bit window) or emits up to four noise coefficients.  With one unit per lane an inner loop makes
+    // every lane of the wave wait for the longest run in flight (measured: 460 k wave instructions per
+    // wave of 64 units, 10x the work of any single lane); here a noise run is a state of the lane.
+    typedef uint32_t u32_any_align __attribute__((aligned(1)));
+    const uint8_t *src = block_ptr(c, blk);
+    int bitpos = c.unitStart[(size_t)blk * c.C * 4 + ch * 4 + j];
     uint32_t seed = rng_jump(c.jump, c.blockSeed[blk], (uint32_t)c.unitDraws[(size_t)blk * c.C * 4 + ch * 4 + j]);
-    CoefWriter w; w.dst = c.coef + (size_t)blk * c.C * c.BS + (size_t)ch * c.BS + off; w.n = 0;
-    int draws = 0;
-    decode_subblock<true>(w, S, r, seed, draws);
+    float *dst = c.coef + (size_t)blk * c.C * c.BS + (size_t)ch * c.BS + off;       // pre-zeroed: zero runs just skip
+    int N = S, pos = 0, pend = 0;
+    float quant = 0.0f, lev = 0.0f, rr = 1.0f;
+    bool first = true;                                     // the unit opens with a quantizer code without its Fh prefix
+    int guard = 2 * c.slot + S + 64;                       // codes of a slot + noise coefficients: cannot be exceeded
+    bool done = false;
+    while (!done && guard-- > 0) {
+        if (pend > 0) {
+            // ulcDecoder.c:156-160 / :181-184: draw, flip on the MSB (cumulative), store, decay (rr = 1 for runs)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (pend > 0) {
+                    seed = xorshift32(seed);
+                    if (seed & 0x80000000u) lev = -lev;
+                    dst[pos] = lev;
+                    lev *= rr;
+                    pos++; pend--; N--;
+                }
+            }
+            done = (N == 0);
+        } else {
+            uint32_t w = *(const u32_any_align *)(src + (bitpos >> 3));
+            w >>= (bitpos & 4);                            // >= 7 valid nybbles, low nybble first (ulcDecoder.c:82-88)
+            // unit start: same grammar as after an Fh, except that a leading Fh there is quantizer 15 (ScanFsm S_Q0)
+            const bool q15 = first & ((w & 0xF) == 0xF);
+            w = first ? ((w << 4) | 0xF) : w;
+            const int v0 = w & 0xF, v1 = (w >> 4) & 0xF, v2 = (w >> 8) & 0xF, v3 = (w >> 12) & 0xF, v4 = (w >> 16) & 0xF;
+            const bool plain = (v0 != 0x0) & (v0 != 0x1) & (v0 != 0x8) & (v0 != 0xF);
+            const bool z0 = (v0 == 0x0), z1 = (v0 == 0x1), n8 = (v0 == 0x8), esc = (v0 == 0xF);
+            const bool tail = esc & (v1 == 0xF) & !q15;                     // Fh,Fh,Z,Y,X : noise to the end
+            const bool qext = esc & (v1 == 0xE);                            // Fh,Eh,X     : extended quantizer / stop
+            const bool stop = qext & (v2 == 0xF);
+            const bool q1 = esc & !tail & !qext;                            // Fh,X
+            // coefficient (ulcDecoder.c:69-73)
+            int sv = (v0 ^ 0x8) - 0x8;
+            sv = (sv < 0) ? (-sv * sv) : (+sv * sv);
+            if (plain) dst[pos] = (float)sv * quant;
+            // code length in nybbles and coefficients consumed now
+            int len = plain ? 1 : z0 ? 2 : z1 ? 3 : n8 ? 4 : tail ? 5 : qext ? 3 : 2;
+            len -= first ? 1 : 0;
+            int n = plain ? 1 : z0 ? v1 + 1 : z1 ? ((v1 << 4) | v2) + 33 : 0;
+            n = (n > N) ? N : n;                                            // (cannot happen in a block the scan accepted)
+            // noise run / tail parameters (ulcDecoder.c:95-115, :123-137)
+            int np = n8 ? ((((v1 << 4) | v2) << 1) | (v3 & 1)) + 16 : tail ? N : 0;
+            np = (np > N) ? N : np;
+            const int l = n8 ? (v3 >> 1) + 1 : v2 + 1;
+            const float lvl = (float)(l * l) * quant * (n8 ? (1.0f / 4) : (1.0f / 16));
+            const int dn = (v3 << 4) | v4;
+            lev = (n8 | tail) ? lvl : lev;
+            rr = tail ? 1.0f + (float)(dn * dn) * -0x1.0p-19f : (n8 ? 1.0f : rr);
+            pend = np;
+            // quantizer change (ulcDecoder.c:89-98)
+            quant = q1 ? expand_quantizer(v1) : (qext & !stop) ? expand_quantizer(0xE + v2) : quant;
+            bitpos += 4 * len;
+            pos += n; N -= n;
+            first = false;
+            done = (N == 0) | stop;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
