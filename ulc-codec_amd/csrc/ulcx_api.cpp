@@ -354,6 +354,9 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     DA(c.lastSub, B, true);
     DA(c.seed, B, true);
     DA(c.dead, B, true);
+    DA(c.seedNext, B, true);
+    DA(c.deadNext, B, true);
+    DA(c.wcScan, NB, true);
     DA(c.coef, NB * cb, false);
     DA(c.wc, NB, true);
     DA(c.draws, NB, true);
@@ -362,6 +365,9 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     DA(c.blkOff, NB, true);
     DA(c.unitStart, NB * nChan * 4, true);
     DA(c.unitDraws, NB * nChan * 4, true);
+    DA(c.cp, NB * nChan * 4 * 8, true);
+    DA(c.decList, NB, true);
+    DA(c.decCount, 1, true);
     {
         // columns of T^(2^i) for the xorshift32 step T (ulcDecoder.c:75-81): J0[c] = T(e_c), J(i+1) = J(i)*J(i)
         std::vector<uint32_t> J(32 * 32);

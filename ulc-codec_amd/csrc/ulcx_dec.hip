@@ -18,28 +18,6 @@
 #include "ulcx_fft.h"
 
 // ---------------------------------------------------------------------------
-struct NybReader {                                                // ulcDecoder.c:82-88, low nybble first
-    const uint8_t *p; int size;                                   // size in bits, like the reference's counter
-    int limit;                                                    // a valid block never reaches the last 4 bytes of its slot;
-                                                                  // past that the block is corrupt (the reference would run off its buffer)
-    __device__ __forceinline__ void init(const uint8_t *base, int bitpos, int slotBytes) { p = base; size = bitpos; limit = slotBytes * 8 - 32; }
-    __device__ __forceinline__ bool overrun() const { return size > limit; }
-    __device__ __forceinline__ unsigned get() {
-        unsigned x = p[size >> 3];
-        unsigned n = (size & 4) ? (x >> 4) : (x & 0xF);
-        size += 4;
-        return n;
-    }
-};
-#define ESC_STOP (-1)
-#define ESC_STOP_NOISE (-2)
-__device__ __forceinline__ int get_quantizer(NybReader &r) {      // ulcDecoder.c:89-95
-    int q = (int)r.get();
-    if (q == 0xF) return ESC_STOP_NOISE;
-    if (q == 0xE) q += (int)r.get();
-    if (q == 0xE + 0xF) return ESC_STOP;
-    return q;
-}
 __device__ __forceinline__ float expand_quantizer(int q) {        // ulcDecoder.c:96-98
     return 0x1.0p-31f * (float)((1u << (31 - 5)) >> q);
 }
@@ -47,148 +25,65 @@ __device__ __forceinline__ uint32_t xorshift32(uint32_t s) {      // ulcDecoder.
     s ^= s << 13; s ^= s >> 17; s ^= s << 5;
     return s;
 }
-struct CoefWriter {                                               // the destination is pre-zeroed: zero runs just skip
-    float *dst; int n;
-    __device__ __forceinline__ void put(float v) { dst[n++] = v; }
-    __device__ __forceinline__ void skip(int k) { n += k; }
-};
 
-// ulcDecoder.c:99-197.  Returns 0 on a run that overruns the subblock (corrupt).
-// GEN = false: syntax walk only, counting the RNG draws the subblock consumes (one per
-// noise coefficient, ulcDecoder.c:156-160,181-184); GEN = true: also emits coefficients.
-template <bool GEN>
-__device__ int decode_subblock(CoefWriter &w, int N, NybReader &r, uint32_t &seed, int &draws) {
-    int n, v;
-    bool bad = false;
-    v = get_quantizer(r);
-    if (v == ESC_STOP) { if (GEN) w.skip(N); return 1; }
-    float quant = expand_quantizer(v);
-    for (;;) {
-        v = (int)r.get();
-        if (v != 0x0 && v != 0x1 && v != 0x8 && v != 0xF) {
-            if (GEN) {
-                v = (v ^ 0x8) - 0x8;
-                v = (v < 0) ? (-v * v) : (+v * v);
-                w.put((float)v * quant);
-            }
-            if (--N == 0) break;
-            continue;
-        }
-        if (v == 0x0) {
-            n = (int)r.get() + 1;
-            if (n > N) return 0;
-            N -= n;
-            if (GEN) w.skip(n);
-            if (N == 0) break;
-            continue;
-        }
-        if (v == 0x1) {
-            n = (int)r.get();
-            n = (int)r.get() | (n << 4);
-            n += 33;
-            if (n > N) return 0;
-            N -= n;
-            if (GEN) w.skip(n);
-            if (N == 0) break;
-            continue;
-        }
-        if (v == 0x8) {
-            n = (int)r.get();
-            n = (int)r.get() | (n << 4);
-            v = (int)r.get();
-            n = (v & 1) | (n << 1);
-            v = (v >> 1) + 1;
-            n += 16;
-            if (n > N) return 0;
-            N -= n;
-            draws += n;
-            if (GEN) {
-                float p = (float)(v * v) * quant * (1.0f / 4);
-                do {
-                    seed = xorshift32(seed);
-                    if (seed & 0x80000000u) p = -p;
-                    w.put(p);
-                } while (--n);
-            }
-            if (N == 0) break;
-            continue;
-        }
-        v = get_quantizer(r);
-        // quantizer changes are the only codes that consume no coefficient: bound them by the slot so a
-        // corrupt stream cannot walk off the buffer (every other code shrinks N).  Branch-free on purpose:
-        // an extra early return here cost +80 % kernel time (control-flow restructuring).
-        bad |= (r.size > r.limit);
-        v = bad ? ESC_STOP : v;
-        if (v >= 0) { quant = expand_quantizer(v); continue; }
-        if (v == ESC_STOP_NOISE) {
-            v = (int)r.get() + 1;
-            n = (int)r.get();
-            n = (int)r.get() | (n << 4);
-            draws += N;
-            if (GEN) {
-                float p = (float)(v * v) * quant * (1.0f / 16);
-                float rr = 1.0f + (float)(n * n) * -0x1.0p-19f;
-                do {
-                    seed = xorshift32(seed);
-                    if (seed & 0x80000000u) p = -p;
-                    w.put(p); p *= rr;
-                } while (--N);
-            }
-            break;
-        }
-        if (v == ESC_STOP) { if (GEN) w.skip(N); break; }
-    }
-    return bad ? 0 : 1;
+// ---------------------------------------------------------------------------
+// One whole code of the block syntax (FormatSpecs.md:57-141, ulcDecoder.c:99-197) decoded from a
+// 32-bit window (>= 7 nybbles, low nybble first), with selects instead of a branch cascade:
+// every lane of a wave executes the same instruction stream whatever its own code is.
+//   plain  +-2..+-7          1 nybble   one coefficient
+//   0h,X                     2          X+1 zeros
+//   1h,Y,X                   3          YX+33 zeros
+//   8h,Z,Y,X                 4          noise run: n = (ZY<<1 | X&1) + 16, level (X>>1)+1
+//   Fh,X (X < Eh)            2          quantizer X
+//   Fh,Eh,X (X < Fh)         3          quantizer Eh+X;  Fh,Eh,Fh = stop (zeros to the end)
+//   Fh,Fh,Z,Y,X              5          noise to the end: level Z+1, decay YX
+// A unit opens with a quantizer code without its Fh prefix (`first`); a leading Fh there is
+// quantizer 15.
+// ---------------------------------------------------------------------------
+struct Code {
+    int len;            // nybbles
+    int n;              // coefficients consumed at once (1, or a zero run)
+    int np;             // noise coefficients of a run (tail: the caller uses N)
+    int l, dn, sv;      // noise level / tail decay / signed square of a plain coefficient
+    int qnew;           // new quantizer index or -1
+    bool plain, zrun, n8, tail, stop;
+};
+__device__ __forceinline__ Code decode_code(uint32_t w, bool first) {
+    Code k;
+    const bool q15 = first & ((w & 0xF) == 0xF);
+    w = first ? ((w << 4) | 0xF) : w;
+    const int v0 = w & 0xF, v1 = (w >> 4) & 0xF, v2 = (w >> 8) & 0xF, v3 = (w >> 12) & 0xF, v4 = (w >> 16) & 0xF;
+    k.plain = (v0 != 0x0) & (v0 != 0x1) & (v0 != 0x8) & (v0 != 0xF);
+    const bool z0 = (v0 == 0x0), z1 = (v0 == 0x1), esc = (v0 == 0xF);
+    k.n8 = (v0 == 0x8);
+    k.zrun = z0 | z1;
+    k.tail = esc & (v1 == 0xF) & !q15;
+    const bool qext = esc & (v1 == 0xE);
+    k.stop = qext & (v2 == 0xF);
+    const bool q1 = esc & !k.tail & !qext;
+    int sv = (v0 ^ 0x8) - 0x8;
+    k.sv = (sv < 0) ? (-sv * sv) : (+sv * sv);
+    int len = k.plain ? 1 : z0 ? 2 : z1 ? 3 : k.n8 ? 4 : k.tail ? 5 : qext ? 3 : 2;
+    k.len = len - (first ? 1 : 0);
+    k.n = k.plain ? 1 : z0 ? v1 + 1 : z1 ? ((v1 << 4) | v2) + 33 : 0;
+    k.np = k.n8 ? ((((v1 << 4) | v2) << 1) | (v3 & 1)) + 16 : 0;
+    k.l = k.n8 ? (v3 >> 1) + 1 : v2 + 1;
+    k.dn = (v3 << 4) | v4;
+    k.qnew = q1 ? v1 : (qext & !k.stop) ? 0xE + v2 : -1;
+    return k;
 }
-
-// ---------------------------------------------------------------------------
-// Branch-free syntax walk for the scan pass.  The block syntax (FormatSpecs.md:57-141,
-// ulcDecoder.c:99-197) is a small finite-state machine over nybbles; written with selects
-// instead of a per-lane branch cascade, every lane of a wave executes the same instruction
-// stream per nybble whatever its own state.
-// ---------------------------------------------------------------------------
-enum { S_CODE = 0, S_Z0, S_Z1a, S_Z1b, S_N8a, S_N8b, S_N8c, S_QF, S_QFE, S_TN1, S_TN2, S_TN3, S_Q0, S_Q0E };
-struct ScanFsm {
-    int state, acc, N, draws;          // N = coefficients still to come in the current subblock
-    bool done, bad;
-    __device__ __forceinline__ void start(int n) { state = S_Q0; acc = 0; N = n; done = false; }
-    __device__ __forceinline__ void step(int v) {
-        const int st = state;
-        const bool plain = (v != 0x0) & (v != 0x1) & (v != 0x8) & (v != 0xF);      // +-2..+-7: one coefficient
-        // next state
-        int nxCode = plain ? S_CODE : (v == 0x0) ? S_Z0 : (v == 0x1) ? S_Z1a : (v == 0x8) ? S_N8a : S_QF;
-        int nxQF = (v == 0xF) ? S_TN1 : (v == 0xE) ? S_QFE : S_CODE;               // Fh,Fh.. / Fh,Eh.. / quantizer change
-        int nx = S_CODE;
-        nx = (st == S_CODE) ? nxCode : nx;
-        nx = (st == S_Z1a) ? S_Z1b : nx;
-        nx = (st == S_N8a) ? S_N8b : nx;
-        nx = (st == S_N8b) ? S_N8c : nx;
-        nx = (st == S_QF) ? nxQF : nx;
-        nx = (st == S_TN1) ? S_TN2 : nx;
-        nx = (st == S_TN2) ? S_TN3 : nx;
-        nx = (st == S_Q0 && v == 0xE) ? S_Q0E : nx;                                 // first quantizer, extended form
-        // effects of the code completed by this nybble
-        const int a2 = (acc << 4) | v;
-        int n = (st == S_CODE && plain) ? 1 : 0;
-        n = (st == S_Z0) ? v + 1 : n;                                               // 0h,X      : 1..16 zeros
-        n = (st == S_Z1b) ? a2 + 33 : n;                                            // 1h,Y,X    : 33..288 zeros
-        const int nn = ((acc << 1) | (v & 1)) + 16;                                 // 8h,Z,Y,X  : 16..527 noise coefficients
-        n = (st == S_N8c) ? nn : n;
-        int dr = (st == S_N8c) ? nn : 0;
-        const bool chk = (st == S_Z0) | (st == S_Z1b) | (st == S_N8c);
-        const bool stopZ = ((st == S_QFE) | (st == S_Q0E)) & (v == 0xF);            // [Fh,]Eh,Fh : zeros to the end
-        const bool stopN = (st == S_TN3);                                            // Fh,Fh,Z,Y,X: noise to the end
-        dr = stopN ? N : dr;
-        n = (stopZ | stopN) ? N : n;
-        const bool over = chk & (n > N);                                            // ulcDecoder.c:127,139,154
-        bad = bad | over;
-        N -= over ? 0 : n;
-        draws += over ? 0 : dr;
-        acc = ((st == S_Z1a) | (st == S_N8a)) ? v : (st == S_N8b) ? a2 : acc;
-        state = nx;
-        done = (N == 0) | over;
+typedef uint32_t u32_any_align __attribute__((aligned(1)));
+// 32-bit window at bit position pos; bytes at or past readBytes read as 0
+__device__ __forceinline__ uint32_t code_window(const uint8_t *p, int pos, int readBytes) {
+    int b = pos >> 3;
+    uint32_t w;
+    if (b + 4 <= readBytes) w = *(const u32_any_align *)(p + b);
+    else {
+        w = 0;
+        for (int i = 0; i < 4; i++) if (b + i < readBytes) w |= (uint32_t)p[b + i] << (8 * i);
     }
-};
+    return w >> (pos & 4);
+}
 
 // base pointer of block blk's bytes: its slot, or (packed mode) its parsed offset inside the stream payload
 __device__ __forceinline__ const uint8_t *block_ptr(const UlcxDecCtx &c, int blk) {
@@ -196,53 +91,84 @@ __device__ __forceinline__ const uint8_t *block_ptr(const UlcxDecCtx &c, int blk
     return c.in + (size_t)(blk / c.K) * c.payStride + c.blkOff[blk];
 }
 
-// Syntax walk of one block starting at p (limitBits readable): records unit starts / draw counts.
-// Returns bits consumed (0 = corrupt).
-__device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const uint8_t *p, int limit) {
+// Checkpoints: every unit is cut at the first code that starts at or after coefficient q*S/8
+// (q = 0..7), so pass 3 can decode eight pieces of a unit on eight lanes.  {bit position, coefficients
+// still to come, draws so far in the block, quantizer index (-1: the unit's opening code)}; N = 0 = no piece.
+#define DCP_PER_UNIT 8
+
+// Syntax walk of one block starting at p (limit = bits that may be consumed, readBytes = bytes that may be
+// touched): records unit starts / draw counts / checkpoints.  Returns bits consumed (0 = corrupt).
+// One flat loop, one code (or one checkpoint) per trip.
+__device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const uint8_t *p, int limit, int readBytes) {
     int pos = 0;
-    // never reads at or past `limit` bits (a clamped read of byte 0 instead): running past it marks the block corrupt below
-    auto get = [&]() { unsigned x = p[(pos < limit ? pos : 0) >> 3]; int v = (pos & 4) ? (x >> 4) : (x & 0xF); pos += 4; return v; };
-    int wc = get();                                                 // ulcDecoder.c:211-216
-    { int v2 = (int)((p[(pos < limit ? pos : 0) >> 3] >> (pos & 4)) & 0xF); bool dec = (wc & 0x8) != 0; wc |= dec ? (v2 << 4) : (1 << 4); pos += dec ? 4 : 0; }
+    int wc;
+    {
+        uint32_t w0 = (limit >= 8) ? code_window(p, 0, readBytes) : 0;     // ulcDecoder.c:211-216
+        wc = w0 & 0xF;
+        bool dec = (wc & 0x8) != 0;
+        wc |= dec ? (int)(w0 & 0xF0) : (1 << 4);
+        pos = dec ? 8 : 4;
+    }
     unsigned pat = ulcx_pattern(wc);                                // (code 0000 behaves as one plain N/1 block, as in the reference)
     int nsub = 0; { unsigned q = pat; do nsub++; while (q >>= 4); }
     if ((c.BS >> (pat & 7)) == c.BS) nsub = 1;                      // ulcDecoder.c:242-245
     int total = c.C * nsub;
+    if (nsub > 1) c.decList[atomicAdd(c.decCount, 1)] = blk;        // its units j >= 1 get their own (small) pass-3 launch
     int *ustart = c.unitStart + (size_t)blk * c.C * 4;
     int *udraw  = c.unitDraws + (size_t)blk * c.C * 4;
-    ScanFsm f; f.draws = 0; f.bad = false;
-    int u = 0;
+    int4 *cp = c.cp + (size_t)blk * c.C * 4 * DCP_PER_UNIT;
+    int u = 0, draws = 0, qidx = 0, nextQ = 0, uslot = 0;
     ustart[0] = pos; udraw[0] = 0;
-    f.start(c.BS >> (pat & 7));
-    bool fin = (limit < 16);
-    f.bad = fin;
+    int S = c.BS >> (pat & 7), N = S;
+    bool first = true;
+    bool fin = (limit < 16), bad = fin;
     while (!fin) {
-        int v = get();
-        f.step(v);
-        if (f.done) {
+        if (nextQ < DCP_PER_UNIT && (S - N) >= nextQ * (S >> 3)) {
+            cp[uslot * DCP_PER_UNIT + nextQ] = make_int4(pos, N, draws, first ? -1 : qidx);
+            nextQ++;
+            continue;
+        }
+        Code k = decode_code(code_window(p, pos, readBytes), first);
+        const bool over = (k.zrun & (k.n > N)) | (k.n8 & (k.np > N));     // ulcDecoder.c:127,139,154
+        const bool toEnd = k.stop | k.tail;
+        const int used = over ? 0 : (toEnd ? N : k.n + k.np);
+        draws += over ? 0 : (k.tail ? N : k.np);
+        qidx = (k.qnew >= 0) ? k.qnew : qidx;
+        pos += 4 * k.len;
+        N -= used;
+        bad |= over;
+        first = false;
+        if ((N == 0) | over) {
             u++;
-            fin = f.bad | (u >= total);
+            fin = bad | (u >= total);
             if (!fin) {
                 int ch = u / nsub, j = u - ch * nsub;
-                ustart[ch * 4 + j] = pos; udraw[ch * 4 + j] = f.draws;
-                f.start(c.BS >> ((pat >> (4 * j)) & 7));
+                uslot = ch * 4 + j;
+                ustart[uslot] = pos; udraw[uslot] = draws;
+                S = c.BS >> ((pat >> (4 * j)) & 7); N = S;
+                first = true; nextQ = 0;
             }
         }
-        if (pos > limit) { f.bad = true; fin = true; }              // ran off the readable bytes: corrupt
+        if (pos > limit) { bad = true; fin = true; }               // ran off the readable bytes: corrupt
     }
-    bool ok = !f.bad;
+    bool ok = !bad;
     c.bits[blk] = ok ? pos : 0;
-    c.wc[blk] = ok ? wc : 0;
-    c.draws[blk] = f.draws;
+    c.wcScan[blk] = ok ? wc : 0;
+    c.draws[blk] = draws;
     return ok ? pos : 0;
 }
 
 // Pass 1 — one lane per block: walk the syntax, record where each (channel, subblock)
 // unit starts (nybble offset) and how many RNG draws precede it inside the block.
+// The walk is one long dependent chain per lane, so a full wave per SIMD would sit at ~10 cycles per
+// instruction: only DSCAN_LANES lanes of each wave are used, which puts 64/DSCAN_LANES times the waves
+// (more chains) on every SIMD.
+#define DSCAN_LANES 64
 __global__ __launch_bounds__(64) void k_dscan(UlcxDecCtx c) {
-    int blk = blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x >= DSCAN_LANES) return;
+    int blk = blockIdx.x * DSCAN_LANES + threadIdx.x;
     if (blk >= c.B * c.K) return;
-    scan_block(c, blk, c.in + (size_t)blk * c.slot, c.slot * 8 - 32);
+    scan_block(c, blk, c.in + (size_t)blk * c.slot, c.slot * 8 - 32, c.slot);
 }
 
 // Pass 1, packed payloads — one lane per stream: a block's start is only known once the previous
@@ -258,8 +184,8 @@ __global__ __launch_bounds__(64) void k_dscan_packed(UlcxDecCtx c) {
         int blk = s * c.K + k;
         c.blkOff[blk] = off;
         int bits = 0;
-        if (!dead && off < avail) bits = scan_block(c, blk, base + off, (avail - off) * 8);
-        else { c.bits[blk] = 0; c.wc[blk] = 0; c.draws[blk] = 0; }
+        if (!dead && off < avail) bits = scan_block(c, blk, base + off, (avail - off) * 8, avail - off);
+        else { c.bits[blk] = 0; c.wcScan[blk] = 0; c.draws[blk] = 0; }
         if (!bits) dead = true;
         off += (bits + 7) >> 3;                                     // the tool rounds every block up to a byte
     }
@@ -280,110 +206,128 @@ __device__ __forceinline__ uint32_t rng_jump(const uint32_t *__restrict__ jump, 
     return s;
 }
 
-// Pass 2 — one lane per stream: the RNG chain across blocks (ulcDecoder.c:75-81 keeps one
-// seed for the life of the stream) and "a corrupt block ends the stream" (ulcDecodeTool.c:154-157).
+// Pass 2 — the RNG chain across blocks (ulcDecoder.c:75-81 keeps one seed for the life of the stream)
+// and "a corrupt block ends the stream" (ulcDecodeTool.c:154-157).  The chain is linear, so block k's
+// seed is the stream's seed jumped by the draws of blocks 0..k-1: one lane per BLOCK, each summing its
+// predecessors' counts itself (K is small) - no stream-long serial walk.  The stream's state for the
+// next call is staged (seedNext/deadNext) and committed by a second tiny kernel, because every block
+// of the stream reads the old value here.
 __global__ __launch_bounds__(64) void k_dseed(UlcxDecCtx c) {
+    int blk = blockIdx.x * 64 + threadIdx.x;
+    if (blk >= c.B * c.K) return;
+    int s = blk / c.K, k = blk - s * c.K;
+    int dead = c.dead[s];
+    unsigned before = 0;
+    for (int i = 0; i < k; i++) {
+        if (c.wcScan[s * c.K + i] == 0) dead = 1;
+        before += dead ? 0u : (unsigned)c.draws[s * c.K + i];
+    }
+    int wcMine = c.wcScan[blk];
+    if (wcMine == 0) dead = 1;
+    c.wc[blk] = dead ? 0 : wcMine;
+    if (dead) c.bits[blk] = 0;
+    uint32_t seed0 = c.seed[s];
+    if (!dead) c.blockSeed[blk] = rng_jump(c.jump, seed0, before);
+    if (k == c.K - 1) {
+        unsigned total = before + (dead ? 0u : (unsigned)c.draws[blk]);
+        c.seedNext[s] = rng_jump(c.jump, seed0, total);
+        c.deadNext[s] = dead;
+    }
+}
+__global__ __launch_bounds__(64) void k_dseed_commit(UlcxDecCtx c) {
     int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= c.B) return;
-    uint32_t seed = c.seed[s];
-    int dead = c.dead[s];
-    for (int k = 0; k < c.K; k++) {
-        int blk = s * c.K + k;
-        if (!dead && c.wc[blk] == 0) dead = 1;
-        if (dead) { c.bits[blk] = 0; c.wc[blk] = 0; continue; }
-        c.blockSeed[blk] = seed;
-        seed = rng_jump(c.jump, seed, (uint32_t)c.draws[blk]);
-    }
-    c.seed[s] = seed;
-    c.dead[s] = dead;
+    c.seed[s] = c.seedNext[s];
+    c.dead[s] = c.deadNext[s];
 }
 
-// Pass 3 — one lane per (block, channel, subblock): dequantise + noise synthesis.
-__global__ __launch_bounds__(64) void k_dgen(UlcxDecCtx c) {
-    int tid0 = blockIdx.x * 64 + threadIdx.x;
-    int nBC = c.B * c.K * c.C;
-    if (tid0 >= nBC * 4) return;
-    // subblock index slowest: waves of j >= 1 are empty for un-decimated blocks
-    int j = tid0 / nBC, rem = tid0 - j * nBC, blk = rem / c.C, ch = rem - blk * c.C;
+// Pass 3 — dequantise + noise synthesis, one lane per PIECE of a (block, channel, subblock) unit:
+// the scan cut every unit at eight checkpoints, so a lane's serial walk is ~1/8 of a unit and there are
+// eight times the lanes (a wave runs as long as its longest lane, and whole units differ several-fold).
+// ONE flat loop, no inner loops: a trip either decodes one whole code or emits up to four noise
+// coefficients - a noise run is a state of the lane (with inner loops every lane of the wave waited for
+// the longest run in flight: measured 460 k wave instructions per wave of 64 units).
+__device__ __forceinline__ void dgen_piece(const UlcxDecCtx &c, int blk, int ch, int j, int q) {
     int wc = c.wc[blk];
     if (wc == 0) return;
+    const int4 *cpU = c.cp + ((size_t)(blk * c.C + ch) * 4 + j) * DCP_PER_UNIT;
+    int4 cp = cpU[q];
+    int N = cp.y;
+    if (N == 0) return;                                    // no such piece (unit ended before this checkpoint / no such unit)
+    int Nstop = (q + 1 < DCP_PER_UNIT) ? cpU[q + 1].y : 0;
+    if (N <= Nstop) return;                                // a long run jumped over this piece
     unsigned pat = ulcx_pattern(wc);
-    int off = 0, S = c.BS;
-    for (int i = 0;; i++) {
-        S = c.BS >> (pat & 7);
-        if (i == j) break;
-        if (S == c.BS) return;
-        off += S;
-        pat >>= 4;
-        if (!pat) return;
-    }
-    // Only blocks the scan pass found well-formed get here (wc != 0), so the walk below follows a valid syntax.
-    // ONE flat loop, no inner loops: an iteration either decodes one whole code (1-5 nybbles, read as one
-    // 32-bit window) or emits up to four noise coefficients.  With one unit per lane an inner loop makes
-    // every lane of the wave wait for the longest run in flight (measured: 460 k wave instructions per
-    // wave of 64 units, 10x the work of any single lane); here a noise run is a state of the lane.
-    typedef uint32_t u32_any_align __attribute__((aligned(1)));
+    int off = 0;
+    for (int i = 0; i < j; i++) { off += c.BS >> (pat & 7); pat >>= 4; }
+    const int S = c.BS >> (pat & 7);
     const uint8_t *src = block_ptr(c, blk);
-    int bitpos = c.unitStart[(size_t)blk * c.C * 4 + ch * 4 + j];
-    uint32_t seed = rng_jump(c.jump, c.blockSeed[blk], (uint32_t)c.unitDraws[(size_t)blk * c.C * 4 + ch * 4 + j]);
+    const int readBytes = c.packed ? (1 << 30) : c.slot;   // (a block the scan accepted is never read past its end)
+    int bitpos = cp.x;
+    uint32_t seed = rng_jump(c.jump, c.blockSeed[blk], (uint32_t)cp.z);
     float *dst = c.coef + (size_t)blk * c.C * c.BS + (size_t)ch * c.BS + off;       // pre-zeroed: zero runs just skip
-    int N = S, pos = 0, pend = 0;
-    float quant = 0.0f, lev = 0.0f, rr = 1.0f;
-    bool first = true;                                     // the unit opens with a quantizer code without its Fh prefix
+    bool first = cp.w < 0;
+    float quant = first ? 0.0f : expand_quantizer(cp.w);
+    int pos = S - N, pend = 0;
+    float lev = 0.0f, rr = 1.0f;
     int guard = 2 * c.slot + S + 64;                       // codes of a slot + noise coefficients: cannot be exceeded
-    bool done = false;
-    while (!done && guard-- > 0) {
+    while (N > Nstop && guard-- > 0) {
         if (pend > 0) {
-            // ulcDecoder.c:156-160 / :181-184: draw, flip on the MSB (cumulative), store, decay (rr = 1 for runs)
+            // ulcDecoder.c:156-160 / :181-184: draw, flip on the MSB (cumulative), store, decay (rr = 1 for runs).
+            // Up to the next multiple of four positions per trip, so the body of a long run goes out as
+            // aligned 16-byte stores (this kernel is bound by the number of store requests, not by arithmetic).
+            const int room = 4 - (pos & 3);
+            const int cnt = pend < room ? pend : room;
+            float v[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                if (pend > 0) {
+                if (k < cnt) {
                     seed = xorshift32(seed);
                     if (seed & 0x80000000u) lev = -lev;
-                    dst[pos] = lev;
+                    v[k] = lev;
                     lev *= rr;
-                    pos++; pend--; N--;
                 }
             }
-            done = (N == 0);
+            if (cnt == 4) *(float4 *)(dst + pos) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int k = 0; k < 3; k++) if (k < cnt) dst[pos + k] = v[k];
+            }
+            pos += cnt; pend -= cnt; N -= cnt;
         } else {
-            uint32_t w = *(const u32_any_align *)(src + (bitpos >> 3));
-            w >>= (bitpos & 4);                            // >= 7 valid nybbles, low nybble first (ulcDecoder.c:82-88)
-            // unit start: same grammar as after an Fh, except that a leading Fh there is quantizer 15 (ScanFsm S_Q0)
-            const bool q15 = first & ((w & 0xF) == 0xF);
-            w = first ? ((w << 4) | 0xF) : w;
-            const int v0 = w & 0xF, v1 = (w >> 4) & 0xF, v2 = (w >> 8) & 0xF, v3 = (w >> 12) & 0xF, v4 = (w >> 16) & 0xF;
-            const bool plain = (v0 != 0x0) & (v0 != 0x1) & (v0 != 0x8) & (v0 != 0xF);
-            const bool z0 = (v0 == 0x0), z1 = (v0 == 0x1), n8 = (v0 == 0x8), esc = (v0 == 0xF);
-            const bool tail = esc & (v1 == 0xF) & !q15;                     // Fh,Fh,Z,Y,X : noise to the end
-            const bool qext = esc & (v1 == 0xE);                            // Fh,Eh,X     : extended quantizer / stop
-            const bool stop = qext & (v2 == 0xF);
-            const bool q1 = esc & !tail & !qext;                            // Fh,X
-            // coefficient (ulcDecoder.c:69-73)
-            int sv = (v0 ^ 0x8) - 0x8;
-            sv = (sv < 0) ? (-sv * sv) : (+sv * sv);
-            if (plain) dst[pos] = (float)sv * quant;
-            // code length in nybbles and coefficients consumed now
-            int len = plain ? 1 : z0 ? 2 : z1 ? 3 : n8 ? 4 : tail ? 5 : qext ? 3 : 2;
-            len -= first ? 1 : 0;
-            int n = plain ? 1 : z0 ? v1 + 1 : z1 ? ((v1 << 4) | v2) + 33 : 0;
+            Code k = decode_code(code_window(src, bitpos, readBytes), first);
+            if (k.plain) dst[pos] = (float)k.sv * quant;                    // ulcDecoder.c:69-73
+            int n = k.stop ? N : k.n;
             n = (n > N) ? N : n;                                            // (cannot happen in a block the scan accepted)
-            // noise run / tail parameters (ulcDecoder.c:95-115, :123-137)
-            int np = n8 ? ((((v1 << 4) | v2) << 1) | (v3 & 1)) + 16 : tail ? N : 0;
+            int np = k.tail ? N : k.np;
             np = (np > N) ? N : np;
-            const int l = n8 ? (v3 >> 1) + 1 : v2 + 1;
-            const float lvl = (float)(l * l) * quant * (n8 ? (1.0f / 4) : (1.0f / 16));
-            const int dn = (v3 << 4) | v4;
-            lev = (n8 | tail) ? lvl : lev;
-            rr = tail ? 1.0f + (float)(dn * dn) * -0x1.0p-19f : (n8 ? 1.0f : rr);
+            // noise run / tail parameters (ulcDecoder.c:95-115, :123-137)
+            const float lvl = (float)(k.l * k.l) * quant * (k.n8 ? (1.0f / 4) : (1.0f / 16));
+            lev = (k.n8 | k.tail) ? lvl : lev;
+            rr = k.tail ? 1.0f + (float)(k.dn * k.dn) * -0x1.0p-19f : (k.n8 ? 1.0f : rr);
             pend = np;
-            // quantizer change (ulcDecoder.c:89-98)
-            quant = q1 ? expand_quantizer(v1) : (qext & !stop) ? expand_quantizer(0xE + v2) : quant;
-            bitpos += 4 * len;
+            quant = (k.qnew >= 0) ? expand_quantizer(k.qnew) : quant;      // ulcDecoder.c:89-98
+            bitpos += 4 * k.len;
             pos += n; N -= n;
             first = false;
-            done = (N == 0) | stop;
         }
+    }
+}
+// units j = 0 of every block: lane = (piece q, channel, block), block fastest
+__global__ __launch_bounds__(256) void k_dgen(UlcxDecCtx c) {
+    int tid0 = blockIdx.x * 256 + threadIdx.x;
+    int NBd = c.B * c.K;
+    if (tid0 >= NBd * c.C * DCP_PER_UNIT) return;
+    int blk = tid0 % NBd, r = tid0 / NBd, ch = r % c.C, q = r / c.C;
+    dgen_piece(c, blk, ch, 0, q);
+}
+// units j >= 1 (decimated blocks only): a small grid walks the list the scan made
+__global__ __launch_bounds__(256) void k_dgen_dec(UlcxDecCtx c) {
+    int n = *c.decCount;
+    int per = 3 * c.C * DCP_PER_UNIT;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < (long long)n * per; t += (long long)gridDim.x * 256) {
+        int e = (int)(t / per), r = (int)(t % per);
+        int q = r % DCP_PER_UNIT, ch = (r / DCP_PER_UNIT) % c.C, j = 1 + r / (DCP_PER_UNIT * c.C);
+        dgen_piece(c, c.decList[e], ch, j, q);
     }
 }
 
@@ -571,13 +515,17 @@ int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev) {
     int stage = 0;
     if (ev) CK(hipEventRecord(ev[stage++], st));
     int NB = c.B * c.K;
+    CK(hipMemsetAsync(c.cp, 0, sizeof(int4) * (size_t)NB * c.C * 4 * DCP_PER_UNIT, st));   // N = 0: no piece
+    CK(hipMemsetAsync(c.decCount, 0, sizeof(int), st));
     if (c.packed) hipLaunchKernelGGL(k_dscan_packed, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
-    else hipLaunchKernelGGL(k_dscan, dim3((NB + 63) / 64), dim3(64), 0, st, c);
+    else hipLaunchKernelGGL(k_dscan, dim3((NB + DSCAN_LANES - 1) / DSCAN_LANES), dim3(64), 0, st, c);
     if (ev) CK(hipEventRecord(ev[stage++], st));
-    hipLaunchKernelGGL(k_dseed, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
+    hipLaunchKernelGGL(k_dseed, dim3((NB + 63) / 64), dim3(64), 0, st, c);
+    hipLaunchKernelGGL(k_dseed_commit, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
     if (ev) CK(hipEventRecord(ev[stage++], st));
     CK(hipMemsetAsync(c.coef, 0, sizeof(float) * (size_t)NB * c.C * c.BS, st));     // zero runs are not written by k_dgen
-    hipLaunchKernelGGL(k_dgen, dim3((NB * c.C * 4 + 63) / 64), dim3(64), 0, st, c);
+    hipLaunchKernelGGL(k_dgen, dim3((NB * c.C * DCP_PER_UNIT + 255) / 256), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_dgen_dec, dim3(NB < 2048 ? NB : 2048), dim3(256), 0, st, c);
     if (ev) CK(hipEventRecord(ev[stage++], st));
     size_t lds = ulcx_dec_lds_bytes(c.BS, c.C);
     if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_dimdct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

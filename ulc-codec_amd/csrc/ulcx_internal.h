@@ -99,12 +99,16 @@ struct UlcxDecCtx {
     int   *lastSub;                      // [B] LastSubBlockSize
     uint32_t *seed;                      // [B] noise RNG state (ulcDecoder.c:75-81)
     int   *dead;                         // [B] stream hit a corrupt block
+    uint32_t *seedNext; int *deadNext;   // [B] staged by k_dseed, committed by k_dseed_commit
+    int   *wcScan;                       // [NB] WindowCtrl as the scan saw it (0 = corrupt); wc[] also carries "stream already dead"
     // per-call scratch
     float *coef;                         // [NB][C*BS] dequantised coefficients
     int   *wc;                           // [NB] WindowCtrl per block (0 = corrupt)
     int   *draws;                        // [NB] RNG draws consumed by the block
     uint32_t *blockSeed;                 // [NB] RNG state at the start of the block
     int   *unitStart, *unitDraws;        // [NB][C*4] nybble offset / draws before each (chan,subblock) unit
+    int4  *cp;                           // [NB][C*4][8] checkpoints inside each unit (ulcx_dec.hip DCP_PER_UNIT)
+    int   *decList, *decCount;           // blocks with more than one subblock, found by the scan
     const uint32_t *jump;                // [32][32] columns of T^(2^i), T = one xorshift32 step
     // packed-stream mode (.ulc payloads): blocks are located by parsing, not by slot
     int   packed;
