@@ -344,6 +344,8 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
     float  *dec   = (float *)(z + 2 * H2);
     float  *tmpq  = dec + BS;
     float  *stage = tmpq + H2;
+    float2 *twl   = (float2 *)tmpq;                          // BS/4 complex: FFT twiddles of the full-size transform live in tmpq
+    bool twlValid = false;                                   // (a decimated block reuses tmpq for its FIFO and invalidates them)
     float *glap = c.lap + (size_t)s * C * H2;
     for (int i = tid; i < C * H2; i += WG) lap[i] = glap[i];
     int lastSub = c.lastSub[s];
@@ -368,20 +370,21 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
             if (pat0 & 8) ov >>= (wc & 7);
             if (ov > lastSub) ov = lastSub;
             const float2 *pre = c.T.pre[0];
+            if (!twlValid) { for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i]; twlValid = true; }   // (made visible by the barrier below)
             float2 *z0 = z, *z1 = z + M;
             const float *X0 = coefB, *X1 = coefB + BS;
-            for (int n = tid; n < M; n += WG) {
+            if (!(c.dbgSkip & 1)) for (int n = tid; n < M; n += WG) {
                 float2 P = pre[n];
                 z0[n] = cmulc(make_float2(X0[2 * n], X0[S - 1 - 2 * n]), P);
                 z1[n] = cmulc(make_float2(X1[2 * n], X1[S - 1 - 2 * n]), P);
             }
             __syncthreads();
-            fftn_dif(z, 2, M, c.T.tw[0], tid);
+            if (!(c.dbgSkip & 2)) fftn_dif(z, 2, M, twl, tid);
             int a = (S - ov) >> 1;
             const float *fall = c.T.winFall + ov, *rise = c.T.winRise + ov;
             int bits = 31 - __clz(M);
             float *L0 = lap, *L1 = lap + H2;
-            for (int kk = tid; kk < M / 2; kk += WG) {
+            if (!(c.dbgSkip & 4)) for (int kk = tid; kk < M / 2; kk += WG) {
                 int k1 = kk, k2 = M - 1 - kk;
                 int r1 = (int)(__brev((unsigned)k1) >> (32 - bits));
                 int r2 = (int)(__brev((unsigned)k2) >> (32 - bits));
@@ -468,6 +471,7 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
                 if (S == BS) break;                                 // ulcDecoder.c:242-245
                 // reversed-time centring FIFO in lap[M .. BS/2) (ulcDecoder.c:253-272)
                 int avail = (BS - S) >> 1;
+                twlValid = false;
                 for (int q = tid; q < avail; q += WG) tmpq[q] = L[H2 - 1 - q];      // queue[q], q = 0 is the oldest
                 __syncthreads();
                 for (int n = tid; n < S; n += WG)

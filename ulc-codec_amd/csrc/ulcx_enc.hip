@@ -310,6 +310,7 @@ __global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c, int k0, int k1) {
     int tid = threadIdx.x;
     float2 *z    = (float2 *)lds;                     // 4 arrays of up to BS/2 complex: {MDCT, MDST} x {ch, ch+1}
     float  *amp2 = lds + 4 * FFT_PADDED(BS);          // BS/2
+    float2 *twl  = (float2 *)(amp2 + BS / 2 + 4);     // BS/4 complex: this subblock's FFT twiddles (global-memory latency out of the FFT passes)
     int    &s_nnz = *(int *)(amp2 + BS / 2);          // (inside the dynamic region: no static LDS in front of it)
     if (tid == 0) s_nnz = 0;
     for (int i = tid; i < BS / 2; i += WG) amp2[i] = 0.0f;
@@ -358,6 +359,8 @@ __global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c, int k0, int k1) {
             //    mirror images (n >= M/2); n = M/2-1-j and n = M/2+j use ADJACENT positions in all four
             //    quarters of the frame, so one lane takes both: four 16-byte loads per lane, each wave
             //    reading four contiguous 1 KB runs.
+            const bool twInLds = (size_t)BS * 21 + 16 <= ULCX_LDS_LIMIT;          // (BlockSize 8192 has no room: twiddles stay in global memory)
+            if (twInLds) for (int i = tid; i < M / 2; i += WG) twl[i] = c.T.tw[d][i];       // visible after the barrier that ends the fold
             if (!(c.dbgSkip & 2)) for (int jj = tid; jj < M / 2; jj += WG) {
                 const int iA = 2 * jj, iB = S - 2 - 2 * jj, iC = S + 2 * jj, iD = 2 * S - 2 - 2 * jj;
                 float2 xs[8];                           // (ch0, ch0+1) after M/S at iA, iA+1, iB, iB+1, iC, iC+1, iD, iD+1
@@ -425,7 +428,10 @@ __global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c, int k0, int k1) {
             __syncthreads();
 
             // 2. 2*nch M-point FFTs in LDS, one wave per array, no barriers in between
-            if (!(c.dbgSkip & 1)) for (int a = tid >> 6; a < 2 * nch; a += WG / 64) fft_wave_dif(z + a * Mp, M, c.T.tw[d], tid & 63);
+            if (!(c.dbgSkip & 1)) for (int a = tid >> 6; a < 2 * nch; a += WG / 64) {
+                if (twInLds) fft_wave_dif(z + a * Mp, M, twl, tid & 63);
+                else fft_wave_dif(z + a * Mp, M, c.T.tw[d], tid & 63);
+            }
             __syncthreads();
 
             // 3. post-twiddle + normalise + keys + per-line energies (BlockTransform.c:243-281)
@@ -1518,6 +1524,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
     }
     bool overflow = nK > E2_KCAP;
     WAVE_SYNC();
+    if ((c.dbgSkip >> 8) == 1) return;
 
     // C. zone segmentation: greedy scan (Encode.c:218-269), uniform across the wave
     int nZ = 0;
@@ -1547,6 +1554,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
         if (nZ > E2_ZCAP) overflow = true;
     }
     WAVE_SYNC();
+    if ((c.dbgSkip >> 8) == 2) return;
 
     // D. quantizer per zone + nybbles of its change code (Encode.c:240-244, 32-45)
     if (!overflow) {
@@ -1567,6 +1575,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
         }
     }
     WAVE_SYNC();
+    if ((c.dbgSkip >> 8) == 3) return;
 
     // E. quantise kept items, drop the ones that collapse (Encode.c:114), compact in place.
     //    Bit 15 of the compacted index records "the kept item right before me was coded too",
@@ -1595,6 +1604,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
         }
     }
     WAVE_SYNC();
+    if ((c.dbgSkip >> 8) == 4) return;
 
     // F+H. gaps -> run codes; positions by prefix sum; emission
     int total = 0;
@@ -1634,6 +1644,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
         }
         overflow = __any(overflow);
     }
+    if ((c.dbgSkip >> 8) == 5) return;
 
     // G. tail (Encode.c:271-312)
     if (!overflow) {
@@ -2021,7 +2032,8 @@ __global__ __launch_bounds__(WG) void k_state_update(UlcxEncCtx c) {
 // ---------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------
-size_t ulcx_enc_xf_lds_bytes(int BS) { return (size_t)BS * 19 + 16; }   // 4 padded arrays of BS/2 complex + BS/2 floats + counter
+// 4 padded arrays of BS/2 complex + BS/2 floats + counter (+ BS/4 twiddles when they fit)
+size_t ulcx_enc_xf_lds_bytes(int BS) { size_t full = (size_t)BS * 21 + 16; return full <= ULCX_LDS_LIMIT ? full : (size_t)BS * 19 + 16; }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)
 
@@ -2099,21 +2111,31 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
             MARK();
         }
     }
-    hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c);                                  MARK();
     int nUnits = NB * c.C * 4;
+    // (the noise log-spectrum does not feed the keys: it is launched after the selection so that the
+    //  main stream has work to run beside the side-stream heapsort of tie-straddle blocks)
+    auto launch_noise = [&](hipStream_t s2, bool ev0) -> int {
+        hipLaunchKernelGGL(k_nbark, dim3((nUnits + 63) / 64), dim3(64), 0, s2, c);                         if (ev0) MARK();
+        size_t tot = (size_t)NB * c.C * (c.BS / 2);
+        hipLaunchKernelGGL(k_nline, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, s2, c);            if (ev0) MARK();
+        return ULCX_OK;
+    };
+    // The noise log-spectrum (k_nbark: lane-serial ordered sums, latency-bound; k_nline) depends on the
+    // transform only: it runs on a side stream beside the psychoacoustics / selection chain.
+    const bool noiseAside = (side2 != nullptr);
+    hipEvent_t evN0 = evWC[1 + 3 * ULCX_WC_MAXCH], evNoise = evWC[2 + 3 * ULCX_WC_MAXCH];
+    if (noiseAside) {
+        CK(hipEventRecord(evN0, st));
+        CK(hipStreamWaitEvent(side2, evN0, 0));
+        int rcn = launch_noise(side2, false); if (rcn) return rcn;
+        CK(hipEventRecord(evNoise, side2));
+    }
+    hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c);                                  MARK();
     {
         hipLaunchKernelGGL(k_pbark, dim3((NB * 4 + 63) / 64), dim3(64), 0, st, c);                         MARK();
         size_t tot = (size_t)NB * (c.BS / 2);
         hipLaunchKernelGGL(k_mask, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);             MARK();
     }
-    // (the noise log-spectrum does not feed the keys: it is launched after the selection so that the
-    //  main stream has work to run beside the side-stream heapsort of tie-straddle blocks)
-    auto launch_noise = [&](bool ev0) -> int {
-        hipLaunchKernelGGL(k_nbark, dim3((nUnits + 63) / 64), dim3(64), 0, st, c);                         if (ev0) MARK();
-        size_t tot = (size_t)NB * c.C * (c.BS / 2);
-        hipLaunchKernelGGL(k_nline, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);            if (ev0) MARK();
-        return ULCX_OK;
-    };
     // --- selection + encode pass(es)
     int N = c.C * c.BS;
     int ldsEntries = ((size_t)N * 8 <= ULCX_HEAP_LDS_BYTES) ? N : 0;
@@ -2213,7 +2235,10 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
             CK(hipStreamWaitEvent(side, evFork, 0));
             int rc = exact_sort(side, 0); if (rc) return rc;   // needs only the keys: starts right behind the select
         }
-        if (p == 0) { int rcn = launch_noise(ev0); if (rcn) return rcn; }
+        if (p == 0) {
+            if (noiseAside) { CK(hipStreamWaitEvent(st, evNoise, 0)); MARK(); MARK(); }     // (k_nbark / k_nline intervals: hidden)
+            else { int rcn = launch_noise(st, ev0); if (rcn) return rcn; }
+        }
         if (async_fb) {
             CK(hipEventRecord(evFork2, st));                    // the exact path's encode pass needs the noise pairs too
             CK(hipStreamWaitEvent(side, evFork2, 0));

@@ -92,6 +92,7 @@ struct UlcxEncCtx {
 struct UlcxDecCtx {
     int B, K, C, BS, lgBS, maxK;
     int slot;
+    int dbgSkip;                         // timing experiments only (ULCX_DBG_SKIP)
     UlcxTables T;
     const uint8_t *in; float *pcm; int32_t *bits;
     // persistent
@@ -139,11 +140,12 @@ void ulcx_set_error(const char *fmt, ...);
 extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES_REPORTED];
 #define ULCX_DEC_STAGES 4
 #define ULCX_WC_MAXCH 8
+#define ULCX_LDS_LIMIT (160 * 1024)     // LDS per workgroup on gfx950
 // streams and events the encoder launch uses beside the caller's stream
 struct UlcxEncAux {
     hipStream_t side, side2, side3;      // NULL: everything on the caller's stream
     hipEvent_t evFork, evJoin, evFork2;  // exact-path fork/join
-    hipEvent_t *evWC;                    // [1 + 3*ULCX_WC_MAXCH] window-control pipeline
+    hipEvent_t *evWC;                    // [3 + 3*ULCX_WC_MAXCH] window-control pipeline; last two: noise-spectrum fork/join
     hipEvent_t *evXf;                    // [2*ULCX_WC_MAXCH] timing pairs around each transform chunk (used when ev != NULL)
     int wcPipe;                          // chunks of blocks pipelined between window control and transform; 1 = off
     int *nXf;                            // out: transform chunk launches this call
