@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_dgen_dec(UlcxDecCtx c) {
 
 // ---------------------------------------------------------------------------
 // IMDCT + overlap-add.  LDS carve (floats): lap [C][BS/2] | z [2*BS] (two arrays of BS/2 complex) |
-// dec [BS] | tmpq [BS/2] | stage [2][BS]
+// dec [BS] | tmpq [BS/2]
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
     extern __shared__ float lds[];
@@ -343,7 +343,6 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
     float2 *z     = (float2 *)(lap + (size_t)C * H2);
     float  *dec   = (float *)(z + 2 * H2);
     float  *tmpq  = dec + BS;
-    float  *stage = tmpq + H2;
     float2 *twl   = (float2 *)tmpq;                          // BS/4 complex: FFT twiddles of the full-size transform live in tmpq
     bool twlValid = false;                                   // (a decimated block reuses tmpq for its FIFO and invalidates them)
     float *glap = c.lap + (size_t)s * C * H2;
@@ -420,7 +419,9 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
         }
         for (int ch = 0; ch < C; ch++) {
             int last = lastSub;                                     // ulcDecoder.c:219
-            float *dst = stage + (size_t)(ch & 1) * BS;
+            // the channel's time samples are staged over its own (already consumed) coefficients in global memory:
+            // keeps 2*BS floats out of LDS (occupancy of the common path) - only mono/odd/decimated blocks come here
+            float *dst = c.coef + (size_t)blk * C * BS + (size_t)ch * BS;
             float *L = lap + (size_t)ch * H2;
             unsigned pat = ulcx_pattern(wc);
             int off = 0, dpos = 0;
@@ -492,13 +493,13 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
                 __syncthreads();
                 if (ch & 1) {
                     for (int n = tid; n < BS; n += WG) {
-                        float m = stage[n], sd = stage[BS + n];                 // ulcDecoder.c:281-289
+                        float m = dst[(ptrdiff_t)n - BS], sd = dst[n];                 // ulcDecoder.c:281-289
                         float l = m + sd, r = m - sd;
                         if (C == 2) *(float2 *)(outp + 2 * n) = make_float2(l, r);
                         else { outp[(size_t)n * C + ch - 1] = l; outp[(size_t)n * C + ch] = r; }
                     }
                 } else {
-                    for (int n = tid; n < BS; n += WG) outp[(size_t)n * C + ch] = stage[n];
+                    for (int n = tid; n < BS; n += WG) outp[(size_t)n * C + ch] = dst[n];
                 }
                 __syncthreads();
             }
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
 }
 
 size_t ulcx_dec_lds_bytes(int BS, int C) {
-    return sizeof(float) * ((size_t)C * (BS / 2) + 2 * (size_t)BS + BS + BS / 2 + 2 * (size_t)BS);
+    return sizeof(float) * ((size_t)C * (BS / 2) + 2 * (size_t)BS + BS + BS / 2);
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)

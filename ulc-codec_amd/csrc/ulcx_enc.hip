@@ -294,7 +294,7 @@ __device__ __forceinline__ float win_apply(float x, int i, int S, int aL, int ov
     return (n < aR) ? x : (n < aR + ov) ? x * fall[n - aR] : 0.0f;
 }
 
-__global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c, int k0, int k1) {
+__global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
     extern __shared__ float lds[];
     const int BS = c.BS, C = c.C;
     // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its own L2).
@@ -309,11 +309,14 @@ __global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c, int k0, int k1) {
     int blk = s * c.K + k;
     int tid = threadIdx.x;
     float2 *z    = (float2 *)lds;                     // 4 arrays of up to BS/2 complex: {MDCT, MDST} x {ch, ch+1}
-    float  *amp2 = lds + 4 * FFT_PADDED(BS);          // BS/2
-    float2 *twl  = (float2 *)(amp2 + BS / 2 + 4);     // BS/4 complex: this subblock's FFT twiddles (global-memory latency out of the FFT passes)
-    int    &s_nnz = *(int *)(amp2 + BS / 2);          // (inside the dynamic region: no static LDS in front of it)
+    float2 *twl  = (float2 *)(lds + 4 * FFT_PADDED(BS));    // BS/4 complex: this subblock's FFT twiddles (no global-memory latency inside the FFT passes)
+    int    &s_nnz = *(int *)(lds + 4 * FFT_PADDED(BS) + BS / 2);  // (inside the dynamic region: no static LDS in front of it)
+    const bool ampLds = (C > 2);                             // line energies accumulate across channel pairs: only then in LDS
+    const bool twInLds = !(ampLds && (size_t)BS * 21 + 16 > ULCX_LDS_LIMIT);   // (BlockSize 8192 with C > 2: no room, twiddles from global memory)
+    float  *amp2 = twInLds ? lds + 4 * FFT_PADDED(BS) + BS / 2 + 4 : lds + 4 * FFT_PADDED(BS);   // BS/2 (takes the twiddles' place when they are not resident)
+    float *ampO = c.amp2 + (size_t)blk * (BS / 2);
     if (tid == 0) s_nnz = 0;
-    for (int i = tid; i < BS / 2; i += WG) amp2[i] = 0.0f;
+    if (ampLds) for (int i = tid; i < BS / 2; i += WG) amp2[i] = 0.0f;
 
     const int *wrow = c.wcArr + (size_t)s * (c.maxK + 2) + k;
     int wcPrev = wrow[0], wc = wrow[1], wcNext = wrow[2];
@@ -359,7 +362,6 @@ __global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c, int k0, int k1) {
             //    mirror images (n >= M/2); n = M/2-1-j and n = M/2+j use ADJACENT positions in all four
             //    quarters of the frame, so one lane takes both: four 16-byte loads per lane, each wave
             //    reading four contiguous 1 KB runs.
-            const bool twInLds = (size_t)BS * 21 + 16 <= ULCX_LDS_LIMIT;          // (BlockSize 8192 has no room: twiddles stay in global memory)
             if (twInLds) for (int i = tid; i < M / 2; i += WG) twl[i] = c.T.tw[d][i];       // visible after the barrier that ends the fold
             if (!(c.dbgSkip & 2)) for (int jj = tid; jj < M / 2; jj += WG) {
                 const int iA = 2 * jj, iB = S - 2 - 2 * jj, iC = S + 2 * jj, iD = 2 * S - 2 - 2 * jj;
@@ -442,7 +444,8 @@ __global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c, int k0, int k1) {
                 int r1 = (int)(__brev((unsigned)k1) >> (32 - bits));
                 int r2 = (int)(__brev((unsigned)k2) >> (32 - bits));
                 float2 P1 = pre[k1], P2 = pre[k2];
-                float am1 = amp2[off / 2 + k1], am2 = amp2[off / 2 + k2];
+                float am1 = 0.0f, am2 = 0.0f;
+                if (ampLds) { am1 = amp2[off / 2 + k1]; am2 = amp2[off / 2 + k2]; }
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     if (q >= nch) break;
@@ -470,7 +473,8 @@ __global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c, int k0, int k1) {
                         if (p) { am2 += a0; am2 += a1; } else { am1 += a0; am1 += a1; } // channel order preserved
                     }
                 }
-                amp2[off / 2 + k1] = am1; amp2[off / 2 + k2] = am2;
+                if (ampLds) { amp2[off / 2 + k1] = am1; amp2[off / 2 + k2] = am2; }
+                else { ampO[off / 2 + k1] = am1; ampO[off / 2 + k2] = am2; }
             }
             __syncthreads();
             off += S; ovL = ov;
@@ -479,8 +483,7 @@ __global__ __launch_bounds__(WG) void k_xf(UlcxEncCtx c, int k0, int k1) {
     // wave-reduce the non-zero count
     for (int o = 32; o > 0; o >>= 1) nnz += __shfl_down(nnz, o);
     if ((tid & 63) == 0) atomicAdd(&s_nnz, nnz);
-    float *ampO = c.amp2 + (size_t)blk * (BS / 2);
-    for (int i = tid; i < BS / 2; i += WG) ampO[i] = amp2[i];
+    if (ampLds) for (int i = tid; i < BS / 2; i += WG) ampO[i] = amp2[i];
     __syncthreads();
     if (tid == 0) c.nnz[blk] = s_nnz;
 }
@@ -615,30 +618,33 @@ __global__ __launch_bounds__(64) void k_nbark(UlcxEncCtx c) {
     (void)N;
 }
 
-// Psyopt.c:236-248: per-line interpolation + {w, w*(log+ln2)} pairs
+// Psyopt.c:236-248: per-line interpolation + {w, w*(log+ln2)} pairs.
+// One workgroup per (block, channel): the unit's Bark levels sit in LDS, every thread does
+// BS/512 line pairs (independent chains of table gathers + expf to overlap).
 __global__ __launch_bounds__(WG) void k_nline(UlcxEncCtx c) {
-    size_t gid = (size_t)blockIdx.x * WG + threadIdx.x;
+    __shared__ float sbark[4 * ULCX_NBARK];
+    int bc = blockIdx.x, tid = threadIdx.x;
+    int blk = bc / c.C, ch = bc - blk * c.C;
     int half = c.BS / 2;
-    size_t total = (size_t)c.B * c.K * c.C * half;
-    if (gid >= total) return;
-    int jp = (int)(gid % half);
-    int ch = (int)((gid / half) % c.C);
-    int blk = (int)(gid / ((size_t)half * c.C));
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
-    unsigned pat = ulcx_pattern(wc);
-    int off = 0, d = 0, S = c.BS, j = 0;
-    for (;; j++) { d = pat & 7; S = c.BS >> d; if (2 * jp < off + S) break; off += S; pat >>= 4; }
-    int line = jp - off / 2;
-    const float *bark = c.barkN + ((size_t)(blk * c.C + ch) * 4 + j) * ULCX_NBARK;
-    int bi = c.T.bandIdx[d][line];
-    float fr = c.T.bandFrac[d][line];
-    float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
-    float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
-    float noise = L * (1.0f - fr) + R * fr;
-    float w = ulcx_expf(0.5f * noise);
-    float2 o = make_float2(w, w * (noise + 0x1.62E430p-1f));
-    *(float2 *)(c.npair + (size_t)blk * (c.C * c.BS) + (size_t)ch * c.BS + 2 * jp) = o;
+    if (tid < 4 * ULCX_NBARK) sbark[tid] = c.barkN[(size_t)(blk * c.C + ch) * 4 * ULCX_NBARK + tid];
+    __syncthreads();
+    float2 *dst = (float2 *)(c.npair + (size_t)blk * (c.C * c.BS) + (size_t)ch * c.BS);
+    for (int jp = tid; jp < half; jp += WG) {
+        unsigned pat = ulcx_pattern(wc);
+        int off = 0, d = 0, S = c.BS, j = 0;
+        for (;; j++) { d = pat & 7; S = c.BS >> d; if (2 * jp < off + S) break; off += S; pat >>= 4; }
+        int line = jp - off / 2;
+        const float *bark = sbark + j * ULCX_NBARK;
+        int bi = c.T.bandIdx[d][line];
+        float fr = c.T.bandFrac[d][line];
+        float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
+        float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
+        float noise = L * (1.0f - fr) + R * fr;
+        float w = ulcx_expf(0.5f * noise);
+        dst[jp] = make_float2(w, w * (noise + 0x1.62E430p-1f));
+    }
 }
 
 // Psyopt.c:86-137 on the channel-summed energies
@@ -686,24 +692,27 @@ __device__ __forceinline__ float load_final_key(const UlcxEncCtx &c, int blk, in
 
 // Psyopt.c:140-150: masking level per line
 __global__ __launch_bounds__(WG) void k_mask(UlcxEncCtx c) {
-    size_t gid = (size_t)blockIdx.x * WG + threadIdx.x;
+    // one workgroup per block: Bark levels in LDS, BS/512 lines per thread
+    __shared__ float sbark[4 * ULCX_NBARK];
+    int blk = blockIdx.x, tid = threadIdx.x;
     int half = c.BS / 2;
-    size_t total = (size_t)c.B * c.K * half;
-    if (gid >= total) return;
-    int jp = (int)(gid % half);
-    int blk = (int)(gid / half);
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
-    unsigned pat = ulcx_pattern(wc);
-    int off = 0, d = 0, S = c.BS, j = 0;
-    for (;; j++) { d = pat & 7; S = c.BS >> d; if (2 * jp < off + S) break; off += S; pat >>= 4; }
-    int line = jp - off / 2;
-    const float *bark = c.barkP + ((size_t)blk * 4 + j) * ULCX_NBARK;
-    int bi = c.T.bandIdx[d][line];
-    float fr = c.T.bandFrac[d][line];
-    float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
-    float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
-    c.mask[(size_t)blk * half + jp] = L * (1.0f - fr) + R * fr;
+    if (tid < 4 * ULCX_NBARK) sbark[tid] = c.barkP[(size_t)blk * 4 * ULCX_NBARK + tid];
+    __syncthreads();
+    float *dst = c.mask + (size_t)blk * half;
+    for (int jp = tid; jp < half; jp += WG) {
+        unsigned pat = ulcx_pattern(wc);
+        int off = 0, d = 0, S = c.BS, j = 0;
+        for (;; j++) { d = pat & 7; S = c.BS >> d; if (2 * jp < off + S) break; off += S; pat >>= 4; }
+        int line = jp - off / 2;
+        const float *bark = sbark + j * ULCX_NBARK;
+        int bi = c.T.bandIdx[d][line];
+        float fr = c.T.bandFrac[d][line];
+        float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
+        float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
+        dst[jp] = L * (1.0f - fr) + R * fr;
+    }
 }
 
 // debug/parity tap only: materialise the final keys in c.key (ulcx_encoder_debug_fetch)
@@ -2032,8 +2041,11 @@ __global__ __launch_bounds__(WG) void k_state_update(UlcxEncCtx c) {
 // ---------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------
-// 4 padded arrays of BS/2 complex + BS/2 floats + counter (+ BS/4 twiddles when they fit)
-size_t ulcx_enc_xf_lds_bytes(int BS) { size_t full = (size_t)BS * 21 + 16; return full <= ULCX_LDS_LIMIT ? full : (size_t)BS * 19 + 16; }
+// 4 padded arrays of BS/2 complex + BS/4 twiddles + counter (+ BS/2 floats of line energies for C > 2)
+size_t ulcx_enc_xf_lds_bytes(int BS, int C) {
+    size_t full = (size_t)BS * 19 + 32 + (C > 2 ? (size_t)BS * 2 : 0);
+    return full <= ULCX_LDS_LIMIT ? full : (size_t)BS * 19 + 32;
+}
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)
 
@@ -2061,7 +2073,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
         // hundred waves: latency-bound, nearly no machine resources) run on the side stream beside the
         // transform of chunk j on the main stream.  wcPipe = 1 keeps everything on the main stream.
         const int nCh = wcPipe;
-        size_t lds = ulcx_enc_xf_lds_bytes(c.BS);
+        size_t lds = ulcx_enc_xf_lds_bytes(c.BS, c.C);
         if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_xf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         auto launch_wc = [&](hipStream_t s2, int k0, int k1, bool marks) -> int {
             int kc = k1 - k0;
@@ -2116,8 +2128,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
     //  main stream has work to run beside the side-stream heapsort of tie-straddle blocks)
     auto launch_noise = [&](hipStream_t s2, bool ev0) -> int {
         hipLaunchKernelGGL(k_nbark, dim3((nUnits + 63) / 64), dim3(64), 0, s2, c);                         if (ev0) MARK();
-        size_t tot = (size_t)NB * c.C * (c.BS / 2);
-        hipLaunchKernelGGL(k_nline, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, s2, c);            if (ev0) MARK();
+        hipLaunchKernelGGL(k_nline, dim3(NB * c.C), dim3(WG), 0, s2, c);                                   if (ev0) MARK();
         return ULCX_OK;
     };
     // The noise log-spectrum (k_nbark: lane-serial ordered sums, latency-bound; k_nline) depends on the
@@ -2133,8 +2144,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
     hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c);                                  MARK();
     {
         hipLaunchKernelGGL(k_pbark, dim3((NB * 4 + 63) / 64), dim3(64), 0, st, c);                         MARK();
-        size_t tot = (size_t)NB * (c.BS / 2);
-        hipLaunchKernelGGL(k_mask, dim3((unsigned)((tot + WG - 1) / WG)), dim3(WG), 0, st, c);             MARK();
+        hipLaunchKernelGGL(k_mask, dim3(NB), dim3(WG), 0, st, c);                                          MARK();
     }
     // --- selection + encode pass(es)
     int N = c.C * c.BS;
