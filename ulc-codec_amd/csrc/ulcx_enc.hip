@@ -848,7 +848,17 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
 #pragma unroll
         for (int r = 0; r < R; r++) cnt += (u[r] >= t) ? 1 : 0;
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-        if (cnt >= kSel) T = t;
+        if (cnt == kSel) {
+            // t falls between the kSel-th and the next key: the answer is the smallest key >= t, no need to
+            // resolve the remaining bits (typically half of them)
+            uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < R; r++) { uint32_t v = (u[r] >= t) ? u[r] : 0xFFFFFFFFu; mn = v < mn ? v : mn; }
+            for (int o = 32; o > 0; o >>= 1) { uint32_t w = (uint32_t)__shfl_xor((int)mn, o); mn = w < mn ? w : mn; }
+            T = mn;
+            break;
+        }
+        if (cnt > kSel) T = t;
     }
     int g = 0, e = 0;
 #pragma unroll
@@ -2133,7 +2143,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
     };
     // The noise log-spectrum (k_nbark: lane-serial ordered sums, latency-bound; k_nline) depends on the
     // transform only: it runs on a side stream beside the psychoacoustics / selection chain.
-    const bool noiseAside = (side2 != nullptr);
+    const bool noiseAside = (side2 != nullptr && side3 != nullptr);
     hipEvent_t evN0 = evWC[1 + 3 * ULCX_WC_MAXCH], evNoise = evWC[2 + 3 * ULCX_WC_MAXCH];
     if (noiseAside) {
         CK(hipEventRecord(evN0, st));
@@ -2141,11 +2151,19 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
         int rcn = launch_noise(side2, false); if (rcn) return rcn;
         CK(hipEventRecord(evNoise, side2));
     }
-    hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c);                                  MARK();
+    // k_cplx (one lane per block, a long serial walk: ~1000 waves) only feeds the selection: beside k_pbark/k_mask
+    hipEvent_t evCplx = evWC[3 + 3 * ULCX_WC_MAXCH];
+    if (noiseAside) {
+        CK(hipStreamWaitEvent(side3, evN0, 0));
+        hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, side3, c);
+        CK(hipEventRecord(evCplx, side3));
+        MARK();
+    } else { hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c);                         MARK(); }
     {
         hipLaunchKernelGGL(k_pbark, dim3((NB * 4 + 63) / 64), dim3(64), 0, st, c);                         MARK();
         hipLaunchKernelGGL(k_mask, dim3(NB), dim3(WG), 0, st, c);                                          MARK();
     }
+    if (noiseAside) CK(hipStreamWaitEvent(st, evCplx, 0));
     // --- selection + encode pass(es)
     int N = c.C * c.BS;
     int ldsEntries = ((size_t)N * 8 <= ULCX_HEAP_LDS_BYTES) ? N : 0;
