@@ -35,6 +35,7 @@ struct ulcx_decoder {
     hipEvent_t ev[ULCX_DEC_STAGES + 1];
     bool evOk, evRecorded;
     uint8_t *d_in; int d_in_bytes; float *d_pcm; int32_t *d_bits;
+    hipStream_t side; hipEvent_t evFork, evSide; bool sideOk;
 };
 
 extern "C" int ulcx_device_count(void) {
@@ -319,6 +320,7 @@ static void cleanup(ulcx_decoder *e) {
     for (void *p : e->allocs) hipFree(p);
     if (e->tables) hipFree(e->tables);
     if (e->evOk) for (auto &v : e->ev) hipEventDestroy(v);
+    if (e->sideOk) { hipStreamDestroy(e->side); hipEventDestroy(e->evFork); hipEventDestroy(e->evSide); }
     delete e;
 }
 static int dec_reset_state(ulcx_decoder *e) {
@@ -342,7 +344,7 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     if (rc) return rc;
     ulcx_decoder *e = new ulcx_decoder();
     e->device = device; e->B = nStreams; e->C = nChan; e->BS = BlockSize; e->maxK = maxBlocksPerCall;
-    e->tables = nullptr; e->evOk = false; e->evRecorded = false;
+    e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->sideOk = false;
     e->d_in = nullptr; e->d_in_bytes = 0; e->d_pcm = nullptr; e->d_bits = nullptr;
     UlcxDecCtx &c = e->ctx;
     memset(&c, 0, sizeof(c));
@@ -387,6 +389,14 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     }
     for (auto &v : e->ev) { if (hipEventCreate(&v) != hipSuccess) { ulcx_set_error("hipEventCreate failed"); cleanup(e); return ULCX_ERR_HIP; } }
     e->evOk = true;
+    e->sideOk = false;
+    {
+        const char *evs = getenv("ULCX_ASYNC_FB");      // (same switch as the encoder: 0 = everything on the caller's stream)
+        if (!(evs && evs[0] == '0') &&
+            hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&e->evSide, hipEventDisableTiming) == hipSuccess) e->sideOk = true;
+    }
     rc = dec_reset_state(e);
     if (rc) { cleanup(e); return rc; }
     *out = e;
@@ -400,7 +410,7 @@ extern "C" int ulcx_decode_dev(ulcx_decoder *e, const uint8_t *d_in, int slotByt
     CKR(hipSetDevice(e->device));
     UlcxDecCtx c = e->ctx;
     c.K = nBlocks; c.slot = slotBytes; c.in = d_in; c.pcm = d_pcm; c.bits = d_bits;
-    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->ev);
+    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->ev, e->sideOk ? e->side : nullptr, e->evFork, e->evSide);
     e->evRecorded = (rc == ULCX_OK);
     return rc;
 }
@@ -465,7 +475,7 @@ extern "C" int ulcx_decode_packed_dev(ulcx_decoder *e, const uint8_t *d_payload,
     UlcxDecCtx c = e->ctx;
     c.K = nBlocks; c.slot = 0; c.in = d_payload; c.pcm = d_pcm; c.bits = d_bits;
     c.packed = 1; c.payStride = payloadStride; c.payBytes = d_payloadBytes;
-    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->ev);
+    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->ev, e->sideOk ? e->side : nullptr, e->evFork, e->evSide);
     e->evRecorded = (rc == ULCX_OK);
     return rc;
 }

@@ -312,23 +312,26 @@ __device__ __forceinline__ void dgen_piece(const UlcxDecCtx &c, int blk, int ch,
         }
     }
 }
-// units j = 0 of every block: lane = (piece q, channel, block), block fastest
+// Units j = 0 of every block: lane = (piece q, channel, block), block fastest.  Units j >= 1 exist only
+// in decimated blocks: the first DGEN_DEC_WGS workgroups of the same launch walk the list the scan made
+// (first, so they start early and run beside the rest instead of after it).
+#define DGEN_DEC_WGS 1024
 __global__ __launch_bounds__(256) void k_dgen(UlcxDecCtx c) {
-    int tid0 = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x < DGEN_DEC_WGS) {
+        int n = *c.decCount;
+        int per = 3 * c.C * DCP_PER_UNIT;
+        for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < (long long)n * per; t += (long long)DGEN_DEC_WGS * 256) {
+            int e = (int)(t / per), r = (int)(t % per);
+            int q = r % DCP_PER_UNIT, ch = (r / DCP_PER_UNIT) % c.C, j = 1 + r / (DCP_PER_UNIT * c.C);
+            dgen_piece(c, c.decList[e], ch, j, q);
+        }
+        return;
+    }
+    int tid0 = (blockIdx.x - DGEN_DEC_WGS) * 256 + threadIdx.x;
     int NBd = c.B * c.K;
     if (tid0 >= NBd * c.C * DCP_PER_UNIT) return;
     int blk = tid0 % NBd, r = tid0 / NBd, ch = r % c.C, q = r / c.C;
     dgen_piece(c, blk, ch, 0, q);
-}
-// units j >= 1 (decimated blocks only): a small grid walks the list the scan made
-__global__ __launch_bounds__(256) void k_dgen_dec(UlcxDecCtx c) {
-    int n = *c.decCount;
-    int per = 3 * c.C * DCP_PER_UNIT;
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < (long long)n * per; t += (long long)gridDim.x * 256) {
-        int e = (int)(t / per), r = (int)(t % per);
-        int q = r % DCP_PER_UNIT, ch = (r / DCP_PER_UNIT) % c.C, j = 1 + r / (DCP_PER_UNIT * c.C);
-        dgen_piece(c, c.decList[e], ch, j, q);
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -516,10 +519,17 @@ size_t ulcx_dec_lds_bytes(int BS, int C) {
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)
 
-int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev) {
+int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev, hipStream_t side, hipEvent_t evFork, hipEvent_t evSide) {
     int stage = 0;
     if (ev) CK(hipEventRecord(ev[stage++], st));
     int NB = c.B * c.K;
+    // zero runs are not written by pass 3: the coefficient buffer is cleared beside the (latency-bound) scan
+    if (side) {
+        CK(hipEventRecord(evFork, st));
+        CK(hipStreamWaitEvent(side, evFork, 0));
+        CK(hipMemsetAsync(c.coef, 0, sizeof(float) * (size_t)NB * c.C * c.BS, side));
+        CK(hipEventRecord(evSide, side));
+    }
     CK(hipMemsetAsync(c.cp, 0, sizeof(int4) * (size_t)NB * c.C * 4 * DCP_PER_UNIT, st));   // N = 0: no piece
     CK(hipMemsetAsync(c.decCount, 0, sizeof(int), st));
     if (c.packed) hipLaunchKernelGGL(k_dscan_packed, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
@@ -528,9 +538,9 @@ int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev) {
     hipLaunchKernelGGL(k_dseed, dim3((NB + 63) / 64), dim3(64), 0, st, c);
     hipLaunchKernelGGL(k_dseed_commit, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
     if (ev) CK(hipEventRecord(ev[stage++], st));
-    CK(hipMemsetAsync(c.coef, 0, sizeof(float) * (size_t)NB * c.C * c.BS, st));     // zero runs are not written by k_dgen
-    hipLaunchKernelGGL(k_dgen, dim3((NB * c.C * DCP_PER_UNIT + 255) / 256), dim3(256), 0, st, c);
-    hipLaunchKernelGGL(k_dgen_dec, dim3(NB < 2048 ? NB : 2048), dim3(256), 0, st, c);
+    if (!side) CK(hipMemsetAsync(c.coef, 0, sizeof(float) * (size_t)NB * c.C * c.BS, st));
+    if (side) CK(hipStreamWaitEvent(st, evSide, 0));                                   // the coefficient buffer is zeroed
+    hipLaunchKernelGGL(k_dgen, dim3(DGEN_DEC_WGS + (NB * c.C * DCP_PER_UNIT + 255) / 256), dim3(256), 0, st, c);
     if (ev) CK(hipEventRecord(ev[stage++], st));
     size_t lds = ulcx_dec_lds_bytes(c.BS, c.C);
     if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_dimdct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

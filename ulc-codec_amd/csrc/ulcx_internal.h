@@ -151,7 +151,7 @@ struct UlcxEncAux {
     int *nXf;                            // out: transform chunk launches this call
 };
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, const UlcxEncAux &aux);
-int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev);
+int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev, hipStream_t side /* or NULL */, hipEvent_t evFork, hipEvent_t evSide);
 int ulcx_pack_launch(int nStreams, int nBlocks, int slotBytes, const uint8_t *d_slots, const int32_t *d_bits, uint8_t *d_payload,
                      long long stride, int32_t *d_payloadBytes, int32_t *d_maxBlock, hipStream_t st);
 size_t ulcx_enc_xf_lds_bytes(int BS, int C);
