@@ -72,6 +72,15 @@ __device__ __forceinline__ Code decode_code(uint32_t w, bool first) {
     k.qnew = q1 ? v1 : (qext & !k.stop) ? 0xE + v2 : -1;
     return k;
 }
+// number of leading nybbles of w (low first, at most 7) that are plain coefficients, i.e. none of 0h 1h 8h Fh
+__device__ __forceinline__ int plain_prefix(uint32_t w) {
+    // a nybble is special iff its low three bits are all equal and ... : {0,1,8,F} = {0000,0001,1000,1111}
+    // zero-nybble detector on w ^ pattern for each of the four values
+    auto zn = [](uint32_t x) { return (x - 0x11111111u) & ~x & 0x88888888u; };       // bit 3 of every nybble that is 0 (exact for the lowest such nybble)
+    uint32_t sp = zn(w) | zn(w ^ 0x11111111u) | zn(w ^ 0x88888888u) | zn(w ^ 0xFFFFFFFFu);
+    sp |= 0x80000000u;                                   // the 8th nybble is not part of the window
+    return (__ffs((int)sp) - 1) >> 2;                    // index of the first special nybble
+}
 typedef uint32_t u32_any_align __attribute__((aligned(1)));
 // 32-bit window at bit position pos; bytes at or past readBytes read as 0
 __device__ __forceinline__ uint32_t code_window(const uint8_t *p, int pos, int readBytes) {
@@ -128,7 +137,32 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
             nextQ++;
             continue;
         }
-        Code k = decode_code(code_window(p, pos, readBytes), first);
+        const uint32_t w = code_window(p, pos, readBytes);
+        if (!first) {
+            // a run of plain coefficient nybbles (+-2..+-7) is consumed in one trip: the scan needs nothing
+            // from them but their count.  Never across the next checkpoint position, the unit end or the
+            // 7 nybbles the window holds.
+            int m = plain_prefix(w);
+            int room = (nextQ < DCP_PER_UNIT) ? nextQ * (S >> 3) - (S - N) : N;
+            m = m < room ? m : room;
+            m = m < N ? m : N;
+            if (m > 0 && pos + 4 * m <= limit) {
+                pos += 4 * m; N -= m;
+                if (N > 0) continue;
+                // (unit complete: fall through the common end-of-unit code below with a zero-length code)
+                u++;
+                fin = bad | (u >= total);
+                if (!fin) {
+                    int ch = u / nsub, j = u - ch * nsub;
+                    uslot = ch * 4 + j;
+                    ustart[uslot] = pos; udraw[uslot] = draws;
+                    S = c.BS >> ((pat >> (4 * j)) & 7); N = S;
+                    first = true; nextQ = 0;
+                }
+                continue;
+            }
+        }
+        Code k = decode_code(w, first);
         const bool over = (k.zrun & (k.n > N)) | (k.n8 & (k.np > N));     // ulcDecoder.c:127,139,154
         const bool toEnd = k.stop | k.tail;
         const int used = over ? 0 : (toEnd ? N : k.n + k.np);
@@ -294,7 +328,33 @@ __device__ __forceinline__ void dgen_piece(const UlcxDecCtx &c, int blk, int ch,
             }
             pos += cnt; pend -= cnt; N -= cnt;
         } else {
-            Code k = decode_code(code_window(src, bitpos, readBytes), first);
+            const uint32_t w = code_window(src, bitpos, readBytes);
+            if (!first) {
+                // a run of plain coefficients (ulcDecoder.c:69-73): up to the next multiple of four positions in
+                // one trip, an aligned 16-byte store when that is a full group
+                int m = plain_prefix(w);
+                const int room = 4 - (pos & 3);
+                m = m < room ? m : room;
+                m = m < N - Nstop ? m : N - Nstop;
+                if (m > 0) {
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        int sv = (int)((w >> (4 * k)) & 0xF);
+                        sv = (sv ^ 0x8) - 0x8;
+                        sv = (sv < 0) ? (-sv * sv) : (+sv * sv);
+                        v[k] = (float)sv * quant;
+                    }
+                    if (m == 4) *(float4 *)(dst + pos) = make_float4(v[0], v[1], v[2], v[3]);
+                    else {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) if (k < m) dst[pos + k] = v[k];
+                    }
+                    bitpos += 4 * m; pos += m; N -= m;
+                    continue;
+                }
+            }
+            Code k = decode_code(w, first);
             if (k.plain) dst[pos] = (float)k.sv * quant;                    // ulcDecoder.c:69-73
             int n = k.stop ? N : k.n;
             n = (n > N) ? N : n;                                            // (cannot happen in a block the scan accepted)
