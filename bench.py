@@ -177,15 +177,24 @@ def main():
     pseudo = ("cbr_probe_passes", "k_heapsel", "wc_pipeline_exposed")   # intervals, not kernels (join wait / side-stream launches)
     allk = {**{("enc", k_): v for k_, v in acc_enc.items() if k_ not in pseudo}, **{("dec", k_): v for k_, v in acc_dec.items()}}
     (side, kname), kms = max(allk.items(), key=lambda kv: kv[1])
-    launch_bytes = alg_bytes_block * B * K
-    achieved = launch_bytes / (kms * 1e-3) / 1e9
+    # kms is the kernel's time per step; a kernel launched n times per step (k_xf: one launch per chunk of blocks of
+    # the window-control pipeline) has kms = sum of its n launches, each timed by its own hipEvent pair on its stream.
+    # Per launch: bytes/n over kms/n - the same ratio.  profiles/*_pmc_summary.json carries n and the measured traffic.
+    launches = 1.0
     traffic = None
     pj = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
     if os.path.exists(pj):
         try:
-            traffic = json.load(open(pj)).get(kname, {}).get("hbm_bytes_per_launch")
+            ent = json.load(open(pj)).get(kname, {})
+            launches = float(ent.get("launches_per_step", 1.0)) or 1.0
+            traffic = ent.get("hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic = traffic * (B * K / 65536.0) / launches        # summary is per step of 65536 blocks
         except Exception:
             traffic = None
+    launch_bytes = alg_bytes_block * B * K / launches
+    kms_launch = kms / launches
+    achieved = launch_bytes / (kms_launch * 1e-3) / 1e9
     enc_total = sum(acc_enc.values()); dec_total = sum(acc_dec.values())
 
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -206,12 +215,13 @@ def main():
                        "parallelism": f"batch split over {world} GPU(s), no collective on the data path"},
             "roofline": {"bound": "hbm", "kernel": f"{kname} ({side})", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_block": alg_bytes_block, "blocks_per_launch": B * K, "kernel_ms": kms},
+                         "algorithmic_bytes_per_block": alg_bytes_block, "blocks_per_launch": B * K / launches,
+                         "launches_per_step": launches, "kernel_ms": kms_launch},
             "whole_pipeline": {"encode_ms": enc_total, "decode_ms": dec_total,
                                "encode_Msamples_s": B * K * BS * CH / (enc_total * 1e-3) / 1e6,
                                "decode_Msamples_s": B * K * BS * CH / (dec_total * 1e-3) / 1e6,
-                               "encode_hbm_frac": launch_bytes / (enc_total * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "decode_hbm_frac": launch_bytes / (dec_total * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "encode_hbm_frac": alg_bytes_block * B * K / (enc_total * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "decode_hbm_frac": alg_bytes_block * B * K / (dec_total * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "mean_block_bytes": mean_bytes, "decode_ok": ok},
             "kernels_ms": {**{f"enc.{k_}": round(v, 4) for k_, v in acc_enc.items()}, **{f"dec.{k_}": round(v, 4) for k_, v in acc_dec.items()}},
         }

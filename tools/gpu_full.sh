@@ -13,3 +13,4 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_wr -- python3 bench.py --steps 2 --warmup 1 --no-cpu > /dev/null 2> gpurun_out/pmc_wr.err
 cp $(find gpurun_out/pmc_rd -name "*counter_collection.csv" | head -1) gpurun_out/pmc_fetch.csv
 cp $(find gpurun_out/pmc_wr -name "*counter_collection.csv" | head -1) gpurun_out/pmc_write.csv
+python tools/pmc_summary.py gpurun_out/pmc_fetch.csv gpurun_out/pmc_write.csv gpurun_out/pmc_summary.json > gpurun_out/pmc_summary.txt
