@@ -119,27 +119,34 @@ __global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c, int k0, int k1)
     float env = live ? c.wcs[s].tf[f] : 0.0f;
     float cc = f ? c.cBP : c.cHP;
     int n = (k1 - k0) * c.BS;
-    constexpr int U = 16, D = 4;          // D batches of U steps in flight: one wave per CU must cover HBM latency by itself
+    // Groups of U steps addressed from one pointer with immediate offsets (rows are 512 bytes apart), loads
+    // D-1 groups ahead of the arithmetic: the chain is bound by instructions per step (3 dependent VALU + 1 load
+    // + 1 store), so address arithmetic and loop control are kept out of it.
+    constexpr int U = 8, D = 8;           // (K*BS is a multiple of U*D)
+    const float *rp = v;
+    float *wp = v;
     float x[D][U];
 #pragma unroll
-    for (int b2 = 0; b2 < D - 1; b2++)
+    for (int g = 0; g < D - 1; g++) {
 #pragma unroll
-        for (int j = 0; j < U; j++) { int t = b2 * U + j; x[b2][j] = v[(size_t)(t < n ? t : 0) * 128]; }
+        for (int j = 0; j < U; j++) x[g][j] = rp[(size_t)j * 128];
+        rp += U * 128;
+    }
     for (int i = 0; i < n; i += D * U) {
 #pragma unroll
-        for (int b2 = 0; b2 < D; b2++) {
-            int base = i + b2 * U;
-            int pf = base + (D - 1) * U;            // batch to prefetch into the slot freed last
+        for (int g = 0; g < D; g++) {
+            const bool more = (i + (g + D - 1) * U) < n;
+            const float *lp = more ? rp : v;                // past the end: re-read row 0 (unused)
 #pragma unroll
-            for (int j = 0; j < U; j++) { int t = pf + j; x[(b2 + D - 1) % D][j] = v[(size_t)(t < n ? t : 0) * 128]; }
-            if (base < n) {
+            for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = lp[(size_t)j * 128];
+            rp += U * 128;
 #pragma unroll
-                for (int j = 0; j < U; j++) { float d = x[b2][j] - env; env += d * cc; x[b2][j] = env; }
-                if (live) {
+            for (int j = 0; j < U; j++) { float d = x[g][j] - env; env += d * cc; x[g][j] = env; }
+            if (live) {
 #pragma unroll
-                    for (int j = 0; j < U; j++) v[(size_t)(base + j) * 128] = x[b2][j];
-                }
+                for (int j = 0; j < U; j++) wp[(size_t)j * 128] = x[g][j];
             }
+            wp += U * 128;
         }
     }
     if (live) c.wcs[s].tf[f] = env;                                   // state for the next call
@@ -151,35 +158,44 @@ __global__ __launch_bounds__(64) void k_wc_backward(UlcxEncCtx c, int k0, int k1
     int sl = threadIdx.x;
     int k = k0 + blockIdx.x % (k1 - k0), sg = blockIdx.x / (k1 - k0);
     float2 *e = c.env + ((size_t)sg * c.maxK * c.BS + (size_t)k * c.BS) * 64 + sl;
-    float2 last = e[(size_t)(c.BS - 1) * 64];
-    float pHP = last.x, pBP = last.y;
-    // walk the block backwards, step r = 0 is sample BS-1; D batches of U steps in flight (BS is a multiple of D*U)
-    constexpr int U = 16, D = 4;
     const int n = c.BS;
+    float2 last = e[(size_t)(n - 1) * 64];
+    float pHP = last.x, pBP = last.y;
+    const float qHP = c.qHP, qBP = c.qBP;
+    // Walk the block backwards in groups of U steps; a group's rows are addressed from one pointer with
+    // immediate offsets (rows are 512 bytes apart), and the loads run D-1 groups ahead of the arithmetic:
+    // the chain is bound by instructions per step, so address arithmetic is kept out of it.
+    constexpr int U = 8, D = 4;                          // BS is a multiple of U*D
+    const float2 *rp = e + (size_t)(n - 1) * 64;         // row of the step being loaded (group head)
+    float2 *wp = e + (size_t)(n - 1) * 64;               // row of the step being computed (group head)
     float2 x[D][U];
 #pragma unroll
-    for (int b2 = 0; b2 < D - 1; b2++)
+    for (int g = 0; g < D - 1; g++) {
 #pragma unroll
-        for (int j = 0; j < U; j++) { int r = b2 * U + j; x[b2][j] = e[(size_t)(n - 1 - (r < n ? r : 0)) * 64]; }
-    for (int i = 0; i < n; i += D * U) {
+        for (int j = 0; j < U; j++) x[g][j] = rp[-(ptrdiff_t)j * 64];
+        rp -= U * 64;
+    }
+    for (int i = 0; i < n; i += U * D) {
 #pragma unroll
-        for (int b2 = 0; b2 < D; b2++) {
-            int base = i + b2 * U;
-            int pf = base + (D - 1) * U;
+        for (int g = 0; g < D; g++) {
+            // prefetch the group D-1 ahead into the slot freed last (past the block start: re-read row 0, unused)
+            const bool more = (i + (g + D - 1) * U) < n;
+            const float2 *lp = more ? rp : e + (size_t)(U - 1) * 64;
 #pragma unroll
-            for (int j = 0; j < U; j++) { int r = pf + j; x[(b2 + D - 1) % D][j] = e[(size_t)(n - 1 - (r < n ? r : 0)) * 64]; }
-            if (base < n) {
+            for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = lp[-(ptrdiff_t)j * 64];
+            rp -= U * 64;
+            float o[U];
 #pragma unroll
-                for (int j = 0; j < U; j++) {
-                    float dHP = x[b2][j].x - pHP, dBP = x[b2][j].y - pBP;
-                    pHP += dHP * c.qHP;
-                    pBP += dBP * c.qBP;
-                    float a = dHP * pBP, bb = dBP * pHP;
-                    x[b2][j].x = a * a + bb * bb;
-                }
-#pragma unroll
-                for (int j = 0; j < U; j++) e[(size_t)(n - 1 - (base + j)) * 64].x = x[b2][j].x;
+            for (int j = 0; j < U; j++) {
+                float dHP = x[g][j].x - pHP, dBP = x[g][j].y - pBP;
+                pHP += dHP * qHP;
+                pBP += dBP * qBP;
+                float a = dHP * pBP, bb = dBP * pHP;
+                o[j] = a * a + bb * bb;
             }
+#pragma unroll
+            for (int j = 0; j < U; j++) wp[-(ptrdiff_t)j * 64].x = o[j];
+            wp -= U * 64;
         }
     }
 }
@@ -194,29 +210,36 @@ __global__ __launch_bounds__(64) void k_wc_integrate(UlcxEncCtx c, int k0, int k
     float *bins = c.bins + (size_t)sc * (c.maxK + 1) * 16;
     if (live && k0 == 0) for (int i = 0; i < 8; i++) { bins[i] = c.wcs[s].binSum[i]; bins[8 + i] = c.wcs[s].binW[i]; }
     const float2 *e = c.env + env_idx(c, s, k0 * c.BS);
-    int bin = c.BS / 8;                   // >= 32, multiple of U
-    int n = (k1 - k0) * c.BS;
-    constexpr int U = 16, D = 4;
+    const int bin = c.BS / 8;             // >= 32, a multiple of U
+    const int n = (k1 - k0) * c.BS;
+    // same structure as k_wc_forward: U-step groups off one pointer, loads D-1 groups ahead
+    constexpr int U = 8, D = 8;
+    const float *v = (const float *)e;    // .x of each {x, -} pair, rows 128 floats apart
+    const float *rp = v;
     float x[D][U];
 #pragma unroll
-    for (int b = 0; b < D - 1; b++)
+    for (int g = 0; g < D - 1; g++) {
 #pragma unroll
-        for (int j = 0; j < U; j++) { int t = b * U + j; x[b][j] = e[(size_t)(t < n ? t : 0) * 64].x; }
-    float sum = 0.0f, sw = 0.0f;
+        for (int j = 0; j < U; j++) x[g][j] = rp[(size_t)j * 128];
+        rp += U * 128;
+    }
+    const float cBlk = c.cBlk;
+    float sum = 0.0f;
+    int inBin = 0, gbin = k0 * 8;         // steps accumulated in the current bin; global bin index = k*8 + i
     for (int i = 0; i < n; i += D * U) {
 #pragma unroll
-        for (int b = 0; b < D; b++) {
-            int base = i + b * U;
-            int pf = base + (D - 1) * U;
+        for (int g = 0; g < D; g++) {
+            const bool more = (i + (g + D - 1) * U) < n;
+            const float *lp = more ? rp : v;
 #pragma unroll
-            for (int j = 0; j < U; j++) { int t = pf + j; x[(b + D - 1) % D][j] = e[(size_t)(t < n ? t : 0) * 64].x; }
+            for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = lp[(size_t)j * 128];
+            rp += U * 128;
 #pragma unroll
-            for (int j = 0; j < U; j++) { float d = x[b][j] - env; env += d * c.cBlk; sum += env; sw += 1; }
-            int done = base + U;
-            if (done % bin == 0) {        // bin boundary (bins never straddle a batch)
-                int gbin = done / bin - 1 + k0 * 8;   // global bin index = k*8 + i
-                if (live) { float *o = bins + (size_t)(gbin / 8 + 1) * 16; o[gbin & 7] = sum; o[8 + (gbin & 7)] = sw; }
-                sum = 0.0f; sw = 0.0f;
+            for (int j = 0; j < U; j++) { float d = x[g][j] - env; env += d * cBlk; sum += env; }
+            inBin += U;
+            if (inBin == bin) {           // bin boundary (bins never straddle a group); the weight is the step count
+                if (live) { float *o = bins + (size_t)(gbin / 8 + 1) * 16; o[gbin & 7] = sum; o[8 + (gbin & 7)] = (float)bin; }
+                sum = 0.0f; inBin = 0; gbin++;
             }
         }
     }
