@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ulc-codec_amd"))
-from ulc_testlib import synth_pcm, oracle_encode_debug, oracle_decode_stream
+from ulc_testlib import synth_pcm, oracle_encode_debug, oracle_decode_stream, synth_block_stream
 
 pytestmark = pytest.mark.gpu
 
@@ -136,6 +136,30 @@ def test_decode_bit_exact(bs, ch, rate, q):
         assert rc == 0
         assert np.array_equal(gbits[s], ref_bits), f"stream {s}: bits consumed differ"
         assert np.array_equal(got[s], ref_pcm), f"stream {s}: decoded PCM differs (max {np.abs(got[s]-ref_pcm).max()})"
+    dec.close()
+
+
+@pytest.mark.parametrize("bs,ch,B,K,calls", [(512, 2, 40, 6, 2), (2048, 2, 70, 5, 2), (1024, 1, 33, 7, 1), (256, 3, 20, 4, 2), (4096, 2, 9, 3, 1)])
+def test_decode_hand_assembled_streams(bs, ch, B, K, calls):
+    """Every code of the block syntax, including those the encoder never emits: decimation codes
+    2h-7h, all overlap scales, extended quantizers, long zero runs, both stop codes, units that open with a stop."""
+    amd = _amd()
+    slot = 2 * ch * bs + 16
+    streams = [synth_block_stream(1000 + 17 * s + bs, calls * K, ch, bs, slot) for s in range(B)]
+    blocks = np.stack([st[0] for st in streams])
+    dec = amd.BatchDecoder(B, ch, bs, K)
+    got, gbits = [], []
+    for c in range(calls):
+        p, b = dec.decode(blocks[:, c * K:(c + 1) * K])
+        got.append(p); gbits.append(b)
+    got = np.concatenate(got, axis=1); gbits = np.concatenate(gbits, axis=1)
+    for s in range(B):
+        rc, ref_pcm, ref_bits = oracle_decode_stream(blocks[s], ch, bs)
+        assert rc == 0, f"oracle rejected hand-assembled stream {s} at block {rc - 1}"
+        assert np.array_equal(ref_bits, streams[s][1]), f"stream {s}: oracle consumed {ref_bits} bits, assembled {streams[s][1]}"
+        assert np.array_equal(gbits[s], ref_bits), f"stream {s}: bits consumed differ: {gbits[s]} vs {ref_bits}"
+        assert np.array_equal(got[s].view(np.uint32), ref_pcm.view(np.uint32)), \
+            f"stream {s}: decoded PCM differs (max {np.abs(got[s]-ref_pcm).max()})"
     dec.close()
 
 

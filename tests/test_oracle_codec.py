@@ -185,3 +185,18 @@ def test_cbr_never_exceeds_budget():
     out, bits, wc, cplx = oracle_encode_stream(pcm, bs, rate, kbps=kbps)
     budget = int((bs * kbps) * 1000.0 / rate)
     assert (bits[2:] <= budget + 7).all() and bits[2:].mean() > 0.9 * budget
+
+
+def test_oracle_decodes_hand_assembled_streams_consuming_exactly_their_bits():
+    """Streams assembled code by code from FormatSpecs.md:57-141 (every code, including decimation codes 2h-7h,
+    extended quantizers, both stop codes): the oracle decoder must accept them and consume exactly the
+    assembled number of bits per block."""
+    from ulc_testlib import synth_block_stream, oracle_decode_stream
+    for bs, ch in ((512, 2), (2048, 2), (1024, 1), (256, 3)):
+        slot = 2 * ch * bs + 16
+        for s in range(4):
+            blk, nbits = synth_block_stream(77 + 13 * s + bs, 6, ch, bs, slot)
+            rc, pcm, bits = oracle_decode_stream(blk, ch, bs)
+            assert rc == 0, f"bs={bs} ch={ch} stream {s}: rejected at block {rc - 1}"
+            assert np.array_equal(bits, nbits)
+            assert np.isfinite(pcm).all()

@@ -157,3 +157,94 @@ def oracle_encode_debug(pcm, block_size, rate, mode=0, p0=50.0, p1=0.0, slot=Non
                                      ptr(r["noise"], f32p), ptr(r["keys"], f32p), ptr(r["ranks"], i32p), ptr(r["nout"], i32p))
     assert rc == 0, rc
     return r
+
+
+# ---------------------------------------------------------------------------
+# Hand-assembled block streams (SURVEY.md §8c): every code of FormatSpecs.md:57-141, including the ones the
+# encoder never emits (decimation codes 2h-7h at any block size, all overlap scales, extended quantizers,
+# long zero runs, both stop codes).  Always valid syntax; the decoder under test and the oracle must agree.
+# ---------------------------------------------------------------------------
+_PATTERNS = [0x0000, 0x0008, 0x0019, 0x0091, 0x012A, 0x01A2, 0x02A1, 0x0A21,
+             0x123B, 0x12B3, 0x13B2, 0x1B32, 0x23B1, 0x2B31, 0x3B21, 0xB321]      # ulcHelper.h:24-46
+
+
+def _gen_unit(rng, S, nyb):
+    N = S
+    r = rng.random()
+    if r < 0.04:
+        nyb += [0xE, 0xF]                                  # unit opens with the stop code: all zeros
+        return
+    if r < 0.3:
+        nyb += [0xE, int(rng.integers(0, 15))]             # extended quantizer Eh,X
+    else:
+        nyb += [int(rng.integers(0, 14))]
+    dense = rng.random() < 0.5
+    while N > 0:
+        r = rng.random()
+        if r < (0.7 if dense else 0.35):
+            v = int(rng.integers(2, 8))
+            nyb.append(v if rng.random() < 0.5 else 16 - v)
+            N -= 1
+        elif r < 0.78:
+            n = int(rng.integers(1, min(16, N) + 1))
+            nyb += [0x0, n - 1]
+            N -= n
+        elif r < 0.83 and N >= 33:
+            n = int(rng.integers(33, min(288, N) + 1))
+            v = n - 33
+            nyb += [0x1, v >> 4, v & 15]
+            N -= n
+        elif r < 0.91 and N >= 16:
+            n = int(rng.integers(16, min(527, N) + 1))
+            v = n - 16
+            lvl = int(rng.integers(1, 9))
+            nyb += [0x8, (v >> 5) & 15, (v >> 1) & 15, ((lvl - 1) << 1) | (v & 1)]
+            N -= n
+        elif r < 0.955:
+            if rng.random() < 0.7:
+                nyb += [0xF, int(rng.integers(0, 14))]
+            else:
+                nyb += [0xF, 0xE, int(rng.integers(0, 15))]
+        elif r < 0.975:
+            nyb += [0xF, 0xE, 0xF]                         # stop: zeros to the end
+            return
+        elif r < 1.0:
+            nyb += [0xF, 0xF, int(rng.integers(0, 16)), int(rng.integers(0, 16)), int(rng.integers(0, 16))]   # noise to the end
+            return
+
+
+def synth_block_stream(seed, n_blocks, n_chan, block_size, slot):
+    """[n_blocks][slot] uint8: random valid blocks, low nybble first (ulcDecoder.c:82-88)."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((n_blocks, slot), np.uint8)
+    nbits = np.zeros(n_blocks, np.int32)
+    for b in range(n_blocks):
+        nyb = []
+        f = int(rng.integers(0, 16))
+        if rng.random() < 0.5:
+            f &= 7                                         # un-decimated, overlap scale 0..7
+        nyb.append(f)
+        pat = _PATTERNS[1]
+        if f & 8:
+            p = int(rng.integers(0, 16))
+            nyb.append(p)
+            pat = _PATTERNS[p]
+        subs = []
+        q = pat
+        while True:
+            subs.append(block_size >> (q & 7))
+            q >>= 4
+            if not q:
+                break
+        if subs[0] == block_size:
+            subs = subs[:1]                                # ulcDecoder.c:242-245
+        for ch in range(n_chan):
+            for S in subs:
+                _gen_unit(rng, S, nyb)
+        assert len(nyb) <= 2 * (slot - 4), "block does not fit its slot"
+        nbits[b] = 4 * len(nyb)
+        if len(nyb) & 1:
+            nyb.append(0)
+        a = np.array(nyb, np.uint8)
+        out[b, :len(a) // 2] = a[0::2] | (a[1::2] << 4)
+    return out, nbits
