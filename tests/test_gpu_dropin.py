@@ -1,0 +1,84 @@
+"""The drop-in boundary end to end (BASELINE configs[0]): the reference's OWN tools
+(tools/ulcEncodeTool.c, tools/ulcDecodeTool.c, WAV reader/writer - compiled unchanged from /root/reference by
+oracle/Makefile into oracle/_ref/, linked against libulc_amd.so instead of libulc + libfourier) run on the GPU box;
+the .ulc file they write must be byte-identical to the container assembled from the oracle's blocks, and the WAV
+they decode must be sample-identical to the oracle's decode."""
+import os
+import struct
+import subprocess
+import sys
+import wave
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ulc-codec_amd"))
+from ulc_testlib import synth_pcm, oracle_encode_debug, oracle_decode_stream
+
+pytestmark = pytest.mark.gpu
+ENC = os.path.join(ROOT, "oracle", "_ref", "ulcencodetool_amd")
+DEC = os.path.join(ROOT, "oracle", "_ref", "ulcdecodetool_amd")
+needs_tools = pytest.mark.skipif(not (os.path.exists(ENC) and os.path.exists(DEC)),
+                                 reason="oracle/_ref tools not built (needs /root/reference at build time)")
+
+
+def _write_wav16(path, pcm16, rate):
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(pcm16.shape[1]); w.setsampwidth(2); w.setframerate(rate)
+        w.writeframes(pcm16.astype("<i2").tobytes())
+
+
+def _expected_ulc(pcm16, rate, bs, mode, p0):
+    n, ch = pcm16.shape
+    nblk = (n + bs - 1) // bs + 2                                   # ulcEncodeTool.c:93-98
+    x = np.zeros((nblk * bs, ch), np.float32)
+    x[:n] = pcm16.astype(np.float32) * np.float32(2.0 ** -15)        # WavIO_Helper.c:49-55
+    ref = oracle_encode_debug(x, bs, rate, mode, p0, slot=2 * ch * bs + 16)
+    sizes = (ref["bits"] + 7) // 8
+    payload = b"".join(ref["out"][k, :sizes[k]].tobytes() for k in range(nblk))
+    total = int(sizes.sum())
+    kbps = int(np.rint(total * 8.0 * rate / 1000.0 / (bs * nblk)))    # ulcEncodeTool.c:173,190 (lrint)
+    hdr = struct.pack("<IHHIIHHI", 0x32434C55, bs, int(sizes.max()), nblk, rate, ch, kbps, 24)   # tools/ulc_Helper.h:10-20
+    return hdr + payload, ref, nblk
+
+
+def _run(cmd):
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "ulc-codec_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    p = subprocess.run(cmd, capture_output=True, env=env, timeout=600)
+    assert p.returncode == 0, f"{cmd[0]} failed ({p.returncode}): {p.stdout.decode()[-400:]} {p.stderr.decode()[-400:]}"
+    return p
+
+
+@needs_tools
+@pytest.mark.parametrize("ch,rate,seconds,arg,mode,p0,bs", [
+    (1, 44100, 10.0, "-50", 0, 50.0, 2048),        # BASELINE configs[0]: 10 s mono 44.1 kHz PCM16, BlockSize 2048, VBR -50
+    (2, 44100, 2.0, "-50", 0, 50.0, 2048),
+    (2, 48000, 1.5, "64", 1, 64.0, 2048),          # CBR 64 kbps
+    (2, 44100, 1.5, "-70", 0, 70.0, 4096),
+])
+def test_reference_tools_over_libulc_amd_write_the_oracles_bytes(ch, rate, seconds, arg, mode, p0, bs, tmp_path):
+    n = int(seconds * rate)
+    pcm = synth_pcm(3, n, ch, rate, transient=True, seed=11)
+    pcm16 = np.clip(np.rint(pcm * 32767.0), -32768, 32767).astype(np.int16)
+    wav_in, ulc, wav_f32, wav_16 = tmp_path / "in.wav", tmp_path / "out.ulc", tmp_path / "dec_f32.wav", tmp_path / "dec_16.wav"
+    _write_wav16(wav_in, pcm16, rate)
+    args = [ENC, str(wav_in), str(ulc), arg] + ([f"-blocksize:{bs}"] if bs != 2048 else [])
+    _run(args)
+    want, ref, nblk = _expected_ulc(pcm16, rate, bs, mode, p0)
+    got = open(ulc, "rb").read()
+    assert got[:24] == want[:24], f"container header differs: {got[:24].hex()} vs {want[:24].hex()}"
+    assert len(got) == len(want), f".ulc size {len(got)} != {len(want)}"
+    assert got == want, "the .ulc bytes written by ulcencodetool over libulc_amd.so differ from the oracle's"
+    # decode with the reference's decode tool (float32 and the default PCM16)
+    rc, ref_pcm, _ = oracle_decode_stream(ref["out"], ch, bs)
+    assert rc == 0
+    _run([DEC, str(ulc), str(wav_f32), "-format:FLOAT32"])
+    raw = open(wav_f32, "rb").read()
+    data = np.frombuffer(raw[-nblk * bs * ch * 4:], dtype="<f4").reshape(nblk * bs, ch)
+    assert np.array_equal(data.view(np.uint32), ref_pcm.view(np.uint32)), "decoded float samples differ from the oracle's"
+    _run([DEC, str(ulc), str(wav_16)])
+    raw = open(wav_16, "rb").read()
+    d16 = np.frombuffer(raw[-nblk * bs * ch * 2:], dtype="<i2").reshape(nblk * bs, ch)
+    want16 = np.rint(np.clip(ref_pcm * np.float32(32768.0), -32768.0, 32767.0)).astype(np.int16)   # WavIO_Helper.c:57-63
+    assert np.array_equal(d16, want16), "decoded PCM16 differs from the oracle's"
