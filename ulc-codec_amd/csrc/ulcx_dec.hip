@@ -16,6 +16,7 @@
 
 #define WG 256
 #include "ulcx_fft.h"
+#define DPS 4        // FFT array padding of k_dimdct (ulcx_fft.h; 3 measured no faster)
 
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float expand_quantizer(int q) {        // ulcDecoder.c:96-98
@@ -395,8 +396,8 @@ __global__ __launch_bounds__(256) void k_dgen(UlcxDecCtx c) {
 }
 
 // ---------------------------------------------------------------------------
-// IMDCT + overlap-add.  LDS carve (floats): lap [C][BS/2] | z [2*BS] (two arrays of BS/2 complex) |
-// dec [BS] | tmpq [BS/2]
+// IMDCT + overlap-add.  LDS carve (floats): lap [C][BS/2] | z [4.25*BS] (four padded arrays of BS/2 complex;
+// the general path uses the first BS floats as one array and keeps dec [BS] | tmpq [BS/2] behind it) | twl [BS/2]
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
     extern __shared__ float lds[];
@@ -404,14 +405,73 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
     int s = blockIdx.x, tid = threadIdx.x;
     float  *lap   = lds;
     float2 *z     = (float2 *)(lap + (size_t)C * H2);
-    float  *dec   = (float *)(z + 2 * H2);
+    float  *dec   = (float *)z + BS;
     float  *tmpq  = dec + BS;
-    float2 *twl   = (float2 *)tmpq;                          // BS/4 complex: FFT twiddles of the full-size transform live in tmpq
-    bool twlValid = false;                                   // (a decimated block reuses tmpq for its FIFO and invalidates them)
+    float2 *twl   = (float2 *)((float *)z + 4 * FFT_PADDEDS(BS, DPS));   // BS/4 complex: FFT twiddles of the full-size transform
     float *glap = c.lap + (size_t)s * C * H2;
     for (int i = tid; i < C * H2; i += WG) lap[i] = glap[i];
+    for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
     int lastSub = c.lastSub[s];
     __syncthreads();
+
+    // stereo, un-decimated block (the common case): both channels at once, inverse M/S in registers,
+    // interleaved stores.  Post-twiddle fused with the windowed overlap (oracle/orc_fourier.c orc_imdct).
+    auto fast_block = [&](int wcv) { return C == 2 && wcv != 0 && (BS >> (ulcx_pattern(wcv) & 7)) == BS; };
+    auto fast_overlap = [&](int wcv, int last) {
+        int ov = BS;                                                // ulcDecoder.c:234-239
+        if (ulcx_pattern(wcv) & 8) ov >>= (wcv & 7);
+        return ov > last ? last : ov;
+    };
+    auto fast_pre = [&](const float *coefB, float2 *za, float2 *zb, bool padded) {
+        const int S = BS, M = BS >> 1;
+        const float2 *pre = c.T.pre[0];
+        const float *X0 = coefB, *X1 = coefB + BS;
+        for (int n = tid; n < M; n += WG) {
+            float2 P = pre[n];
+            int pn = padded ? FFT_PADS(n, DPS) : n;
+            za[pn] = cmulc(make_float2(X0[2 * n], X0[S - 1 - 2 * n]), P);
+            zb[pn] = cmulc(make_float2(X1[2 * n], X1[S - 1 - 2 * n]), P);
+        }
+    };
+    auto fast_post = [&](const float2 *z0, const float2 *z1, float *outp, int ov, bool padded) {
+        const int S = BS, M = BS >> 1;
+        const float2 *pre = c.T.pre[0];
+        int a = (S - ov) >> 1;
+        const float *fall = c.T.winFall + ov, *rise = c.T.winRise + ov;
+        int bits = 31 - __clz(M);
+        float *L0 = lap, *L1 = lap + H2;
+        for (int kk = tid; kk < M / 2; kk += WG) {
+            int k1 = kk, k2 = M - 1 - kk;
+            int r1 = (int)(__brev((unsigned)k1) >> (32 - bits));
+            int r2 = (int)(__brev((unsigned)k2) >> (32 - bits));
+            if (padded) { r1 = FFT_PADS(r1, DPS); r2 = FFT_PADS(r2, DPS); }
+            float2 P1 = pre[k1], P2 = pre[k2];
+            float2 ya1 = cmulc(z0[r1], P1), ya2 = cmulc(z0[r2], P2);     // channel 0 (M)
+            float2 yb1 = cmulc(z1[r1], P1), yb2 = cmulc(z1[r2], P2);     // channel 1 (S)
+            float A0m = L0[2 * k1], A1m = L0[2 * k1 + 1], A0s = L1[2 * k1], A1s = L1[2 * k1 + 1];
+            float Bm[2] = { -ya1.y, ya2.x }, Bs[2] = { -yb1.y, yb2.x };
+            float Am[2] = { A0m, A1m }, As[2] = { A0s, A1s };
+            int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                int p = pv[q];
+                float mLo, mHi, sLo, sHi;                                  // outputs at positions p and S-1-p
+                if (p < a) { mLo = Am[q]; mHi = Bm[q]; sLo = As[q]; sHi = Bs[q]; }
+                else {
+                    float cw = fall[p - a], sw = rise[p - a];
+                    float m0 = cw * Am[q], m1 = sw * Bm[q], m2 = sw * Am[q], m3 = cw * Bm[q];
+                    mLo = m0 - m1; mHi = m2 + m3;
+                    float s0 = cw * As[q], s1 = sw * Bs[q], s2 = sw * As[q], s3 = cw * Bs[q];
+                    sLo = s0 - s1; sHi = s2 + s3;
+                }
+                // inverse M/S (ulcDecoder.c:281-289) + interleave (:292-297)
+                *(float2 *)(outp + 2 * p) = make_float2(mLo + sLo, mLo - sLo);
+                *(float2 *)(outp + 2 * (S - 1 - p)) = make_float2(mHi + sHi, mHi - sHi);
+            }
+            L0[2 * k1] = ya1.x; L0[2 * k1 + 1] = -ya2.y;
+            L1[2 * k1] = yb1.x; L1[2 * k1 + 1] = -yb2.y;
+        }
+    };
 
     for (int k = 0; k < c.K; k++) {
         int blk = s * c.K + k;
@@ -423,61 +483,31 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
         }
         const float *coefB = c.coef + (size_t)blk * C * BS;
         int newLast = lastSub;
-        // ---- stereo, un-decimated block (the common case): both channels at once, inverse M/S in
-        //      registers, interleaved stores; no staging through LDS
-        if (C == 2 && (BS >> (ulcx_pattern(wc) & 7)) == BS) {
-            const int S = BS, M = BS >> 1;
-            unsigned pat0 = ulcx_pattern(wc);
-            int ov = S;                                             // ulcDecoder.c:234-239
-            if (pat0 & 8) ov >>= (wc & 7);
-            if (ov > lastSub) ov = lastSub;
-            const float2 *pre = c.T.pre[0];
-            if (!twlValid) { for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i]; twlValid = true; }   // (made visible by the barrier below)
-            float2 *z0 = z, *z1 = z + M;
-            const float *X0 = coefB, *X1 = coefB + BS;
-            if (!(c.dbgSkip & 1)) for (int n = tid; n < M; n += WG) {
-                float2 P = pre[n];
-                z0[n] = cmulc(make_float2(X0[2 * n], X0[S - 1 - 2 * n]), P);
-                z1[n] = cmulc(make_float2(X1[2 * n], X1[S - 1 - 2 * n]), P);
+        if (fast_block(wc)) {
+            const int M = BS >> 1, Mp = FFT_PADDEDS(M, DPS);
+            int wc2 = (k + 1 < c.K) ? c.wc[blk + 1] : 0;
+            if (fast_block(wc2)) {
+                // ---- two consecutive blocks: four transforms, ONE WAVE PER ARRAY (16 points per lane through
+                //      four radix-2 stages in registers, no barrier between passes), then the two overlap-adds in order
+                if (!(c.dbgSkip & 1)) { fast_pre(coefB, z, z + Mp, true);
+                fast_pre(coefB + (size_t)C * BS, z + 2 * Mp, z + 3 * Mp, true); }
+                __syncthreads();
+                if (!(c.dbgSkip & 2)) fft_wave_dif(z + (tid >> 6) * Mp, M, twl, tid & 63, DPS);
+                __syncthreads();
+                if (!(c.dbgSkip & 4)) fast_post(z, z + Mp, outp, fast_overlap(wc, lastSub), true);
+                __syncthreads();
+                if (!(c.dbgSkip & 4)) fast_post(z + 2 * Mp, z + 3 * Mp, outp + (size_t)C * BS, fast_overlap(wc2, BS), true);
+                __syncthreads();
+                lastSub = BS;
+                k++;
+                continue;
             }
+            fast_pre(coefB, z, z + M, false);
             __syncthreads();
-            if (!(c.dbgSkip & 2)) fftn_dif(z, 2, M, twl, tid);
-            int a = (S - ov) >> 1;
-            const float *fall = c.T.winFall + ov, *rise = c.T.winRise + ov;
-            int bits = 31 - __clz(M);
-            float *L0 = lap, *L1 = lap + H2;
-            if (!(c.dbgSkip & 4)) for (int kk = tid; kk < M / 2; kk += WG) {
-                int k1 = kk, k2 = M - 1 - kk;
-                int r1 = (int)(__brev((unsigned)k1) >> (32 - bits));
-                int r2 = (int)(__brev((unsigned)k2) >> (32 - bits));
-                float2 P1 = pre[k1], P2 = pre[k2];
-                float2 ya1 = cmulc(z0[r1], P1), ya2 = cmulc(z0[r2], P2);     // channel 0 (M)
-                float2 yb1 = cmulc(z1[r1], P1), yb2 = cmulc(z1[r2], P2);     // channel 1 (S)
-                float A0m = L0[2 * k1], A1m = L0[2 * k1 + 1], A0s = L1[2 * k1], A1s = L1[2 * k1 + 1];
-                float Bm[2] = { -ya1.y, ya2.x }, Bs[2] = { -yb1.y, yb2.x };
-                float Am[2] = { A0m, A1m }, As[2] = { A0s, A1s };
-                int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    int p = pv[q];
-                    float mLo, mHi, sLo, sHi;                                  // outputs at positions p and S-1-p
-                    if (p < a) { mLo = Am[q]; mHi = Bm[q]; sLo = As[q]; sHi = Bs[q]; }
-                    else {
-                        float cw = fall[p - a], sw = rise[p - a];
-                        float m0 = cw * Am[q], m1 = sw * Bm[q], m2 = sw * Am[q], m3 = cw * Bm[q];
-                        mLo = m0 - m1; mHi = m2 + m3;
-                        float s0 = cw * As[q], s1 = sw * Bs[q], s2 = sw * As[q], s3 = cw * Bs[q];
-                        sLo = s0 - s1; sHi = s2 + s3;
-                    }
-                    // inverse M/S (ulcDecoder.c:281-289) + interleave (:292-297)
-                    *(float2 *)(outp + 2 * p) = make_float2(mLo + sLo, mLo - sLo);
-                    *(float2 *)(outp + 2 * (S - 1 - p)) = make_float2(mHi + sHi, mHi - sHi);
-                }
-                L0[2 * k1] = ya1.x; L0[2 * k1 + 1] = -ya2.y;
-                L1[2 * k1] = yb1.x; L1[2 * k1 + 1] = -yb2.y;
-            }
+            fftn_dif(z, 2, M, twl, tid);
+            fast_post(z, z + M, outp, fast_overlap(wc, lastSub), false);
             __syncthreads();
-            lastSub = S;
+            lastSub = BS;
             continue;
         }
         for (int ch = 0; ch < C; ch++) {
@@ -535,7 +565,6 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
                 if (S == BS) break;                                 // ulcDecoder.c:242-245
                 // reversed-time centring FIFO in lap[M .. BS/2) (ulcDecoder.c:253-272)
                 int avail = (BS - S) >> 1;
-                twlValid = false;
                 for (int q = tid; q < avail; q += WG) tmpq[q] = L[H2 - 1 - q];      // queue[q], q = 0 is the oldest
                 __syncthreads();
                 for (int n = tid; n < S; n += WG)
@@ -574,7 +603,7 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
 }
 
 size_t ulcx_dec_lds_bytes(int BS, int C) {
-    return sizeof(float) * ((size_t)C * (BS / 2) + 2 * (size_t)BS + BS + BS / 2);
+    return sizeof(float) * ((size_t)C * (BS / 2) + 4 * (size_t)FFT_PADDEDS(BS, DPS) + BS / 2);
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)

@@ -331,12 +331,13 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
     int s = vb / kc, k = k0 + vb % kc;
     int blk = s * c.K + k;
     int tid = threadIdx.x;
+    const int ps = ulcx_xf_pad_shift(BS, C);          // FFT array padding (ulcx_fft.h)
     float2 *z    = (float2 *)lds;                     // 4 arrays of up to BS/2 complex: {MDCT, MDST} x {ch, ch+1}
-    float2 *twl  = (float2 *)(lds + 4 * FFT_PADDED(BS));    // BS/4 complex: this subblock's FFT twiddles (no global-memory latency inside the FFT passes)
-    int    &s_nnz = *(int *)(lds + 4 * FFT_PADDED(BS) + BS / 2);  // (inside the dynamic region: no static LDS in front of it)
+    float2 *twl  = (float2 *)(lds + 4 * FFT_PADDEDS(BS, ps));    // BS/4 complex: this subblock's FFT twiddles (no global-memory latency inside the FFT passes)
+    int    &s_nnz = *(int *)(lds + 4 * FFT_PADDEDS(BS, ps) + BS / 2);  // (inside the dynamic region: no static LDS in front of it)
     const bool ampLds = (C > 2);                             // line energies accumulate across channel pairs: only then in LDS
-    const bool twInLds = !(ampLds && (size_t)BS * 21 + 16 > ULCX_LDS_LIMIT);   // (BlockSize 8192 with C > 2: no room, twiddles from global memory)
-    float  *amp2 = twInLds ? lds + 4 * FFT_PADDED(BS) + BS / 2 + 4 : lds + 4 * FFT_PADDED(BS);   // BS/2 (takes the twiddles' place when they are not resident)
+    const bool twInLds = !(ampLds && (size_t)16 * (BS + (BS >> ps)) + (size_t)BS * 4 + 32 > ULCX_LDS_LIMIT);   // (BlockSize 8192 with C > 2: no room, twiddles from global memory)
+    float  *amp2 = twInLds ? lds + 4 * FFT_PADDEDS(BS, ps) + BS / 2 + 4 : lds + 4 * FFT_PADDEDS(BS, ps);   // BS/2 (takes the twiddles' place when they are not resident)
     float *ampO = c.amp2 + (size_t)blk * (BS / 2);
     if (tid == 0) s_nnz = 0;
     if (ampLds) for (int i = tid; i < BS / 2; i += WG) amp2[i] = 0.0f;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
             int aL = (S - ovL) >> 1, aR = (S - ov) >> 1;
             const float *rise = c.T.winRise + ovL, *fall = c.T.winFall + ov;
             const float2 *pre = c.T.pre[d];
-            const int Mp = FFT_PADDED(M);                // arrays are stored padded (ulcx_fft.h)
+            const int Mp = FFT_PADDEDS(M, ps);                // arrays are stored padded (ulcx_fft.h)
             float2 *zc0 = z, *zs0 = z + Mp, *zc1 = z + 2 * Mp, *zs1 = z + 3 * Mp;
 
             // 1. TDAC fold + DCT-IV pre-twiddle straight from the input timeline.
@@ -445,8 +446,8 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
                         float v1 = hsel ? vl : vr, v2 = hsel ? vr : vl;  // v[2n], v[S-1-2n]
                         float w1 = hsel ? wl : wr, w2 = hsel ? wr : wl;  // w[2n], w[S-1-2n]
                         float2 *zc = q ? zc1 : zc0, *zs = q ? zs1 : zs0;
-                        zc[FFT_PAD(n)] = cmulc(make_float2(v1, v2), P);       // u = v      : (u[2n], u[S-1-2n])
-                        zs[FFT_PAD(n)] = cmulc(make_float2(w2, w1), P);       // u = rev(w) : (w[S-1-2n], w[2n])
+                        zc[FFT_PADS(n, ps)] = cmulc(make_float2(v1, v2), P);       // u = v      : (u[2n], u[S-1-2n])
+                        zs[FFT_PADS(n, ps)] = cmulc(make_float2(w2, w1), P);       // u = rev(w) : (w[S-1-2n], w[2n])
                     }
                 }
             }
@@ -454,8 +455,8 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
 
             // 2. 2*nch M-point FFTs in LDS, one wave per array, no barriers in between
             if (!(c.dbgSkip & 1)) for (int a = tid >> 6; a < 2 * nch; a += WG / 64) {
-                if (twInLds) fft_wave_dif(z + a * Mp, M, twl, tid & 63);
-                else fft_wave_dif(z + a * Mp, M, c.T.tw[d], tid & 63);
+                if (twInLds) fft_wave_dif(z + a * Mp, M, twl, tid & 63, ps);
+                else fft_wave_dif(z + a * Mp, M, c.T.tw[d], tid & 63, ps);
             }
             __syncthreads();
 
@@ -474,8 +475,8 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
                     if (q >= nch) break;
                     int ch = ch0 + q;
                     float2 *zc = q ? zc1 : zc0, *zs = q ? zs1 : zs0;
-                    float2 yc1 = cmulc(zc[FFT_PAD(r1)], P1), yc2 = cmulc(zc[FFT_PAD(r2)], P2);
-                    float2 ys1 = cmulc(zs[FFT_PAD(r1)], P1), ys2 = cmulc(zs[FFT_PAD(r2)], P2);
+                    float2 yc1 = cmulc(zc[FFT_PADS(r1, ps)], P1), yc2 = cmulc(zc[FFT_PADS(r2, ps)], P2);
+                    float2 ys1 = cmulc(zs[FFT_PADS(r1, ps)], P1), ys2 = cmulc(zs[FFT_PADS(r2, ps)], P2);
                     // pair j = k1: coefficients 2k1, 2k1+1 ; pair j = k2: coefficients 2k2, 2k2+1
                     float mdct[4] = { yc1.x, -yc2.y, yc2.x, -yc1.y };
                     float mdst[4] = { ys1.x,  ys2.y, ys2.x,  ys1.y };
@@ -2076,8 +2077,10 @@ __global__ __launch_bounds__(WG) void k_state_update(UlcxEncCtx c) {
 // ---------------------------------------------------------------------------
 // 4 padded arrays of BS/2 complex + BS/4 twiddles + counter (+ BS/2 floats of line energies for C > 2)
 size_t ulcx_enc_xf_lds_bytes(int BS, int C) {
-    size_t full = (size_t)BS * 19 + 32 + (C > 2 ? (size_t)BS * 2 : 0);
-    return full <= ULCX_LDS_LIMIT ? full : (size_t)BS * 19 + 32;
+    int ps = ulcx_xf_pad_shift(BS, C);
+    size_t z = (size_t)4 * (BS + (BS >> ps)) * 4;               // four padded arrays of BS/2 complex
+    size_t full = z + (size_t)BS * 2 + 32 + (C > 2 ? (size_t)BS * 2 : 0);
+    return full <= ULCX_LDS_LIMIT ? full : z + (size_t)BS * 2 + 32;   // (C > 2 at BlockSize 8192: twiddles stay in global memory)
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)

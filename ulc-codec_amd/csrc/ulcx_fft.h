@@ -147,14 +147,16 @@ __device__ void fftn_dif(float2 *z0, int nArr, int M, const float2 *__restrict__
 // (R <= 4: 16 points, <= 3 LDS round trips for M <= 4096), so no workgroup barrier is
 // needed between passes: LDS operations of one wave execute in order.  Stage by stage
 // the butterflies, twiddle values and rounding are exactly those of fftn_dif.
-// Arrays are stored padded (one complex of padding after every 16) so that the late
-// passes, where a lane's points are adjacent, do not pile onto the same LDS banks.
+// Arrays are stored padded: one complex of padding after every 2^ps.  ps = 3 makes the 8-byte accesses of all
+// three pass shapes of a 1024-point transform (stride 64, stride 4 inside 32-point blocks, adjacent) hit 16
+// distinct slots per 16-lane group; ps = 4 leaves the middle pass 2-way conflicted but is what ships - the
+// transforms are not LDS-bandwidth-bound and the smaller arrays keep one more workgroup per CU.
 // ---------------------------------------------------------------------------
-#define FFT_PAD(p) ((p) + ((p) >> 4))
-#define FFT_PADDED(M) ((M) + ((M) >> 4))
+#define FFT_PADS(p, ps) ((p) + ((p) >> (ps)))
+#define FFT_PADDEDS(M, ps) ((M) + ((M) >> (ps)))
 
 template <int R>
-__device__ __forceinline__ void fft_wave_pass(float2 *z, int M, int h, const float2 *__restrict__ tw, int lane) {
+__device__ __forceinline__ void fft_wave_pass(float2 *z, int M, int h, const float2 *__restrict__ tw, int lane, int ps) {
     constexpr int NP = 1 << R;
     const int q = h >> (R - 1);                    // spacing of one lane's points
     const int stepA = M / (2 * h);
@@ -163,7 +165,7 @@ __device__ __forceinline__ void fft_wave_pass(float2 *z, int M, int h, const flo
         int p0 = ((gg - j) << R) + j;
         float2 x[NP];
 #pragma unroll
-        for (int m = 0; m < NP; m++) x[m] = z[FFT_PAD(p0 + m * q)];
+        for (int m = 0; m < NP; m++) x[m] = z[FFT_PADS(p0 + m * q, ps)];
 #pragma unroll
         for (int s = 0; s < R; s++) {
             constexpr int dummy = 0; (void)dummy;
@@ -179,22 +181,22 @@ __device__ __forceinline__ void fft_wave_pass(float2 *z, int M, int h, const flo
             }
         }
 #pragma unroll
-        for (int m = 0; m < NP; m++) z[FFT_PAD(p0 + m * q)] = x[m];
+        for (int m = 0; m < NP; m++) z[FFT_PADS(p0 + m * q, ps)] = x[m];
     }
 }
 
 // whole M-point transform of one padded array by one wave (M = 16 .. 4096)
-__device__ __forceinline__ void fft_wave_dif(float2 *z, int M, const float2 *__restrict__ tw, int lane) {
+__device__ __forceinline__ void fft_wave_dif(float2 *z, int M, const float2 *__restrict__ tw, int lane, int ps) {
     int rem = 31 - __clz(M);
     int h = M >> 1;
     while (rem > 0) {
         int passes = (rem + 3) >> 2;
         int r = (rem + passes - 1) / passes;       // 10 -> 4,3,3   9 -> 3,3,3   8 -> 4,4   5 -> 3,2
         switch (r) {
-            case 4: fft_wave_pass<4>(z, M, h, tw, lane); break;
-            case 3: fft_wave_pass<3>(z, M, h, tw, lane); break;
-            case 2: fft_wave_pass<2>(z, M, h, tw, lane); break;
-            default: fft_wave_pass<1>(z, M, h, tw, lane); break;
+            case 4: fft_wave_pass<4>(z, M, h, tw, lane, ps); break;
+            case 3: fft_wave_pass<3>(z, M, h, tw, lane, ps); break;
+            case 2: fft_wave_pass<2>(z, M, h, tw, lane, ps); break;
+            default: fft_wave_pass<1>(z, M, h, tw, lane, ps); break;
         }
         h >>= r; rem -= r;
     }
