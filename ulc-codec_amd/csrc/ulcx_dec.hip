@@ -17,6 +17,11 @@
 #define WG 256
 #include "ulcx_fft.h"
 #define DPS 4        // FFT array padding of k_dimdct (ulcx_fft.h; 3 measured no faster)
+// Two blocks per trip with one wave per transform (four padded arrays) needs 4.25*BS floats of LDS for z instead of
+// 2.5*BS (two arrays | dec | tmpq) and makes BlockSize 8192 stereo unsupported: measured 1.11 ms vs 1.13 ms for one block per
+// trip at 5 workgroups per CU - kept off.
+#define DIMDCT_PAIRS 0
+#define DIMDCT_ZFLOATS(BS) (DIMDCT_PAIRS ? 4 * FFT_PADDEDS(BS, DPS) : (5 * (BS)) / 2)
 
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float expand_quantizer(int q) {        // ulcDecoder.c:96-98
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
     float2 *z     = (float2 *)(lap + (size_t)C * H2);
     float  *dec   = (float *)z + BS;
     float  *tmpq  = dec + BS;
-    float2 *twl   = (float2 *)((float *)z + 4 * FFT_PADDEDS(BS, DPS));   // BS/4 complex: FFT twiddles of the full-size transform
+    float2 *twl   = (float2 *)((float *)z + DIMDCT_ZFLOATS(BS));   // BS/4 complex: FFT twiddles of the full-size transform
     float *glap = c.lap + (size_t)s * C * H2;
     for (int i = tid; i < C * H2; i += WG) lap[i] = glap[i];
     for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
         if (fast_block(wc)) {
             const int M = BS >> 1, Mp = FFT_PADDEDS(M, DPS);
             int wc2 = (k + 1 < c.K) ? c.wc[blk + 1] : 0;
-            if (fast_block(wc2)) {
+            if (DIMDCT_PAIRS && fast_block(wc2)) {
                 // ---- two consecutive blocks: four transforms, ONE WAVE PER ARRAY (16 points per lane through
                 //      four radix-2 stages in registers, no barrier between passes), then the two overlap-adds in order
                 if (!(c.dbgSkip & 1)) { fast_pre(coefB, z, z + Mp, true);
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
 }
 
 size_t ulcx_dec_lds_bytes(int BS, int C) {
-    return sizeof(float) * ((size_t)C * (BS / 2) + 4 * (size_t)FFT_PADDEDS(BS, DPS) + BS / 2);
+    return sizeof(float) * ((size_t)C * (BS / 2) + (size_t)DIMDCT_ZFLOATS(BS) + BS / 2);
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)
