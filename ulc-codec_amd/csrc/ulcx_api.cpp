@@ -159,7 +159,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     if (const char *ev = getenv("ULCX_WAVE")) c.useWave = (ev[0] != '0');
     c.dbgSkip = 0; if (const char *ev = getenv("ULCX_DBG_SKIP")) c.dbgSkip = atoi(ev);   // timing experiments only (breaks results)
     if (const char *ev = getenv("ULCX_FUSED")) if (ev[0] == '1' && (size_t)cb * 8 + cb / 8 + 2048 * (size_t)nChan + 2048 <= 150 * 1024) { c.useFused = 1; c.useWave = 0; }
-    DA(c.cbrLo, NB, true); DA(c.cbrHi, NB, true); DA(c.cbrDone, NB, true); DA(c.cbrBudget, NB, true);
+    DA(c.cbrLo, NB, true); DA(c.cbrHi, NB, true); DA(c.cbrDone, NB, true); DA(c.cbrBudget, NB, true); DA(c.cbrMaxRange, 1, true);
     DA(c.keep, NB * cb / 32, true);
     DA(c.fbList, NB, true);
     DA(c.fbCount, 4, true);

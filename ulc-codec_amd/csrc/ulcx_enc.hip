@@ -521,6 +521,7 @@ __global__ __launch_bounds__(64) void k_cplx(UlcxEncCtx c) {
     int n = c.C * c.BS;
     const float4 *p = (const float4 *)(c.coef + (size_t)blk * n);
     float cx = 0.0f, cw = 0.0f;
+    int tiny = 0;
     for (int i = 0; i < n / 4; i += 4) {                  // n is a multiple of 256: 4 x 16-byte loads in flight per step
         float4 q[4];
 #pragma unroll
@@ -532,6 +533,11 @@ __global__ __launch_bounds__(64) void k_cplx(UlcxEncCtx c) {
             cx += v.y * v.y; cw += fabsf(v.y);
             cx += v.z * v.z; cw += fabsf(v.z);
             cx += v.w * v.w; cw += fabsf(v.w);
+            // non-zero coefficients so small that the coarsest quantizer (2^31) could collapse them (Encode.c:114)
+            tiny += (fabsf(v.x) >= 0.5f * ULCX_COEF_EPS && fabsf(v.x) < 0x1.0p-29f) ? 1 : 0;
+            tiny += (fabsf(v.y) >= 0.5f * ULCX_COEF_EPS && fabsf(v.y) < 0x1.0p-29f) ? 1 : 0;
+            tiny += (fabsf(v.z) >= 0.5f * ULCX_COEF_EPS && fabsf(v.z) < 0x1.0p-29f) ? 1 : 0;
+            tiny += (fabsf(v.w) >= 0.5f * ULCX_COEF_EPS && fabsf(v.w) < 0x1.0p-29f) ? 1 : 0;
         }
     }
     if (cx != 0.0f) {
@@ -553,9 +559,23 @@ __global__ __launch_bounds__(64) void k_cplx(UlcxEncCtx c) {
         float kbps = c.p0;
         if (c.mode == ULCX_MODE_ABR) kbps = c.p0 * cx / c.p1;
         int budget = (int)((c.BS * kbps) * 1000.0f / c.rateHz);
-        c.cbrLo[blk] = 0; c.cbrHi[blk] = maxCoef;
-        c.cbrDone[blk] = (0 < maxCoef) ? 0 : 1;
-        c.nout[blk] = (0 < maxCoef) ? (int)((unsigned)(0 + maxCoef) / 2u) : 0;
+        int lo = 0, hi = maxCoef;
+        int done = (0 < maxCoef) ? 0 : 1;
+        int nOut = (0 < maxCoef) ? (int)((unsigned)(0 + maxCoef) / 2u) : 0;
+        // Probes that are over budget for certain are taken without encoding anything.
+        // A kept coefficient is coded with >= 1 nybble unless it collapses (|c|*2^q < 2.5, Encode.c:114), and inside a
+        // quantizer zone max <= 4*min with max*2^q in (12, 48] unless q is clamped at 31 (Encode.c:50-87, :218-269):
+        // only coefficients below 2.5*2^-31 can collapse.  So a probe at nOut writes more than nOut - tiny nybbles,
+        // and 4*(nOut - tiny + 1) > budget is exactly the "Size > BitBudget" branch of ulcEncoder.c:103-110.
+        while (!done && 4 * (nOut - tiny + 1) > budget) {
+            hi = nOut - 1;
+            if (!(lo < hi - 1)) { done = 1; nOut = lo; }
+            else nOut = (int)((unsigned)(lo + hi) / 2u);
+        }
+        c.cbrLo[blk] = lo; c.cbrHi[blk] = hi;
+        c.cbrDone[blk] = done;
+        if (!done) atomicMax(c.cbrMaxRange, hi - lo);      // the host sizes the probe loop from it
+        c.nout[blk] = nOut;
         c.cbrBudget[blk] = budget;
     }
     int s = blk / c.K, k = blk % c.K;
@@ -2098,6 +2118,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
     hipEvent_t evFork = aux.evFork, evJoin = aux.evJoin, evFork2 = aux.evFork2, *evWC = aux.evWC;
     const int wcPipe = (side && side2 && side3) ? aux.wcPipe : 1;
     if (aux.nXf) *aux.nXf = 0;
+    if (c.mode != ULCX_MODE_VBR) CK(hipMemsetAsync(c.cbrMaxRange, 0, sizeof(int), st));
     int NB = c.B * c.K;
     int stage = 0;
 #define MARK() do { if (ev) CK(hipEventRecord(ev[stage++], st)); } while (0)
@@ -2199,7 +2220,17 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
     // VBR: one pass.  CBR/ABR: the reference's binary search (ulcEncoder.c:98-110) needs at most
     // ceil(log2(MaxCoef))+1 probes; every block runs its own search in lock step, then one final pass.
     int probes = 0;
-    if (c.mode != ULCX_MODE_VBR) { probes = 2; int m = N; while (m > 1) { probes++; m >>= 1; } }
+    if (c.mode != ULCX_MODE_VBR) {
+        probes = 2; int m = N; while (m > 1) { probes++; m >>= 1; }
+        // The search interval halves per probe, and k_cplx has already taken the probes that are over budget for
+        // certain: read back the widest interval left (one 4-byte copy behind k_cplx; the only host wait of the
+        // call, CBR/ABR only) and run just ceil(log2(range)) + 2 lock-step passes instead of log2(N) + 2.
+        hipStream_t cs = noiseAside ? side3 : st;
+        int range = -1;
+        CK(hipMemcpyAsync(&range, c.cbrMaxRange, sizeof(int), hipMemcpyDeviceToHost, cs));
+        CK(hipStreamSynchronize(cs));
+        if (range >= 0) { int need = 2; int r = range; while (r > 1) { need++; r = (r + 1) >> 1; } if (need < probes) probes = need; }
+    }
     auto launch_select = [&](int fin) {
         int R = N / 64;
         if (c.useFused) return false;
@@ -2219,6 +2250,11 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
         capF.k = (capF.k / 2 + 63) & ~63; capF.z = (capF.z / 2 + 63) & ~63; capF.nyb = capF.nyb / 2 + 32;
     }
     bool haveFull = capF.k > capS.k;
+    // rate-control probes: k_cplx has already taken every probe that is over budget for certain, so a probe keeps at most
+    // ~BitBudget/4 coefficients per block: the retry of the small launch runs with medium capacities (2 workgroups per CU
+    // instead of 1), and what even they cannot hold goes to k_encode_units
+    WaveCaps capM = { 1024, 512, 4096 };
+    const bool haveMid = capM.k < capF.k;
     if (haveFull && (size_t)wavecaps_lds(capF) * 4 > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_encode_wave<false>, hipFuncAttributeMaxDynamicSharedMemorySize, wavecaps_lds(capF) * 4));
     auto launch_encode = [&](UlcxEncCtx cc, hipStream_t s2, int fin, bool ev0, bool bigFirst) -> int {
         const bool fb2 = (cc.fbMode == 2);                 // exact path: small grids that walk the list of owned blocks
@@ -2239,7 +2275,10 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
             if (bigFirst && haveFull) hipLaunchKernelGGL(k_encode_wave<false>, dim3(fb2 ? fbW : (nBC + 3) / 4), dim3(256), (size_t)wavecaps_lds(first) * 4, s2, cc, fin, first, 2);
             else hipLaunchKernelGGL(k_encode_wave<true>, dim3(fb2 ? fbW : (nBC + 3) / 4), dim3(256), (size_t)wavecaps_lds(first) * 4, s2, cc, fin, first, twoPhase ? 0 : 2);
             if (twoPhase)
-                hipLaunchKernelGGL(k_encode_wave<false>, dim3(fb2 ? fbW : ((nBC + 3) / 4 < 512 ? (nBC + 3) / 4 : 512)), dim3(256), (size_t)wavecaps_lds(capF) * 4, s2, cc, fin, capF, 1);
+            {
+                const WaveCaps capR = (probes > 0 && !fin && haveMid) ? capM : capF;
+                hipLaunchKernelGGL(k_encode_wave<false>, dim3(fb2 ? fbW : ((nBC + 3) / 4 < 512 ? (nBC + 3) / 4 : 512)), dim3(256), (size_t)wavecaps_lds(capR) * 4, s2, cc, fin, capR, 1);
+            }
         }
         if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
         hipLaunchKernelGGL(k_encode_units, dim3(fb2 ? fbW : (nUnits + 63) / 64), dim3(64), 0, s2, cc, fin);
@@ -2262,7 +2301,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
             int fin = (p == probes) ? 1 : 0;
             hipLaunchKernelGGL(k_keep_ranks, dim3(fbGrid), dim3(WG), 0, s2, cf, fin);
             if (resetSlow && cf.useWave) CK(hipMemsetAsync(cf.slow, 0, sizeof(int) * ((size_t)NB + 2), s2));
-            int rc = launch_encode(cf, s2, fin, false, p < 3 && probes > 0); if (rc) return rc;
+            int rc = launch_encode(cf, s2, fin, false, false); if (rc) return rc;
         }
         return ULCX_OK;
     };
@@ -2305,7 +2344,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
         }
         if (ev0) MARK();                                       // ("k_heapsel": empty interval on the main stream)
         UlcxEncCtx cm = c; cm.fbMode = c.useFused ? 0 : 1;
-        int rc = launch_encode(cm, st, fin, ev0, probes > 0 && p < 3); if (rc) return rc;
+        int rc = launch_encode(cm, st, fin, ev0, false); if (rc) return rc;
         if (async_fb) CK(hipStreamWaitEvent(st, evJoin, 0));
     }
     if (!async_fb && !c.useFused) {
