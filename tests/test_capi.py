@@ -113,3 +113,14 @@ def test_ulc_container_header_roundtrip(lib):
     assert lib.ulcx_ulc_header_parse(C.byref(g), bad, 24) == -1 and lib.ulcx_ulc_header_parse(C.byref(g), buf, 23) == -1
     lib.ulcx_ulc_rate_kbps.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
     assert lib.ulcx_ulc_rate_kbps(70632, 44100, 2048, 218) == round(70632 * 8 * 44100 / 1000 / (2048 * 218))
+
+
+def test_batched_front_end_is_built_and_prints_usage():
+    """ulc-codec_amd/ulcx-tool links against libulc_amd.so only; without arguments it prints its
+    usage and touches no GPU."""
+    exe = os.path.join(os.path.dirname(LIB), "ulcx-tool")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, env=dict(os.environ, LD_LIBRARY_PATH=os.path.dirname(LIB) + ":/opt/rocm/lib"))
+    assert r.returncode == 1 and b"ulcx-tool encode" in r.stderr
+    und = subprocess.check_output(["nm", "-u", exe]).decode()
+    assert "ulcx_encode_host" in und and "orc_" not in und

@@ -82,3 +82,39 @@ def test_reference_tools_over_libulc_amd_write_the_oracles_bytes(ch, rate, secon
     d16 = np.frombuffer(raw[-nblk * bs * ch * 2:], dtype="<i2").reshape(nblk * bs, ch)
     want16 = np.rint(np.clip(ref_pcm * np.float32(32768.0), -32768.0, 32767.0)).astype(np.int16)   # WavIO_Helper.c:57-63
     assert np.array_equal(d16, want16), "decoded PCM16 differs from the oracle's"
+
+
+TOOL = os.path.join(ROOT, "ulc-codec_amd", "ulcx-tool")
+
+
+@needs_tools
+@pytest.mark.skipif(not os.path.exists(TOOL), reason="ulc-codec_amd/ulcx-tool not built")
+@pytest.mark.parametrize("arg,fmt", [("-50", "FLOAT32"), ("64", "PCM16")])
+def test_batched_front_end_matches_the_reference_tools_file_for_file(arg, fmt, tmp_path):
+    """ulcx-tool encodes and decodes MANY files per call; every file it writes must be
+    byte-identical to what the reference's one-file-per-process tools write for the same input."""
+    rate, ch = 44100, 2
+    lens = [1.3, 0.7, 2.05, 0.31, 1.0]                       # different lengths in one batch
+    ins = []
+    for i, sec in enumerate(lens):
+        pcm = synth_pcm(20 + i, int(sec * rate), ch, rate, transient=(i & 1) == 0, seed=5)
+        p = tmp_path / f"in{i}.wav"
+        _write_wav16(p, np.clip(np.rint(pcm * 32767.0), -32768, 32767).astype(np.int16), rate)
+        ins.append(p)
+    refdir, gotdir = tmp_path / "ref", tmp_path / "got"
+    refdir.mkdir(); gotdir.mkdir()
+    _run([TOOL, "encode", str(gotdir), arg] + [str(p) for p in ins])
+    for p in ins:
+        _run([ENC, str(p), str(refdir / (p.stem + ".ulc")), arg])
+        assert open(gotdir / (p.stem + ".ulc"), "rb").read() == open(refdir / (p.stem + ".ulc"), "rb").read(), \
+            f"{p.name}: batched encode differs from ulcencodetool"
+    ulcs = [gotdir / (p.stem + ".ulc") for p in ins]
+    wavdir = tmp_path / "wav"; wavdir.mkdir()
+    _run([TOOL, "decode", str(wavdir), f"-format:{fmt}"] + [str(u) for u in ulcs])
+    for u in ulcs:
+        ref_wav = refdir / (u.stem + ".wav")
+        _run([DEC, str(u), str(ref_wav), f"-format:{fmt}"])
+        got = open(wavdir / (u.stem + ".wav"), "rb").read()
+        ref = open(ref_wav, "rb").read()
+        nbytes = struct.unpack("<I", open(u, "rb").read()[8:12])[0] * 2048 * ch * (4 if fmt == "FLOAT32" else 2)
+        assert got[-nbytes:] == ref[-nbytes:], f"{u.name}: batched decode differs from ulcdecodetool"

@@ -1,0 +1,252 @@
+/*
+ * ulcx_tool.c — batched front-end over libulc_amd.so.
+ *
+ *   ulcx-tool encode OUTDIR RATE[,AvgComplexity] [-blocksize:N] IN1.wav IN2.wav ...
+ *   ulcx-tool decode OUTDIR [-format:PCM16|FLOAT32]            IN1.ulc IN2.ulc ...
+ *
+ * What tools/ulcEncodeTool.c / tools/ulcDecodeTool.c of the reference do for ONE file per
+ * process, done for MANY files per call: every input is one stream of the batch, all streams
+ * advance K blocks per library call.  RATE follows the reference's convention
+ * (ulcEncodeTool.c:38-50): negative = VBR quality, positive = CBR kbps, "kbps,complexity" = ABR.
+ * Files written are byte-identical to the reference tools' (tests/test_gpu_dropin.py):
+ * container layout tools/ulc_Helper.h:10-20, block count ulcEncodeTool.c:93-98 (+2 blocks of
+ * coding/MDCT delay), sample conversion WavIO_Helper.c:49-63 (x 2^-15 in, lrintf(clamp(x 2^15)) out).
+ * All inputs of one call must share rate / channel count (encode) or rate / channels / block size
+ * (decode); inputs may have different lengths (shorter ones are padded with silence and trimmed
+ * to their own block count on output).
+ *
+ * WAV support is deliberately minimal: RIFF/WAVE, "fmt " PCM 16-bit or IEEE float 32-bit, one
+ * "data" chunk.  Host code is plain C over the C ABI of include/ulc_amd.h.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/ulc_amd.h"
+
+#define KBLOCKS 16                      /* blocks per stream per library call */
+
+struct wav { int rate, chan, bits, isFloat; uint32_t nFrames; long dataOffs; FILE *f; };
+
+static uint32_t rd32(const uint8_t *p) { return p[0] | p[1] << 8 | p[2] << 16 | (uint32_t)p[3] << 24; }
+static uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | p[1] << 8); }
+
+static int wav_open(struct wav *w, const char *path) {
+    uint8_t h[12], ck[8], fmt[40];
+    memset(w, 0, sizeof(*w));
+    w->f = fopen(path, "rb");
+    if (!w->f) return -1;
+    if (fread(h, 1, 12, w->f) != 12 || memcmp(h, "RIFF", 4) || memcmp(h + 8, "WAVE", 4)) return -2;
+    int haveFmt = 0;
+    for (;;) {
+        if (fread(ck, 1, 8, w->f) != 8) return -3;
+        uint32_t sz = rd32(ck + 4);
+        if (!memcmp(ck, "fmt ", 4)) {
+            uint32_t n = sz < sizeof(fmt) ? sz : (uint32_t)sizeof(fmt);
+            if (sz < 16 || fread(fmt, 1, n, w->f) != n) return -4;
+            if (sz > n) fseek(w->f, (long)(sz - n), SEEK_CUR);
+            int tag = rd16(fmt);
+            if (tag == 0xFFFE && sz >= 26) tag = rd16(fmt + 24);          /* WAVE_FORMAT_EXTENSIBLE: sub-format */
+            w->chan = rd16(fmt + 2); w->rate = (int)rd32(fmt + 4); w->bits = rd16(fmt + 14);
+            w->isFloat = (tag == 3);
+            if (!((tag == 1 && w->bits == 16) || (tag == 3 && w->bits == 32))) return -5;
+            haveFmt = 1;
+        } else if (!memcmp(ck, "data", 4)) {
+            if (!haveFmt) return -6;
+            w->dataOffs = ftell(w->f);
+            w->nFrames = sz / (uint32_t)(w->chan * w->bits / 8);
+            return 0;
+        } else fseek(w->f, (long)(sz + (sz & 1)), SEEK_CUR);
+    }
+}
+/* frames [pos, pos+n) as float, zero padded past the end (WavIO_Reader.c:115-150) */
+static void wav_read(struct wav *w, uint32_t pos, uint32_t n, float *dst, void *tmp) {
+    uint32_t have = pos < w->nFrames ? w->nFrames - pos : 0;
+    if (have > n) have = n;
+    size_t fb = (size_t)w->chan * w->bits / 8;
+    if (have) {
+        fseek(w->f, w->dataOffs + (long)(pos * fb), SEEK_SET);
+        size_t got = fread(tmp, fb, have, w->f);
+        if (got < have) have = (uint32_t)got;
+    }
+    size_t ns = (size_t)have * w->chan;
+    if (w->isFloat) memcpy(dst, tmp, ns * 4);
+    else { const int16_t *s = (const int16_t *)tmp; for (size_t i = 0; i < ns; i++) dst[i] = (float)s[i] * 0x1.0p-15f; }
+    for (size_t i = ns; i < (size_t)n * w->chan; i++) dst[i] = 0.0f;
+}
+static void wav_write_header(FILE *f, int rate, int chan, int isFloat, uint32_t nFrames) {
+    int bits = isFloat ? 32 : 16;
+    uint32_t dataBytes = nFrames * (uint32_t)(chan * bits / 8);
+    uint8_t h[44] = { 'R','I','F','F', 0,0,0,0, 'W','A','V','E', 'f','m','t',' ', 16,0,0,0 };
+    uint32_t riff = 36 + dataBytes, bps = (uint32_t)(rate * chan * bits / 8);
+    memcpy(h + 4, &riff, 4);
+    h[20] = isFloat ? 3 : 1; h[22] = (uint8_t)chan; h[23] = (uint8_t)(chan >> 8);
+    memcpy(h + 24, &rate, 4); memcpy(h + 28, &bps, 4);
+    h[32] = (uint8_t)(chan * bits / 8); h[34] = (uint8_t)bits;
+    memcpy(h + 36, "data", 4); memcpy(h + 40, &dataBytes, 4);
+    fwrite(h, 1, 44, f);
+}
+static const char *base_name(const char *p) { const char *s = strrchr(p, '/'); return s ? s + 1 : p; }
+static void out_path(char *dst, size_t n, const char *dir, const char *in, const char *ext) {
+    char stem[512];
+    snprintf(stem, sizeof(stem), "%s", base_name(in));
+    char *dot = strrchr(stem, '.'); if (dot) *dot = 0;
+    snprintf(dst, n, "%s/%s%s", dir, stem, ext);
+}
+#define DIE(...) do { fprintf(stderr, "ulcx-tool: " __VA_ARGS__); fprintf(stderr, "\n"); return 2; } while (0)
+
+static int do_encode(int argc, char **argv) {
+    if (argc < 5) DIE("usage: ulcx-tool encode OUTDIR RATE[,AvgComplexity] [-blocksize:N] IN.wav ...");
+    const char *outdir = argv[2];
+    float rate = 0.0f, avgc = 0.0f;
+    sscanf(argv[3], "%f,%f", &rate, &avgc);
+    if (rate == 0.0f || avgc < 0.0f) DIE("invalid coding rate '%s'", argv[3]);
+    int bs = 2048, a = 4;
+    if (a < argc && !strncmp(argv[a], "-blocksize:", 11)) { bs = atoi(argv[a] + 11); a++; }
+    if (bs < 256 || bs > 8192 || (bs & -bs) != bs) DIE("unsupported block size %d", bs);
+    int B = argc - a;
+    if (B < 1) DIE("no input files");
+    struct wav *w = (struct wav *)calloc((size_t)B, sizeof(*w));
+    uint32_t maxBlk = 0;
+    for (int s = 0; s < B; s++) {
+        int e = wav_open(&w[s], argv[a + s]);
+        if (e) DIE("cannot read '%s' (error %d: RIFF PCM16 / float32 only)", argv[a + s], e);
+        if (w[s].rate != w[0].rate || w[s].chan != w[0].chan) DIE("'%s': all inputs of one call must share rate and channel count", argv[a + s]);
+        uint32_t nb = (w[s].nFrames + (uint32_t)bs - 1) / (uint32_t)bs + 2;      /* ulcEncodeTool.c:93-98 */
+        if (nb > maxBlk) maxBlk = nb;
+    }
+    const int C = w[0].chan, hz = w[0].rate;
+    int mode = rate < 0.0f ? ULCX_MODE_VBR : (avgc > 0.0f ? ULCX_MODE_ABR : ULCX_MODE_CBR);
+    float p0 = rate < 0.0f ? -rate : rate;
+    ulcx_encoder *enc = NULL;
+    if (ulcx_encoder_create(&enc, 0, B, C, bs, hz, KBLOCKS) != ULCX_OK) DIE("encoder: %s", ulcx_last_error());
+    const int slot = ulcx_encoder_slot_bytes(enc);
+    size_t frame = (size_t)bs * C;
+    float *pcm = (float *)malloc(sizeof(float) * (size_t)B * KBLOCKS * frame);
+    uint8_t *out = (uint8_t *)malloc((size_t)B * KBLOCKS * slot);
+    int32_t *bits = (int32_t *)malloc(sizeof(int32_t) * (size_t)B * KBLOCKS);
+    void *tmp = malloc(frame * 4 * KBLOCKS);
+    FILE **fo = (FILE **)calloc((size_t)B, sizeof(FILE *));
+    uint64_t *total = (uint64_t *)calloc((size_t)B, sizeof(uint64_t));
+    uint32_t *maxb = (uint32_t *)calloc((size_t)B, sizeof(uint32_t));
+    char path[1024];
+    for (int s = 0; s < B; s++) {
+        out_path(path, sizeof(path), outdir, argv[a + s], ".ulc");
+        fo[s] = fopen(path, "wb");
+        if (!fo[s]) DIE("cannot create '%s'", path);
+        fseek(fo[s], 24, SEEK_SET);
+    }
+    for (uint32_t k0 = 0; k0 < maxBlk; k0 += KBLOCKS) {
+        int K = (maxBlk - k0 < KBLOCKS) ? (int)(maxBlk - k0) : KBLOCKS;
+        for (int s = 0; s < B; s++)
+            wav_read(&w[s], k0 * (uint32_t)bs, (uint32_t)(K * bs), pcm + (size_t)s * K * frame, tmp);
+        if (ulcx_encode_host(enc, mode, p0, avgc, pcm, K, out, bits, NULL, NULL) != ULCX_OK) DIE("encode: %s", ulcx_last_error());
+        for (int s = 0; s < B; s++) {
+            uint32_t nb = (w[s].nFrames + (uint32_t)bs - 1) / (uint32_t)bs + 2;
+            for (int k = 0; k < K && k0 + (uint32_t)k < nb; k++) {
+                uint32_t sz = (uint32_t)(bits[s * K + k] + 7) / 8u;
+                fwrite(out + ((size_t)s * K + k) * slot, 1, sz, fo[s]);               /* ulcEncodeTool.c:160-169 */
+                total[s] += sz; if (sz > maxb[s]) maxb[s] = sz;
+            }
+        }
+    }
+    for (int s = 0; s < B; s++) {
+        uint32_t nb = (w[s].nFrames + (uint32_t)bs - 1) / (uint32_t)bs + 2;
+        ulcx_file_header h;
+        h.Magic = ULCX_ULC_MAGIC; h.BlockSize = (uint16_t)bs; h.MaxBlockSize = (uint16_t)maxb[s]; h.nBlocks = nb;
+        h.RateHz = (uint32_t)hz; h.nChan = (uint16_t)C; h.StreamOffs = 24;
+        h.RateKbps = (uint16_t)ulcx_ulc_rate_kbps(total[s], (uint32_t)hz, (uint32_t)bs, nb);
+        uint8_t hb[24]; ulcx_ulc_header_pack(hb, &h);
+        fseek(fo[s], 0, SEEK_SET); fwrite(hb, 1, 24, fo[s]); fclose(fo[s]); fclose(w[s].f);
+        printf("%s: %u blocks, %.2f KiB, %u kbps\n", base_name(argv[a + s]), nb, total[s] / 1024.0, h.RateKbps);
+    }
+    ulcx_encoder_destroy(enc);
+    free(pcm); free(out); free(bits); free(tmp); free(fo); free(total); free(maxb); free(w);
+    return 0;
+}
+
+static int do_decode(int argc, char **argv) {
+    if (argc < 4) DIE("usage: ulcx-tool decode OUTDIR [-format:PCM16|FLOAT32] IN.ulc ...");
+    const char *outdir = argv[2];
+    int a = 3, isFloat = 0;
+    if (!strncmp(argv[a], "-format:", 8)) {
+        const char *f = argv[a] + 8;
+        if (!strcmp(f, "FLOAT32") || !strcmp(f, "float32")) isFloat = 1;
+        else if (strcmp(f, "PCM16") && strcmp(f, "pcm16")) DIE("unsupported output format '%s'", f);
+        a++;
+    }
+    int B = argc - a;
+    if (B < 1) DIE("no input files");
+    ulcx_file_header *h = (ulcx_file_header *)calloc((size_t)B, sizeof(*h));
+    uint8_t **pay = (uint8_t **)calloc((size_t)B, sizeof(uint8_t *));
+    int32_t *payBytes = (int32_t *)calloc((size_t)B, sizeof(int32_t));
+    long long stride = 0;
+    uint32_t maxBlk = 0;
+    for (int s = 0; s < B; s++) {
+        FILE *f = fopen(argv[a + s], "rb");
+        if (!f) DIE("cannot open '%s'", argv[a + s]);
+        fseek(f, 0, SEEK_END); long len = ftell(f); fseek(f, 0, SEEK_SET);
+        uint8_t *buf = (uint8_t *)malloc((size_t)len + 16);
+        if (fread(buf, 1, (size_t)len, f) != (size_t)len) DIE("short read on '%s'", argv[a + s]);
+        fclose(f);
+        if (ulcx_ulc_header_parse(&h[s], buf, (size_t)len)) DIE("'%s' is not a ULC2 container", argv[a + s]);
+        if (h[s].BlockSize != h[0].BlockSize || h[s].nChan != h[0].nChan || h[s].RateHz != h[0].RateHz)
+            DIE("'%s': all inputs of one call must share block size, channels and rate", argv[a + s]);
+        pay[s] = buf; payBytes[s] = (int32_t)(len - (long)h[s].StreamOffs);
+        if (payBytes[s] + 8 > stride) stride = payBytes[s] + 8;
+        if (h[s].nBlocks > maxBlk) maxBlk = h[s].nBlocks;
+    }
+    const int bs = h[0].BlockSize, C = h[0].nChan;
+    stride = (stride + 15) & ~15LL;
+    uint8_t *payload = (uint8_t *)calloc((size_t)B, (size_t)stride);
+    for (int s = 0; s < B; s++) { memcpy(payload + (size_t)s * stride, pay[s] + h[s].StreamOffs, (size_t)payBytes[s]); free(pay[s]); }
+    ulcx_decoder *dec = NULL;
+    if (ulcx_decoder_create(&dec, 0, B, C, bs, KBLOCKS) != ULCX_OK) DIE("decoder: %s", ulcx_last_error());
+    size_t frame = (size_t)bs * C;
+    float *pcm = (float *)malloc(sizeof(float) * (size_t)B * KBLOCKS * frame);
+    int32_t *bits = (int32_t *)malloc(sizeof(int32_t) * (size_t)B * KBLOCKS);
+    int16_t *tmp = (int16_t *)malloc(sizeof(int16_t) * frame);
+    FILE **fo = (FILE **)calloc((size_t)B, sizeof(FILE *));
+    char path[1024];
+    for (int s = 0; s < B; s++) {
+        out_path(path, sizeof(path), outdir, argv[a + s], ".wav");
+        fo[s] = fopen(path, "wb");
+        if (!fo[s]) DIE("cannot create '%s'", path);
+        wav_write_header(fo[s], (int)h[s].RateHz, C, isFloat, h[s].nBlocks * (uint32_t)bs);
+    }
+    int rcAll = 0;
+    for (uint32_t k0 = 0; k0 < maxBlk; k0 += KBLOCKS) {
+        int K = (maxBlk - k0 < KBLOCKS) ? (int)(maxBlk - k0) : KBLOCKS;
+        if (ulcx_decode_packed_host(dec, payload, stride, payBytes, K, pcm, bits) != ULCX_OK) DIE("decode: %s", ulcx_last_error());
+        for (int s = 0; s < B; s++)
+            for (int k = 0; k < K && k0 + (uint32_t)k < h[s].nBlocks; k++) {
+                if (!bits[s * K + k]) { fprintf(stderr, "ulcx-tool: %s: corrupted stream at block %u\n", argv[a + s], k0 + (uint32_t)k); rcAll = 1; }
+                const float *src = pcm + ((size_t)s * K + k) * frame;
+                if (isFloat) fwrite(src, 4, frame, fo[s]);
+                else {
+                    for (size_t i = 0; i < frame; i++) {                                  /* WavIO_Helper.c:57-63 */
+                        float v = src[i] * 0x1.0p+15f;
+                        v = v < -32768.0f ? -32768.0f : (v > 32767.0f ? 32767.0f : v);
+                        tmp[i] = (int16_t)lrintf(v);
+                    }
+                    fwrite(tmp, 2, frame, fo[s]);
+                }
+            }
+    }
+    for (int s = 0; s < B; s++) fclose(fo[s]);
+    ulcx_decoder_destroy(dec);
+    free(payload); free(pcm); free(bits); free(tmp); free(fo); free(h); free(pay); free(payBytes);
+    return rcAll;
+}
+
+int main(int argc, char **argv) {
+    if (argc >= 2 && !strcmp(argv[1], "encode")) return do_encode(argc, argv);
+    if (argc >= 2 && !strcmp(argv[1], "decode")) return do_decode(argc, argv);
+    fprintf(stderr,
+            "ulcx-tool - batched ulc-codec front-end over libulc_amd.so (MI355X)\n"
+            "  ulcx-tool encode OUTDIR RATE[,AvgComplexity] [-blocksize:N] IN1.wav IN2.wav ...\n"
+            "      RATE < 0: VBR quality; RATE > 0: CBR kbps; RATE,AvgComplexity: ABR  (as ulcencodetool)\n"
+            "  ulcx-tool decode OUTDIR [-format:PCM16|FLOAT32] IN1.ulc IN2.ulc ...\n");
+    return 1;
+}
