@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (GPU vs oracle): geometry, rate-control mode, quality, signal type, call pattern.
+Not part of the test suite (minutes of oracle time); run on the GPU box:  python tools/fuzz_parity.py [seconds]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ulc-codec_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ulc_amd
+from ulc_testlib import synth_pcm, oracle_encode_debug, oracle_decode_stream
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0 = time.time(); n = 0; nblk = 0
+while time.time() - t0 < budget:
+    bs = int(rng.choice([256, 512, 1024, 2048, 2048, 4096, 8192]))
+    ch = int(rng.choice([1, 2, 2, 2, 3]))
+    rate = int(rng.choice([22050, 32000, 44100, 48000, 96000]))
+    B = int(rng.integers(1, 9)); K = int(rng.integers(1, 7)); calls = int(rng.integers(1, 4))
+    mode = int(rng.choice([0, 0, 1, 2]))
+    p0 = float(rng.uniform(5, 100)) if mode == 0 else float(rng.uniform(16, 192))
+    p1 = float(rng.uniform(0.2, 0.9)) if mode == 2 else 0.0
+    transient = bool(rng.integers(0, 2))
+    amp = float(rng.choice([1.0, 1.0, 0.05, 1e-4, 0.0]))           # loud, quiet, near-silent, digital silence
+    seed = int(rng.integers(0, 1 << 30))
+    pcm = np.stack([synth_pcm(s, calls * K * bs, ch, rate, transient=transient, seed=seed) for s in range(B)]) * np.float32(amp)
+    tag = f"bs={bs} ch={ch} rate={rate} B={B} K={K} calls={calls} mode={mode} p0={p0:.2f} p1={p1:.2f} transient={transient} amp={amp} seed={seed}"
+    slot = 2 * ch * bs + 16
+    enc = ulc_amd.BatchEncoder(B, ch, bs, rate, K)
+    try:
+        dec = ulc_amd.BatchDecoder(B, ch, bs, K)
+    except Exception:
+        dec = None
+    outs = []
+    for c in range(calls):
+        outs.append(enc.encode(pcm[:, c * K * bs:(c + 1) * K * bs], mode, p0, p1))
+    out = np.concatenate([o[0] for o in outs], axis=1); bits = np.concatenate([o[1] for o in outs], axis=1)
+    wc = np.concatenate([o[2] for o in outs], axis=1); cplx = np.concatenate([o[3] for o in outs], axis=1)
+    for s in range(B):
+        ref = oracle_encode_debug(pcm[s], bs, rate, mode, p0, p1, slot=slot)
+        assert np.array_equal(wc[s], ref["wc"]), f"{tag}: stream {s} WindowCtrl"
+        assert cplx[s].tobytes() == ref["cplx"].tobytes(), f"{tag}: stream {s} BlockComplexity"
+        assert np.array_equal(bits[s], ref["bits"]), f"{tag}: stream {s} sizes {bits[s]} vs {ref['bits']}"
+        for k in range(calls * K):
+            nb = bits[s, k] // 8
+            assert np.array_equal(out[s, k, :nb], ref["out"][k, :nb]), f"{tag}: stream {s} block {k} bytes"
+    if dec is not None:
+        got = np.concatenate([dec.decode(out[:, c * K:(c + 1) * K])[0] for c in range(calls)], axis=1)
+        for s in range(B):
+            rc, rp, rb = oracle_decode_stream(out[s], ch, bs)
+            assert rc == 0 and np.array_equal(got[s].view(np.uint32), rp.view(np.uint32)), f"{tag}: stream {s} decoded PCM"
+        dec.close()
+    enc.close()
+    n += 1; nblk += B * K * calls
+print(f"fuzz_parity: {n} random configurations, {nblk} blocks, all bit-exact (encode stream/WindowCtrl/complexity, decode PCM) in {time.time()-t0:.0f} s")
