@@ -2199,7 +2199,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
         CK(hipEventRecord(evNoise, side2));
     }
     // k_cplx (one lane per block, a long serial walk: ~1000 waves) only feeds the selection: beside k_pbark/k_mask
-    hipEvent_t evCplx = evWC[3 + 3 * ULCX_WC_MAXCH];
+    hipEvent_t evCplx = evWC[3 + 3 * ULCX_WC_MAXCH], evTail0 = evWC[4 + 3 * ULCX_WC_MAXCH], evTail1 = evWC[5 + 3 * ULCX_WC_MAXCH];
     if (noiseAside) {
         CK(hipStreamWaitEvent(side3, evN0, 0));
         hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, side3, c);
@@ -2262,9 +2262,19 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
         if (cc.useGapSums) {
             size_t glds = (size_t)N * 4 + N / 8 + 8 * E_GAPCAP + 16;
             if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+            // the two speculative-sum kernels are independent and both latency-bound: on the main path k_tailsums
+            // runs on a side stream beside k_gapsums
+            const bool tailAside = !fb2 && side2 != nullptr && s2 == st;
+            if (tailAside) {
+                CK(hipEventRecord(evTail0, s2));
+                CK(hipStreamWaitEvent(side2, evTail0, 0));
+                hipLaunchKernelGGL(k_tailsums, dim3((nUnits * 8 + 63) / 64), dim3(64), 0, side2, cc, fin);
+                CK(hipEventRecord(evTail1, side2));
+            }
             hipLaunchKernelGGL(k_gapsums, dim3(fb2 ? fbW : NB), dim3(WG), glds, s2, cc, fin);
             if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
-            hipLaunchKernelGGL(k_tailsums, dim3(fb2 ? fbW : (nUnits * 8 + 63) / 64), dim3(64), 0, s2, cc, fin);
+            if (tailAside) CK(hipStreamWaitEvent(s2, evTail1, 0));
+            else hipLaunchKernelGGL(k_tailsums, dim3(fb2 ? fbW : (nUnits * 8 + 63) / 64), dim3(64), 0, s2, cc, fin);
             if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
         } else if (ev0 && ev) { CK(hipEventRecord(ev[stage++], s2)); CK(hipEventRecord(ev[stage++], s2)); }
         if (cc.useWave && !cc.useFused) {
