@@ -2192,15 +2192,12 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
     // transform only: it runs on a side stream beside the psychoacoustics / selection chain.
     const bool noiseAside = (side2 != nullptr && side3 != nullptr);
     hipEvent_t evN0 = evWC[1 + 3 * ULCX_WC_MAXCH], evNoise = evWC[2 + 3 * ULCX_WC_MAXCH];
-    if (noiseAside) {
-        CK(hipEventRecord(evN0, st));
-        CK(hipStreamWaitEvent(side2, evN0, 0));
-        int rcn = launch_noise(side2, false); if (rcn) return rcn;
-        CK(hipEventRecord(evNoise, side2));
-    }
-    // k_cplx (one lane per block, a long serial walk: ~1000 waves) only feeds the selection: beside k_pbark/k_mask
+    // Three lane-serial latency-bound kernels (k_pbark, k_cplx, k_nbark) fill the machine's wave slots by themselves:
+    // running all three at once only makes each slower.  k_cplx (~1000 waves) runs beside k_pbark; the noise chain
+    // starts behind k_pbark and runs beside the throughput-bound k_mask / k_select.
     hipEvent_t evCplx = evWC[3 + 3 * ULCX_WC_MAXCH], evTail0 = evWC[4 + 3 * ULCX_WC_MAXCH], evTail1 = evWC[5 + 3 * ULCX_WC_MAXCH];
     if (noiseAside) {
+        CK(hipEventRecord(evN0, st));
         CK(hipStreamWaitEvent(side3, evN0, 0));
         hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, side3, c);
         CK(hipEventRecord(evCplx, side3));
@@ -2208,6 +2205,12 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
     } else { hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c);                         MARK(); }
     {
         hipLaunchKernelGGL(k_pbark, dim3((NB * 4 + 63) / 64), dim3(64), 0, st, c);                         MARK();
+        if (noiseAside) {
+            CK(hipEventRecord(evTail0, st));                       // (reused: behind k_pbark)
+            CK(hipStreamWaitEvent(side2, evTail0, 0));
+            int rcn = launch_noise(side2, false); if (rcn) return rcn;
+            CK(hipEventRecord(evNoise, side2));
+        }
         hipLaunchKernelGGL(k_mask, dim3(NB), dim3(WG), 0, st, c);                                          MARK();
     }
     if (noiseAside) CK(hipStreamWaitEvent(st, evCplx, 0));
