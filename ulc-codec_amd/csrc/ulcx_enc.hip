@@ -2195,13 +2195,16 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
     // Three lane-serial latency-bound kernels (k_pbark, k_cplx, k_nbark) fill the machine's wave slots by themselves:
     // running all three at once only makes each slower.  k_cplx (~1000 waves) runs beside k_pbark; the noise chain
     // starts behind k_pbark and runs beside the throughput-bound k_mask / k_select.
-    hipEvent_t evCplx = evWC[3 + 3 * ULCX_WC_MAXCH], evTail0 = evWC[4 + 3 * ULCX_WC_MAXCH], evTail1 = evWC[5 + 3 * ULCX_WC_MAXCH];
+    hipEvent_t evCplx = evWC[3 + 3 * ULCX_WC_MAXCH], evTail0 = evWC[4 + 3 * ULCX_WC_MAXCH], evTail1 = evWC[5 + 3 * ULCX_WC_MAXCH], evState = evWC[6 + 3 * ULCX_WC_MAXCH];
     if (noiseAside) {
         CK(hipEventRecord(evN0, st));
         CK(hipStreamWaitEvent(side3, evN0, 0));
         hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, side3, c);
         CK(hipEventRecord(evCplx, side3));
         MARK();
+        // the state for the next call only needs the transform to be done with the history: off the main stream
+        hipLaunchKernelGGL(k_state_update, dim3(c.B), dim3(WG), 0, side3, c);
+        CK(hipEventRecord(evState, side3));
     } else { hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c);                         MARK(); }
     {
         hipLaunchKernelGGL(k_pbark, dim3((NB * 4 + 63) / 64), dim3(64), 0, st, c);                         MARK();
@@ -2367,7 +2370,8 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
         }
     }
     MARK();   // cbr_probe_passes (empty interval for VBR)
-    hipLaunchKernelGGL(k_state_update, dim3(c.B), dim3(WG), 0, st, c);                                     MARK();
+    if (noiseAside) { CK(hipStreamWaitEvent(st, evState, 0));                                               MARK(); }
+    else { hipLaunchKernelGGL(k_state_update, dim3(c.B), dim3(WG), 0, st, c);                              MARK(); }
     CK(hipGetLastError());
     return ULCX_OK;
 }

@@ -146,7 +146,7 @@ extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES_REPORTED];
 struct UlcxEncAux {
     hipStream_t side, side2, side3;      // NULL: everything on the caller's stream
     hipEvent_t evFork, evJoin, evFork2;  // exact-path fork/join
-    hipEvent_t *evWC;                    // [6 + 3*ULCX_WC_MAXCH] window-control pipeline; then noise-spectrum fork/join, k_cplx join, k_tailsums fork/join
+    hipEvent_t *evWC;                    // [7 + 3*ULCX_WC_MAXCH] window-control pipeline; then noise-spectrum fork/join, k_cplx join, k_tailsums fork/join, k_state_update join
     hipEvent_t *evXf;                    // [2*ULCX_WC_MAXCH] timing pairs around each transform chunk (used when ev != NULL)
     int wcPipe;                          // chunks of blocks pipelined between window control and transform; 1 = off
     int *nXf;                            // out: transform chunk launches this call
