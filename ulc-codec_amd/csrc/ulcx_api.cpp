@@ -22,7 +22,7 @@ struct ulcx_encoder {
     bool evOk, evRecorded;
     int lastK;
     hipStream_t side; hipEvent_t evFork, evJoin, evFork2; bool sideOk;
-    hipEvent_t evWC[7 + 3 * ULCX_WC_MAXCH]; int wcPipe; hipStream_t side2, side3; hipEvent_t evXf[2 * ULCX_WC_MAXCH]; int nXf;      // window-control / transform chunk pipeline (ULCX_WC_PIPE chunks, default 4)
+    hipEvent_t evWC[7 + 3 * ULCX_WC_MAXCH]; int wcPipe; hipStream_t side2, side3; hipEvent_t evXf[2 * ULCX_XF_MAXCH]; int nXf;      // window-control / transform chunk pipeline (ULCX_WC_PIPE chunks, default 4)
     bool keysFinal;
     // staging for the host-pointer API
     float *d_pcm; uint8_t *d_out; int32_t *d_bits, *d_wc; float *d_cplx;
@@ -187,7 +187,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
             }
         }
         e->wcPipe = e->sideOk ? 5 : 1;
-        if (const char *pv = getenv("ULCX_WC_PIPE")) { int n = atoi(pv); if (n >= 1 && n <= ULCX_WC_MAXCH && n != 2 && (n == 1 || e->sideOk)) e->wcPipe = n; }
+        if (const char *pv = getenv("ULCX_WC_PIPE")) { int n = atoi(pv); if (n >= 1 && n <= ULCX_XF_MAXCH && n != 2 && (n == 1 || e->sideOk)) e->wcPipe = n; }
     }
     DA(c.isFb, NB, true);
     DA(c.ownSlot, NB, true);
@@ -222,6 +222,7 @@ extern "C" int ulcx_encode_dev(ulcx_encoder *e, int mode, float p0, float p1, co
     aux.side = e->sideOk ? e->side : nullptr; aux.side2 = e->sideOk ? e->side2 : nullptr; aux.side3 = e->sideOk ? e->side3 : nullptr;
     aux.evFork = e->evFork; aux.evJoin = e->evJoin; aux.evFork2 = e->evFork2; aux.evWC = e->evWC; aux.evXf = e->evXf;
     aux.wcPipe = (nBlocks >= 2 * e->wcPipe) ? e->wcPipe : 1; aux.nXf = &e->nXf;
+    aux.wcSteps = 0; if (const char *sv = getenv("ULCX_WC_STEPS")) aux.wcSteps = atoi(sv);   // 0: the transform's chunks
     int rc = ulcx_enc_launch(c, (hipStream_t)hipStream, e->ev, aux);
     e->evRecorded = (rc == ULCX_OK);
     e->lastK = nBlocks;

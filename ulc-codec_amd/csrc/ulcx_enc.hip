@@ -2150,31 +2150,42 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
             // side2: backward_j behind forward_j;  side3: integrate_j, decide_j behind backward_j;
             // main: xf_j behind decide_j.  The first chunk is a single block so the transform starts early.
             hipEvent_t ev0 = evWC[0], *evF = evWC + 1, *evB = evWC + 1 + ULCX_WC_MAXCH, *evD = evWC + 1 + 2 * ULCX_WC_MAXCH;
-            int cut[ULCX_WC_MAXCH + 1];
+            // The window-control kernels advance in the same chunks as the transform (first chunk = one block, then
+            // quarters) unless ULCX_WC_STEPS asks for uniform finer steps: measured, finer steps lose - every
+            // k_wc_backward launch costs a full 2048-step chain whatever its size, and they queue on one stream.
+            int nW = aux.wcSteps;
+            if (nW > ULCX_WC_MAXCH) nW = ULCX_WC_MAXCH;
+            if (nW > c.K) nW = c.K;
+            const bool sameCuts = nW < 1;
+            if (sameCuts) nW = nCh;
+            int cut[ULCX_XF_MAXCH + 1];
             cut[0] = 0; cut[1] = 1;
             for (int j = 2; j <= nCh; j++) cut[j] = 1 + (c.K - 1) * (j - 1) / (nCh - 1);
             CK(hipEventRecord(ev0, st));
             CK(hipStreamWaitEvent(side, ev0, 0));
-            for (int j = 0; j < nCh; j++) {
-                int k0 = cut[j], k1 = cut[j + 1], kc = k1 - k0;
+            int jx = 0;                                        // next transform chunk to enqueue
+            for (int w = 0; w < nW; w++) {
+                int k0 = sameCuts ? cut[w] : (int)((long long)c.K * w / nW), k1 = sameCuts ? cut[w + 1] : (int)((long long)c.K * (w + 1) / nW), kc = k1 - k0;
                 hipLaunchKernelGGL(k_wc_energy, dim3((unsigned)(SG * ((kc * c.BS) / 64))), dim3(WG), 0, side, c, k0, k1);
                 hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, side, c, k0, k1);
-                CK(hipEventRecord(evF[j], side));
-                CK(hipStreamWaitEvent(side2, evF[j], 0));
+                CK(hipEventRecord(evF[w], side));
+                CK(hipStreamWaitEvent(side2, evF[w], 0));
                 hipLaunchKernelGGL(k_wc_backward, dim3(SG * kc), dim3(64), 0, side2, c, k0, k1);
-                CK(hipEventRecord(evB[j], side2));
-                CK(hipStreamWaitEvent(side3, evB[j], 0));
+                CK(hipEventRecord(evB[w], side2));
+                CK(hipStreamWaitEvent(side3, evB[w], 0));
                 hipLaunchKernelGGL(k_wc_integrate, dim3((c.B + 63) / 64), dim3(64), 0, side3, c, k0, k1);
                 hipLaunchKernelGGL(k_wc_decide, dim3((c.B * kc + 63) / 64), dim3(64), 0, side3, c, k0, k1);
-                CK(hipEventRecord(evD[j], side3));
-            }
-            for (int j = 0; j < nCh; j++) {
-                int k0 = cut[j], k1 = cut[j + 1];
-                int nbk = c.B * (k1 - k0);
-                CK(hipStreamWaitEvent(st, evD[j], 0));
-                if (ev) CK(hipEventRecord(aux.evXf[2 * j], st));
-                hipLaunchKernelGGL(k_xf, dim3(((nbk + 7) / 8) * 8), dim3(WG), lds, st, c, k0, k1);
-                if (ev) CK(hipEventRecord(aux.evXf[2 * j + 1], st));
+                CK(hipEventRecord(evD[w], side3));
+                // transform chunks whose last block is now decided
+                while (jx < nCh && cut[jx + 1] <= k1) {
+                    int x0 = cut[jx], x1 = cut[jx + 1];
+                    int nbk = c.B * (x1 - x0);
+                    CK(hipStreamWaitEvent(st, evD[w], 0));
+                    if (ev) CK(hipEventRecord(aux.evXf[2 * jx], st));
+                    hipLaunchKernelGGL(k_xf, dim3(((nbk + 7) / 8) * 8), dim3(WG), lds, st, c, x0, x1);
+                    if (ev) CK(hipEventRecord(aux.evXf[2 * jx + 1], st));
+                    jx++;
+                }
             }
             if (aux.nXf) *aux.nXf = nCh;
             MARK();

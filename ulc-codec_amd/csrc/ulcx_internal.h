@@ -140,15 +140,17 @@ void ulcx_set_error(const char *fmt, ...);
 #define ULCX_ENC_STAGES_REPORTED (ULCX_ENC_STAGES + 1)   // + "wc_pipeline_exposed" (computed, not an event interval)
 extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES_REPORTED];
 #define ULCX_DEC_STAGES 4
-#define ULCX_WC_MAXCH 8
+#define ULCX_WC_MAXCH 32    // fine steps of the window-control pipeline per call
+#define ULCX_XF_MAXCH 8     // coarse transform chunks per call
 #define ULCX_LDS_LIMIT (160 * 1024)     // LDS per workgroup on gfx950
 // streams and events the encoder launch uses beside the caller's stream
 struct UlcxEncAux {
     hipStream_t side, side2, side3;      // NULL: everything on the caller's stream
     hipEvent_t evFork, evJoin, evFork2;  // exact-path fork/join
     hipEvent_t *evWC;                    // [7 + 3*ULCX_WC_MAXCH] window-control pipeline; then noise-spectrum fork/join, k_cplx join, k_tailsums fork/join, k_state_update join
-    hipEvent_t *evXf;                    // [2*ULCX_WC_MAXCH] timing pairs around each transform chunk (used when ev != NULL)
+    hipEvent_t *evXf;                    // [2*ULCX_XF_MAXCH] timing pairs around each transform chunk (used when ev != NULL)
     int wcPipe;                          // chunks of blocks pipelined between window control and transform; 1 = off
+    int wcSteps;                         // fine steps of the window-control kernels per call (ULCX_WC_STEPS)
     int *nXf;                            // out: transform chunk launches this call
 };
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, const UlcxEncAux &aux);
