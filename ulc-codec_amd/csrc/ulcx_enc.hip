@@ -1055,6 +1055,7 @@ __global__ __launch_bounds__(WG) void k_keep_ranks(UlcxEncCtx c, int finalPass) 
         if (!finalPass && c.cbrDone[blk]) continue;
         const int *rank = c.rankBuf + (size_t)(idx - c.fbLo) * N;
         uint32_t *keep = c.keep + (size_t)blk * (N / 32);
+        if (threadIdx.x == 0) c.slow[blk] = 0;             // wave-encoder give-up bits of this pass (the main path clears its own)
         int kSel = c.nout[blk];
         for (int i = threadIdx.x; i < N; i += WG) {
             unsigned long long m = __ballot(rank[i] < kSel);
@@ -2322,12 +2323,12 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
         else hipLaunchKernelGGL(k_heapsel, dim3(fbGrid), dim3(64), heapLds, s2, cf, ldsEntries);
         return ULCX_OK;
     };
-    auto exact_passes = [&](hipStream_t s2, int lo, bool resetSlow) -> int {
+    auto exact_passes = [&](hipStream_t s2, int lo) -> int {
         UlcxEncCtx cf = c; cf.fbMode = 2; cf.fbLo = lo; cf.fbHi = lo + c.rankSlots;
         for (int p = 0; p <= probes; p++) {
             int fin = (p == probes) ? 1 : 0;
             hipLaunchKernelGGL(k_keep_ranks, dim3(fbGrid), dim3(WG), 0, s2, cf, fin);
-            if (resetSlow && cf.useWave) CK(hipMemsetAsync(cf.slow, 0, sizeof(int) * ((size_t)NB + 2), s2));
+            if (cf.useWave) CK(hipMemsetAsync(cf.slow + NB + 1, 0, sizeof(int), s2));      // its own retry-queue counter
             int rc = launch_encode(cf, s2, fin, false, false); if (rc) return rc;
         }
         return ULCX_OK;
@@ -2336,10 +2337,13 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
     CK(hipMemsetAsync(c.isFb, 0, sizeof(int) * (size_t)NB, st));
     // VBR (one pass): the exact path runs on a side stream next to the encode pass of all other blocks.
     // CBR/ABR: it runs after the lock-step passes (a block joins it at whatever pass it first straddles).
-    bool async_fb = (side != nullptr) && (c.mode == ULCX_MODE_VBR) && !c.useFused;
+    // The exact path forks at the FINAL pass (a block can first straddle there) and runs beside the main path's
+    // final encode: VBR has only that pass; CBR/ABR blocks replay their whole search from the ranking there.
+    const bool canFork = (side != nullptr) && !c.useFused;
     for (int p = 0; p <= probes; p++) {
         int fin = (p == probes) ? 1 : 0;
         bool ev0 = (p == 0);
+        const bool async_fb = canFork && fin;
         if (c.useWave && !c.useFused) CK(hipMemsetAsync(c.slow, 0, sizeof(int) * ((size_t)NB + 2), st));
         if (c.useFused) {
             int stageBytes = 2048 * c.C;
@@ -2362,10 +2366,10 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
         if (async_fb) {
             CK(hipEventRecord(evFork2, st));                    // the exact path's encode pass needs the noise pairs too
             CK(hipStreamWaitEvent(side, evFork2, 0));
-            int rc = exact_passes(side, 0, false); if (rc) return rc;
+            int rc = exact_passes(side, 0); if (rc) return rc;
             for (int lo = c.rankSlots; lo < NB; lo += c.rankSlots) {
                 rc = exact_sort(side, lo); if (rc) return rc;
-                rc = exact_passes(side, lo, false); if (rc) return rc;
+                rc = exact_passes(side, lo); if (rc) return rc;
             }
             CK(hipEventRecord(evJoin, side));
         }
@@ -2374,10 +2378,10 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
         int rc = launch_encode(cm, st, fin, ev0, false); if (rc) return rc;
         if (async_fb) CK(hipStreamWaitEvent(st, evJoin, 0));
     }
-    if (!async_fb && !c.useFused) {
+    if (!canFork && !c.useFused) {
         for (int lo = 0; lo < NB; lo += c.rankSlots) {
             int rc = exact_sort(st, lo); if (rc) return rc;
-            rc = exact_passes(st, lo, true); if (rc) return rc;
+            rc = exact_passes(st, lo); if (rc) return rc;
         }
     }
     MARK();   // cbr_probe_passes (empty interval for VBR)
