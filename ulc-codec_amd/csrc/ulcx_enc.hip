@@ -810,7 +810,6 @@ __global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
     if (c.isFb[blk]) return;
     int N = c.C * c.BS;
     int kSel = c.nout[blk];
-    const float *key = c.key + (size_t)blk * N;
     uint32_t *keep = c.keep + (size_t)blk * (N / 32);
     if (kSel <= 0) {
         for (int i = tid; i < N / 32; i += WG) keep[i] = 0;
@@ -1904,7 +1903,6 @@ __global__ __launch_bounds__(WG) void k_selenc(UlcxEncCtx c, int finalPass, int 
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     int kSel = c.nout[blk];
-    const float *keyG = c.key + (size_t)blk * N;
     for (int i = tid; i < N; i += WG) ukey[i] = key_ord(load_final_key(c, blk, i));
     if (tid == 0) misc[2] = 0;
     __syncthreads();
@@ -2304,7 +2302,9 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
             else hipLaunchKernelGGL(k_encode_wave<true>, dim3(fb2 ? fbW : (nBC + 3) / 4), dim3(256), (size_t)wavecaps_lds(first) * 4, s2, cc, fin, first, twoPhase ? 0 : 2);
             if (twoPhase)
             {
-                const WaveCaps capR = (probes > 0 && !fin && haveMid) ? capM : capF;
+                // (the exact path's few blocks also retry with the medium capacities: a full-capacity workgroup needs a whole
+                //  CU's LDS and would wait for the main path's kernel to drain)
+                const WaveCaps capR = (haveMid && (fb2 || (probes > 0 && !fin))) ? capM : capF;
                 hipLaunchKernelGGL(k_encode_wave<false>, dim3(fb2 ? fbW : ((nBC + 3) / 4 < 512 ? (nBC + 3) / 4 : 512)), dim3(256), (size_t)wavecaps_lds(capR) * 4, s2, cc, fin, capR, 1);
             }
         }
