@@ -317,9 +317,11 @@ __device__ __forceinline__ float win_apply(float x, int i, int S, int aL, int ov
     return (n < aR) ? x : (n < aR + ov) ? x * fall[n - aR] : 0.0f;
 }
 
+// ST: stereo instantiation (C = 2 as a compile-time constant: one channel pair, no per-pair branches)
+template <bool ST>
 __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
     extern __shared__ float lds[];
-    const int BS = c.BS, C = c.C;
+    const int BS = c.BS, C = ST ? 2 : c.C;
     // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its own L2).
     // Consecutive blocks of a stream read overlapping input (each frame spans two blocks), so give an
     // XCD a contiguous run of blocks: block = (b % 8) * ceil(NB/8) + b / 8.  Speed only, never correctness.
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
     __syncthreads();
 
     for (int ch0 = 0; ch0 < C; ch0 += 2) {             // one M/S pair (or a trailing single channel) at a time
-        const int nch = (ch0 + 1 < C) ? 2 : 1;
+        const int nch = ST ? 2 : ((ch0 + 1 < C) ? 2 : 1);
         unsigned pat = ulcx_pattern(wc);
         int off = 0, ovL = ovFirst;
         do {
@@ -2130,7 +2132,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
         // transform of chunk j on the main stream.  wcPipe = 1 keeps everything on the main stream.
         const int nCh = wcPipe;
         size_t lds = ulcx_enc_xf_lds_bytes(c.BS, c.C);
-        if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_xf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 48 * 1024) { CK(hipFuncSetAttribute((const void *)k_xf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); CK(hipFuncSetAttribute((const void *)k_xf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
         auto launch_wc = [&](hipStream_t s2, int k0, int k1, bool marks) -> int {
             int kc = k1 - k0;
             hipLaunchKernelGGL(k_wc_energy, dim3((unsigned)(SG * ((kc * c.BS) / 64))), dim3(WG), 0, s2, c, k0, k1);   if (marks) MARK();
@@ -2142,7 +2144,9 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
         };
         if (nCh <= 1) {
             int rc = launch_wc(st, 0, c.K, true); if (rc) return rc;
-            hipLaunchKernelGGL(k_xf, dim3(((NB + 7) / 8) * 8), dim3(WG), lds, st, c, 0, c.K);                            MARK();
+            if (c.C == 2) hipLaunchKernelGGL(k_xf<true>, dim3(((NB + 7) / 8) * 8), dim3(WG), lds, st, c, 0, c.K);
+            else hipLaunchKernelGGL(k_xf<false>, dim3(((NB + 7) / 8) * 8), dim3(WG), lds, st, c, 0, c.K);
+            MARK();
         } else {
             for (int i = 0; i < 5; i++) MARK();                    // (window-control stages: hidden in the k_xf interval in this mode)
             // side: energy_j, forward_j (the sample-rate chain, back to back over the chunks);
@@ -2181,7 +2185,8 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
                     int nbk = c.B * (x1 - x0);
                     CK(hipStreamWaitEvent(st, evD[w], 0));
                     if (ev) CK(hipEventRecord(aux.evXf[2 * jx], st));
-                    hipLaunchKernelGGL(k_xf, dim3(((nbk + 7) / 8) * 8), dim3(WG), lds, st, c, x0, x1);
+                    if (c.C == 2) hipLaunchKernelGGL(k_xf<true>, dim3(((nbk + 7) / 8) * 8), dim3(WG), lds, st, c, x0, x1);
+                    else hipLaunchKernelGGL(k_xf<false>, dim3(((nbk + 7) / 8) * 8), dim3(WG), lds, st, c, x0, x1);
                     if (ev) CK(hipEventRecord(aux.evXf[2 * jx + 1], st));
                     jx++;
                 }
