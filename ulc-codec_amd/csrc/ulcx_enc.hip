@@ -18,6 +18,7 @@
 // compiled with -ffp-contract=off: no fused multiply-add is formed anywhere except the
 // explicit ones inside the glibc restatements (ulcx_libm.h).
 #include "ulcx_internal.h"
+#include <type_traits>
 #include "ulcx_libm.h"
 
 #define WG 256
@@ -389,69 +390,86 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
             //    quarters of the frame, so one lane takes both: four 16-byte loads per lane, each wave
             //    reading four contiguous 1 KB runs.
             if (twInLds) for (int i = tid; i < M / 2; i += WG) twl[i] = c.T.tw[d][i];       // visible after the barrier that ends the fold
-            if (!(c.dbgSkip & 2)) for (int jj = tid; jj < M / 2; jj += WG) {
-                const int iA = 2 * jj, iB = S - 2 - 2 * jj, iC = S + 2 * jj, iD = 2 * S - 2 - 2 * jj;
-                float2 xs[8];                           // (ch0, ch0+1) after M/S at iA, iA+1, iB, iB+1, iC, iC+1, iD, iD+1
-                {
-                    const int ip[4] = { iA, iB, iC, iD };
+            // Two wave-uniform specialisations of the same loop: INPCM = the whole frame lies in this call's input (no
+            // history pointer select per load; every block but the first two of a call), FULLOV = both overlaps span the
+            // whole subblock (the steady state: every position is on a ramp, no clamps or selects in the window).
+            auto fold = [&](auto inpcmT, auto fullovT) {
+                constexpr bool INPCM = decltype(inpcmT)::value, FULLOV = decltype(fullovT)::value;
+                const float *frame = c.pcm + ((size_t)s * c.K * BS + (INPCM ? t0 : 0)) * C;
+                for (int jj = tid; jj < M / 2; jj += WG) {
+                    const int iA = 2 * jj, iB = S - 2 - 2 * jj, iC = S + 2 * jj, iD = 2 * S - 2 - 2 * jj;
+                    float2 xs[8];                           // (ch0, ch0+1) after M/S at iA, iA+1, iB, iB+1, iC, iC+1, iD, iD+1
+                    {
+                        const int ip[4] = { iA, iB, iC, iD };
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float *p = smp_ptr(c, s, t0 + ip[r]);
-                        float2 e0, e1;
-                        if (nch == 2) {
-                            if (c.dbgSkip & 8) { e0 = make_float2(1.0f * jj, 2.0f); e1 = make_float2(3.0f, 0.5f * jj); }
-                            else if (C == 2) { float4 v = *(const float4 *)p; e0 = make_float2(v.x, v.y); e1 = make_float2(v.z, v.w); }
-                            else { e0 = make_float2(p[ch0], p[ch0 + 1]); e1 = make_float2(p[C + ch0], p[C + ch0 + 1]); }
-                            // M/S (BlockTransform.c:102-110)
-                            xs[2 * r]     = make_float2((e0.x + e0.y) * 0.5f, (e0.x - e0.y) * 0.5f);
-                            xs[2 * r + 1] = make_float2((e1.x + e1.y) * 0.5f, (e1.x - e1.y) * 0.5f);
+                        for (int r = 0; r < 4; r++) {
+                            const float *p = INPCM ? frame + (size_t)ip[r] * C : smp_ptr(c, s, t0 + ip[r]);
+                            float2 e0, e1;
+                            if (nch == 2) {
+                                if (C == 2) { float4 v = *(const float4 *)p; e0 = make_float2(v.x, v.y); e1 = make_float2(v.z, v.w); }
+                                else { e0 = make_float2(p[ch0], p[ch0 + 1]); e1 = make_float2(p[C + ch0], p[C + ch0 + 1]); }
+                                // M/S (BlockTransform.c:102-110)
+                                xs[2 * r]     = make_float2((e0.x + e0.y) * 0.5f, (e0.x - e0.y) * 0.5f);
+                                xs[2 * r + 1] = make_float2((e1.x + e1.y) * 0.5f, (e1.x - e1.y) * 0.5f);
+                            } else {
+                                xs[2 * r] = make_float2(p[ch0], 0.0f); xs[2 * r + 1] = make_float2(p[C + ch0], 0.0f);
+                            }
+                        }
+                    }
+                    // window, branch-free (same factor for every channel).  Rising half (iA.., iB..): 0 below the ramp,
+                    // rise[] on it, x itself above (x * 1.0f is x); falling half (iC.., iD..) mirrored.  win_apply() is the
+                    // readable form of the same thing.
+                    const int ipos[8] = { iA, iA + 1, iB, iB + 1, iC, iC + 1, iD, iD + 1 };
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        if (FULLOV) {
+                            float f = (r < 4) ? rise[ipos[r]] : fall[ipos[r] - S];
+                            xs[r].x *= f; xs[r].y *= f;
+                            continue;
+                        }
+                        float f; bool zero;
+                        if (r < 4) {
+                            int idx = ipos[r] - aL;
+                            int ci = idx < 0 ? 0 : (idx < ovL ? idx : 0);
+                            float tv = rise[ci];                     // rise[0] exists for ovL = 0 too (table row of the zero overlap)
+                            f = (idx < ovL) ? tv : 1.0f; zero = idx < 0;
                         } else {
-                            xs[2 * r] = make_float2(p[ch0], 0.0f); xs[2 * r + 1] = make_float2(p[C + ch0], 0.0f);
+                            int idx = ipos[r] - S - aR;
+                            int ci = idx < 0 ? 0 : (idx < ov ? idx : 0);
+                            float tv = fall[ci];
+                            f = (idx < 0) ? 1.0f : tv; zero = idx >= ov;
+                        }
+                        float wx = xs[r].x * f, wy = xs[r].y * f;
+                        xs[r].x = zero ? 0.0f : wx;
+                        xs[r].y = zero ? 0.0f : wy;
+                    }
+#pragma unroll
+                    for (int hsel = 0; hsel < 2; hsel++) {
+                        // hsel 0: n = M/2-1-jj (Lb = iA+1, La = iB, Ra = iC+1, Rb = iD);  hsel 1: n = M/2+jj (Lb = iA, La = iB+1, Ra = iC, Rb = iD+1)
+                        const int n = hsel ? M / 2 + jj : M / 2 - 1 - jj;
+                        const float2 lbv = hsel ? xs[0] : xs[1], lav = hsel ? xs[3] : xs[2];
+                        const float2 rav = hsel ? xs[4] : xs[5], rbv = hsel ? xs[7] : xs[6];
+                        float2 P = pre[n];
+#pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            if (q >= nch) break;
+                            float ra = q ? rav.y : rav.x, rb = q ? rbv.y : rbv.x, la = q ? lav.y : lav.x, lb = q ? lbv.y : lbv.x;
+                            float vr = ra + rb, wr = ra - rb;            // v[mr], w[mr]
+                            float vl = la - lb, wl = lb + la;            // v[ml], w[ml]
+                            float v1 = hsel ? vl : vr, v2 = hsel ? vr : vl;  // v[2n], v[S-1-2n]
+                            float w1 = hsel ? wl : wr, w2 = hsel ? wr : wl;  // w[2n], w[S-1-2n]
+                            float2 *zc = q ? zc1 : zc0, *zs = q ? zs1 : zs0;
+                            zc[FFT_PADS(n, ps)] = cmulc(make_float2(v1, v2), P);       // u = v      : (u[2n], u[S-1-2n])
+                            zs[FFT_PADS(n, ps)] = cmulc(make_float2(w2, w1), P);       // u = rev(w) : (w[S-1-2n], w[2n])
                         }
                     }
                 }
-                // window, branch-free (same factor for every channel).  Rising half (iA.., iB..): 0 below the ramp,
-                // rise[] on it, x itself above (x * 1.0f is x); falling half (iC.., iD..) mirrored.  win_apply() is the
-                // readable form of the same thing.
-                const int ipos[8] = { iA, iA + 1, iB, iB + 1, iC, iC + 1, iD, iD + 1 };
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    float f; bool zero;
-                    if (r < 4) {
-                        int idx = ipos[r] - aL;
-                        int ci = idx < 0 ? 0 : (idx < ovL ? idx : 0);
-                        float tv = (c.dbgSkip & 16) ? 0.5f : rise[ci];                     // rise[0] exists for ovL = 0 too (table row of the zero overlap)
-                        f = (idx < ovL) ? tv : 1.0f; zero = idx < 0;
-                    } else {
-                        int idx = ipos[r] - S - aR;
-                        int ci = idx < 0 ? 0 : (idx < ov ? idx : 0);
-                        float tv = (c.dbgSkip & 16) ? 0.5f : fall[ci];
-                        f = (idx < 0) ? 1.0f : tv; zero = idx >= ov;
-                    }
-                    float wx = xs[r].x * f, wy = xs[r].y * f;
-                    xs[r].x = zero ? 0.0f : wx;
-                    xs[r].y = zero ? 0.0f : wy;
-                }
-#pragma unroll
-                for (int hsel = 0; hsel < 2; hsel++) {
-                    // hsel 0: n = M/2-1-jj (Lb = iA+1, La = iB, Ra = iC+1, Rb = iD);  hsel 1: n = M/2+jj (Lb = iA, La = iB+1, Ra = iC, Rb = iD+1)
-                    const int n = hsel ? M / 2 + jj : M / 2 - 1 - jj;
-                    const float2 lbv = hsel ? xs[0] : xs[1], lav = hsel ? xs[3] : xs[2];
-                    const float2 rav = hsel ? xs[4] : xs[5], rbv = hsel ? xs[7] : xs[6];
-                    float2 P = (c.dbgSkip & 32) ? make_float2(0.5f, 0.25f) : pre[n];
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        if (q >= nch) break;
-                        float ra = q ? rav.y : rav.x, rb = q ? rbv.y : rbv.x, la = q ? lav.y : lav.x, lb = q ? lbv.y : lbv.x;
-                        float vr = ra + rb, wr = ra - rb;            // v[mr], w[mr]
-                        float vl = la - lb, wl = lb + la;            // v[ml], w[ml]
-                        float v1 = hsel ? vl : vr, v2 = hsel ? vr : vl;  // v[2n], v[S-1-2n]
-                        float w1 = hsel ? wl : wr, w2 = hsel ? wr : wl;  // w[2n], w[S-1-2n]
-                        float2 *zc = q ? zc1 : zc0, *zs = q ? zs1 : zs0;
-                        zc[FFT_PADS(n, ps)] = cmulc(make_float2(v1, v2), P);       // u = v      : (u[2n], u[S-1-2n])
-                        zs[FFT_PADS(n, ps)] = cmulc(make_float2(w2, w1), P);       // u = rev(w) : (w[S-1-2n], w[2n])
-                    }
-                }
+            };
+            if (!(c.dbgSkip & 2)) {
+                const bool inPcm = (t0 >= 0), fullOv = (ovL == S) && (ov == S);
+                if (inPcm && fullOv) fold(std::true_type{}, std::true_type{});
+                else if (inPcm) fold(std::true_type{}, std::false_type{});
+                else fold(std::false_type{}, std::false_type{});
             }
             __syncthreads();
 
