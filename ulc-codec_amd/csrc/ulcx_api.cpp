@@ -22,7 +22,7 @@ struct ulcx_encoder {
     bool evOk, evRecorded;
     int lastK;
     hipStream_t side; hipEvent_t evFork, evJoin, evFork2; bool sideOk;
-    hipEvent_t evWC[7 + 3 * ULCX_WC_MAXCH]; int wcPipe; hipStream_t side2, side3; hipEvent_t evXf[2 * ULCX_XF_MAXCH]; int nXf;      // window-control / transform chunk pipeline (ULCX_WC_PIPE chunks, default 4)
+    hipEvent_t evWC[7 + 3 * ULCX_WC_MAXCH]; int wcPipe; hipStream_t side2, side3, side4; hipEvent_t evE[ULCX_WC_MAXCH]; hipEvent_t evXf[2 * ULCX_XF_MAXCH]; int nXf;      // window-control / transform chunk pipeline (ULCX_WC_PIPE chunks, default 4)
     bool keysFinal;
     // staging for the host-pointer API
     float *d_pcm; uint8_t *d_out; int32_t *d_bits, *d_wc; float *d_cplx;
@@ -84,7 +84,7 @@ static void cleanup(ulcx_encoder *e) {
     for (void *p : e->allocs) hipFree(p);
     if (e->tables) hipFree(e->tables);
     if (e->evOk) for (auto &v : e->ev) hipEventDestroy(v);
-    if (e->sideOk) { hipStreamDestroy(e->side); hipEventDestroy(e->evFork); hipEventDestroy(e->evJoin); hipEventDestroy(e->evFork2); for (auto &v : e->evWC) hipEventDestroy(v); for (auto &v : e->evXf) hipEventDestroy(v); hipStreamDestroy(e->side2); hipStreamDestroy(e->side3); }
+    if (e->sideOk) { hipStreamDestroy(e->side); hipEventDestroy(e->evFork); hipEventDestroy(e->evJoin); hipEventDestroy(e->evFork2); for (auto &v : e->evWC) hipEventDestroy(v); for (auto &v : e->evXf) hipEventDestroy(v); hipStreamDestroy(e->side2); hipStreamDestroy(e->side3); hipStreamDestroy(e->side4); for (auto &v : e->evE) hipEventDestroy(v); }
     delete e;
 }
 
@@ -180,7 +180,8 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
                 hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&e->evFork2, hipEventDisableTiming) == hipSuccess) {
-                bool ok = hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&e->side3, hipStreamNonBlocking) == hipSuccess;
+                bool ok = hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&e->side3, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&e->side4, hipStreamNonBlocking) == hipSuccess;
+                for (auto &v : e->evE) ok = ok && hipEventCreateWithFlags(&v, hipEventDisableTiming) == hipSuccess;
                 for (auto &v : e->evWC) ok = ok && hipEventCreateWithFlags(&v, hipEventDisableTiming) == hipSuccess;
                 for (auto &v : e->evXf) ok = ok && hipEventCreate(&v) == hipSuccess;
                 e->sideOk = ok;
@@ -219,7 +220,7 @@ extern "C" int ulcx_encode_dev(ulcx_encoder *e, int mode, float p0, float p1, co
     c.vbrTarget = (mode == ULCX_MODE_VBR) ? 0x1.E4EFB7p3f * logf(100.0f / p0) : 0.0f;     // ulcEncoder.c:144 (host libm, data independent)
     c.pcm = d_pcm; c.out = d_out; c.bits = d_bits; c.wcOut = d_wc; c.cplxOut = d_cplx;
     UlcxEncAux aux;
-    aux.side = e->sideOk ? e->side : nullptr; aux.side2 = e->sideOk ? e->side2 : nullptr; aux.side3 = e->sideOk ? e->side3 : nullptr;
+    aux.side = e->sideOk ? e->side : nullptr; aux.side2 = e->sideOk ? e->side2 : nullptr; aux.side3 = e->sideOk ? e->side3 : nullptr; aux.side4 = (e->sideOk && getenv("ULCX_WC_ESTREAM")) ? e->side4 : nullptr; aux.evE = e->evE;
     aux.evFork = e->evFork; aux.evJoin = e->evJoin; aux.evFork2 = e->evFork2; aux.evWC = e->evWC; aux.evXf = e->evXf;
     aux.wcPipe = (nBlocks >= 2 * e->wcPipe) ? e->wcPipe : (nBlocks >= 6 && e->wcPipe > 1 ? 3 : 1); aux.nXf = &e->nXf;
     aux.wcSteps = 0; if (const char *sv = getenv("ULCX_WC_STEPS")) aux.wcSteps = atoi(sv);   // 0: the transform's chunks

@@ -2133,7 +2133,7 @@ const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES_REPORTED] = {
 };
 
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const UlcxEncAux &aux) {
-    hipStream_t side = aux.side, side2 = aux.side2, side3 = aux.side3;
+    hipStream_t side = aux.side, side2 = aux.side2, side3 = aux.side3, side4 = aux.side4;
     hipEvent_t evFork = aux.evFork, evJoin = aux.evJoin, evFork2 = aux.evFork2, *evWC = aux.evWC;
     const int wcPipe = (side && side2 && side3) ? aux.wcPipe : 1;
     if (aux.nXf) *aux.nXf = 0;
@@ -2170,7 +2170,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
             // side: energy_j, forward_j (the sample-rate chain, back to back over the chunks);
             // side2: backward_j behind forward_j;  side3: integrate_j, decide_j behind backward_j;
             // main: xf_j behind decide_j.  The first chunk is a single block so the transform starts early.
-            hipEvent_t ev0 = evWC[0], *evF = evWC + 1, *evB = evWC + 1 + ULCX_WC_MAXCH, *evD = evWC + 1 + 2 * ULCX_WC_MAXCH;
+            hipEvent_t ev0 = evWC[0], *evF = evWC + 1, *evB = evWC + 1 + ULCX_WC_MAXCH, *evD = evWC + 1 + 2 * ULCX_WC_MAXCH, *evE = aux.evE;
             // The window-control kernels advance in the same chunks as the transform (first chunk = one block, then
             // quarters) unless ULCX_WC_STEPS asks for uniform finer steps: measured, finer steps lose - every
             // k_wc_backward launch costs a full 2048-step chain whatever its size, and they queue on one stream.
@@ -2184,10 +2184,16 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
             for (int j = 2; j <= nCh; j++) cut[j] = 1 + (c.K - 1) * (j - 1) / (nCh - 1);
             CK(hipEventRecord(ev0, st));
             CK(hipStreamWaitEvent(side, ev0, 0));
+            if (side4) CK(hipStreamWaitEvent(side4, ev0, 0));
             int jx = 0;                                        // next transform chunk to enqueue
             for (int w = 0; w < nW; w++) {
                 int k0 = sameCuts ? cut[w] : (int)((long long)c.K * w / nW), k1 = sameCuts ? cut[w + 1] : (int)((long long)c.K * (w + 1) / nW), kc = k1 - k0;
-                hipLaunchKernelGGL(k_wc_energy, dim3((unsigned)(SG * ((kc * c.BS) / 64))), dim3(WG), 0, side, c, k0, k1);
+                // (optionally the envelope kernel gets its own stream, ULCX_WC_ESTREAM=1; measured slower: beside it the
+                //  chain kernels slow down by more than the time it takes between two links of the chain)
+                hipStream_t es = side4 ? side4 : side;
+                if (side4 && w >= 2) CK(hipStreamWaitEvent(side4, evF[w - 2], 0));      // run ahead of the chain by one step only
+                hipLaunchKernelGGL(k_wc_energy, dim3((unsigned)(SG * ((kc * c.BS) / 64))), dim3(WG), 0, es, c, k0, k1);
+                if (side4) { CK(hipEventRecord(evE[w], side4)); CK(hipStreamWaitEvent(side, evE[w], 0)); }
                 hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, side, c, k0, k1);
                 CK(hipEventRecord(evF[w], side));
                 CK(hipStreamWaitEvent(side2, evF[w], 0));

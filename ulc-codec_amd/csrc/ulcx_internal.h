@@ -146,6 +146,8 @@ extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES_REPORTED];
 // streams and events the encoder launch uses beside the caller's stream
 struct UlcxEncAux {
     hipStream_t side, side2, side3;      // NULL: everything on the caller's stream
+    hipStream_t side4;                   // envelope kernel of the window-control pipeline (NULL: shares `side`)
+    hipEvent_t *evE;                     // [ULCX_WC_MAXCH]
     hipEvent_t evFork, evJoin, evFork2;  // exact-path fork/join
     hipEvent_t *evWC;                    // [7 + 3*ULCX_WC_MAXCH] window-control pipeline; then noise-spectrum fork/join, k_cplx join, k_tailsums fork/join, k_state_update join
     hipEvent_t *evXf;                    // [2*ULCX_XF_MAXCH] timing pairs around each transform chunk (used when ev != NULL)
