@@ -431,11 +431,17 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
         const int S = BS, M = BS >> 1;
         const float2 *pre = c.T.pre[0];
         const float *X0 = coefB, *X1 = coefB + BS;
-        for (int n = tid; n < M; n += WG) {
-            float2 P = pre[n];
-            int pn = padded ? FFT_PADS(n, DPS) : n;
-            za[pn] = cmulc(make_float2(X0[2 * n], X0[S - 1 - 2 * n]), P);
-            zb[pn] = cmulc(make_float2(X1[2 * n], X1[S - 1 - 2 * n]), P);
+        // n and M-1-n together: their four inputs are the two aligned pairs (X[2n], X[2n+1]) and (X[S-2-2n], X[S-1-2n])
+        for (int n = tid; n < M / 2; n += WG) {
+            const int n2 = M - 1 - n;
+            float2 P = pre[n], P2 = pre[n2];
+            int pn = padded ? FFT_PADS(n, DPS) : n, pn2 = padded ? FFT_PADS(n2, DPS) : n2;
+            float2 a0 = *(const float2 *)(X0 + 2 * n), b0 = *(const float2 *)(X0 + S - 2 - 2 * n);
+            float2 a1 = *(const float2 *)(X1 + 2 * n), b1 = *(const float2 *)(X1 + S - 2 - 2 * n);
+            za[pn]  = cmulc(make_float2(a0.x, b0.y), P);
+            za[pn2] = cmulc(make_float2(b0.x, a0.y), P2);
+            zb[pn]  = cmulc(make_float2(a1.x, b1.y), P);
+            zb[pn2] = cmulc(make_float2(b1.x, a1.y), P2);
         }
     };
     auto fast_post = [&](const float2 *z0, const float2 *z1, float *outp, int ov, bool padded) {
@@ -457,6 +463,7 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
             float Bm[2] = { -ya1.y, ya2.x }, Bs[2] = { -yb1.y, yb2.x };
             float Am[2] = { A0m, A1m }, As[2] = { A0s, A1s };
             int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
+            float2 lo2[2], hi2[2];                                         // interleaved L/R at positions p and S-1-p
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 int p = pv[q];
@@ -470,9 +477,12 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
                     sLo = s0 - s1; sHi = s2 + s3;
                 }
                 // inverse M/S (ulcDecoder.c:281-289) + interleave (:292-297)
-                *(float2 *)(outp + 2 * p) = make_float2(mLo + sLo, mLo - sLo);
-                *(float2 *)(outp + 2 * (S - 1 - p)) = make_float2(mHi + sHi, mHi - sHi);
+                lo2[q] = make_float2(mLo + sLo, mLo - sLo);
+                hi2[q] = make_float2(mHi + sHi, mHi - sHi);
             }
+            // positions pv[1] = pv[0]-1 and S-1-pv[0], S-pv[0] are neighbours: two aligned 16-byte stores
+            *(float4 *)(outp + 2 * pv[1]) = make_float4(lo2[1].x, lo2[1].y, lo2[0].x, lo2[0].y);
+            *(float4 *)(outp + 2 * (S - 1 - pv[0])) = make_float4(hi2[0].x, hi2[0].y, hi2[1].x, hi2[1].y);
             L0[2 * k1] = ya1.x; L0[2 * k1 + 1] = -ya2.y;
             L1[2 * k1] = yb1.x; L1[2 * k1 + 1] = -yb2.y;
         }
