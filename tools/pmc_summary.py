@@ -31,7 +31,7 @@ def main():
                   "launches_per_step": fc.get(k, 0) / steps_f,
                   "note": "per bench step (all launches of the kernel in one step summed); FETCH_SIZE doubled per MI355X_MICROARCH.md"}
     # stage-name aliases used by bench.py
-    for alias, real in (("k_select", "k_select_wave<64>"), ("k_encode_wave", "k_encode_wave<true>")):
+    for alias, real in (("k_select", "k_select_wave<64>"), ("k_encode_wave", "k_encode_wave<true>"), ("k_xf", "k_xf<true>")):
         if real in res: res[alias] = res[real]
     json.dump(res, open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
