@@ -174,7 +174,9 @@ def _gen_unit(rng, S, nyb):
     if r < 0.04:
         nyb += [0xE, 0xF]                                  # unit opens with the stop code: all zeros
         return
-    if r < 0.3:
+    if r < 0.07:
+        nyb += [0xF]                                       # opening Fh (no encoder writes it): the reference expands quantizer -2 = 0.0
+    elif r < 0.3:
         nyb += [0xE, int(rng.integers(0, 15))]             # extended quantizer Eh,X
     else:
         nyb += [int(rng.integers(0, 14))]

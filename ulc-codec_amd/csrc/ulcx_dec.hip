@@ -43,8 +43,8 @@ __device__ __forceinline__ uint32_t xorshift32(uint32_t s) {      // ulcDecoder.
 //   Fh,X (X < Eh)            2          quantizer X
 //   Fh,Eh,X (X < Fh)         3          quantizer Eh+X;  Fh,Eh,Fh = stop (zeros to the end)
 //   Fh,Fh,Z,Y,X              5          noise to the end: level Z+1, decay YX
-// A unit opens with a quantizer code without its Fh prefix (`first`); a leading Fh there is
-// quantizer 15.
+// A unit opens with a quantizer code without its Fh prefix (`first`); a leading Fh there (only a corrupt
+// stream has one) gives the quantizer 0.0 the reference computes for it.
 // ---------------------------------------------------------------------------
 struct Code {
     int len;            // nybbles
@@ -75,7 +75,9 @@ __device__ __forceinline__ Code decode_code(uint32_t w, bool first) {
     k.np = k.n8 ? ((((v1 << 4) | v2) << 1) | (v3 & 1)) + 16 : 0;
     k.l = k.n8 ? (v3 >> 1) + 1 : v2 + 1;
     k.dn = (v3 << 4) | v4;
-    k.qnew = q1 ? v1 : (qext & !k.stop) ? 0xE + v2 : -1;
+    // (opening Fh: the reference expands quantizer -2, ulcDecoder.c:89-98,107 - a shift by -2, i.e. by 30 on x86-64:
+    //  the unit's quantizer is exactly 0 until a change code; index 30 expands to the same 0)
+    k.qnew = q15 ? 30 : q1 ? v1 : (qext & !k.stop) ? 0xE + v2 : -1;
     return k;
 }
 // number of leading nybbles of w (low first, at most 7) that are plain coefficients, i.e. none of 0h 1h 8h Fh
