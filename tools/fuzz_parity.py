@@ -23,7 +23,16 @@ while time.time() - t0 < budget:
     amp = float(rng.choice([1.0, 1.0, 0.05, 1e-4, 0.0]))           # loud, quiet, near-silent, digital silence
     seed = int(rng.integers(0, 1 << 30))
     pcm = np.stack([synth_pcm(s, calls * K * bs, ch, rate, transient=transient, seed=seed) for s in range(B)]) * np.float32(amp)
-    tag = f"bs={bs} ch={ch} rate={rate} B={B} K={K} calls={calls} mode={mode} p0={p0:.2f} p1={p1:.2f} transient={transient} amp={amp} seed={seed}"
+    kind = int(rng.integers(0, 8))                                 # other signal shapes on top of the synthetic mix
+    nT = calls * K * bs
+    if kind == 1:   pcm = (rng.random(pcm.shape, dtype=np.float32) * 2 - 1) * np.float32(amp if amp else 1.0)          # white noise
+    elif kind == 2: pcm = pcm + np.float32(0.25)                                                                       # DC offset
+    elif kind == 3: pcm = np.zeros_like(pcm); pcm[:, ::int(rng.integers(50, 3000))] = np.float32(0.9)                   # impulse train
+    elif kind == 4: pcm[:, : nT // 2] = 0                                                                              # silence then signal
+    elif kind == 5: pcm = np.sign(pcm).astype(np.float32) * np.float32(min(amp, 1.0) if amp else 0.5)                  # square-ish / clipped
+    elif kind == 6: pcm = pcm * np.float32(8.0)                                                                        # beyond full scale
+    elif kind == 7: pcm = np.round(pcm * 32767).astype(np.int16).astype(np.float32) * np.float32(2.0 ** -15)           # PCM16 grid
+    tag = f"kind={kind} bs={bs} ch={ch} rate={rate} B={B} K={K} calls={calls} mode={mode} p0={p0:.2f} p1={p1:.2f} transient={transient} amp={amp} seed={seed}"
     slot = 2 * ch * bs + 16
     enc = ulc_amd.BatchEncoder(B, ch, bs, rate, K)
     try:
