@@ -15,9 +15,10 @@ while time.time() - t0 < budget:
     bs = int(rng.choice([256, 512, 1024, 2048, 2048, 4096, 8192]))
     ch = int(rng.choice([1, 2, 2, 2, 3]))
     rate = int(rng.choice([22050, 32000, 44100, 48000, 96000]))
-    B = int(rng.integers(1, 9)); K = int(rng.integers(1, 7)); calls = int(rng.integers(1, 4))
+    B = int(rng.integers(1, 9)); K = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 9, 10, 12, 16, 21])); calls = int(rng.integers(1, 4))
+    if K > 8: B = min(B, 3)                                         # (long calls exercise the chunked window-control pipeline)
     mode = int(rng.choice([0, 0, 1, 2]))
-    p0 = float(rng.uniform(5, 100)) if mode == 0 else float(rng.uniform(16, 192))
+    p0 = float(rng.uniform(1, 100)) if mode == 0 else float(rng.choice([rng.uniform(1, 16), rng.uniform(16, 192), rng.uniform(192, 700)]))
     p1 = float(rng.uniform(0.2, 0.9)) if mode == 2 else 0.0
     transient = bool(rng.integers(0, 2))
     amp = float(rng.choice([1.0, 1.0, 0.05, 1e-4, 0.0]))           # loud, quiet, near-silent, digital silence
@@ -34,14 +35,18 @@ while time.time() - t0 < budget:
     elif kind == 7: pcm = np.round(pcm * 32767).astype(np.int16).astype(np.float32) * np.float32(2.0 ** -15)           # PCM16 grid
     tag = f"kind={kind} bs={bs} ch={ch} rate={rate} B={B} K={K} calls={calls} mode={mode} p0={p0:.2f} p1={p1:.2f} transient={transient} amp={amp} seed={seed}"
     slot = 2 * ch * bs + 16
-    enc = ulc_amd.BatchEncoder(B, ch, bs, rate, K)
+    Kmax = K
+    ks = [int(rng.integers(1, Kmax + 1)) for _ in range(calls)] if rng.random() < 0.5 else [K] * calls      # blocks per call may vary
+    total = sum(ks)
+    pcm = pcm[:, : total * bs]
+    enc = ulc_amd.BatchEncoder(B, ch, bs, rate, Kmax)
     try:
-        dec = ulc_amd.BatchDecoder(B, ch, bs, K)
+        dec = ulc_amd.BatchDecoder(B, ch, bs, Kmax)
     except Exception:
         dec = None
-    outs = []
-    for c in range(calls):
-        outs.append(enc.encode(pcm[:, c * K * bs:(c + 1) * K * bs], mode, p0, p1))
+    outs = []; k0 = 0
+    for kc in ks:
+        outs.append(enc.encode(pcm[:, k0 * bs:(k0 + kc) * bs], mode, p0, p1)); k0 += kc
     out = np.concatenate([o[0] for o in outs], axis=1); bits = np.concatenate([o[1] for o in outs], axis=1)
     wc = np.concatenate([o[2] for o in outs], axis=1); cplx = np.concatenate([o[3] for o in outs], axis=1)
     for s in range(B):
@@ -49,15 +54,18 @@ while time.time() - t0 < budget:
         assert np.array_equal(wc[s], ref["wc"]), f"{tag}: stream {s} WindowCtrl"
         assert cplx[s].tobytes() == ref["cplx"].tobytes(), f"{tag}: stream {s} BlockComplexity"
         assert np.array_equal(bits[s], ref["bits"]), f"{tag}: stream {s} sizes {bits[s]} vs {ref['bits']}"
-        for k in range(calls * K):
+        for k in range(total):
             nb = bits[s, k] // 8
             assert np.array_equal(out[s, k, :nb], ref["out"][k, :nb]), f"{tag}: stream {s} block {k} bytes"
     if dec is not None:
-        got = np.concatenate([dec.decode(out[:, c * K:(c + 1) * K])[0] for c in range(calls)], axis=1)
+        got = []; k0 = 0
+        for kc in ks:
+            got.append(dec.decode(out[:, k0:k0 + kc])[0]); k0 += kc
+        got = np.concatenate(got, axis=1)
         for s in range(B):
             rc, rp, rb = oracle_decode_stream(out[s], ch, bs)
             assert rc == 0 and np.array_equal(got[s].view(np.uint32), rp.view(np.uint32)), f"{tag}: stream {s} decoded PCM"
         dec.close()
     enc.close()
-    n += 1; nblk += B * K * calls
+    n += 1; nblk += B * total
 print(f"fuzz_parity: {n} random configurations, {nblk} blocks, all bit-exact (encode stream/WindowCtrl/complexity, decode PCM) in {time.time()-t0:.0f} s")
