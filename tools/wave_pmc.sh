@@ -1,0 +1,19 @@
+#!/bin/bash
+# VALU instructions per wave of k_encode_wave with the kernel cut after phase B / C / D / E / F (ULCX_DBG_SKIP >> 8)
+cd "$(dirname "$0")/.."; export TMPDIR=/tmp
+for m in 256 512 768 1024 1280 0; do
+  rm -rf gpurun_out/wp; ULCX_DBG_SKIP=$m ULCX_ASYNC_FB=0 ULCX_WC_PIPE=1 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d gpurun_out/wp -- python3 bench.py --steps 1 --warmup 0 --no-cpu > /dev/null 2>&1
+  python3 - "$m" <<'PY'
+import csv, sys, glob, collections
+f = glob.glob('gpurun_out/wp/**/*counter_collection.csv', recursive=True)[0]
+agg = collections.defaultdict(float); n = 0
+for r in csv.DictReader(open(f)):
+    if 'k_encode_wave<true>' in r['Kernel_Name'] and int(r['Grid_Size']) > 1000000:
+        agg[r['Counter_Name']] += float(r['Counter_Value'])
+w = agg['SQ_WAVES'] or 1
+kt = glob.glob('gpurun_out/wp/**/*kernel_trace.csv', recursive=True)
+d = [ (int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6 for r in csv.DictReader(open(kt[0])) if 'k_encode_wave<true>' in r['Kernel_Name'] and int(r['Grid_Size_X']) > 1000000 ] if kt else [0]
+print("ms=%.3f" % (sum(d)/max(1,len(d))), end='  ')
+print("cut=%s  valu/w=%.0f salu/w=%.0f lds/w=%.0f" % (sys.argv[1], agg['SQ_INSTS_VALU']/w, agg['SQ_INSTS_SALU']/w, agg['SQ_INSTS_LDS']/w))
+PY
+done

@@ -509,7 +509,7 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
                 if (!(c.dbgSkip & 1)) { fast_pre(coefB, z, z + Mp, true);
                 fast_pre(coefB + (size_t)C * BS, z + 2 * Mp, z + 3 * Mp, true); }
                 __syncthreads();
-                if (!(c.dbgSkip & 2)) fft_wave_dif(z + (tid >> 6) * Mp, M, twl, tid & 63, DPS);
+                if (!(c.dbgSkip & 2)) fft_wave_dif(z + __builtin_amdgcn_readfirstlane(tid >> 6) * Mp, M, twl, tid & 63, DPS);
                 __syncthreads();
                 if (!(c.dbgSkip & 4)) fast_post(z, z + Mp, outp, fast_overlap(wc, lastSub), true);
                 __syncthreads();

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c, int k0, int k1) 
     __shared__ float2 tile[64][65];
     int tiles_t = ((k1 - k0) * c.BS) / 64;
     int sg = blockIdx.x / tiles_t, tt = blockIdx.x % tiles_t + (k0 * c.BS) / 64;
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int r = tt * 64 + lane;                              // k*BS + n
     int t = r - c.BS / 2;                                // centre sample
 #pragma unroll 4
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
             __syncthreads();
 
             // 2. 2*nch M-point FFTs in LDS, one wave per array, no barriers in between
-            if (!(c.dbgSkip & 1)) for (int a = tid >> 6; a < 2 * nch; a += WG / 64) {
+            if (!(c.dbgSkip & 1)) for (int a = __builtin_amdgcn_readfirstlane(tid >> 6); a < 2 * nch; a += WG / 64) {
                 if (twInLds) fft_wave_dif(z + a * Mp, M, twl, tid & 63, ps);
                 else fft_wave_dif(z + a * Mp, M, c.T.tw[d], tid & 63, ps);
             }
@@ -900,7 +900,7 @@ __global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
 // the 256-bin histogram of each radix pass lives in a private 1 KB LDS slice.
 template <int R>
 __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass) {
-    int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int blk = blockIdx.x * 4 + wv;                        // 4 waves per workgroup, one block per wave
     if (blk >= c.B * c.K) return;
     if (!finalPass && c.cbrDone[blk]) return;
@@ -1604,56 +1604,96 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
     int8_t   *zqi   = (int8_t *)(kz + E2_KCAP);              // E2_ZCAP
     uint8_t  *nyb   = (uint8_t *)(zqi + E2_ZCAP);            // E2_NYBCAP (one nybble per byte)
 
-    // B. compact the kept coefficients (rank < nOutCoef); loads issued 8 chunks at a time
+    // B. compact the kept coefficients (rank < nOutCoef).  The keep bitmap IS the ballot: lane L holds keep word L of
+    //    the unit, a round of 64 coefficients takes its two words with readlane; rounds without a kept coefficient (most
+    //    of the upper spectrum) cost nothing, and only kept coefficients are loaded.  Loads go out 8 rounds at a time.
     int nK = 0;
-    for (int base = 0; base < S; base += 512) {
-        float cv[8]; uint32_t kwv[8];
+    const int nWords = S >> 5;
+    const uint32_t bit5 = 1u << (lane & 31);
+    const int wsel = (lane >> 5) << 2;                       // byte offset of this half-wave's word inside a round's pair
+    for (int wb = 0; wb < nWords; wb += 64) {
+        const uint32_t kw = (wb + lane < nWords) ? keepU[wb + lane] : 0u;      // words past the unit read as "nothing kept"
+        const int nRounds = (nWords - wb >= 64) ? 32 : (nWords - wb + 1) >> 1;
+        for (int r0 = 0; r0 < nRounds; r0 += 8) {
+            const float *src = coefU + wb * 32 + r0 * 64;    // (wave-uniform)
+            float cv[8]; unsigned long long mm[8];
+            uint32_t wu[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            int i = base + u * 64 + lane;
-            bool in = i < S;
-            cv[u] = in ? coefU[i] : 0.0f;
-            kwv[u] = in ? keepU[i >> 5] : 0u;
-        }
+            for (int u = 0; u < 8; u++) wu[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(wsel + 8 * (r0 + u), (int)kw);
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            int i = base + u * 64 + lane;
-            bool kp = (i < S) && ((kwv[u] >> (i & 31)) & 1);
-            unsigned long long m = __ballot(kp);
-            int pos = nK + __popcll(m & ((1ull << lane) - 1));
-            if (kp && pos < E2_KCAP) { kidx[pos] = (uint16_t)i; kval[pos] = cv[u]; }
-            nK += __popcll(m);
+            for (int u = 0; u < 8; u++) {
+                const bool kp = (wu[u] & bit5) != 0u;
+                mm[u] = __ballot(kp);
+                cv[u] = kp ? src[(unsigned)lane + 64u * u] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const unsigned long long m = mm[u];
+                if (m == 0ull) continue;                         // (wave-uniform)
+                const bool kp = (m >> lane) & 1ull;
+                const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, nK));
+                if (kp && pos < E2_KCAP) { kidx[pos] = (uint16_t)(wb * 32 + (r0 + u) * 64 + lane); kval[pos] = cv[u]; }
+                nK += __popcll(m);
+            }
         }
     }
     bool overflow = nK > E2_KCAP;
     WAVE_SYNC();
     if ((c.dbgSkip >> 8) == 1) return;
 
-    // C. zone segmentation: greedy scan (Encode.c:218-269), uniform across the wave
+    // C. zone segmentation: the greedy scan of Encode.c:218-269 (a zone breaks at the first coefficient whose level puts
+    //    max > 4*min over the zone so far), without walking the coefficients one by one:
+    //    1. every kept coefficient i finds, in parallel, where a zone STARTED at i would break ("next break", kept in kz);
+    //    2. the zone starts are the chain 0 -> nb[0] -> nb[nb[0]] ... : one wave-uniform step per zone, marking bit 15;
+    //    3. a coefficient's zone index is the number of starts up to it; a zone's maximum is an LDS max over its members
+    //       (levels are non-negative floats, so they order as their bit patterns).
     int nZ = 0;
-    if (!overflow) {
-        float qmin = 1000.0f, qmax = -1000.0f;
+    if (!overflow && nK > 0) {
+        if (lane == 0) kval[nK] = __uint_as_float(0x7F800000u);   // +inf breaks any zone: the last one ends at nK (kval[E2_KCAP] is zmax[0], cleared below)
+        WAVE_SYNC();
         for (int base = 0; base < nK; base += 64) {
-            float mine = (base + lane < nK) ? kval[base + lane] : 0.0f;
-            int cntc = (nK - base < 64) ? nK - base : 64;
-            int myz = 0;
-            for (int t = 0; t < cntc; t++) {
-                float lvl = fabsf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mine), t)));
-                float nmin = (lvl < qmin) ? lvl : qmin;
-                float nmax = (lvl > qmax) ? lvl : qmax;
-                if (nmax > nmin * 4.0f) {
-                    if (nZ < E2_ZCAP && lane == 0) zmax[nZ] = qmax;
-                    nZ++;
-                    qmin = qmax = lvl;
-                } else { qmin = nmin; qmax = nmax; }
-                if (lane == t) myz = nZ;
+            const int i = base + lane;
+            if (i < nK) {
+                float mn = fabsf(kval[i]), mx = mn;
+                if (i == 0) mn = (mn < 1000.0f) ? mn : 1000.0f;    // the reference's initial QuantMin (Encode.c:219)
+                const float *nx = kval + i + 1;
+                int t = 0;
+                // min/max against |l| (no NaNs here: plain v_min/v_max are exact); four levels fetched per trip (reads past the
+                // sentinel stay inside this wave's LDS and are never reached by the comparisons)
+#define ZONE_STEP(l) { float nmn, nmx; \
+                    asm("v_min_f32 %0, |%1|, %2" : "=v"(nmn) : "v"(l), "v"(mn)); \
+                    asm("v_max_f32 %0, |%1|, %2" : "=v"(nmx) : "v"(l), "v"(mx)); \
+                    if (nmx > nmn * 4.0f) break; \
+                    mn = nmn; mx = nmx; t++; }
+                for (;;) {
+                    const float l0 = nx[t], l1 = nx[t + 1], l2 = nx[t + 2], l3 = nx[t + 3];
+                    ZONE_STEP(l0) ZONE_STEP(l1) ZONE_STEP(l2) ZONE_STEP(l3)
+                }
+#undef ZONE_STEP
+                kz[i] = (uint16_t)(i + 1 + t);
             }
-            if (base + lane < nK) kz[base + lane] = (uint16_t)myz;
         }
-        if (qmax > 0.0f * 4.0f) {                            // end sentinel: NewMin = 0 (Encode.c:226-238)
-            if (nZ < E2_ZCAP && lane == 0) zmax[nZ] = qmax;
-            nZ++;
+        WAVE_SYNC();
+        for (int z = lane; z < E2_ZCAP; z += 64) ((uint32_t *)zmax)[z] = 0u;
+        for (int i = 0; i < nK; ) {                          // (wave-uniform chain walk)
+            const int nxt = __builtin_amdgcn_readfirstlane((int)kz[i]);
+            if (lane == 0) kz[i] = (uint16_t)(nxt | 0x8000);
+            i = nxt;
         }
+        WAVE_SYNC();
+        for (int base = 0; base < nK; base += 64) {
+            const int i = base + lane;
+            const bool have = i < nK;
+            const unsigned long long m = __ballot(have && (kz[i] & 0x8000));
+            const int myz = nZ + __popcll(m & ((2ull << lane) - 1ull)) - 1;
+            if (have) {
+                kz[i] = (uint16_t)myz;
+                if (myz < E2_ZCAP) atomicMax((uint32_t *)zmax + myz, __float_as_uint(kval[i]) & 0x7FFFFFFFu);
+            }
+            nZ += __popcll(m);
+        }
+        WAVE_SYNC();
+        if (nZ <= E2_ZCAP && __builtin_amdgcn_readfirstlane((int)((uint32_t *)zmax)[nZ - 1]) == 0) nZ--;   // end sentinel: a last zone of zero levels is not closed (Encode.c:226-238)
         if (nZ > E2_ZCAP) overflow = true;
     }
     WAVE_SYNC();
@@ -1834,7 +1874,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
 template <bool SMALL>
 __global__ __launch_bounds__(256) void k_encode_wave(UlcxEncCtx c, int finalPass, WaveCaps caps, int phase) {
     extern __shared__ float e2all[];
-    int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wv: wave-uniform, so is all unit geometry
     const WaveCaps capS = { WAVE_SK, WAVE_SZ, WAVE_SN };
     const int ldsPerWave = SMALL ? wavecaps_lds(capS) : wavecaps_lds(caps);
     float *e2 = (float *)((char *)e2all + (size_t)wv * ldsPerWave);
