@@ -134,6 +134,14 @@ int  ulcx_encode_dev(ulcx_encoder *enc, int mode, float param0, float param1,
                      const float *d_pcm, int nBlocks,
                      uint8_t *d_out, int32_t *d_bits, int32_t *d_wc, float *d_cplx, void *hipStream);
 
+/* PCM16 ingest: as ulcx_encode_dev, with d_pcm16 [nStreams][nBlocks][BlockSize][nChan]
+ * int16 interleaved.  Samples are converted on load exactly as the reference's WAV reader feeds
+ * ULC_EncodeBlock_* (tools/WavIO_Helper.c:49-55: (float)x * 2^-15), so the stream is identical to
+ * converting on the host and calling ulcx_encode_dev; the input traffic is halved. */
+int  ulcx_encode_dev_pcm16(ulcx_encoder *enc, int mode, float param0, float param1,
+                           const int16_t *d_pcm16, int nBlocks,
+                           uint8_t *d_out, int32_t *d_bits, int32_t *d_wc, float *d_cplx, void *hipStream);
+
 /* Host-pointer convenience (H2D, encode, D2H, synchronous). */
 int  ulcx_encode_host(ulcx_encoder *enc, int mode, float param0, float param1,
                       const float *h_pcm, int nBlocks,
@@ -166,6 +174,11 @@ int  ulcx_decode_dev(ulcx_decoder *dec, const uint8_t *d_in, int slotBytes, int 
                      float *d_pcm, int32_t *d_bits, void *hipStream);
 int  ulcx_decode_host(ulcx_decoder *dec, const uint8_t *h_in, int slotBytes, int nBlocks,
                       float *h_pcm, int32_t *h_bits);
+/* PCM16 output: as ulcx_decode_dev, writing d_pcm16 [nStreams][nBlocks][BlockSize][nChan]
+ * int16, converted on store exactly as the reference's WAV writer does with ULC_DecodeBlock's output
+ * (tools/WavIO_Helper.c:9-13,56-63: lrintf(clamp(x * 2^15, -32768, 32767))). */
+int  ulcx_decode_dev_pcm16(ulcx_decoder *dec, const uint8_t *d_in, int slotBytes, int nBlocks,
+                           int16_t *d_pcm16, int32_t *d_bits, void *hipStream);
 
 /* ------------------------------------------------------------------------- */
 /* 3. `.ulc` container and packed streams               */

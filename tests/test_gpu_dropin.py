@@ -118,3 +118,34 @@ def test_batched_front_end_matches_the_reference_tools_file_for_file(arg, fmt, t
         ref = open(ref_wav, "rb").read()
         nbytes = struct.unpack("<I", open(u, "rb").read()[8:12])[0] * 2048 * ch * (4 if fmt == "FLOAT32" else 2)
         assert got[-nbytes:] == ref[-nbytes:], f"{u.name}: batched decode differs from ulcdecodetool"
+
+
+@needs_tools
+@pytest.mark.skipif(not os.path.exists(TOOL), reason="ulc-codec_amd/ulcx-tool not built")
+def test_abr_workflow_analyse_then_encode_matches_the_reference_tools(tmp_path):
+    """SURVEY.md §8f rank 3, the ABR usage of ulcEncodeTool.c:157-188: a first run reports the stream's average
+    complexity, a second run passes it back as "kbps,complexity".  Both numbers printed and both files written by the
+    batched front end must equal the reference tool's (linked over libulc_amd)."""
+    import re
+    rate, ch = 44100, 2
+    ins = []
+    for i, sec in enumerate([1.1, 0.6, 1.7]):
+        pcm = synth_pcm(40 + i, int(sec * rate), ch, rate, transient=(i != 1), seed=9)
+        p = tmp_path / f"abr{i}.wav"
+        _write_wav16(p, np.clip(np.rint(pcm * 32767.0), -32768, 32767).astype(np.int16), rate)
+        ins.append(p)
+    d1 = tmp_path / "pass1"; d1.mkdir()
+    out = _run([TOOL, "encode", str(d1), "-50"] + [str(p) for p in ins]).stdout.decode()
+    got = {m.group(1): m.group(2) for m in re.finditer(r"^(\S+?): .*avg complexity ([0-9.]+)$", out, re.M)}
+    refdir, gotdir = tmp_path / "ref", tmp_path / "got"
+    refdir.mkdir(); gotdir.mkdir()
+    for p in ins:
+        ref_out = _run([ENC, str(p), str(refdir / "a.ulc"), "-50"]).stdout.decode()
+        ref_c = re.search(r"Avg complexity = ([0-9.]+)", ref_out).group(1)
+        assert got[p.name] == ref_c, f"{p.name}: average complexity {got[p.name]} != reference tool's {ref_c}"
+        arg = f"64,{ref_c}"
+        _run([ENC, str(p), str(refdir / (p.stem + ".ulc")), arg])
+        sub = gotdir / p.stem; sub.mkdir()
+        _run([TOOL, "encode", str(sub), arg, str(p)])
+        assert open(sub / (p.stem + ".ulc"), "rb").read() == open(refdir / (p.stem + ".ulc"), "rb").read(), \
+            f"{p.name}: ABR file differs from ulcencodetool's"

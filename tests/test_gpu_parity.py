@@ -279,3 +279,62 @@ def test_encode_decode_unusual_geometries(bs, ch, rate, B, K, calls, q):
         rc, ref_pcm, _ = oracle_decode_stream(refs[s]["out"], ch, bs)
         assert rc == 0 and np.array_equal(got[s], ref_pcm), f"geom bs={bs} ch={ch} stream {s}"
     dec.close()
+
+
+@pytest.mark.parametrize("bs,ch,rate,calls,mode,p0", [
+    (2048, 2, 44100, (3, 1, 4), 0, 50.0),      # stereo fast path; history crossing calls of 1 and of several blocks
+    (2048, 1, 44100, (2, 2), 0, 50.0),
+    (512, 3, 32000, (1, 1, 3), 0, 40.0),       # odd channel count: scalar loads
+    (2048, 2, 48000, (3, 2), 1, 64.0),         # CBR
+])
+def test_pcm16_ingest_and_output_match_the_wav_io_conversions(bs, ch, rate, calls, mode, p0):
+    """SURVEY.md §8f rank 4.  PCM16 ingest must give the stream the float path gives for x * 2^-15
+    (tools/WavIO_Helper.c:49-55) - checked against the oracle too - and PCM16 output must equal
+    lrintf(clamp(y * 2^15)) of the float path's output (tools/WavIO_Helper.c:56-63)."""
+    import torch
+    amd = _amd()
+    B, Kmax = 5, max(calls)
+    nblk = sum(calls)
+    x = _streams(B, nblk, bs, ch, rate, True, seed=31)
+    x16 = np.clip(np.rint(x * 32767.0), -32768, 32767).astype(np.int16)
+    xf = x16.astype(np.float32) * np.float32(2.0 ** -15)
+    modes = (amd.MODE_VBR, amd.MODE_CBR)
+    encF = amd.BatchEncoder(B, ch, bs, rate, Kmax)
+    encS = amd.BatchEncoder(B, ch, bs, rate, Kmax)
+    decF = amd.BatchDecoder(B, ch, bs, Kmax)
+    decS = amd.BatchDecoder(B, ch, bs, Kmax)
+    slot = encS.slot
+    refs = [oracle_encode_debug(xf[s], bs, rate, mode, p0, slot=slot) for s in range(2)]
+    k0 = 0
+    for K in calls:
+        seg16 = np.ascontiguousarray(x16[:, k0 * bs:(k0 + K) * bs])
+        want = encF.encode(xf[:, k0 * bs:(k0 + K) * bs], modes[mode], p0)
+        d_in = torch.from_numpy(seg16).cuda()
+        d_out = torch.zeros((B, K, slot), dtype=torch.uint8, device="cuda")
+        d_bits = torch.zeros((B, K), dtype=torch.int32, device="cuda")
+        d_wc = torch.zeros((B, K), dtype=torch.int32, device="cuda")
+        d_cplx = torch.zeros((B, K), dtype=torch.float32, device="cuda")
+        encS.encode_dev_pcm16(d_in.data_ptr(), K, d_out.data_ptr(), d_bits.data_ptr(), d_wc.data_ptr(), d_cplx.data_ptr(),
+                              mode=modes[mode], p0=p0)
+        torch.cuda.synchronize()
+        got = (d_out.cpu().numpy(), d_bits.cpu().numpy(), d_wc.cpu().numpy(), d_cplx.cpu().numpy())
+        for a, b, name in zip(got[1:], want[1:], ("bits", "WindowCtrl", "BlockComplexity")):
+            assert a.tobytes() == b.tobytes(), f"call at block {k0}: PCM16 ingest {name} differ from the float path"
+        for s in range(B):
+            for k in range(K):
+                nb = got[1][s, k] // 8                      # (bytes of a slot past the block are not defined)
+                assert np.array_equal(got[0][s, k, :nb], want[0][s, k, :nb]), f"stream {s} block {k0 + k}: PCM16 ingest bytes differ from the float path"
+        for s in range(2):
+            _compare_encode(got, refs[s], s, k0, K, what="pcm16")
+        # decoder: float output vs PCM16 output of the same blocks
+        yf, ybits = decF.decode(want[0])
+        d_pcm16 = torch.zeros((B, K * bs, ch), dtype=torch.int16, device="cuda")
+        d_dbits = torch.zeros((B, K), dtype=torch.int32, device="cuda")
+        decS.decode_dev_pcm16(d_out.data_ptr(), slot, K, d_pcm16.data_ptr(), d_dbits.data_ptr())
+        torch.cuda.synchronize()
+        want16 = np.clip(np.rint(yf * np.float32(32768.0)), -32768, 32767).astype(np.int16)
+        assert np.array_equal(d_dbits.cpu().numpy(), ybits)
+        assert np.array_equal(d_pcm16.cpu().numpy(), want16), f"call at block {k0}: PCM16 output differs from lrintf(clamp(y*2^15))"
+        k0 += K
+    for o in (encF, encS, decF, decS):
+        o.close()

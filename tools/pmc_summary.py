@@ -5,7 +5,7 @@ Per kernel and per bench step (a kernel launched several times per step, e.g. th
   hbm_bytes = 2 * FETCH_SIZE + WRITE_SIZE      (both counters are in KiB)
 FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (it tallies 128-byte
 requests at 64 bytes for wide coalesced reads; other access widths are uncalibrated - the same guide).
-The number of steps in a run = launches of k_state_update (encoder) / k_dimdct (decoder)."""
+The number of steps in a run = launches of k_state_update<float> (encoder) / k_dimdct (decoder)."""
 import csv, json, sys, collections
 
 def load(path, counter):
@@ -21,7 +21,7 @@ def main():
     fetch_csv, write_csv, out = sys.argv[1], sys.argv[2], sys.argv[3]
     f, fc = load(fetch_csv, "FETCH_SIZE")
     w, wc = load(write_csv, "WRITE_SIZE")
-    steps_f = max(fc.get("k_state_update", 0), 1); steps_w = max(wc.get("k_state_update", 0), 1)
+    steps_f = max(fc.get("k_state_update<float>", 0), 1); steps_w = max(wc.get("k_state_update<float>", 0), 1)
     res = {}
     for k in sorted(set(f) | set(w)):
         if not k.startswith("k_"): continue
@@ -31,7 +31,8 @@ def main():
                   "launches_per_step": fc.get(k, 0) / steps_f,
                   "note": "per bench step (all launches of the kernel in one step summed); FETCH_SIZE doubled per MI355X_MICROARCH.md"}
     # stage-name aliases used by bench.py
-    for alias, real in (("k_select", "k_select_wave<64>"), ("k_encode_wave", "k_encode_wave<true>"), ("k_xf", "k_xf<true>")):
+    for alias, real in (("k_select", "k_select_wave<64>"), ("k_encode_wave", "k_encode_wave<true>"), ("k_xf", "k_xf<true, float>"),
+                        ("k_wc_energy", "k_wc_energy<float>"), ("k_state_update", "k_state_update<float>")):
         if real in res: res[alias] = res[real]
     json.dump(res, open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):

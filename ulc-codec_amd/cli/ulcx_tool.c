@@ -126,6 +126,8 @@ static int do_encode(int argc, char **argv) {
     float *pcm = (float *)malloc(sizeof(float) * (size_t)B * KBLOCKS * frame);
     uint8_t *out = (uint8_t *)malloc((size_t)B * KBLOCKS * slot);
     int32_t *bits = (int32_t *)malloc(sizeof(int32_t) * (size_t)B * KBLOCKS);
+    float *cplx = (float *)malloc(sizeof(float) * (size_t)B * KBLOCKS);
+    double *cplxSum = (double *)calloc((size_t)B, sizeof(double));   /* ulcEncodeTool.c:130,164: feeds the ABR workflow */
     void *tmp = malloc(frame * 4 * KBLOCKS);
     FILE **fo = (FILE **)calloc((size_t)B, sizeof(FILE *));
     uint64_t *total = (uint64_t *)calloc((size_t)B, sizeof(uint64_t));
@@ -141,13 +143,14 @@ static int do_encode(int argc, char **argv) {
         int K = (maxBlk - k0 < KBLOCKS) ? (int)(maxBlk - k0) : KBLOCKS;
         for (int s = 0; s < B; s++)
             wav_read(&w[s], k0 * (uint32_t)bs, (uint32_t)(K * bs), pcm + (size_t)s * K * frame, tmp);
-        if (ulcx_encode_host(enc, mode, p0, avgc, pcm, K, out, bits, NULL, NULL) != ULCX_OK) DIE("encode: %s", ulcx_last_error());
+        if (ulcx_encode_host(enc, mode, p0, avgc, pcm, K, out, bits, NULL, cplx) != ULCX_OK) DIE("encode: %s", ulcx_last_error());
         for (int s = 0; s < B; s++) {
             uint32_t nb = (w[s].nFrames + (uint32_t)bs - 1) / (uint32_t)bs + 2;
             for (int k = 0; k < K && k0 + (uint32_t)k < nb; k++) {
                 uint32_t sz = (uint32_t)(bits[s * K + k] + 7) / 8u;
                 fwrite(out + ((size_t)s * K + k) * slot, 1, sz, fo[s]);               /* ulcEncodeTool.c:160-169 */
                 total[s] += sz; if (sz > maxb[s]) maxb[s] = sz;
+                cplxSum[s] += cplx[s * K + k];
             }
         }
     }
@@ -159,10 +162,11 @@ static int do_encode(int argc, char **argv) {
         h.RateKbps = (uint16_t)ulcx_ulc_rate_kbps(total[s], (uint32_t)hz, (uint32_t)bs, nb);
         uint8_t hb[24]; ulcx_ulc_header_pack(hb, &h);
         fseek(fo[s], 0, SEEK_SET); fwrite(hb, 1, 24, fo[s]); fclose(fo[s]); fclose(w[s].f);
-        printf("%s: %u blocks, %.2f KiB, %u kbps\n", base_name(argv[a + s]), nb, total[s] / 1024.0, h.RateKbps);
+        printf("%s: %u blocks, %.2f KiB, %u kbps, avg complexity %.5f\n", base_name(argv[a + s]), nb, total[s] / 1024.0, h.RateKbps,
+               cplxSum[s] / nb);                                                      /* ulcEncodeTool.c:176,186 */
     }
     ulcx_encoder_destroy(enc);
-    free(pcm); free(out); free(bits); free(tmp); free(fo); free(total); free(maxb); free(w);
+    free(pcm); free(out); free(bits); free(cplx); free(cplxSum); free(tmp); free(fo); free(total); free(maxb); free(w);
     return 0;
 }
 

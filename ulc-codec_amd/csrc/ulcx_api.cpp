@@ -210,15 +210,15 @@ extern "C" void ulcx_encoder_destroy(ulcx_encoder *e) { if (e) { hipSetDevice(e-
 extern "C" int ulcx_encoder_reset(ulcx_encoder *e) { if (!e) return ULCX_ERR_ARG; CKR(hipSetDevice(e->device)); return enc_reset_state(e); }
 extern "C" int ulcx_encoder_slot_bytes(const ulcx_encoder *e) { return e ? e->ctx.slot : 0; }
 
-extern "C" int ulcx_encode_dev(ulcx_encoder *e, int mode, float p0, float p1, const float *d_pcm, int nBlocks,
-                               uint8_t *d_out, int32_t *d_bits, int32_t *d_wc, float *d_cplx, void *hipStream) {
-    if (!e || !d_pcm || !d_out || !d_bits || nBlocks < 1 || nBlocks > e->maxK) { ulcx_set_error("ulcx_encode_dev: bad argument"); return ULCX_ERR_ARG; }
+static int encode_dev_any(ulcx_encoder *e, int mode, float p0, float p1, const float *d_pcm, const int16_t *d_pcm16, int nBlocks,
+                          uint8_t *d_out, int32_t *d_bits, int32_t *d_wc, float *d_cplx, void *hipStream) {
+    if (!e || (!d_pcm && !d_pcm16) || !d_out || !d_bits || nBlocks < 1 || nBlocks > e->maxK) { ulcx_set_error("ulcx_encode_dev: bad argument"); return ULCX_ERR_ARG; }
     if (mode != ULCX_MODE_VBR && mode != ULCX_MODE_CBR && mode != ULCX_MODE_ABR) { ulcx_set_error("bad mode"); return ULCX_ERR_ARG; }
     CKR(hipSetDevice(e->device));
     UlcxEncCtx c = e->ctx;
     c.K = nBlocks; c.mode = mode; c.p0 = p0; c.p1 = p1;
     c.vbrTarget = (mode == ULCX_MODE_VBR) ? 0x1.E4EFB7p3f * logf(100.0f / p0) : 0.0f;     // ulcEncoder.c:144 (host libm, data independent)
-    c.pcm = d_pcm; c.out = d_out; c.bits = d_bits; c.wcOut = d_wc; c.cplxOut = d_cplx;
+    c.pcm = d_pcm; c.pcm16 = d_pcm16; c.out = d_out; c.bits = d_bits; c.wcOut = d_wc; c.cplxOut = d_cplx;
     UlcxEncAux aux;
     aux.side = e->sideOk ? e->side : nullptr; aux.side2 = e->sideOk ? e->side2 : nullptr; aux.side3 = e->sideOk ? e->side3 : nullptr; aux.side4 = (e->sideOk && getenv("ULCX_WC_ESTREAM")) ? e->side4 : nullptr; aux.evE = e->evE;
     aux.evFork = e->evFork; aux.evJoin = e->evJoin; aux.evFork2 = e->evFork2; aux.evWC = e->evWC; aux.evXf = e->evXf;
@@ -229,6 +229,17 @@ extern "C" int ulcx_encode_dev(ulcx_encoder *e, int mode, float p0, float p1, co
     e->lastK = nBlocks;
     e->keysFinal = false;
     return rc;
+}
+
+extern "C" int ulcx_encode_dev(ulcx_encoder *e, int mode, float p0, float p1, const float *d_pcm, int nBlocks,
+                               uint8_t *d_out, int32_t *d_bits, int32_t *d_wc, float *d_cplx, void *hipStream) {
+    if (!d_pcm) { ulcx_set_error("ulcx_encode_dev: bad argument"); return ULCX_ERR_ARG; }
+    return encode_dev_any(e, mode, p0, p1, d_pcm, nullptr, nBlocks, d_out, d_bits, d_wc, d_cplx, hipStream);
+}
+extern "C" int ulcx_encode_dev_pcm16(ulcx_encoder *e, int mode, float p0, float p1, const int16_t *d_pcm16, int nBlocks,
+                                     uint8_t *d_out, int32_t *d_bits, int32_t *d_wc, float *d_cplx, void *hipStream) {
+    if (!d_pcm16) { ulcx_set_error("ulcx_encode_dev_pcm16: bad argument"); return ULCX_ERR_ARG; }
+    return encode_dev_any(e, mode, p0, p1, nullptr, d_pcm16, nBlocks, d_out, d_bits, d_wc, d_cplx, hipStream);
 }
 
 extern "C" int ulcx_encode_host(ulcx_encoder *e, int mode, float p0, float p1, const float *h_pcm, int nBlocks,
@@ -407,14 +418,22 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
 extern "C" void ulcx_decoder_destroy(ulcx_decoder *e) { if (e) { hipSetDevice(e->device); cleanup(e); } }
 extern "C" int ulcx_decoder_reset(ulcx_decoder *e) { if (!e) return ULCX_ERR_ARG; CKR(hipSetDevice(e->device)); return dec_reset_state(e); }
 
-extern "C" int ulcx_decode_dev(ulcx_decoder *e, const uint8_t *d_in, int slotBytes, int nBlocks, float *d_pcm, int32_t *d_bits, void *hipStream) {
-    if (!e || !d_in || !d_pcm || !d_bits || slotBytes < 1 || nBlocks < 1 || nBlocks > e->maxK) { ulcx_set_error("ulcx_decode_dev: bad argument"); return ULCX_ERR_ARG; }
+static int decode_dev_any(ulcx_decoder *e, const uint8_t *d_in, int slotBytes, int nBlocks, float *d_pcm, int16_t *d_pcm16, int32_t *d_bits, void *hipStream) {
+    if (!e || !d_in || (!d_pcm && !d_pcm16) || !d_bits || slotBytes < 1 || nBlocks < 1 || nBlocks > e->maxK) { ulcx_set_error("ulcx_decode_dev: bad argument"); return ULCX_ERR_ARG; }
     CKR(hipSetDevice(e->device));
     UlcxDecCtx c = e->ctx;
-    c.K = nBlocks; c.slot = slotBytes; c.in = d_in; c.pcm = d_pcm; c.bits = d_bits;
+    c.K = nBlocks; c.slot = slotBytes; c.in = d_in; c.pcm = d_pcm; c.pcm16 = d_pcm16; c.bits = d_bits;
     int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->ev, e->sideOk ? e->side : nullptr, e->evFork, e->evSide);
     e->evRecorded = (rc == ULCX_OK);
     return rc;
+}
+extern "C" int ulcx_decode_dev(ulcx_decoder *e, const uint8_t *d_in, int slotBytes, int nBlocks, float *d_pcm, int32_t *d_bits, void *hipStream) {
+    if (!d_pcm) { ulcx_set_error("ulcx_decode_dev: bad argument"); return ULCX_ERR_ARG; }
+    return decode_dev_any(e, d_in, slotBytes, nBlocks, d_pcm, nullptr, d_bits, hipStream);
+}
+extern "C" int ulcx_decode_dev_pcm16(ulcx_decoder *e, const uint8_t *d_in, int slotBytes, int nBlocks, int16_t *d_pcm16, int32_t *d_bits, void *hipStream) {
+    if (!d_pcm16) { ulcx_set_error("ulcx_decode_dev_pcm16: bad argument"); return ULCX_ERR_ARG; }
+    return decode_dev_any(e, d_in, slotBytes, nBlocks, nullptr, d_pcm16, d_bits, hipStream);
 }
 extern "C" int ulcx_decode_host(ulcx_decoder *e, const uint8_t *h_in, int slotBytes, int nBlocks, float *h_pcm, int32_t *h_bits) {
     if (!e || !h_in || !h_pcm || !h_bits || nBlocks < 1 || nBlocks > e->maxK || slotBytes < 1) return ULCX_ERR_ARG;
@@ -475,7 +494,7 @@ extern "C" int ulcx_decode_packed_dev(ulcx_decoder *e, const uint8_t *d_payload,
     if (!e || !d_payload || !d_payloadBytes || !d_pcm || !d_bits || payloadStride < 1 || nBlocks < 1 || nBlocks > e->maxK) { ulcx_set_error("ulcx_decode_packed_dev: bad argument"); return ULCX_ERR_ARG; }
     CKR(hipSetDevice(e->device));
     UlcxDecCtx c = e->ctx;
-    c.K = nBlocks; c.slot = 0; c.in = d_payload; c.pcm = d_pcm; c.bits = d_bits;
+    c.K = nBlocks; c.slot = 0; c.in = d_payload; c.pcm = d_pcm; c.pcm16 = nullptr; c.bits = d_bits;
     c.packed = 1; c.payStride = payloadStride; c.payBytes = d_payloadBytes;
     int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->ev, e->sideOk ? e->side : nullptr, e->evFork, e->evSide);
     e->evRecorded = (rc == ULCX_OK);

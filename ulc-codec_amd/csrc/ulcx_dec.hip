@@ -406,6 +406,24 @@ __global__ __launch_bounds__(256) void k_dgen(UlcxDecCtx c) {
 // IMDCT + overlap-add.  LDS carve (floats): lap [C][BS/2] | z [4.25*BS] (four padded arrays of BS/2 complex;
 // the general path uses the first BS floats as one array and keeps dec [BS] | tmpq [BS/2] behind it) | twl [BS/2]
 // ---------------------------------------------------------------------------
+// Output samples.  OUT = float: the C API's layout; OUT = int16_t: PCM16 output, converted on store
+// exactly as the reference's WAV writer does (tools/WavIO_Helper.c:9-13,56-63: lrintf(clamp(x * 2^15, -32768, 32767))).
+__device__ __forceinline__ int16_t to_pcm16(float x) {
+    float v = x * 0x1.0p+15f;
+    v = (v < -32768.0f) ? -32768.0f : (v > 32767.0f) ? 32767.0f : v;
+    return (int16_t)__float2int_rn(v);
+}
+__device__ __forceinline__ void st1(float *p, float a) { *p = a; }
+__device__ __forceinline__ void st2(float *p, float a, float b) { *(float2 *)p = make_float2(a, b); }
+__device__ __forceinline__ void st4(float *p, float a, float b, float d, float e) { *(float4 *)p = make_float4(a, b, d, e); }
+__device__ __forceinline__ void st1(int16_t *p, float a) { *p = to_pcm16(a); }
+__device__ __forceinline__ void st2(int16_t *p, float a, float b) { *(short2 *)p = make_short2(to_pcm16(a), to_pcm16(b)); }
+__device__ __forceinline__ void st4(int16_t *p, float a, float b, float d, float e) { *(short4 *)p = make_short4(to_pcm16(a), to_pcm16(b), to_pcm16(d), to_pcm16(e)); }
+template <typename OUT> __device__ __forceinline__ OUT *out_base(const UlcxDecCtx &c);
+template <> __device__ __forceinline__ float *out_base<float>(const UlcxDecCtx &c) { return c.pcm; }
+template <> __device__ __forceinline__ int16_t *out_base<int16_t>(const UlcxDecCtx &c) { return c.pcm16; }
+
+template <typename OUT>
 __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
     extern __shared__ float lds[];
     const int BS = c.BS, C = c.C, H2 = BS / 2;
@@ -446,7 +464,7 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
             zb[pn2] = cmulc(make_float2(b1.x, a1.y), P2);
         }
     };
-    auto fast_post = [&](const float2 *z0, const float2 *z1, float *outp, int ov, bool padded) {
+    auto fast_post = [&](const float2 *z0, const float2 *z1, OUT *outp, int ov, bool padded) {
         const int S = BS, M = BS >> 1;
         const float2 *pre = c.T.pre[0];
         int a = (S - ov) >> 1;
@@ -483,8 +501,8 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
                 hi2[q] = make_float2(mHi + sHi, mHi - sHi);
             }
             // positions pv[1] = pv[0]-1 and S-1-pv[0], S-pv[0] are neighbours: two aligned 16-byte stores
-            *(float4 *)(outp + 2 * pv[1]) = make_float4(lo2[1].x, lo2[1].y, lo2[0].x, lo2[0].y);
-            *(float4 *)(outp + 2 * (S - 1 - pv[0])) = make_float4(hi2[0].x, hi2[0].y, hi2[1].x, hi2[1].y);
+            st4(outp + 2 * pv[1], lo2[1].x, lo2[1].y, lo2[0].x, lo2[0].y);
+            st4(outp + 2 * (S - 1 - pv[0]), hi2[0].x, hi2[0].y, hi2[1].x, hi2[1].y);
             L0[2 * k1] = ya1.x; L0[2 * k1 + 1] = -ya2.y;
             L1[2 * k1] = yb1.x; L1[2 * k1 + 1] = -yb2.y;
         }
@@ -493,9 +511,9 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
     for (int k = 0; k < c.K; k++) {
         int blk = s * c.K + k;
         int wc = c.wc[blk];
-        float *outp = c.pcm + (size_t)blk * C * BS;
+        OUT *outp = out_base<OUT>(c) + (size_t)blk * C * BS;
         if (wc == 0) {                                              // corrupt block / dead stream
-            for (int i = tid; i < C * BS; i += WG) outp[i] = 0.0f;
+            for (int i = tid; i < C * BS; i += WG) st1(outp + i, 0.0f);
             continue;
         }
         const float *coefB = c.coef + (size_t)blk * C * BS;
@@ -604,11 +622,11 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
                     for (int n = tid; n < BS; n += WG) {
                         float m = dst[(ptrdiff_t)n - BS], sd = dst[n];                 // ulcDecoder.c:281-289
                         float l = m + sd, r = m - sd;
-                        if (C == 2) *(float2 *)(outp + 2 * n) = make_float2(l, r);
-                        else { outp[(size_t)n * C + ch - 1] = l; outp[(size_t)n * C + ch] = r; }
+                        if (C == 2) st2(outp + 2 * n, l, r);
+                        else { st1(outp + (size_t)n * C + ch - 1, l); st1(outp + (size_t)n * C + ch, r); }
                     }
                 } else {
-                    for (int n = tid; n < BS; n += WG) outp[(size_t)n * C + ch] = dst[n];
+                    for (int n = tid; n < BS; n += WG) st1(outp + (size_t)n * C + ch, dst[n]);
                 }
                 __syncthreads();
             }
@@ -649,8 +667,12 @@ int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
     hipLaunchKernelGGL(k_dgen, dim3(DGEN_DEC_WGS + (NB * c.C * DCP_PER_UNIT + 255) / 256), dim3(256), 0, st, c);
     if (ev) CK(hipEventRecord(ev[stage++], st));
     size_t lds = ulcx_dec_lds_bytes(c.BS, c.C);
-    if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_dimdct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_dimdct, dim3(c.B), dim3(WG), lds, st, c);
+    if (lds > 48 * 1024) {
+        CK(hipFuncSetAttribute((const void *)k_dimdct<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CK(hipFuncSetAttribute((const void *)k_dimdct<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (c.pcm16) hipLaunchKernelGGL(k_dimdct<int16_t>, dim3(c.B), dim3(WG), lds, st, c);
+    else hipLaunchKernelGGL(k_dimdct<float>, dim3(c.B), dim3(WG), lds, st, c);
     if (ev) CK(hipEventRecord(ev[stage++], st));
     CK(hipGetLastError());
     return ULCX_OK;

@@ -39,17 +39,40 @@ __device__ __forceinline__ int quant_u(float v) {                // ulcHelper.h:
 __device__ __forceinline__ int quant_coef_u(float v, int lim) { int q = quant_u(v); return q < lim ? q : lim; }
 __device__ __forceinline__ int quant_coef(float v, int lim) { int q = quant_coef_u(fabsf(v), lim); return v < 0.0f ? -q : q; }
 
-// pointer to the C interleaved samples at time trel (relative to this call's first
-// sample; negative = the two blocks kept from previous calls)
-__device__ __forceinline__ const float *smp_ptr(const UlcxEncCtx &c, int s, int trel) {
-    if (trel < 0) return c.hist + ((size_t)s * 2 * c.BS + (trel + 2 * c.BS)) * c.C;
-    return c.pcm + ((size_t)s * c.K * c.BS + trel) * c.C;
+// Input samples.  IN = float: the C API's layout; IN = int16_t: PCM16 ingest, converted on load
+// exactly as the reference's WAV reader does (tools/WavIO_Helper.c:49-55: (float)x * 2^-15, exact).  The two blocks kept
+// from previous calls (c.hist) are always float.
+template <typename IN> __device__ __forceinline__ const IN *pcm_base(const UlcxEncCtx &c);
+template <> __device__ __forceinline__ const float *pcm_base<float>(const UlcxEncCtx &c) { return c.pcm; }
+template <> __device__ __forceinline__ const int16_t *pcm_base<int16_t>(const UlcxEncCtx &c) { return c.pcm16; }
+__device__ __forceinline__ float  ld1(const float *p) { return *p; }
+__device__ __forceinline__ float2 ld2(const float *p) { return *(const float2 *)p; }
+__device__ __forceinline__ float4 ld4(const float *p) { return *(const float4 *)p; }
+__device__ __forceinline__ float  ld1(const int16_t *p) { return (float)*p * 0x1.0p-15f; }
+__device__ __forceinline__ float2 ld2(const int16_t *p) { short2 v = *(const short2 *)p; return make_float2((float)v.x * 0x1.0p-15f, (float)v.y * 0x1.0p-15f); }
+__device__ __forceinline__ float4 ld4(const int16_t *p) {
+    short4 v = *(const short4 *)p;
+    return make_float4((float)v.x * 0x1.0p-15f, (float)v.y * 0x1.0p-15f, (float)v.z * 0x1.0p-15f, (float)v.w * 0x1.0p-15f);
+}
+// the C interleaved samples at time trel (relative to this call's first sample; negative = the two blocks kept from
+// previous calls): n = 1, 2 or 4 consecutive floats starting at element e of that time step
+template <typename IN> __device__ __forceinline__ float smp_ld1(const UlcxEncCtx &c, int s, int trel, int e) {
+    if (trel < 0) return ld1(c.hist + ((size_t)s * 2 * c.BS + (trel + 2 * c.BS)) * c.C + e);
+    return ld1(pcm_base<IN>(c) + ((size_t)s * c.K * c.BS + trel) * c.C + e);
+}
+template <typename IN> __device__ __forceinline__ float2 smp_ld2(const UlcxEncCtx &c, int s, int trel) {
+    if (trel < 0) return ld2(c.hist + ((size_t)s * 2 * c.BS + (trel + 2 * c.BS)) * c.C);
+    return ld2(pcm_base<IN>(c) + ((size_t)s * c.K * c.BS + trel) * c.C);
+}
+template <typename IN> __device__ __forceinline__ float4 smp_ld4(const UlcxEncCtx &c, int s, int trel) {   // C == 2: two time steps
+    if (trel < 0) return ld4(c.hist + ((size_t)s * 2 * c.BS + (trel + 2 * c.BS)) * c.C);
+    return ld4(pcm_base<IN>(c) + ((size_t)s * c.K * c.BS + trel) * c.C);
 }
 // sample after the encoder's M/S step (BlockTransform.c:102-110)
-__device__ __forceinline__ float ms_sample(const float *p, int ch, int C) {
-    if (ch & 1) { float a = p[ch - 1], b = p[ch]; return (a - b) * 0.5f; }
-    if (ch + 1 < C) { float a = p[ch], b = p[ch + 1]; return (a + b) * 0.5f; }
-    return p[ch];
+template <typename IN> __device__ __forceinline__ float ms_sample(const UlcxEncCtx &c, int s, int trel, int ch) {
+    if (ch & 1) { float a = smp_ld1<IN>(c, s, trel, ch - 1), b = smp_ld1<IN>(c, s, trel, ch); return (a - b) * 0.5f; }
+    if (ch + 1 < c.C) { float a = smp_ld1<IN>(c, s, trel, ch), b = smp_ld1<IN>(c, s, trel, ch + 1); return (a + b) * 0.5f; }
+    return smp_ld1<IN>(c, s, trel, ch);
 }
 // ---------------------------------------------------------------------------
 // Window control
@@ -68,6 +91,7 @@ __device__ __forceinline__ size_t env_idx(const UlcxEncCtx &c, int s, int t) {
 // All window-control kernels (and k_xf) take a block range [k0, k1) of the call so the host can
 // pipeline chunks of blocks: the stream-sequential recurrences of later chunks run beside the
 // transform of earlier ones.
+template <typename IN>
 __global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c, int k0, int k1) {
     __shared__ float2 tile[64][65];
     int tiles_t = ((k1 - k0) * c.BS) / 64;
@@ -80,10 +104,9 @@ __global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c, int k0, int k1) 
         int s = sg * 64 + sl;
         float2 v = make_float2(0.0f, 0.0f);
         if (s < c.B) {
-            const float *p0 = smp_ptr(c, s, t - 1), *p1 = smp_ptr(c, s, t), *p2 = smp_ptr(c, s, t + 1);
             float ehp = 0.0f, ebp = 0.0f;
-            if (c.C == 2) {                                // stereo fast path: three 8-byte loads
-                float2 a = *(const float2 *)p0, b = *(const float2 *)p1, d = *(const float2 *)p2;
+            if (c.C == 2) {                                // stereo fast path: three 8-byte (PCM16: 4-byte) loads
+                float2 a = smp_ld2<IN>(c, s, t - 1), b = smp_ld2<IN>(c, s, t), d = smp_ld2<IN>(c, s, t + 1);
                 float m0 = (a.x + a.y) * 0.5f, m1 = (b.x + b.y) * 0.5f, m2 = (d.x + d.y) * 0.5f;
                 float s0 = (a.x - a.y) * 0.5f, s1 = (b.x - b.y) * 0.5f, s2 = (d.x - d.y) * 0.5f;
                 float hp = -m0 + 2 * m1 - m2, bp = -m0 + m2;
@@ -92,7 +115,7 @@ __global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c, int k0, int k1) 
                 ehp += hp * hp; ebp += bp * bp;
             } else {
                 for (int ch = 0; ch < c.C; ch++) {
-                    float t0 = ms_sample(p0, ch, c.C), t1 = ms_sample(p1, ch, c.C), t2 = ms_sample(p2, ch, c.C);
+                    float t0 = ms_sample<IN>(c, s, t - 1, ch), t1 = ms_sample<IN>(c, s, t, ch), t2 = ms_sample<IN>(c, s, t + 1, ch);
                     float hp = -t0 + 2 * t1 - t2;
                     float bp = -t0 + t2;
                     ehp += hp * hp;
@@ -319,7 +342,7 @@ __device__ __forceinline__ float win_apply(float x, int i, int S, int aL, int ov
 }
 
 // ST: stereo instantiation (C = 2 as a compile-time constant: one channel pair, no per-pair branches)
-template <bool ST>
+template <bool ST, typename IN>
 __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
     extern __shared__ float lds[];
     const int BS = c.BS, C = ST ? 2 : c.C;
@@ -395,7 +418,9 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
             // whole subblock (the steady state: every position is on a ramp, no clamps or selects in the window).
             auto fold = [&](auto inpcmT, auto fullovT) {
                 constexpr bool INPCM = decltype(inpcmT)::value, FULLOV = decltype(fullovT)::value;
-                const float *frame = c.pcm + ((size_t)s * c.K * BS + (INPCM ? t0 : 0)) * C;
+                const IN *frame = pcm_base<IN>(c) + ((size_t)s * c.K * BS + (INPCM ? t0 : 0)) * C;
+                auto ldE = [&](int pos, int e) -> float { return INPCM ? ld1(frame + (size_t)pos * C + e) : smp_ld1<IN>(c, s, t0 + pos, e); };
+                auto ldQ = [&](int pos) -> float4 { return INPCM ? ld4(frame + (size_t)pos * C) : smp_ld4<IN>(c, s, t0 + pos); };
                 for (int jj = tid; jj < M / 2; jj += WG) {
                     const int iA = 2 * jj, iB = S - 2 - 2 * jj, iC = S + 2 * jj, iD = 2 * S - 2 - 2 * jj;
                     float2 xs[8];                           // (ch0, ch0+1) after M/S at iA, iA+1, iB, iB+1, iC, iC+1, iD, iD+1
@@ -403,16 +428,15 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
                         const int ip[4] = { iA, iB, iC, iD };
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            const float *p = INPCM ? frame + (size_t)ip[r] * C : smp_ptr(c, s, t0 + ip[r]);
-                            float2 e0, e1;
+                            float2 e0, e1;                  // positions ip[r] and ip[r]+1 (same side of the history boundary: ip[r] and t0 are even)
                             if (nch == 2) {
-                                if (C == 2) { float4 v = *(const float4 *)p; e0 = make_float2(v.x, v.y); e1 = make_float2(v.z, v.w); }
-                                else { e0 = make_float2(p[ch0], p[ch0 + 1]); e1 = make_float2(p[C + ch0], p[C + ch0 + 1]); }
+                                if (C == 2) { float4 v = ldQ(ip[r]); e0 = make_float2(v.x, v.y); e1 = make_float2(v.z, v.w); }
+                                else { e0 = make_float2(ldE(ip[r], ch0), ldE(ip[r], ch0 + 1)); e1 = make_float2(ldE(ip[r] + 1, ch0), ldE(ip[r] + 1, ch0 + 1)); }
                                 // M/S (BlockTransform.c:102-110)
                                 xs[2 * r]     = make_float2((e0.x + e0.y) * 0.5f, (e0.x - e0.y) * 0.5f);
                                 xs[2 * r + 1] = make_float2((e1.x + e1.y) * 0.5f, (e1.x - e1.y) * 0.5f);
                             } else {
-                                xs[2 * r] = make_float2(p[ch0], 0.0f); xs[2 * r + 1] = make_float2(p[C + ch0], 0.0f);
+                                xs[2 * r] = make_float2(ldE(ip[r], ch0), 0.0f); xs[2 * r + 1] = make_float2(ldE(ip[r] + 1, ch0), 0.0f);
                             }
                         }
                     }
@@ -2150,17 +2174,18 @@ __global__ __launch_bounds__(WG) void k_selenc(UlcxEncCtx c, int finalPass, int 
 // ---------------------------------------------------------------------------
 // Persistent state for the next call (ulcEncoder_BlockTransform.c:93, :114)
 // ---------------------------------------------------------------------------
+template <typename IN>
 __global__ __launch_bounds__(WG) void k_state_update(UlcxEncCtx c) {
     int s = blockIdx.x, tid = threadIdx.x;
     int n = 2 * c.BS * c.C;                     // floats of history
     float *h = c.hist + (size_t)s * n;
     int newF = c.K * c.BS * c.C;
-    const float *p = c.pcm + (size_t)s * newF;
+    const IN *p = pcm_base<IN>(c) + (size_t)s * newF;
     if (c.K >= 2) {
-        for (int i = tid; i < n; i += WG) h[i] = p[newF - n + i];
+        for (int i = tid; i < n; i += WG) h[i] = ld1(p + newF - n + i);
     } else {
         int half = n / 2;                       // disjoint per-thread index sets: no hazard
-        for (int i = tid; i < half; i += WG) { h[i] = h[half + i]; h[half + i] = p[i]; }
+        for (int i = tid; i < half; i += WG) { h[i] = h[half + i]; h[half + i] = ld1(p + i); }
     }
     if (tid == 0) {
         UlcxWcState &w = c.wcs[s];
@@ -2180,6 +2205,25 @@ size_t ulcx_enc_xf_lds_bytes(int BS, int C) {
     size_t z = (size_t)4 * (BS + (BS >> ps)) * 4;               // four padded arrays of BS/2 complex
     size_t full = z + (size_t)BS * 2 + 32 + (C > 2 ? (size_t)BS * 2 : 0);
     return full <= ULCX_LDS_LIMIT ? full : z + (size_t)BS * 2 + 32;   // (C > 2 at BlockSize 8192: twiddles stay in global memory)
+}
+
+// launch the input-reading kernels for the call's sample type (float | PCM16)
+static void launch_wc_energy(const UlcxEncCtx &c, unsigned grid, hipStream_t st, int k0, int k1) {
+    if (c.pcm16) hipLaunchKernelGGL(k_wc_energy<int16_t>, dim3(grid), dim3(WG), 0, st, c, k0, k1);
+    else hipLaunchKernelGGL(k_wc_energy<float>, dim3(grid), dim3(WG), 0, st, c, k0, k1);
+}
+static void launch_xf(const UlcxEncCtx &c, unsigned grid, size_t lds, hipStream_t st, int k0, int k1) {
+    if (c.pcm16) {
+        if (c.C == 2) hipLaunchKernelGGL((k_xf<true, int16_t>), dim3(grid), dim3(WG), lds, st, c, k0, k1);
+        else hipLaunchKernelGGL((k_xf<false, int16_t>), dim3(grid), dim3(WG), lds, st, c, k0, k1);
+    } else {
+        if (c.C == 2) hipLaunchKernelGGL((k_xf<true, float>), dim3(grid), dim3(WG), lds, st, c, k0, k1);
+        else hipLaunchKernelGGL((k_xf<false, float>), dim3(grid), dim3(WG), lds, st, c, k0, k1);
+    }
+}
+static void launch_state_update(const UlcxEncCtx &c, hipStream_t st) {
+    if (c.pcm16) hipLaunchKernelGGL(k_state_update<int16_t>, dim3(c.B), dim3(WG), 0, st, c);
+    else hipLaunchKernelGGL(k_state_update<float>, dim3(c.B), dim3(WG), 0, st, c);
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)
@@ -2210,10 +2254,15 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
         // transform of chunk j on the main stream.  wcPipe = 1 keeps everything on the main stream.
         const int nCh = wcPipe;
         size_t lds = ulcx_enc_xf_lds_bytes(c.BS, c.C);
-        if (lds > 48 * 1024) { CK(hipFuncSetAttribute((const void *)k_xf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); CK(hipFuncSetAttribute((const void *)k_xf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
+        if (lds > 48 * 1024) {
+            CK(hipFuncSetAttribute((const void *)k_xf<true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CK(hipFuncSetAttribute((const void *)k_xf<false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CK(hipFuncSetAttribute((const void *)k_xf<true, int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CK(hipFuncSetAttribute((const void *)k_xf<false, int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
         auto launch_wc = [&](hipStream_t s2, int k0, int k1, bool marks) -> int {
             int kc = k1 - k0;
-            hipLaunchKernelGGL(k_wc_energy, dim3((unsigned)(SG * ((kc * c.BS) / 64))), dim3(WG), 0, s2, c, k0, k1);   if (marks) MARK();
+            launch_wc_energy(c, (unsigned)(SG * ((kc * c.BS) / 64)), s2, k0, k1);   if (marks) MARK();
             hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, s2, c, k0, k1);                  if (marks) MARK();
             hipLaunchKernelGGL(k_wc_backward, dim3(SG * kc), dim3(64), 0, s2, c, k0, k1);                             if (marks) MARK();
             hipLaunchKernelGGL(k_wc_integrate, dim3((c.B + 63) / 64), dim3(64), 0, s2, c, k0, k1);                    if (marks) MARK();
@@ -2222,8 +2271,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
         };
         if (nCh <= 1) {
             int rc = launch_wc(st, 0, c.K, true); if (rc) return rc;
-            if (c.C == 2) hipLaunchKernelGGL(k_xf<true>, dim3(((NB + 7) / 8) * 8), dim3(WG), lds, st, c, 0, c.K);
-            else hipLaunchKernelGGL(k_xf<false>, dim3(((NB + 7) / 8) * 8), dim3(WG), lds, st, c, 0, c.K);
+            launch_xf(c, ((NB + 7) / 8) * 8, lds, st, 0, c.K);
             MARK();
         } else {
             for (int i = 0; i < 5; i++) MARK();                    // (window-control stages: hidden in the k_xf interval in this mode)
@@ -2252,7 +2300,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
                 //  chain kernels slow down by more than the time it takes between two links of the chain)
                 hipStream_t es = side4 ? side4 : side;
                 if (side4 && w >= 2) CK(hipStreamWaitEvent(side4, evF[w - 2], 0));      // run ahead of the chain by one step only
-                hipLaunchKernelGGL(k_wc_energy, dim3((unsigned)(SG * ((kc * c.BS) / 64))), dim3(WG), 0, es, c, k0, k1);
+                launch_wc_energy(c, (unsigned)(SG * ((kc * c.BS) / 64)), es, k0, k1);
                 if (side4) { CK(hipEventRecord(evE[w], side4)); CK(hipStreamWaitEvent(side, evE[w], 0)); }
                 hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, side, c, k0, k1);
                 CK(hipEventRecord(evF[w], side));
@@ -2269,8 +2317,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
                     int nbk = c.B * (x1 - x0);
                     CK(hipStreamWaitEvent(st, evD[w], 0));
                     if (ev) CK(hipEventRecord(aux.evXf[2 * jx], st));
-                    if (c.C == 2) hipLaunchKernelGGL(k_xf<true>, dim3(((nbk + 7) / 8) * 8), dim3(WG), lds, st, c, x0, x1);
-                    else hipLaunchKernelGGL(k_xf<false>, dim3(((nbk + 7) / 8) * 8), dim3(WG), lds, st, c, x0, x1);
+                    launch_xf(c, ((nbk + 7) / 8) * 8, lds, st, x0, x1);
                     if (ev) CK(hipEventRecord(aux.evXf[2 * jx + 1], st));
                     jx++;
                 }
@@ -2302,7 +2349,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
         CK(hipEventRecord(evCplx, side3));
         MARK();
         // the state for the next call only needs the transform to be done with the history: off the main stream
-        hipLaunchKernelGGL(k_state_update, dim3(c.B), dim3(WG), 0, side3, c);
+        launch_state_update(c, side3);
         CK(hipEventRecord(evState, side3));
     } else { hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c);                         MARK(); }
     {
@@ -2475,7 +2522,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
     }
     MARK();   // cbr_probe_passes (empty interval for VBR)
     if (noiseAside) { CK(hipStreamWaitEvent(st, evState, 0));                                               MARK(); }
-    else { hipLaunchKernelGGL(k_state_update, dim3(c.B), dim3(WG), 0, st, c);                              MARK(); }
+    else { launch_state_update(c, st);                              MARK(); }
     CK(hipGetLastError());
     return ULCX_OK;
 }

@@ -49,7 +49,8 @@ struct UlcxEncCtx {
     int   rateHz;
     UlcxTables T;
     // inputs / outputs of this call
-    const float *pcm; uint8_t *out; int32_t *bits; int32_t *wcOut; float *cplxOut;
+    const float *pcm; const int16_t *pcm16;      // exactly one is set: the C API's f32 input, or PCM16 ingest
+    uint8_t *out; int32_t *bits; int32_t *wcOut; float *cplxOut;
     // persistent state
     float *hist;                         // [B][2*BS][C] previous two input blocks (raw, interleaved)
     UlcxWcState *wcs;                    // [B]
@@ -95,7 +96,8 @@ struct UlcxDecCtx {
     int slot;
     int dbgSkip;                         // timing experiments only (ULCX_DBG_SKIP)
     UlcxTables T;
-    const uint8_t *in; float *pcm; int32_t *bits;
+    const uint8_t *in; float *pcm; int16_t *pcm16;   // exactly one of pcm / pcm16 is set (f32 as the C API, or PCM16 output)
+    int32_t *bits;
     // persistent
     float *lap;                          // [B][C][BS/2] TransformInvLap
     int   *lastSub;                      // [B] LastSubBlockSize

@@ -17,8 +17,8 @@ EXPORTS = [
     "ULC_EncoderState_Init", "ULC_EncoderState_Destroy", "ULC_EncodeBlock_CBR", "ULC_EncodeBlock_ABR",
     "ULC_EncodeBlock_VBR", "ULC_DecoderState_Init", "ULC_DecoderState_Destroy", "ULC_DecodeBlock",
     "ulcx_last_error", "ulcx_device_count", "ulcx_encoder_create", "ulcx_encoder_destroy", "ulcx_encoder_reset",
-    "ulcx_encoder_slot_bytes", "ulcx_encode_dev", "ulcx_encode_host", "ulcx_encoder_debug_fetch",
-    "ulcx_decoder_create", "ulcx_decoder_destroy", "ulcx_decoder_reset", "ulcx_decode_dev", "ulcx_decode_host",
+    "ulcx_encoder_slot_bytes", "ulcx_encode_dev", "ulcx_encode_dev_pcm16", "ulcx_encode_host", "ulcx_encoder_debug_fetch",
+    "ulcx_decoder_create", "ulcx_decoder_destroy", "ulcx_decoder_reset", "ulcx_decode_dev", "ulcx_decode_dev_pcm16", "ulcx_decode_host",
     "ulcx_encoder_last_fallbacks", "ulcx_ulc_header_pack", "ulcx_ulc_header_parse", "ulcx_ulc_rate_kbps",
     "ulcx_pack_streams_dev", "ulcx_decode_packed_dev", "ulcx_decode_packed_host", "ulcx_encoder_stage_ms", "ulcx_encoder_stage_name", "ulcx_decoder_stage_ms", "ulcx_decoder_stage_name",
 ]
@@ -47,12 +47,14 @@ def lib():
         l.ulcx_encoder_slot_bytes.argtypes = [C.c_void_p]
         l.ulcx_encode_dev.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.ulcx_encode_dev_pcm16.argtypes = l.ulcx_encode_dev.argtypes
         l.ulcx_encode_host.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, _f32p, C.c_int, _u8p, _i32p, _i32p, _f32p]
         l.ulcx_encoder_debug_fetch.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, _f32p, _u8p, _i32p]
         l.ulcx_decoder_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         l.ulcx_decoder_destroy.argtypes = [C.c_void_p]
         l.ulcx_decoder_reset.argtypes = [C.c_void_p]
         l.ulcx_decode_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.ulcx_decode_dev_pcm16.argtypes = l.ulcx_decode_dev.argtypes
         l.ulcx_decode_host.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, _f32p, _i32p]
         l.ulcx_encoder_last_fallbacks.argtypes = [C.c_void_p]
         l.ulcx_decode_packed_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -128,6 +130,12 @@ class BatchEncoder:
                                      stream or None), "ulcx_encode_dev")
         self.lastK = n_blocks
 
+    def encode_dev_pcm16(self, d_pcm16, n_blocks, d_out, d_bits, d_wc=0, d_cplx=0, mode=MODE_VBR, p0=50.0, p1=0.0, stream=0):
+        """PCM16 ingest: d_pcm16 is a device pointer to int16 [B][K][BS][C]; converted on load as tools/WavIO_Helper.c:49-55."""
+        _check(lib().ulcx_encode_dev_pcm16(self.h, mode, p0, p1, d_pcm16, n_blocks, d_out, d_bits, d_wc or None, d_cplx or None,
+                                           stream or None), "ulcx_encode_dev_pcm16")
+        self.lastK = n_blocks
+
     def debug_fetch(self, K=None):
         K = K or self.lastK
         n = self.C * self.BS
@@ -194,6 +202,10 @@ class BatchDecoder:
 
     def decode_dev(self, d_in, slot, n_blocks, d_pcm, d_bits, stream=0):
         _check(lib().ulcx_decode_dev(self.h, d_in, slot, n_blocks, d_pcm, d_bits, stream or None), "ulcx_decode_dev")
+
+    def decode_dev_pcm16(self, d_in, slot, n_blocks, d_pcm16, d_bits, stream=0):
+        """PCM16 output: d_pcm16 is a device pointer to int16 [B][K][BS][C]; converted on store as tools/WavIO_Helper.c:56-63."""
+        _check(lib().ulcx_decode_dev_pcm16(self.h, d_in, slot, n_blocks, d_pcm16, d_bits, stream or None), "ulcx_decode_dev_pcm16")
 
     def stage_ms(self):
         ms = np.zeros(8, np.float32)
