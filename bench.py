@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--streams", type=int, default=4096, help="independent streams per GPU (BASELINE configs[1]: 4096)")
     ap.add_argument("--blocks", type=int, default=16, help="consecutive blocks per stream per step")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pcm16", action="store_true", help="separate configuration (SURVEY.md 8f rank 4): PCM16 ingest and PCM16 output "
+                    "fused into the first/last kernel instead of the C API's f32; NOT the headline line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -138,7 +140,19 @@ def main():
     d_dbits = torch.zeros(B * K, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
+    if args.pcm16:
+        pcm16 = torch.clamp(torch.round(pcm * 32767.0), -32768, 32767).to(torch.int16)
+        d_dec16 = torch.zeros(B * n * CH, dtype=torch.int16, device=dev)
+        del pcm
+        pcm = pcm16.to(torch.float32) * (2.0 ** -15)            # what the CPU baseline leg would read
+
+    def step16():
+        enc.encode_dev_pcm16(pcm16.data_ptr(), K, d_out.data_ptr(), d_bits.data_ptr(), mode=ulc_amd.MODE_VBR, p0=QUALITY, stream=stream)
+        dec.decode_dev_pcm16(d_out.data_ptr(), slot, K, d_dec16.data_ptr(), d_dbits.data_ptr(), stream=stream)
+
     def step():
+        if args.pcm16:
+            return step16()
         enc.encode_dev(pcm.data_ptr(), K, d_out.data_ptr(), d_bits.data_ptr(), mode=ulc_amd.MODE_VBR, p0=QUALITY, stream=stream)
         dec.decode_dev(d_out.data_ptr(), slot, K, d_dec.data_ptr(), d_dbits.data_ptr(), stream=stream)
 
@@ -173,7 +187,8 @@ def main():
 
     # ---- roofline of the dominant kernel (algorithmic bytes: SURVEY.md §8d / BASELINE.md §4)
     mean_bytes = float(bits_host.mean()) / 8.0
-    alg_bytes_block = 4 * CH * BS + mean_bytes + 8          # f32 in (or out) + stream bytes + size/WindowCtrl metadata
+    smp_bytes = 2 if args.pcm16 else 4
+    alg_bytes_block = smp_bytes * CH * BS + mean_bytes + 8  # f32 (PCM16 with --pcm16) in (or out) + stream bytes + size/WindowCtrl metadata
     pseudo = ("cbr_probe_passes", "k_heapsel", "wc_pipeline_exposed")   # intervals, not kernels (join wait / side-stream launches)
     allk = {**{("enc", k_): v for k_, v in acc_enc.items() if k_ not in pseudo}, **{("dec", k_): v for k_, v in acc_dec.items()}}
     (side, kname), kms = max(allk.items(), key=lambda kv: kv[1])
@@ -210,7 +225,8 @@ def main():
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Batch={B} independent 44.1 kHz stereo streams/GPU x {K} blocks, BlockSize=2048, VBR -50 encode "
-                                   f"(BASELINE configs[1]) then decode of the {B*K} blocks produced (configs[2] shape)",
+                                   f"(BASELINE configs[1]) then decode of the {B*K} blocks produced (configs[2] shape)"
+                                   + (" -- PCM16 ingest/output variant (int16 samples in HBM, not the C API's f32)" if args.pcm16 else ""),
                        "streams_per_gpu": B, "blocks_per_stream_per_step": K, "block_size": BS, "channels": CH, "rate_hz": RATE,
                        "parallelism": f"batch split over {world} GPU(s), no collective on the data path"},
             "roofline": {"bound": "hbm", "kernel": f"{kname} ({side})", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

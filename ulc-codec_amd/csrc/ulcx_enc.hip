@@ -77,11 +77,13 @@ template <typename IN> __device__ __forceinline__ float ms_sample(const UlcxEncC
 // ---------------------------------------------------------------------------
 // Window control
 // ---------------------------------------------------------------------------
-// Scratch layout for the transient detector: env[(sg*T + t)*64 + sl], stream s = sg*64+sl,
-// T = maxK*BS, i.e. time-major inside groups of 64 streams, so the kernels that walk time
-// with one lane per stream touch one contiguous 512-byte row per step.
-__device__ __forceinline__ size_t env_idx(const UlcxEncCtx &c, int s, int t) {
-    return ((size_t)(s >> 6) * c.maxK * c.BS + t) * 64 + (s & 63);
+// Scratch layout for the transient detector, in floats: a record of 8 per (stream, time quad),
+//   env[(((sg*T/4 + q)*64 + sl)*2 + f)*4 + j],  stream s = sg*64+sl, time t = 4q+j, f = 0 (HP) | 1 (BP), T = maxK*BS:
+// time-major inside groups of 64 streams, FOUR consecutive steps of one filter adjacent.  The kernels that walk time
+// with one lane per stream[, filter] take four steps per 16-byte load/store (they are bound by instructions per step),
+// and a wave still touches one contiguous 1-2 KB run per access.
+__device__ __forceinline__ size_t envq_idx(const UlcxEncCtx &c, int s, int q) {
+    return (((size_t)(s >> 6) * (c.maxK * c.BS / 4) + q) * 64 + (s & 63)) * 8;
 }
 
 // WindowControl.c:31-70: E[n] = sum_ch (hp^2, bp^2) of the 3-tap FIRs centred on the
@@ -127,8 +129,13 @@ __global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c, int k0, int k1) 
         tile[lane][sl] = v;
     }
     __syncthreads();
-    float2 *dst = c.env + ((size_t)sg * c.maxK * c.BS + (size_t)tt * 64) * 64;
-    for (int tl = wv; tl < 64; tl += 4) dst[(size_t)tl * 64 + lane] = tile[tl][lane];
+    float *dst = (float *)c.env + envq_idx(c, sg * 64, tt * 16);      // 16 quads x 64 streams of 8-float records
+    for (int ql = wv; ql < 16; ql += 4) {
+        const float2 a0 = tile[4 * ql][lane], a1 = tile[4 * ql + 1][lane], a2 = tile[4 * ql + 2][lane], a3 = tile[4 * ql + 3][lane];
+        float4 *o = (float4 *)(dst + ((size_t)ql * 64 + lane) * 8);
+        o[0] = make_float4(a0.x, a1.x, a2.x, a3.x);
+        o[1] = make_float4(a0.y, a1.y, a2.y, a3.y);
+    }
 }
 
 // WindowControl.c:72-88: forward one-pole smear, the only sample-rate recurrence that
@@ -139,38 +146,47 @@ __global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c, int k0, int k1)
     int gl = blockIdx.x * 64 + threadIdx.x;
     int s = gl >> 1, f = gl & 1;
     bool live = s < c.B;
-    float *v = (float *)(c.env + env_idx(c, live ? s : 0, k0 * c.BS)) + f;     // this lane's float inside each {hp,bp} pair
+    float4 *v = (float4 *)((float *)c.env + envq_idx(c, live ? s : 0, k0 * c.BS / 4) + f * 4);   // this lane's four steps of each record
     float env = live ? c.wcs[s].tf[f] : 0.0f;
     float cc = f ? c.cBP : c.cHP;
-    int n = (k1 - k0) * c.BS;
-    // Groups of U steps addressed from one pointer with immediate offsets (rows are 512 bytes apart), loads
-    // D-1 groups ahead of the arithmetic: the chain is bound by instructions per step (3 dependent VALU + 1 load
-    // + 1 store), so address arithmetic and loop control are kept out of it.
-    constexpr int U = 8, D = 8;           // (K*BS is a multiple of U*D)
-    const float *rp = v;
-    float *wp = v;
-    float x[D][U];
+    const int nq = (k1 - k0) * c.BS / 4;
+    // Groups of U quads (4 steps each) addressed from one pointer with immediate offsets (records of one stream are
+    // 2 KB apart), loads D-1 groups ahead of the arithmetic: the chain is bound by instructions per step (3 dependent
+    // VALU + a quarter of a load and of a store), so address arithmetic and loop control are kept out of it.
+    constexpr int U = 2, D = 8;           // (K*BS/4 is a multiple of U*D)
+    constexpr int QS = 64 * 8 / 4;        // float4s between consecutive quads of a stream
+    const float4 *rp = v;
+    float4 *wp = v;
+    float4 x[D][U];
 #pragma unroll
     for (int g = 0; g < D - 1; g++) {
 #pragma unroll
-        for (int j = 0; j < U; j++) x[g][j] = rp[(size_t)j * 128];
-        rp += U * 128;
+        for (int j = 0; j < U; j++) x[g][j] = rp[(size_t)j * QS];
+        rp += U * QS;
     }
-    for (int i = 0; i < n; i += D * U) {
+    for (int i = 0; i < nq; i += D * U) {
 #pragma unroll
         for (int g = 0; g < D; g++) {
-            const bool more = (i + (g + D - 1) * U) < n;
-            const float *lp = more ? rp : v;                // past the end: re-read row 0 (unused)
+            const bool more = (i + (g + D - 1) * U) < nq;
+            const float4 *lp = more ? rp : v;               // past the end: re-read record 0 (unused)
 #pragma unroll
-            for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = lp[(size_t)j * 128];
-            rp += U * 128;
+            for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = lp[(size_t)j * QS];
+            rp += U * QS;
 #pragma unroll
-            for (int j = 0; j < U; j++) { float d = x[g][j] - env; env += d * cc; x[g][j] = env; }
+            for (int j = 0; j < U; j++) {
+                float4 q = x[g][j];
+                float d;
+                d = q.x - env; env += d * cc; q.x = env;
+                d = q.y - env; env += d * cc; q.y = env;
+                d = q.z - env; env += d * cc; q.z = env;
+                d = q.w - env; env += d * cc; q.w = env;
+                x[g][j] = q;
+            }
             if (live) {
 #pragma unroll
-                for (int j = 0; j < U; j++) wp[(size_t)j * 128] = x[g][j];
+                for (int j = 0; j < U; j++) wp[(size_t)j * QS] = x[g][j];
             }
-            wp += U * 128;
+            wp += U * QS;
         }
     }
     if (live) c.wcs[s].tf[f] = env;                                   // state for the next call
@@ -181,45 +197,45 @@ __global__ __launch_bounds__(64) void k_wc_backward(UlcxEncCtx c, int k0, int k1
     __builtin_amdgcn_s_setprio(3);                       // a serial chain: let it issue ahead of co-resident throughput kernels
     int sl = threadIdx.x;
     int k = k0 + blockIdx.x % (k1 - k0), sg = blockIdx.x / (k1 - k0);
-    float2 *e = c.env + ((size_t)sg * c.maxK * c.BS + (size_t)k * c.BS) * 64 + sl;
-    const int n = c.BS;
-    float2 last = e[(size_t)(n - 1) * 64];
-    float pHP = last.x, pBP = last.y;
+    float *e = (float *)c.env + envq_idx(c, sg * 64 + sl, k * c.BS / 4);      // record of the block's first quad
+    const int nq = c.BS / 4;
+    constexpr int QS = 64 * 8 / 4;                       // float4s between consecutive quads of a stream
+    float pHP = e[(size_t)(nq - 1) * 512 + 3], pBP = e[(size_t)(nq - 1) * 512 + 7];   // the forward end state = the block's last step
     const float qHP = c.qHP, qBP = c.qBP;
-    // Walk the block backwards in groups of U steps; a group's rows are addressed from one pointer with
-    // immediate offsets (rows are 512 bytes apart), and the loads run D-1 groups ahead of the arithmetic:
-    // the chain is bound by instructions per step, so address arithmetic is kept out of it.
-    constexpr int U = 8, D = 4;                          // BS is a multiple of U*D
-    const float2 *rp = e + (size_t)(n - 1) * 64;         // row of the step being loaded (group head)
-    float2 *wp = e + (size_t)(n - 1) * 64;               // row of the step being computed (group head)
-    float2 x[D][U];
+    // Walk the block backwards in groups of U quads; a group's records are addressed from one pointer with
+    // immediate offsets, and the loads run D-1 groups ahead of the arithmetic: the chain is bound by instructions
+    // per step, so address arithmetic is kept out of it.  The result overwrites the HP half of each record.
+    constexpr int U = 2, D = 4;                          // BS/4 is a multiple of U*D
+    const float4 *rp = (const float4 *)(e + (size_t)(nq - 1) * 512);   // record being loaded (group head)
+    float4 *wp = (float4 *)(e + (size_t)(nq - 1) * 512);               // record being computed (group head)
+    float4 xh[D][U], xb[D][U];
 #pragma unroll
     for (int g = 0; g < D - 1; g++) {
 #pragma unroll
-        for (int j = 0; j < U; j++) x[g][j] = rp[-(ptrdiff_t)j * 64];
-        rp -= U * 64;
+        for (int j = 0; j < U; j++) { xh[g][j] = rp[-(ptrdiff_t)j * QS]; xb[g][j] = rp[-(ptrdiff_t)j * QS + 1]; }
+        rp -= U * QS;
     }
-    for (int i = 0; i < n; i += U * D) {
+    for (int i = 0; i < nq; i += U * D) {
 #pragma unroll
         for (int g = 0; g < D; g++) {
-            // prefetch the group D-1 ahead into the slot freed last (past the block start: re-read row 0, unused)
-            const bool more = (i + (g + D - 1) * U) < n;
-            const float2 *lp = more ? rp : e + (size_t)(U - 1) * 64;
+            // prefetch the group D-1 ahead into the slot freed last (past the block start: re-read a record of the block, unused)
+            const bool more = (i + (g + D - 1) * U) < nq;
+            const float4 *lp = more ? rp : (const float4 *)(e + (size_t)(U - 1) * 512);
 #pragma unroll
-            for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = lp[-(ptrdiff_t)j * 64];
-            rp -= U * 64;
-            float o[U];
+            for (int j = 0; j < U; j++) { xh[(g + D - 1) % D][j] = lp[-(ptrdiff_t)j * QS]; xb[(g + D - 1) % D][j] = lp[-(ptrdiff_t)j * QS + 1]; }
+            rp -= U * QS;
+            float4 o[U];
 #pragma unroll
             for (int j = 0; j < U; j++) {
-                float dHP = x[g][j].x - pHP, dBP = x[g][j].y - pBP;
-                pHP += dHP * qHP;
-                pBP += dBP * qBP;
-                float a = dHP * pBP, bb = dBP * pHP;
-                o[j] = a * a + bb * bb;
+                const float4 h = xh[g][j], b4 = xb[g][j];
+#define WC_BACK_STEP(H, B, O) { float dHP = (H) - pHP, dBP = (B) - pBP; pHP += dHP * qHP; pBP += dBP * qBP; \
+                                float a = dHP * pBP, bb = dBP * pHP; (O) = a * a + bb * bb; }
+                WC_BACK_STEP(h.w, b4.w, o[j].w) WC_BACK_STEP(h.z, b4.z, o[j].z) WC_BACK_STEP(h.y, b4.y, o[j].y) WC_BACK_STEP(h.x, b4.x, o[j].x)
+#undef WC_BACK_STEP
             }
 #pragma unroll
-            for (int j = 0; j < U; j++) wp[-(ptrdiff_t)j * 64].x = o[j];
-            wp -= U * 64;
+            for (int j = 0; j < U; j++) wp[-(ptrdiff_t)j * QS] = o[j];
+            wp -= U * QS;
         }
     }
 }
@@ -233,34 +249,41 @@ __global__ __launch_bounds__(64) void k_wc_integrate(UlcxEncCtx c, int k0, int k
     float env = c.wcs[sc].tf[2];
     float *bins = c.bins + (size_t)sc * (c.maxK + 1) * 16;
     if (live && k0 == 0) for (int i = 0; i < 8; i++) { bins[i] = c.wcs[s].binSum[i]; bins[8 + i] = c.wcs[s].binW[i]; }
-    const float2 *e = c.env + env_idx(c, s, k0 * c.BS);
-    const int bin = c.BS / 8;             // >= 32, a multiple of U
-    const int n = (k1 - k0) * c.BS;
-    // same structure as k_wc_forward: U-step groups off one pointer, loads D-1 groups ahead
-    constexpr int U = 8, D = 8;
-    const float *v = (const float *)e;    // .x of each {x, -} pair, rows 128 floats apart
-    const float *rp = v;
-    float x[D][U];
+    const float4 *v = (const float4 *)((const float *)c.env + envq_idx(c, s, k0 * c.BS / 4));   // HP half of each record: k_wc_backward's output
+    const int bin = c.BS / 8;             // >= 32, a multiple of 4*U
+    const int nq = (k1 - k0) * c.BS / 4;
+    // same structure as k_wc_forward: groups of U quads off one pointer, loads D-1 groups ahead
+    constexpr int U = 2, D = 8;
+    constexpr int QS = 64 * 8 / 4;
+    const float4 *rp = v;
+    float4 x[D][U];
 #pragma unroll
     for (int g = 0; g < D - 1; g++) {
 #pragma unroll
-        for (int j = 0; j < U; j++) x[g][j] = rp[(size_t)j * 128];
-        rp += U * 128;
+        for (int j = 0; j < U; j++) x[g][j] = rp[(size_t)j * QS];
+        rp += U * QS;
     }
     const float cBlk = c.cBlk;
     float sum = 0.0f;
     int inBin = 0, gbin = k0 * 8;         // steps accumulated in the current bin; global bin index = k*8 + i
-    for (int i = 0; i < n; i += D * U) {
+    for (int i = 0; i < nq; i += D * U) {
 #pragma unroll
         for (int g = 0; g < D; g++) {
-            const bool more = (i + (g + D - 1) * U) < n;
-            const float *lp = more ? rp : v;
+            const bool more = (i + (g + D - 1) * U) < nq;
+            const float4 *lp = more ? rp : v;
 #pragma unroll
-            for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = lp[(size_t)j * 128];
-            rp += U * 128;
+            for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = lp[(size_t)j * QS];
+            rp += U * QS;
 #pragma unroll
-            for (int j = 0; j < U; j++) { float d = x[g][j] - env; env += d * cBlk; sum += env; }
-            inBin += U;
+            for (int j = 0; j < U; j++) {
+                const float4 q = x[g][j];
+                float d;
+                d = q.x - env; env += d * cBlk; sum += env;
+                d = q.y - env; env += d * cBlk; sum += env;
+                d = q.z - env; env += d * cBlk; sum += env;
+                d = q.w - env; env += d * cBlk; sum += env;
+            }
+            inBin += 4 * U;
             if (inBin == bin) {           // bin boundary (bins never straddle a group); the weight is the step count
                 if (live) { float *o = bins + (size_t)(gbin / 8 + 1) * 16; o[gbin & 7] = sum; o[8 + (gbin & 7)] = (float)bin; }
                 sum = 0.0f; inBin = 0; gbin++;
@@ -1568,7 +1591,7 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
 // amp0 >= -1: noise amplitude of the gap's FIRST run already evaluated by k_gapsums (-1 = "Sum == 0");
 // anything else (and every later run of the gap) is summed here from the pairs in HBM.
 __device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const float *coefU, const float *pairU, float amp0,
-                                          unsigned long long &lo, unsigned long long &hi, int &cnt) {
+                                          unsigned long long &lo, unsigned long long &hi, int &cnt, bool dbgNoSum = false) {
     auto put = [&](unsigned x) {
         x &= 0xF;
         if (cnt < 16) lo |= (unsigned long long)x << (4 * cnt);
@@ -1592,7 +1615,7 @@ __device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const flo
             v = zr - 16; if (v > 0x1FF) v = 0x1FF;
             n = v + 16;
             if (amp0 > -1.5f) nq = (amp0 < 0.0f) ? 0 : quant_coef_u(amp0 * quant, 8);
-            else nq = get_noise_q(pairU, nc, n, quant);
+            else nq = dbgNoSum ? 0 : get_noise_q(pairU, nc, n, quant);
         }
         amp0 = -2.0f;
         if (nq) { put(0x8); put((unsigned)(v >> 5)); put((unsigned)(v >> 1)); put((unsigned)((v & 1) | ((nq - 1) << 1))); }
@@ -1789,7 +1812,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
                 int zr = idx - start;
                 float amp0 = -2.0f;
                 if (zr >= 16 && (raw & 0x8000) && c.useGapSums) amp0 = gapU[idx].x;
-                gap_codes(start, zr, (float)(1u << zqi[z]), coefU, pairU, amp0, lo, hi, cnt);
+                gap_codes(start, zr, (float)(1u << zqi[z]), coefU, pairU, amp0, lo, hi, cnt, (c.dbgSkip & 0x40) != 0);
             }
             int mine = (m < nC) ? pre + cnt + 1 : 0;
             int tot, ex = wave_excl_scan(mine, lane, tot);
