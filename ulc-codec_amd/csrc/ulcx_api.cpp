@@ -148,9 +148,6 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.cplx, NB, true);
     DA(c.nout, NB, true);
     DA(c.slow, 3 * NB + 2, true);                      // flags [NB], retry-queue counters [2], retry queues [2][NB]
-    // experimental fused select+encode+pack kernel (k_selenc): measured slower than the lane-per-unit
-    // kernels on MI355X (profiles/r01 notes in DESIGN.md §6), so opt-in only.
-    c.useFused = 0;
     c.useWave = 1;        // wave-per-unit encode pass fed by k_gapsums; ULCX_WAVE=0 selects the serial lane-per-unit kernel
     c.useGapSums = ((size_t)cb * 4 + cb / 8 + 8192 + 16 <= 150 * 1024 && cb <= 16384) ? 1 : 0;
     if (const char *ev = getenv("ULCX_GAPSUMS")) c.useGapSums = (ev[0] != '0');
@@ -158,7 +155,6 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.tailSum, NB * nChan * 4 * 8, true);
     if (const char *ev = getenv("ULCX_WAVE")) c.useWave = (ev[0] != '0');
     c.dbgSkip = 0; if (const char *ev = getenv("ULCX_DBG_SKIP")) c.dbgSkip = atoi(ev);   // timing experiments only (breaks results)
-    if (const char *ev = getenv("ULCX_FUSED")) if (ev[0] == '1' && (size_t)cb * 8 + cb / 8 + 2048 * (size_t)nChan + 2048 <= 150 * 1024) { c.useFused = 1; c.useWave = 0; }
     DA(c.cbrLo, NB, true); DA(c.cbrHi, NB, true); DA(c.cbrDone, NB, true); DA(c.cbrBudget, NB, true); DA(c.cbrMaxRange, 1, true);
     DA(c.keep, NB * cb / 32, true);
     DA(c.fbList, NB, true);

@@ -589,24 +589,33 @@ __global__ __launch_bounds__(64) void k_cplx(UlcxEncCtx c) {
     const float4 *p = (const float4 *)(c.coef + (size_t)blk * n);
     float cx = 0.0f, cw = 0.0f;
     int tiny = 0;
-    for (int i = 0; i < n / 4; i += 4) {                  // n is a multiple of 256: 4 x 16-byte loads in flight per step
-        float4 q[4];
+    // n is a multiple of 256: 4 x 16-byte loads in flight per step.  The count of collapsible coefficients only feeds
+    // the CBR/ABR probe shortcut below: VBR calls take the loop without it (half the instructions of this
+    // issue-bound kernel; the branch is uniform for the whole launch).
+    auto sums = [&](auto tinyT) {
+        constexpr bool TINY = decltype(tinyT)::value;
+        for (int i = 0; i < n / 4; i += 4) {
+            float4 q[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) q[u] = p[i + u];
+            for (int u = 0; u < 4; u++) q[u] = p[i + u];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            float4 v = q[u];
-            cx += v.x * v.x; cw += fabsf(v.x);
-            cx += v.y * v.y; cw += fabsf(v.y);
-            cx += v.z * v.z; cw += fabsf(v.z);
-            cx += v.w * v.w; cw += fabsf(v.w);
-            // non-zero coefficients so small that the coarsest quantizer (2^31) could collapse them (Encode.c:114)
-            tiny += (fabsf(v.x) >= 0.5f * ULCX_COEF_EPS && fabsf(v.x) < 0x1.0p-29f) ? 1 : 0;
-            tiny += (fabsf(v.y) >= 0.5f * ULCX_COEF_EPS && fabsf(v.y) < 0x1.0p-29f) ? 1 : 0;
-            tiny += (fabsf(v.z) >= 0.5f * ULCX_COEF_EPS && fabsf(v.z) < 0x1.0p-29f) ? 1 : 0;
-            tiny += (fabsf(v.w) >= 0.5f * ULCX_COEF_EPS && fabsf(v.w) < 0x1.0p-29f) ? 1 : 0;
+            for (int u = 0; u < 4; u++) {
+                float4 v = q[u];
+                cx += v.x * v.x; cw += fabsf(v.x);
+                cx += v.y * v.y; cw += fabsf(v.y);
+                cx += v.z * v.z; cw += fabsf(v.z);
+                cx += v.w * v.w; cw += fabsf(v.w);
+                if (TINY) {
+                    // non-zero coefficients so small that the coarsest quantizer (2^31) could collapse them (Encode.c:114)
+                    tiny += (fabsf(v.x) >= 0.5f * ULCX_COEF_EPS && fabsf(v.x) < 0x1.0p-29f) ? 1 : 0;
+                    tiny += (fabsf(v.y) >= 0.5f * ULCX_COEF_EPS && fabsf(v.y) < 0x1.0p-29f) ? 1 : 0;
+                    tiny += (fabsf(v.z) >= 0.5f * ULCX_COEF_EPS && fabsf(v.z) < 0x1.0p-29f) ? 1 : 0;
+                    tiny += (fabsf(v.w) >= 0.5f * ULCX_COEF_EPS && fabsf(v.w) < 0x1.0p-29f) ? 1 : 0;
+                }
+            }
         }
-    }
+    };
+    if (c.mode == ULCX_MODE_VBR) sums(std::false_type{}); else sums(std::true_type{});
     if (cx != 0.0f) {
         cx = ulcx_logf((cw * cw) / cx) / c.cplxScale;
         if (cx < 0.0f) cx = 0.0f;
@@ -1492,8 +1501,7 @@ __device__ void encode_units_lane(const UlcxEncCtx &c, int finalPass, int gid, i
     int j = gid & 3, ch = (gid >> 2) % c.C, blk = gid / (4 * c.C);
     if (c.fbMode == 2) { blk = c.fbList[c.fbLo + blk]; gid = (blk * c.C + ch) * 4 + j; }
     if (skip_block(c, blk, finalPass)) return;
-    if (c.useFused && !c.slow[blk]) return;
-    if (c.useWave && !c.useFused && !(c.slow[blk] & 2)) return;      // only what both wave-kernel attempts could not hold
+    if (c.useWave && !(c.slow[blk] & 2)) return;      // only what both wave-kernel attempts could not hold
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     int d, off, S;
@@ -1951,7 +1959,6 @@ __global__ __launch_bounds__(256) void k_encode_wave(UlcxEncCtx c, int finalPass
 __device__ void pack_block(const UlcxEncCtx &c, int finalPass, int blk) {
     int lane = threadIdx.x;
     if (skip_block(c, blk, finalPass)) return;
-    if (c.useFused && !c.slow[blk]) return;
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     int nU = c.C * 4;
@@ -2005,193 +2012,6 @@ __global__ __launch_bounds__(64) void k_pack(UlcxEncCtx c, int finalPass) {
     if (c.fbMode != 2) { pack_block(c, finalPass, blockIdx.x); return; }
     int n = fb_count(c);
     for (int v = blockIdx.x; v < n; v += gridDim.x) pack_block(c, finalPass, c.fbList[c.fbLo + v]);
-}
-
-// ---------------------------------------------------------------------------
-// Fast path: select + encode + pack fused, one workgroup per block, everything the
-// serial bitstream state machine touches (coefficients, noise pairs, kept-set bitmap,
-// nybble staging) resident in LDS.  Blocks whose threshold tie group straddles the cut,
-// or whose nybbles overflow the LDS staging, are left to the slow path
-// (k_heapsel -> k_encode_units -> k_pack restricted to blocks flagged in c.slow).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void k_selenc(UlcxEncCtx c, int finalPass, int stageBytes) {
-    extern __shared__ uint32_t sm[];
-    const int N = c.C * c.BS;
-    int blk = blockIdx.x, tid = threadIdx.x;
-    uint32_t *ukey  = sm;                               // N  (ordered keys; later the noise pairs)
-    float    *coefL = (float *)(sm + N);                // N
-    uint32_t *keepL = sm + 2 * N;                       // N/32
-    uint8_t  *stage = (uint8_t *)(keepL + N / 32);      // stageBytes
-    int      *hist  = (int *)(stage + stageBytes);      // 256
-    int      *unitN = hist + 256;                       // C*4
-    int      *misc  = unitN + c.C * 4;                  // [0]=prefix [1]=need [2]=overflow
-    if (tid == 0) c.slow[blk] = 0;
-    if (!finalPass && c.cbrDone[blk]) return;
-    int s = blk / c.K, k = blk % c.K;
-    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
-    int kSel = c.nout[blk];
-    for (int i = tid; i < N; i += WG) ukey[i] = key_ord(load_final_key(c, blk, i));
-    if (tid == 0) misc[2] = 0;
-    __syncthreads();
-
-    // --- radix select of the kSel-th largest key (see k_select)
-    bool straddle = false;
-    if (kSel <= 0) {
-        for (int i = tid; i < N / 32; i += WG) keepL[i] = 0;
-    } else {
-        uint32_t prefix = 0, pmask = 0;
-        int need = kSel;
-        for (int pass = 0; pass < 4; pass++) {
-            int shift = 24 - 8 * pass;
-            hist[tid] = 0;
-            __syncthreads();
-            for (int i = tid; i < N; i += WG) {
-                uint32_t u = ukey[i];
-                if ((u & pmask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
-            }
-            __syncthreads();
-            if (tid < 64) {
-                // suffix scan over 256 bins by one wave: lane l owns bins 4l..4l+3
-                int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-                int tot = h0 + h1 + h2 + h3;
-                int suf = tot;                           // inclusive suffix sum over lanes >= tid
-                for (int o = 1; o < 64; o <<= 1) { int t = __shfl_down(suf, o); if (tid + o < 64) suf += t; }
-                int above = suf - tot;                   // count in bins of higher lanes
-                // digit d is chosen when (count above d) < need <= (count above d) + hist[d]
-                int a3 = above, a2 = above + h3, a1 = a2 + h2, a0 = a1 + h1;
-                int dsel = -1, acc = 0;
-                if (a3 < need && need <= a3 + h3) { dsel = 4 * tid + 3; acc = a3; }
-                else if (a2 < need && need <= a2 + h2) { dsel = 4 * tid + 2; acc = a2; }
-                else if (a1 < need && need <= a1 + h1) { dsel = 4 * tid + 1; acc = a1; }
-                else if (a0 < need && need <= a0 + h0) { dsel = 4 * tid + 0; acc = a0; }
-                if (dsel >= 0) { misc[0] = (int)(prefix | ((uint32_t)dsel << shift)); misc[1] = need - acc; }
-            }
-            __syncthreads();
-            prefix = (uint32_t)misc[0]; need = misc[1];
-            pmask |= 0xFFu << shift;
-            __syncthreads();
-        }
-        int e = hist[prefix & 255];
-        straddle = (need < e);
-        for (int i = tid; i < N; i += WG) {
-            bool kp = (ukey[i] >= prefix);
-            unsigned long long m = __ballot(kp);
-            int lane = tid & 63;
-            if (lane == 0)  keepL[i >> 5] = (uint32_t)m;
-            if (lane == 32) keepL[i >> 5] = (uint32_t)(m >> 32);
-        }
-    }
-    if (straddle) {                                       // exact heap order needed: slow path
-        if (tid == 0) { int slot = atomicAdd(c.fbCount, 1); c.fbList[slot] = blk; c.slow[blk] = 1; }
-        return;
-    }
-    __syncthreads();
-
-    // --- stage coefficients and noise pairs in LDS
-    float *pairL = (float *)ukey;
-    {
-        const float4 *cg = (const float4 *)(c.coef + (size_t)blk * N);
-        const float4 *pg = (const float4 *)(c.npair + (size_t)blk * N);
-        for (int i = tid; i < N / 4; i += WG) { ((float4 *)coefL)[i] = cg[i]; ((float4 *)pairL)[i] = pg[i]; }
-    }
-    // unit geometry
-    int nsub = 0; { unsigned p = ulcx_pattern(wc); do nsub++; while (p >>= 4); }
-    int nU = c.C * nsub;
-    int cap = (stageBytes / nU) & ~7;
-    __syncthreads();
-
-    // --- serial bitstream state machine, one lane per (channel, subblock) unit (Encode.c:200-313)
-    for (int u = tid; u < c.C * 4; u += WG) {
-        int ch = u >> 2, j = u & 3;
-        if (j >= nsub) { unitN[u] = 0; continue; }
-        int d, off, S;
-        unit_geom(wc, j, c.BS, d, off, S);
-        NybWriter w;
-        w.cap = cap;
-        w.dst = stage + (size_t)(ch * nsub + j) * cap;
-        w.n = 0; w.acc = 0;
-        int idx = ch * c.BS + off;
-        int end = idx + S;
-        int nextCoded = idx;
-        int prevQ = -1, zoneStart = -1;
-        float qmin = 1000.0f, qmax = -1000.0f;
-        do {
-            idx = next_kept(keepL, idx, end);
-            float nmin = 0.0f, nmax = qmax, lvl = 0.0f;
-            if (idx < end) {
-                lvl = fabsf(coefL[idx]);
-                nmin = (lvl < qmin) ? lvl : qmin;
-                nmax = (lvl > qmax) ? lvl : qmax;
-                if (zoneStart == -1) zoneStart = idx;
-            }
-            if (nmax > nmin * 4.0f) {
-                int qi = build_quantizer(qmax);
-                if (qi != prevQ) { put_quantizer(w, qi, prevQ != -1); prevQ = qi; }
-                nextCoded = write_zone(w, zoneStart, idx, (float)(1u << qi), coefL, pairL, keepL, nextCoded);
-                zoneStart = idx;
-                qmin = qmax = lvl;
-            } else { qmin = nmin; qmax = nmax; }
-        } while (++idx <= end);
-        int n = end - nextCoded;
-        if (n > 4) {
-            if (prevQ != -1) w.put(0xF);
-            int nq = 0, nd = 0;
-            if (prevQ != -1 && n >= 16) get_hfext(pairL, nextCoded, n, (float)(1u << prevQ), nq, nd);
-            if (nq) { w.put(0xF); w.put((unsigned)(nq - 1)); w.put((unsigned)(nd >> 4)); w.put((unsigned)nd); }
-            else { w.put(0xE); w.put(0xF); }
-        } else if (n > 0) {
-            w.put(0x0); w.put((unsigned)(n - 1));
-        }
-        w.flush();
-        unitN[u] = w.n;
-        if ((w.n + 1) / 2 > cap) misc[2] = 1;            // staging overflow (benign race: any writer sets 1)
-    }
-    __syncthreads();
-
-    int hdr = (wc & 8) ? 2 : 1;
-    int total = hdr;
-    for (int u = 0; u < c.C * 4; u++) total += unitN[u];
-    int bitsTot = ((total * 4) + 7) & ~7;
-    if (!finalPass) {                                     // rate-control probe (ulcEncoder.c:100-110); size is exact even on overflow
-        if (tid == 0) {
-            int budget = c.cbrBudget[blk];
-            int lo = c.cbrLo[blk], hi = c.cbrHi[blk], nOut = kSel;
-            bool stop = false;
-            if (bitsTot < budget) lo = nOut;
-            else if (bitsTot > budget) hi = nOut - 1;
-            else { lo = nOut; stop = true; }
-            if (stop || !(lo < hi - 1)) { c.cbrDone[blk] = 1; c.nout[blk] = lo; }
-            else c.nout[blk] = (int)((unsigned)(lo + hi) / 2u);
-            c.cbrLo[blk] = lo; c.cbrHi[blk] = hi;
-        }
-        return;
-    }
-    for (int i = tid; i < N / 32; i += WG) c.keep[(size_t)blk * (N / 32) + i] = keepL[i];
-    if (misc[2]) {                                        // too many nybbles for LDS staging: slow path re-encodes from HBM
-        if (tid == 0) c.slow[blk] = 2;
-        return;
-    }
-    // --- pack (Encode.c:329-359)
-    uint8_t *out = c.out + (size_t)blk * c.slot;
-    int nBytes = bitsTot / 8;
-    for (int b = tid; b < nBytes; b += WG) {
-        unsigned byte = 0;
-        for (int h = 0; h < 2; h++) {
-            int q = 2 * b + h;
-            unsigned nyb = 0;
-            if (q < hdr) nyb = (q == 0) ? (wc & 0xF) : ((wc >> 4) & 0xF);
-            else if (q < total) {
-                int r = q - hdr;
-                int u = 0;
-                while (r >= unitN[u]) { r -= unitN[u]; u++; }
-                const uint8_t *src = stage + (size_t)((u >> 2) * nsub + (u & 3)) * cap;
-                nyb = (src[r >> 1] >> ((r & 1) * 4)) & 0xF;
-            }
-            byte |= nyb << (4 * h);
-        }
-        if (b < c.slot) out[b] = (uint8_t)byte;
-    }
-    if (tid == 0) c.bits[blk] = bitsTot;
 }
 
 // ---------------------------------------------------------------------------
@@ -2408,7 +2228,6 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
     }
     auto launch_select = [&](int fin) {
         int R = N / 64;
-        if (c.useFused) return false;
         switch (R) {
             case 64: hipLaunchKernelGGL(k_select_wave<64>, dim3((NB + 3) / 4), dim3(256), 0, st, c, fin); return true;
             case 32: hipLaunchKernelGGL(k_select_wave<32>, dim3((NB + 3) / 4), dim3(256), 0, st, c, fin); return true;
@@ -2452,7 +2271,7 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
             else hipLaunchKernelGGL(k_tailsums, dim3(fb2 ? fbW : (nUnits * 8 + 63) / 64), dim3(64), 0, s2, cc, fin);
             if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
         } else if (ev0 && ev) { CK(hipEventRecord(ev[stage++], s2)); CK(hipEventRecord(ev[stage++], s2)); }
-        if (cc.useWave && !cc.useFused) {
+        if (cc.useWave) {
             int nBC = NB * cc.C;
             // early CBR probes keep ~N/2 coefficients per block: go straight to the full-size caps there
             WaveCaps first = (bigFirst && haveFull) ? capF : capS;
@@ -2498,18 +2317,13 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
     // CBR/ABR: it runs after the lock-step passes (a block joins it at whatever pass it first straddles).
     // The exact path forks at the FINAL pass (a block can first straddle there) and runs beside the main path's
     // final encode: VBR has only that pass; CBR/ABR blocks replay their whole search from the ranking there.
-    const bool canFork = (side != nullptr) && !c.useFused;
+    const bool canFork = (side != nullptr);
     for (int p = 0; p <= probes; p++) {
         int fin = (p == probes) ? 1 : 0;
         bool ev0 = (p == 0);
         const bool async_fb = canFork && fin;
-        if (c.useWave && !c.useFused) CK(hipMemsetAsync(c.slow, 0, sizeof(int) * ((size_t)NB + 2), st));
-        if (c.useFused) {
-            int stageBytes = 2048 * c.C;
-            size_t lds = (size_t)N * 8 + N / 8 + stageBytes + 256 * 4 + c.C * 16 + 16;
-            if (p == 0 && lds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_selenc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_selenc, dim3(NB), dim3(WG), lds, st, c, fin, stageBytes);
-        } else if (!launch_select(fin)) {
+        if (c.useWave) CK(hipMemsetAsync(c.slow, 0, sizeof(int) * ((size_t)NB + 2), st));
+        if (!launch_select(fin)) {
             hipLaunchKernelGGL(k_select, dim3(NB), dim3(WG), 0, st, c, fin);
         }
         if (ev0) MARK();
@@ -2533,11 +2347,11 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
             CK(hipEventRecord(evJoin, side));
         }
         if (ev0) MARK();                                       // ("k_heapsel": empty interval on the main stream)
-        UlcxEncCtx cm = c; cm.fbMode = c.useFused ? 0 : 1;
+        UlcxEncCtx cm = c; cm.fbMode = 1;
         int rc = launch_encode(cm, st, fin, ev0, false); if (rc) return rc;
         if (async_fb) CK(hipStreamWaitEvent(st, evJoin, 0));
     }
-    if (!canFork && !c.useFused) {
+    if (!canFork) {
         for (int lo = 0; lo < NB; lo += c.rankSlots) {
             int rc = exact_sort(st, lo); if (rc) return rc;
             rc = exact_passes(st, lo); if (rc) return rc;

@@ -77,7 +77,6 @@ struct UlcxEncCtx {
     int    *cbrBudget;                   // [NB] bit budget (ulcEncoder.c:96)
     int    *cbrMaxRange;                 // [1] widest Hi-Lo left after k_cplx (sizes the host's probe loop)
     int    *slow;                        // [NB] wave-encoder give-up bits (1: small caps, 2: full caps -> k_encode_units); then 2 queue counters, 2 retry queues [NB]
-    int     useFused;                    // fused select+encode+pack kernel usable (LDS fits)
     float2 *gapSum;                      // [NB][C*BS] {Sum, SumW} of the noise run in front of each kept coefficient (speculative)
     float  *tailSum;                     // [NB][C*4][8] five HF-extension sums + start index of the tail they assume
     int     useGapSums;
