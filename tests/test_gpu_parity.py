@@ -338,3 +338,47 @@ def test_pcm16_ingest_and_output_match_the_wav_io_conversions(bs, ch, rate, call
         k0 += K
     for o in (encF, encS, decF, decS):
         o.close()
+
+
+@pytest.mark.parametrize("env", [
+    {"ULCX_ASYNC_FB": "0"},                        # no side streams at all (the mode the per-kernel profiles use)
+    {"ULCX_WC_PIPE": "1"},                         # window control not pipelined with the transform
+    {"ULCX_WC_PIPE": "3"}, {"ULCX_WC_PIPE": "8"},
+    {"ULCX_WC_STEPS": "4"}, {"ULCX_WC_ESTREAM": "1"},
+    {"ULCX_WAVE": "0"},                            # serial lane-per-unit writer as the main path
+    {"ULCX_GAPSUMS": "0"},                         # no speculative noise sums
+    {"ULCX_ASYNC_FB": "0", "ULCX_WC_PIPE": "1", "ULCX_WAVE": "0", "ULCX_GAPSUMS": "0"},
+])
+def test_runtime_switches_keep_parity(env):
+    """Every launch-structure switch of DESIGN.md §8 (read from the environment when the codec objects are created and
+    at each call) must leave the results bit-exact: VBR and CBR over 16-block calls (long enough for the chunked
+    window-control pipeline), encode vs the oracle and decode of the result vs the oracle decoder."""
+    amd = _amd()
+    bs, ch, rate, B, K = 1024, 2, 44100, 5, 16
+    pcm = _streams(B, 2 * K, bs, ch, rate, True, seed=808)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for mode, p0 in ((amd.MODE_VBR, 45.0), (amd.MODE_CBR, 96.0)):
+            enc = amd.BatchEncoder(B, ch, bs, rate, K)
+            dec = amd.BatchDecoder(B, ch, bs, K)
+            refs = [oracle_encode_debug(pcm[s], bs, rate, 0 if mode == amd.MODE_VBR else 1, p0, slot=enc.slot) for s in range(B)]
+            outs = []
+            for call in range(2):
+                res = enc.encode(pcm[:, call * K * bs:(call + 1) * K * bs], mode, p0)
+                for s in range(B):
+                    _compare_encode(res, refs[s], s, call * K, K, None, f"{env}")
+                got, gbits = dec.decode(res[0])
+                outs.append((got, gbits))
+            for s in range(2):
+                rc, ref_pcm, ref_bits = oracle_decode_stream(refs[s]["out"], ch, bs)
+                assert rc == 0
+                got = np.concatenate([o[0][s] for o in outs])
+                assert np.array_equal(got.view(np.uint32), ref_pcm.view(np.uint32)), f"{env}: decoded PCM differs (stream {s})"
+            enc.close(); dec.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
