@@ -77,13 +77,14 @@ template <typename IN> __device__ __forceinline__ float ms_sample(const UlcxEncC
 // ---------------------------------------------------------------------------
 // Window control
 // ---------------------------------------------------------------------------
-// Scratch layout for the transient detector, in floats: a record of 8 per (stream, time quad),
-//   env[(((sg*T/4 + q)*64 + sl)*2 + f)*4 + j],  stream s = sg*64+sl, time t = 4q+j, f = 0 (HP) | 1 (BP), T = maxK*BS:
+// Scratch layout for the transient detector, in floats: per (group of 64 streams sg, time quad q) two planes of 64x4,
+//   env[((sg*T/4 + q)*2 + f)*256 + sl*4 + j],  stream s = sg*64+sl, time t = 4q+j, f = 0 (HP) | 1 (BP), T = maxK*BS:
 // time-major inside groups of 64 streams, FOUR consecutive steps of one filter adjacent.  The kernels that walk time
 // with one lane per stream[, filter] take four steps per 16-byte load/store (they are bound by instructions per step),
-// and a wave still touches one contiguous 1-2 KB run per access.
-__device__ __forceinline__ size_t envq_idx(const UlcxEncCtx &c, int s, int q) {
-    return (((size_t)(s >> 6) * (c.maxK * c.BS / 4) + q) * 64 + (s & 63)) * 8;
+// a wave touches whole contiguous 1 KB planes, and the kernels that need one filter only (k_wc_backward's output,
+// k_wc_integrate's input: the HP plane) move no bytes of the other.
+__device__ __forceinline__ size_t envq_idx(const UlcxEncCtx &c, int s, int q) {      // HP quad of stream s; the BP quad is 256 floats on
+    return ((size_t)(s >> 6) * (c.maxK * c.BS / 4) + q) * 512 + (size_t)(s & 63) * 4;
 }
 
 // WindowControl.c:31-70: E[n] = sum_ch (hp^2, bp^2) of the 3-tap FIRs centred on the
@@ -129,12 +130,12 @@ __global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c, int k0, int k1) 
         tile[lane][sl] = v;
     }
     __syncthreads();
-    float *dst = (float *)c.env + envq_idx(c, sg * 64, tt * 16);      // 16 quads x 64 streams of 8-float records
+    float *dst = (float *)c.env + envq_idx(c, sg * 64, tt * 16);      // 16 quads x 2 planes x 64 streams x 4 steps
     for (int ql = wv; ql < 16; ql += 4) {
         const float2 a0 = tile[4 * ql][lane], a1 = tile[4 * ql + 1][lane], a2 = tile[4 * ql + 2][lane], a3 = tile[4 * ql + 3][lane];
-        float4 *o = (float4 *)(dst + ((size_t)ql * 64 + lane) * 8);
-        o[0] = make_float4(a0.x, a1.x, a2.x, a3.x);
-        o[1] = make_float4(a0.y, a1.y, a2.y, a3.y);
+        float4 *o = (float4 *)(dst + (size_t)ql * 512 + lane * 4);
+        o[0]  = make_float4(a0.x, a1.x, a2.x, a3.x);
+        o[64] = make_float4(a0.y, a1.y, a2.y, a3.y);
     }
 }
 
@@ -146,15 +147,15 @@ __global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c, int k0, int k1)
     int gl = blockIdx.x * 64 + threadIdx.x;
     int s = gl >> 1, f = gl & 1;
     bool live = s < c.B;
-    float4 *v = (float4 *)((float *)c.env + envq_idx(c, live ? s : 0, k0 * c.BS / 4) + f * 4);   // this lane's four steps of each record
+    float4 *v = (float4 *)((float *)c.env + envq_idx(c, live ? s : 0, k0 * c.BS / 4) + f * 256);   // this lane's four steps of each quad
     float env = live ? c.wcs[s].tf[f] : 0.0f;
     float cc = f ? c.cBP : c.cHP;
     const int nq = (k1 - k0) * c.BS / 4;
-    // Groups of U quads (4 steps each) addressed from one pointer with immediate offsets (records of one stream are
+    // Groups of U quads (4 steps each) addressed from one pointer with immediate offsets (quads of one stream are
     // 2 KB apart), loads D-1 groups ahead of the arithmetic: the chain is bound by instructions per step (3 dependent
     // VALU + a quarter of a load and of a store), so address arithmetic and loop control are kept out of it.
     constexpr int U = 2, D = 8;           // (K*BS/4 is a multiple of U*D)
-    constexpr int QS = 64 * 8 / 4;        // float4s between consecutive quads of a stream
+    constexpr int QS = 512 / 4;           // float4s between consecutive quads of a stream
     const float4 *rp = v;
     float4 *wp = v;
     float4 x[D][U];
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c, int k0, int k1)
 #pragma unroll
         for (int g = 0; g < D; g++) {
             const bool more = (i + (g + D - 1) * U) < nq;
-            const float4 *lp = more ? rp : v;               // past the end: re-read record 0 (unused)
+            const float4 *lp = more ? rp : v;               // past the end: re-read quad 0 (unused)
 #pragma unroll
             for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = lp[(size_t)j * QS];
             rp += U * QS;
@@ -197,32 +198,32 @@ __global__ __launch_bounds__(64) void k_wc_backward(UlcxEncCtx c, int k0, int k1
     __builtin_amdgcn_s_setprio(3);                       // a serial chain: let it issue ahead of co-resident throughput kernels
     int sl = threadIdx.x;
     int k = k0 + blockIdx.x % (k1 - k0), sg = blockIdx.x / (k1 - k0);
-    float *e = (float *)c.env + envq_idx(c, sg * 64 + sl, k * c.BS / 4);      // record of the block's first quad
+    float *e = (float *)c.env + envq_idx(c, sg * 64 + sl, k * c.BS / 4);      // HP quad of the block's first four steps
     const int nq = c.BS / 4;
-    constexpr int QS = 64 * 8 / 4;                       // float4s between consecutive quads of a stream
-    float pHP = e[(size_t)(nq - 1) * 512 + 3], pBP = e[(size_t)(nq - 1) * 512 + 7];   // the forward end state = the block's last step
+    constexpr int QS = 512 / 4;                          // float4s between consecutive quads of a stream
+    float pHP = e[(size_t)(nq - 1) * 512 + 3], pBP = e[(size_t)(nq - 1) * 512 + 256 + 3];   // the forward end state = the block's last step
     const float qHP = c.qHP, qBP = c.qBP;
-    // Walk the block backwards in groups of U quads; a group's records are addressed from one pointer with
+    // Walk the block backwards in groups of U quads; a group's quads are addressed from one pointer with
     // immediate offsets, and the loads run D-1 groups ahead of the arithmetic: the chain is bound by instructions
-    // per step, so address arithmetic is kept out of it.  The result overwrites the HP half of each record.
+    // per step, so address arithmetic is kept out of it.  The result overwrites the HP plane.
     constexpr int U = 2, D = 4;                          // BS/4 is a multiple of U*D
-    const float4 *rp = (const float4 *)(e + (size_t)(nq - 1) * 512);   // record being loaded (group head)
-    float4 *wp = (float4 *)(e + (size_t)(nq - 1) * 512);               // record being computed (group head)
+    const float4 *rp = (const float4 *)(e + (size_t)(nq - 1) * 512);   // quad being loaded (group head)
+    float4 *wp = (float4 *)(e + (size_t)(nq - 1) * 512);               // quad being computed (group head)
     float4 xh[D][U], xb[D][U];
 #pragma unroll
     for (int g = 0; g < D - 1; g++) {
 #pragma unroll
-        for (int j = 0; j < U; j++) { xh[g][j] = rp[-(ptrdiff_t)j * QS]; xb[g][j] = rp[-(ptrdiff_t)j * QS + 1]; }
+        for (int j = 0; j < U; j++) { xh[g][j] = rp[-(ptrdiff_t)j * QS]; xb[g][j] = rp[-(ptrdiff_t)j * QS + 64]; }
         rp -= U * QS;
     }
     for (int i = 0; i < nq; i += U * D) {
 #pragma unroll
         for (int g = 0; g < D; g++) {
-            // prefetch the group D-1 ahead into the slot freed last (past the block start: re-read a record of the block, unused)
+            // prefetch the group D-1 ahead into the slot freed last (past the block start: re-read a quad of the block, unused)
             const bool more = (i + (g + D - 1) * U) < nq;
             const float4 *lp = more ? rp : (const float4 *)(e + (size_t)(U - 1) * 512);
 #pragma unroll
-            for (int j = 0; j < U; j++) { xh[(g + D - 1) % D][j] = lp[-(ptrdiff_t)j * QS]; xb[(g + D - 1) % D][j] = lp[-(ptrdiff_t)j * QS + 1]; }
+            for (int j = 0; j < U; j++) { xh[(g + D - 1) % D][j] = lp[-(ptrdiff_t)j * QS]; xb[(g + D - 1) % D][j] = lp[-(ptrdiff_t)j * QS + 64]; }
             rp -= U * QS;
             float4 o[U];
 #pragma unroll
@@ -249,12 +250,12 @@ __global__ __launch_bounds__(64) void k_wc_integrate(UlcxEncCtx c, int k0, int k
     float env = c.wcs[sc].tf[2];
     float *bins = c.bins + (size_t)sc * (c.maxK + 1) * 16;
     if (live && k0 == 0) for (int i = 0; i < 8; i++) { bins[i] = c.wcs[s].binSum[i]; bins[8 + i] = c.wcs[s].binW[i]; }
-    const float4 *v = (const float4 *)((const float *)c.env + envq_idx(c, s, k0 * c.BS / 4));   // HP half of each record: k_wc_backward's output
+    const float4 *v = (const float4 *)((const float *)c.env + envq_idx(c, s, k0 * c.BS / 4));   // the HP plane: k_wc_backward's output
     const int bin = c.BS / 8;             // >= 32, a multiple of 4*U
     const int nq = (k1 - k0) * c.BS / 4;
     // same structure as k_wc_forward: groups of U quads off one pointer, loads D-1 groups ahead
     constexpr int U = 2, D = 8;
-    constexpr int QS = 64 * 8 / 4;
+    constexpr int QS = 512 / 4;
     const float4 *rp = v;
     float4 x[D][U];
 #pragma unroll
