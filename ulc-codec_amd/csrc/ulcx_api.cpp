@@ -219,7 +219,7 @@ static int encode_dev_any(ulcx_encoder *e, int mode, float p0, float p1, const f
     aux.side = e->sideOk ? e->side : nullptr; aux.side2 = e->sideOk ? e->side2 : nullptr; aux.side3 = e->sideOk ? e->side3 : nullptr; aux.side4 = (e->sideOk && getenv("ULCX_WC_ESTREAM")) ? e->side4 : nullptr; aux.evE = e->evE;
     aux.evFork = e->evFork; aux.evJoin = e->evJoin; aux.evFork2 = e->evFork2; aux.evWC = e->evWC; aux.evXf = e->evXf;
     aux.wcPipe = (nBlocks >= 2 * e->wcPipe) ? e->wcPipe : (nBlocks >= 6 && e->wcPipe > 1 ? 3 : 1); aux.nXf = &e->nXf;
-    aux.wcSteps = 0; if (const char *sv = getenv("ULCX_WC_STEPS")) aux.wcSteps = atoi(sv);   // 0: the transform's chunks
+    aux.wcSteps = -1; if (const char *sv = getenv("ULCX_WC_STEPS")) aux.wcSteps = atoi(sv);   // -1: default; 0: the transform's chunks
     int rc = ulcx_enc_launch(c, (hipStream_t)hipStream, e->ev, aux);
     e->evRecorded = (rc == ULCX_OK);
     e->lastK = nBlocks;

@@ -2123,10 +2123,13 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
             // side2: backward_j behind forward_j;  side3: integrate_j, decide_j behind backward_j;
             // main: xf_j behind decide_j.  The first chunk is a single block so the transform starts early.
             hipEvent_t ev0 = evWC[0], *evF = evWC + 1, *evB = evWC + 1 + ULCX_WC_MAXCH, *evD = evWC + 1 + 2 * ULCX_WC_MAXCH, *evE = aux.evE;
-            // The window-control kernels advance in the same chunks as the transform (first chunk = one block, then
-            // quarters) unless ULCX_WC_STEPS asks for uniform finer steps: measured, finer steps lose - every
-            // k_wc_backward launch costs a full 2048-step chain whatever its size, and they queue on one stream.
+            // The window-control kernels advance in uniform steps of a few blocks (ULCX_WC_STEPS; 0 = in the same chunks as
+            // the transform: first chunk one block, then quarters), and a transform chunk is launched as soon as the step
+            // holding its last block is decided.  Measured on the bench shape: 4, 8 or 16 steps 9.57-9.60 ms per step,
+            // the transform's own chunks 9.66-9.73 (every k_wc_backward launch costs a full 2048-step chain whatever
+            // its size, so very fine steps stop paying).
             int nW = aux.wcSteps;
+            if (nW < 0) nW = (c.K >= 8) ? ((c.K / 2 < 8) ? c.K / 2 : 8) : 0;     // default: up to 8 uniform steps of >= 2 blocks
             if (nW > ULCX_WC_MAXCH) nW = ULCX_WC_MAXCH;
             if (nW > c.K) nW = c.K;
             const bool sameCuts = nW < 1;
