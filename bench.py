@@ -195,16 +195,15 @@ def main():
     # kms is the kernel's time per step; a kernel launched n times per step (k_xf: one launch per chunk of blocks of
     # the window-control pipeline) has kms = sum of its n launches, each timed by its own hipEvent pair on its stream.
     # Per launch: bytes/n over kms/n - the same ratio.  profiles/*_pmc_summary.json carries n and the measured traffic.
-    launches = 1.0
+    launches = float(enc.xf_launches()) if kname == "k_xf" else 1.0      # from the library: chunks of the last call
     traffic = None
     pj = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
     if os.path.exists(pj):
         try:
             ent = json.load(open(pj)).get(kname, {})
-            launches = float(ent.get("launches_per_step", 1.0)) or 1.0
-            traffic = ent.get("hbm_bytes_per_launch")
+            traffic = ent.get("hbm_bytes_per_launch")                   # (key name: it is the kernel's bytes per STEP of 65536 blocks)
             if traffic is not None:
-                traffic = traffic * (B * K / 65536.0) / launches        # summary is per step of 65536 blocks
+                traffic = traffic * (B * K / 65536.0) / launches
         except Exception:
             traffic = None
     launch_bytes = alg_bytes_block * B * K / launches

@@ -221,6 +221,9 @@ int  ulcx_decode_packed_host(ulcx_decoder *dec, const uint8_t *h_payload, long l
  * Only valid after the stream has been synchronised. */
 int  ulcx_encoder_stage_ms(ulcx_encoder *enc, float *ms, int maxStages);
 const char *ulcx_encoder_stage_name(int stage);
+/* Launches of the transform kernel (k_xf) in the last call: the stage time above is their sum (1 when the
+ * window-control pipeline is off). */
+int  ulcx_encoder_last_xf_launches(ulcx_encoder *enc);
 int  ulcx_decoder_stage_ms(ulcx_decoder *dec, float *ms, int maxStages);
 const char *ulcx_decoder_stage_name(int stage);
 
