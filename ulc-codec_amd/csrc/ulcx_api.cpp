@@ -212,7 +212,7 @@ static int encode_dev_any(ulcx_encoder *e, int mode, float p0, float p1, const f
     if (mode != ULCX_MODE_VBR && mode != ULCX_MODE_CBR && mode != ULCX_MODE_ABR) { ulcx_set_error("bad mode"); return ULCX_ERR_ARG; }
     CKR(hipSetDevice(e->device));
     UlcxEncCtx c = e->ctx;
-    c.K = nBlocks; c.mode = mode; c.p0 = p0; c.p1 = p1;
+    c.K = nBlocks; c.keyFinal = 0; c.mode = mode; c.p0 = p0; c.p1 = p1;
     c.vbrTarget = (mode == ULCX_MODE_VBR) ? 0x1.E4EFB7p3f * logf(100.0f / p0) : 0.0f;     // ulcEncoder.c:144 (host libm, data independent)
     c.pcm = d_pcm; c.pcm16 = d_pcm16; c.out = d_out; c.bits = d_bits; c.wcOut = d_wc; c.cplxOut = d_cplx;
     UlcxEncAux aux;
@@ -273,7 +273,7 @@ extern "C" int ulcx_encoder_debug_fetch(ulcx_encoder *e, int nBlocks, float *h_c
     if (h_noise) CKR(hipMemcpy(h_noise, e->ctx.npair, sizeof(float) * NB * cb, hipMemcpyDeviceToHost));
     if (h_keys) {
         if (!e->keysFinal) {                       // the pipeline never writes final keys back; materialise them for the tap
-            UlcxEncCtx c2 = e->ctx; c2.K = nBlocks;
+            UlcxEncCtx c2 = e->ctx; c2.K = nBlocks; c2.keyFinal = 0;
             ulcx_enc_finalize_keys(c2, nullptr);
             CKR(hipDeviceSynchronize());
             e->keysFinal = true;

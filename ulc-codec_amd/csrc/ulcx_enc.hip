@@ -405,7 +405,6 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
     }
     size_t cb = (size_t)C * BS;
     float *coefO = c.coef + (size_t)blk * cb;
-    float *keyO  = c.key  + (size_t)blk * cb;
     float *nsumO = c.nsum + (size_t)blk * (cb / 2);
     int nnz = 0;
     __syncthreads();
@@ -554,13 +553,13 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
                         float re1 = mdct[2*p+1] * norm, im1 = mdst[2*p+1] * norm;
                         float re0s = re0 * re0, im0s = im0 * im0, re1s = re1 * re1, im1s = im1 * im1;
                         float a0 = re0s + im0s, a1 = re1s + im1s;
-                        float k0v, k1v;
-                        if (fabsf(re0) < 0.5f * ULCX_COEF_EPS) k0v = __uint_as_float(0xff800000u); else { k0v = fastlog(re0s); nnz++; }
-                        if (fabsf(re1) < 0.5f * ULCX_COEF_EPS) k1v = __uint_as_float(0xff800000u); else { k1v = fastlog(re1s); nnz++; }
+                        // (the importance key FastLog(Re^2) is a function of the stored coefficient: the kernels that consume
+                        //  keys form it from there, key0_of(), instead of this one writing 4 more bytes per coefficient)
+                        nnz += (fabsf(re0) < 0.5f * ULCX_COEF_EPS) ? 0 : 1;
+                        nnz += (fabsf(re1) < 0.5f * ULCX_COEF_EPS) ? 0 : 1;
                         int j = p ? k2 : k1;
                         size_t gi = (size_t)ch * BS + off + 2 * j;
                         *(float2 *)(coefO + gi) = make_float2(re0, re1);
-                        *(float2 *)(keyO + gi)  = make_float2(k0v, k1v);
                         nsumO[(size_t)ch * (BS / 2) + off / 2 + j] = a0 + a1;          // (0 + a0) + a1
                         if (p) { am2 += a0; am2 += a1; } else { am1 += a0; am1 += a1; } // channel order preserved
                     }
@@ -824,11 +823,19 @@ __device__ __forceinline__ float final_key(float v, float m, int ch) {
     if (ch & 1) t = t + -0x1.62E430p0f;
     return t;
 }
-// key of coefficient i of block blk (c.key holds key0 = FastLog(Re^2) or -inf, c.mask the masking level per line)
-// (recomputing key0 from the coefficient instead of storing it was tried: -0.08 ms in k_xf, +1.15 ms in the select)
+// BlockTransform.c:250-253: key0 = FastLog(Re^2), or -inf for a coefficient that counts as zero
+__device__ __forceinline__ float key0_of(float re) {
+    float k = fastlog(re * re);                            // evaluated unconditionally: a select, not a branch per coefficient
+    asm volatile("" : "+v"(k));
+    return (fabsf(re) < 0.5f * ULCX_COEF_EPS) ? __uint_as_float(0xff800000u) : k;
+}
+// key of coefficient i of block blk, from the stored coefficient and c.mask (the masking level per line); once
+// k_keys_finalize has run for the call (c.keyFinal: the multi-pass selection kernel of unusual geometries, the parity
+// tap) c.key holds the same values
 __device__ __forceinline__ float load_final_key(const UlcxEncCtx &c, int blk, int i) {
+    if (c.keyFinal) return c.key[(size_t)blk * (c.C * c.BS) + i];
     int ch = i >> c.lgBS, n = i & (c.BS - 1);
-    return final_key(c.key[(size_t)blk * (c.C * c.BS) + i], c.mask[(size_t)blk * (c.BS / 2) + (n >> 1)], ch);
+    return final_key(key0_of(c.coef[(size_t)blk * (c.C * c.BS) + i]), c.mask[(size_t)blk * (c.BS / 2) + (n >> 1)], ch);
 }
 
 // Psyopt.c:140-150: masking level per line
@@ -862,6 +869,7 @@ __global__ __launch_bounds__(WG) void k_keys_finalize(UlcxEncCtx c) {
     size_t N = (size_t)c.C * c.BS;
     if (gid >= (size_t)c.B * c.K * N) return;
     int blk = (int)(gid / N), i = (int)(gid % N);
+    c.keyFinal = 0;                                       // (this is the kernel that forms them)
     c.key[gid] = load_final_key(c, blk, i);
 }
 void ulcx_enc_finalize_keys(const UlcxEncCtx &c, hipStream_t st) {
@@ -964,7 +972,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
     if (c.isFb[blk]) return;                              // already handed to the exact (heapsort-rank) path this call
     const int N = R * 64;
     int kSel = c.nout[blk];
-    const float *key = c.key + (size_t)blk * N;
+    const float *coef = c.coef + (size_t)blk * N;
     uint32_t *keep = c.keep + (size_t)blk * (N / 32);
     if (kSel <= 0) {
         for (int i = lane; i < N / 32; i += 64) keep[i] = 0;
@@ -973,10 +981,16 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
     uint32_t u[R];
     {
         const float *msk = c.mask + (size_t)blk * (c.BS / 2);
+        // batches of 8: the loads of one batch are in flight together, but the compiler may not hoist all R of them
+        // above the arithmetic (that doubled the register count and halved the occupancy)
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            int i = r * 64 + lane;
-            u[r] = key_ord(final_key(key[i], msk[(i & (c.BS - 1)) >> 1], i >> c.lgBS));
+        for (int r0 = 0; r0 < R; r0 += 8) {
+            float cv[8], mv[8];
+#pragma unroll
+            for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; cv[q] = coef[i]; mv[q] = msk[(i & (c.BS - 1)) >> 1]; }
+#pragma unroll
+            for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; u[r0 + q] = key_ord(final_key(key0_of(cv[q]), mv[q], i >> c.lgBS)); }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // T = kSel-th largest ordered key = the largest t with count(u >= t) >= kSel; found bit by bit
@@ -2080,7 +2094,8 @@ const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES_REPORTED] = {
     "k_select", "k_nbark", "k_nline", "k_heapsel", "k_gapsums", "k_tailsums", "k_encode_wave", "k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update", "wc_pipeline_exposed",
 };
 
-int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const UlcxEncAux &aux) {
+int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const UlcxEncAux &aux) {
+    UlcxEncCtx c = cIn;                                        // (keyFinal is set below for geometries without a wave selection kernel)
     hipStream_t side = aux.side, side2 = aux.side2, side3 = aux.side3, side4 = aux.side4;
     hipEvent_t evFork = aux.evFork, evJoin = aux.evJoin, evFork2 = aux.evFork2, *evWC = aux.evWC;
     const int wcPipe = (side && side2 && side3) ? aux.wcPipe : 1;
@@ -2211,6 +2226,13 @@ int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev, const U
     }
     if (noiseAside) CK(hipStreamWaitEvent(st, evCplx, 0));
     // --- selection + encode pass(es)
+    {
+        // geometries the one-wave-per-block selection does not cover go through the multi-pass kernel, which reads every
+        // key several times: form the final keys once for it (and for the exact path's heapsort)
+        const int Nk = c.C * c.BS, R = Nk / 64;
+        const bool selWave = (Nk % 64 == 0) && (R == 4 || R == 8 || R == 16 || R == 32 || R == 64);
+        if (!selWave) { ulcx_enc_finalize_keys(c, st); c.keyFinal = 1; }
+    }
     int N = c.C * c.BS;
     int ldsEntries = ((size_t)N * 8 <= ULCX_HEAP_LDS_BYTES) ? N : 0;
     size_t heapLds = ldsEntries ? (size_t)N * 8 + (size_t)N / 8 : 0;

@@ -49,6 +49,7 @@ struct UlcxEncCtx {
     int   rateHz;
     UlcxTables T;
     // inputs / outputs of this call
+    int keyFinal;                        // c.key holds this call's final keys (k_keys_finalize has run): consumers read them instead of forming them
     const float *pcm; const int16_t *pcm16;      // exactly one is set: the C API's f32 input, or PCM16 ingest
     uint8_t *out; int32_t *bits; int32_t *wcOut; float *cplxOut;
     // persistent state
