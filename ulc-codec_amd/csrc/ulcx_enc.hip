@@ -83,6 +83,10 @@ template <typename IN> __device__ __forceinline__ float ms_sample(const UlcxEncC
 // with one lane per stream[, filter] take four steps per 16-byte load/store (they are bound by instructions per step),
 // a wave touches whole contiguous 1 KB planes, and the kernels that need one filter only (k_wc_backward's output,
 // k_wc_integrate's input: the HP plane) move no bytes of the other.
+// streamed once: loads/stores of the envelope scratch carry the non-temporal hint
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldnt(const float4 *p) { f32x4 v = __builtin_nontemporal_load((const f32x4 *)p); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void stnt(float4 *p, float4 v) { f32x4 w = { v.x, v.y, v.z, v.w }; __builtin_nontemporal_store(w, (f32x4 *)p); }
 __device__ __forceinline__ size_t envq_idx(const UlcxEncCtx &c, int s, int q) {      // HP quad of stream s; the BP quad is 256 floats on
     return ((size_t)(s >> 6) * (c.maxK * c.BS / 4) + q) * 512 + (size_t)(s & 63) * 4;
 }
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c, int k0, int k1)
 #pragma unroll
     for (int g = 0; g < D - 1; g++) {
 #pragma unroll
-        for (int j = 0; j < U; j++) x[g][j] = rp[(size_t)j * QS];
+        for (int j = 0; j < U; j++) x[g][j] = ldnt(rp + (size_t)j * QS);
         rp += U * QS;
     }
     for (int i = 0; i < nq; i += D * U) {
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c, int k0, int k1)
             const bool more = (i + (g + D - 1) * U) < nq;
             const float4 *lp = more ? rp : v;               // past the end: re-read quad 0 (unused)
 #pragma unroll
-            for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = lp[(size_t)j * QS];
+            for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = ldnt(lp + (size_t)j * QS);
             rp += U * QS;
 #pragma unroll
             for (int j = 0; j < U; j++) {
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c, int k0, int k1)
             }
             if (live) {
 #pragma unroll
-                for (int j = 0; j < U; j++) wp[(size_t)j * QS] = x[g][j];
+                for (int j = 0; j < U; j++) stnt(wp + (size_t)j * QS, x[g][j]);
             }
             wp += U * QS;
         }
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(64) void k_wc_backward(UlcxEncCtx c, int k0, int k1
 #pragma unroll
     for (int g = 0; g < D - 1; g++) {
 #pragma unroll
-        for (int j = 0; j < U; j++) { xh[g][j] = rp[-(ptrdiff_t)j * QS]; xb[g][j] = rp[-(ptrdiff_t)j * QS + 64]; }
+        for (int j = 0; j < U; j++) { xh[g][j] = ldnt(rp - (ptrdiff_t)j * QS); xb[g][j] = ldnt(rp - (ptrdiff_t)j * QS + 64); }
         rp -= U * QS;
     }
     for (int i = 0; i < nq; i += U * D) {
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(64) void k_wc_backward(UlcxEncCtx c, int k0, int k1
             const bool more = (i + (g + D - 1) * U) < nq;
             const float4 *lp = more ? rp : (const float4 *)(e + (size_t)(U - 1) * 512);
 #pragma unroll
-            for (int j = 0; j < U; j++) { xh[(g + D - 1) % D][j] = lp[-(ptrdiff_t)j * QS]; xb[(g + D - 1) % D][j] = lp[-(ptrdiff_t)j * QS + 64]; }
+            for (int j = 0; j < U; j++) { xh[(g + D - 1) % D][j] = ldnt(lp - (ptrdiff_t)j * QS); xb[(g + D - 1) % D][j] = ldnt(lp - (ptrdiff_t)j * QS + 64); }
             rp -= U * QS;
             float4 o[U];
 #pragma unroll
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(64) void k_wc_backward(UlcxEncCtx c, int k0, int k1
 #undef WC_BACK_STEP
             }
 #pragma unroll
-            for (int j = 0; j < U; j++) wp[-(ptrdiff_t)j * QS] = o[j];
+            for (int j = 0; j < U; j++) stnt(wp - (ptrdiff_t)j * QS, o[j]);
             wp -= U * QS;
         }
     }
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(64) void k_wc_integrate(UlcxEncCtx c, int k0, int k
 #pragma unroll
     for (int g = 0; g < D - 1; g++) {
 #pragma unroll
-        for (int j = 0; j < U; j++) x[g][j] = rp[(size_t)j * QS];
+        for (int j = 0; j < U; j++) x[g][j] = ldnt(rp + (size_t)j * QS);
         rp += U * QS;
     }
     const float cBlk = c.cBlk;
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(64) void k_wc_integrate(UlcxEncCtx c, int k0, int k
             const bool more = (i + (g + D - 1) * U) < nq;
             const float4 *lp = more ? rp : v;
 #pragma unroll
-            for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = lp[(size_t)j * QS];
+            for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = ldnt(lp + (size_t)j * QS);
             rp += U * QS;
 #pragma unroll
             for (int j = 0; j < U; j++) {
