@@ -74,6 +74,14 @@ template <typename IN> __device__ __forceinline__ float ms_sample(const UlcxEncC
     if (ch + 1 < c.C) { float a = smp_ld1<IN>(c, s, trel, ch), b = smp_ld1<IN>(c, s, trel, ch + 1); return (a + b) * 0.5f; }
     return smp_ld1<IN>(c, s, trel, ch);
 }
+// Arrays that one kernel streams out and a later kernel streams in once (envelope scratch, transform outputs, noise
+// pairs, masking levels): their loads/stores carry the non-temporal hint so they do not evict what is re-read.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ldnt(const float4 *p) { f32x4 v = __builtin_nontemporal_load((const f32x4 *)p); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void stnt(float4 *p, float4 v) { f32x4 w = { v.x, v.y, v.z, v.w }; __builtin_nontemporal_store(w, (f32x4 *)p); }
+__device__ __forceinline__ void stnt(float2 *p, float2 v) { f32x2 w = { v.x, v.y }; __builtin_nontemporal_store(w, (f32x2 *)p); }
+__device__ __forceinline__ void stnt(float *p, float v) { __builtin_nontemporal_store(v, p); }
 // ---------------------------------------------------------------------------
 // Window control
 // ---------------------------------------------------------------------------
@@ -83,10 +91,6 @@ template <typename IN> __device__ __forceinline__ float ms_sample(const UlcxEncC
 // with one lane per stream[, filter] take four steps per 16-byte load/store (they are bound by instructions per step),
 // a wave touches whole contiguous 1 KB planes, and the kernels that need one filter only (k_wc_backward's output,
 // k_wc_integrate's input: the HP plane) move no bytes of the other.
-// streamed once: loads/stores of the envelope scratch carry the non-temporal hint
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ldnt(const float4 *p) { f32x4 v = __builtin_nontemporal_load((const f32x4 *)p); return make_float4(v.x, v.y, v.z, v.w); }
-__device__ __forceinline__ void stnt(float4 *p, float4 v) { f32x4 w = { v.x, v.y, v.z, v.w }; __builtin_nontemporal_store(w, (f32x4 *)p); }
 __device__ __forceinline__ size_t envq_idx(const UlcxEncCtx &c, int s, int q) {      // HP quad of stream s; the BP quad is 256 floats on
     return ((size_t)(s >> 6) * (c.maxK * c.BS / 4) + q) * 512 + (size_t)(s & 63) * 4;
 }
@@ -138,8 +142,8 @@ __global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c, int k0, int k1) 
     for (int ql = wv; ql < 16; ql += 4) {
         const float2 a0 = tile[4 * ql][lane], a1 = tile[4 * ql + 1][lane], a2 = tile[4 * ql + 2][lane], a3 = tile[4 * ql + 3][lane];
         float4 *o = (float4 *)(dst + (size_t)ql * 512 + lane * 4);
-        o[0]  = make_float4(a0.x, a1.x, a2.x, a3.x);
-        o[64] = make_float4(a0.y, a1.y, a2.y, a3.y);
+        stnt(o, make_float4(a0.x, a1.x, a2.x, a3.x));
+        stnt(o + 64, make_float4(a0.y, a1.y, a2.y, a3.y));
     }
 }
 
@@ -563,8 +567,8 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
                         nnz += (fabsf(re1) < 0.5f * ULCX_COEF_EPS) ? 0 : 1;
                         int j = p ? k2 : k1;
                         size_t gi = (size_t)ch * BS + off + 2 * j;
-                        *(float2 *)(coefO + gi) = make_float2(re0, re1);
-                        nsumO[(size_t)ch * (BS / 2) + off / 2 + j] = a0 + a1;          // (0 + a0) + a1
+                        stnt((float2 *)(coefO + gi), make_float2(re0, re1));
+                        stnt(nsumO + (size_t)ch * (BS / 2) + off / 2 + j, a0 + a1);       // (0 + a0) + a1
                         if (p) { am2 += a0; am2 += a1; } else { am1 += a0; am1 += a1; } // channel order preserved
                     }
                 }
@@ -785,7 +789,7 @@ __global__ __launch_bounds__(WG) void k_nline(UlcxEncCtx c) {
         float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
         float noise = L * (1.0f - fr) + R * fr;
         float w = ulcx_expf(0.5f * noise);
-        dst[jp] = make_float2(w, w * (noise + 0x1.62E430p-1f));
+        stnt(dst + jp, make_float2(w, w * (noise + 0x1.62E430p-1f)));
     }
 }
 
