@@ -413,9 +413,13 @@ __device__ __forceinline__ int16_t to_pcm16(float x) {
     v = (v < -32768.0f) ? -32768.0f : (v > 32767.0f) ? 32767.0f : v;
     return (int16_t)__float2int_rn(v);
 }
-__device__ __forceinline__ void st1(float *p, float a) { *p = a; }
-__device__ __forceinline__ void st2(float *p, float a, float b) { *(float2 *)p = make_float2(a, b); }
-__device__ __forceinline__ void st4(float *p, float a, float b, float d, float e) { *(float4 *)p = make_float4(a, b, d, e); }
+// (the decoded samples are written once and not read again by the decoder, the coefficients are read once: non-temporal)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st1(float *p, float a) { __builtin_nontemporal_store(a, p); }
+__device__ __forceinline__ void st2(float *p, float a, float b) { f32x2 w = { a, b }; __builtin_nontemporal_store(w, (f32x2 *)p); }
+__device__ __forceinline__ void st4(float *p, float a, float b, float d, float e) { f32x4 w = { a, b, d, e }; __builtin_nontemporal_store(w, (f32x4 *)p); }
+__device__ __forceinline__ float2 ld2nt(const float *p) { f32x2 v = __builtin_nontemporal_load((const f32x2 *)p); return make_float2(v.x, v.y); }
 __device__ __forceinline__ void st1(int16_t *p, float a) { *p = to_pcm16(a); }
 __device__ __forceinline__ void st2(int16_t *p, float a, float b) { *(short2 *)p = make_short2(to_pcm16(a), to_pcm16(b)); }
 __device__ __forceinline__ void st4(int16_t *p, float a, float b, float d, float e) { *(short4 *)p = make_short4(to_pcm16(a), to_pcm16(b), to_pcm16(d), to_pcm16(e)); }
@@ -456,8 +460,8 @@ __global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
             const int n2 = M - 1 - n;
             float2 P = pre[n], P2 = pre[n2];
             int pn = padded ? FFT_PADS(n, DPS) : n, pn2 = padded ? FFT_PADS(n2, DPS) : n2;
-            float2 a0 = *(const float2 *)(X0 + 2 * n), b0 = *(const float2 *)(X0 + S - 2 - 2 * n);
-            float2 a1 = *(const float2 *)(X1 + 2 * n), b1 = *(const float2 *)(X1 + S - 2 - 2 * n);
+            float2 a0 = ld2nt(X0 + 2 * n), b0 = ld2nt(X0 + S - 2 - 2 * n);
+            float2 a1 = ld2nt(X1 + 2 * n), b1 = ld2nt(X1 + S - 2 - 2 * n);
             za[pn]  = cmulc(make_float2(a0.x, b0.y), P);
             za[pn2] = cmulc(make_float2(b0.x, a0.y), P2);
             zb[pn]  = cmulc(make_float2(a1.x, b1.y), P);
