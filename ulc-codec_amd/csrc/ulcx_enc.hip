@@ -82,6 +82,7 @@ __device__ __forceinline__ float4 ldnt(const float4 *p) { f32x4 v = __builtin_no
 __device__ __forceinline__ void stnt(float4 *p, float4 v) { f32x4 w = { v.x, v.y, v.z, v.w }; __builtin_nontemporal_store(w, (f32x4 *)p); }
 __device__ __forceinline__ void stnt(float2 *p, float2 v) { f32x2 w = { v.x, v.y }; __builtin_nontemporal_store(w, (f32x2 *)p); }
 __device__ __forceinline__ void stnt(float *p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ float ldnt(const float *p) { return __builtin_nontemporal_load(p); }
 // ---------------------------------------------------------------------------
 // Window control
 // ---------------------------------------------------------------------------
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(WG) void k_mask(UlcxEncCtx c) {
         float fr = c.T.bandFrac[d][line];
         float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
         float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
-        dst[jp] = L * (1.0f - fr) + R * fr;
+        stnt(dst + jp, L * (1.0f - fr) + R * fr);
     }
 }
 
@@ -995,7 +996,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
         for (int r0 = 0; r0 < R; r0 += 8) {
             float cv[8], mv[8];
 #pragma unroll
-            for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; cv[q] = coef[i]; mv[q] = msk[(i & (c.BS - 1)) >> 1]; }
+            for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; cv[q] = ldnt(coef + i); mv[q] = msk[(i & (c.BS - 1)) >> 1]; }
 #pragma unroll
             for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; u[r0 + q] = key_ord(final_key(key0_of(cv[q]), mv[q], i >> c.lgBS)); }
             __builtin_amdgcn_sched_barrier(0);
@@ -1207,7 +1208,7 @@ __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
     for (int i = tid; i < N / 32; i += WG) kw[i] = keepB[i];
     {
         const float4 *pg = (const float4 *)(c.npair + (size_t)blk * N);
-        for (int i = tid; i < N / 4; i += WG) ((float4 *)pairs)[i] = pg[i];
+        for (int i = tid; i < N / 4; i += WG) ((float4 *)pairs)[i] = ldnt(pg + i);
     }
     __syncthreads();
     float2 *gs = c.gapSum + (size_t)blk * N;
