@@ -320,19 +320,25 @@ __device__ __forceinline__ void dgen_piece(const UlcxDecCtx &c, int blk, int ch,
             const int room = 4 - (pos & 3);
             const int cnt = pend < room ? pend : room;
             float v[4];
+            if (cnt == 4) {                                // the body of a run: a full aligned group, nothing predicated
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (k < cnt) {
+                for (int k = 0; k < 4; k++) {
                     seed = xorshift32(seed);
-                    if (seed & 0x80000000u) lev = -lev;
+                    lev = __uint_as_float(__float_as_uint(lev) ^ (seed & 0x80000000u));      // flip on the MSB
                     v[k] = lev;
                     lev *= rr;
                 }
-            }
-            if (cnt == 4) *(float4 *)(dst + pos) = make_float4(v[0], v[1], v[2], v[3]);
-            else {
+                *(float4 *)(dst + pos) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
 #pragma unroll
-                for (int k = 0; k < 3; k++) if (k < cnt) dst[pos + k] = v[k];
+                for (int k = 0; k < 3; k++) {
+                    if (k < cnt) {
+                        seed = xorshift32(seed);
+                        lev = __uint_as_float(__float_as_uint(lev) ^ (seed & 0x80000000u));
+                        dst[pos + k] = lev;
+                        lev *= rr;
+                    }
+                }
             }
             pos += cnt; pend -= cnt; N -= cnt;
         } else {
