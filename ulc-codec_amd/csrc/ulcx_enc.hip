@@ -103,6 +103,28 @@ __device__ __forceinline__ size_t envq_idx(const UlcxEncCtx &c, int s, int q) { 
 // All window-control kernels (and k_xf) take a block range [k0, k1) of the call so the host can
 // pipeline chunks of blocks: the stream-sequential recurrences of later chunks run beside the
 // transform of earlier ones.
+// {sqrt(E_hp), sqrt(E_bp)} of stream s at centre sample t (relative to the call's first sample)
+template <typename IN> __device__ __forceinline__ float2 wc_energy_at(const UlcxEncCtx &c, int s, int t) {
+    float ehp = 0.0f, ebp = 0.0f;
+    if (c.C == 2) {                                // stereo fast path: three 8-byte (PCM16: 4-byte) loads
+        float2 a = smp_ld2<IN>(c, s, t - 1), b = smp_ld2<IN>(c, s, t), d = smp_ld2<IN>(c, s, t + 1);
+        float m0 = (a.x + a.y) * 0.5f, m1 = (b.x + b.y) * 0.5f, m2 = (d.x + d.y) * 0.5f;
+        float s0 = (a.x - a.y) * 0.5f, s1 = (b.x - b.y) * 0.5f, s2 = (d.x - d.y) * 0.5f;
+        float hp = -m0 + 2 * m1 - m2, bp = -m0 + m2;
+        ehp += hp * hp; ebp += bp * bp;
+        hp = -s0 + 2 * s1 - s2; bp = -s0 + s2;
+        ehp += hp * hp; ebp += bp * bp;
+    } else {
+        for (int ch = 0; ch < c.C; ch++) {
+            float t0 = ms_sample<IN>(c, s, t - 1, ch), t1 = ms_sample<IN>(c, s, t, ch), t2 = ms_sample<IN>(c, s, t + 1, ch);
+            float hp = -t0 + 2 * t1 - t2;
+            float bp = -t0 + t2;
+            ehp += hp * hp;
+            ebp += bp * bp;
+        }
+    }
+    return make_float2(sqrtf(ehp), sqrtf(ebp));
+}
 template <typename IN>
 __global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c, int k0, int k1) {
     __shared__ float2 tile[64][65];
@@ -114,29 +136,7 @@ __global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c, int k0, int k1) 
 #pragma unroll 4
     for (int sl = wv; sl < 64; sl += 4) {
         int s = sg * 64 + sl;
-        float2 v = make_float2(0.0f, 0.0f);
-        if (s < c.B) {
-            float ehp = 0.0f, ebp = 0.0f;
-            if (c.C == 2) {                                // stereo fast path: three 8-byte (PCM16: 4-byte) loads
-                float2 a = smp_ld2<IN>(c, s, t - 1), b = smp_ld2<IN>(c, s, t), d = smp_ld2<IN>(c, s, t + 1);
-                float m0 = (a.x + a.y) * 0.5f, m1 = (b.x + b.y) * 0.5f, m2 = (d.x + d.y) * 0.5f;
-                float s0 = (a.x - a.y) * 0.5f, s1 = (b.x - b.y) * 0.5f, s2 = (d.x - d.y) * 0.5f;
-                float hp = -m0 + 2 * m1 - m2, bp = -m0 + m2;
-                ehp += hp * hp; ebp += bp * bp;
-                hp = -s0 + 2 * s1 - s2; bp = -s0 + s2;
-                ehp += hp * hp; ebp += bp * bp;
-            } else {
-                for (int ch = 0; ch < c.C; ch++) {
-                    float t0 = ms_sample<IN>(c, s, t - 1, ch), t1 = ms_sample<IN>(c, s, t, ch), t2 = ms_sample<IN>(c, s, t + 1, ch);
-                    float hp = -t0 + 2 * t1 - t2;
-                    float bp = -t0 + t2;
-                    ehp += hp * hp;
-                    ebp += bp * bp;
-                }
-            }
-            v = make_float2(sqrtf(ehp), sqrtf(ebp));
-        }
-        tile[lane][sl] = v;
+        tile[lane][sl] = (s < c.B) ? wc_energy_at<IN>(c, s, t) : make_float2(0.0f, 0.0f);
     }
     __syncthreads();
     float *dst = (float *)c.env + envq_idx(c, sg * 64, tt * 16);      // 16 quads x 2 planes x 64 streams x 4 steps
@@ -200,6 +200,124 @@ __global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c, int k0, int k1)
         }
     }
     if (live) c.wcs[s].tf[f] = env;                                   // state for the next call
+}
+
+// k_wc_energy + k_wc_forward in one kernel: the envelope never goes through HBM on its way into the recurrence.
+// One workgroup = 32 streams: wave 0 runs the two one-pole chains of each (lane = stream, filter), waves 1-3 produce
+// the energies a few tiles of 64 steps ahead (lane = time step: coalesced input rows) into an LDS ring, transposed.
+// Producers and chain are decoupled by counters in LDS (tiles finished per producer wave, tiles taken by the chain),
+// not by barriers: the chain never waits as long as the producers are ahead, and they have EF_RT tiles of slack
+// for their load latency.
+#define EF_TS 68                                          // floats per (stream, filter) row of a tile: 64 steps + pad (rows stay 16-byte aligned, b128 reads conflict-free)
+#define EF_RT 6                                           // tiles in the ring
+#define EF_SPW 16                                         // streams per workgroup
+#define EF_NW 16                                          // waves per workgroup: the chain + 15 producers
+#define EF_TILE_FLOATS (EF_SPW * 2 * EF_TS)
+#define EF_LDS_BYTES (EF_RT * EF_TILE_FLOATS * 4 + 4 * EF_NW)
+// (stereo only: the producers split the envelope computation into its three 8-byte loads, issued tiles ahead,
+//  and the arithmetic)
+__device__ __forceinline__ float2 wc_energy_stereo(float2 a, float2 b, float2 d) {        // as wc_energy_at, C == 2
+    float m0 = (a.x + a.y) * 0.5f, m1 = (b.x + b.y) * 0.5f, m2 = (d.x + d.y) * 0.5f;
+    float s0 = (a.x - a.y) * 0.5f, s1 = (b.x - b.y) * 0.5f, s2 = (d.x - d.y) * 0.5f;
+    float ehp = 0.0f, ebp = 0.0f;
+    float hp = -m0 + 2 * m1 - m2, bp = -m0 + m2;
+    ehp += hp * hp; ebp += bp * bp;
+    hp = -s0 + 2 * s1 - s2; bp = -s0 + s2;
+    ehp += hp * hp; ebp += bp * bp;
+    return make_float2(sqrtf(ehp), sqrtf(ebp));
+}
+template <int NW, typename IN>
+__global__ __launch_bounds__(NW * 64) void k_wc_ef(UlcxEncCtx c, int k0, int k1) {
+    extern __shared__ float efs[];
+    float *ring = efs;
+    int *flags = (int *)(ring + EF_RT * EF_TILE_FLOATS);  // [0..NW-2] tiles finished by producer wave p, [NW-1] tiles taken by the chain
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int s0 = blockIdx.x * EF_SPW;
+    const int nT = (k1 - k0) * c.BS / 64;
+    constexpr int NP = NW - 1, NS = (EF_SPW + NP - 1) / NP;   // producer waves, streams per producer wave
+    if (threadIdx.x < NW) flags[threadIdx.x] = 0;
+    __syncthreads();
+    if (wv > 0) {
+        const int p = wv - 1;
+        if (p >= EF_SPW) {                                // (more producer waves than streams: nothing to produce, but the chain counts every wave)
+            if (lane == 0) __atomic_store_n(&flags[p], 0x7ffffff0, __ATOMIC_RELEASE);
+            return;
+        }
+        // THREE tiles of loads in flight per producer wave (a tile period is shorter than the latency of a load when the
+        // transform runs beside this kernel): register sets A0/A1/A2 rotate by unrolling the tile loop three times
+        float2 A0[NS][3], A1[NS][3], A2[NS][3];
+        auto issue = [&](float2 (&A)[NS][3], int j) {     // the three samples of this lane's time step of tile j, every stream of this wave
+            const int t = (k0 * c.BS + j * 64 + lane) - c.BS / 2;                                               // centre sample
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                const int s = s0 + p + NP * i;
+                const bool on = (p + NP * i < EF_SPW) && (s < c.B);
+                const int sc = on ? s : 0;                // (a stream that exists: the values are not used)
+                A[i][0] = smp_ld2<IN>(c, sc, t - 1); A[i][1] = smp_ld2<IN>(c, sc, t); A[i][2] = smp_ld2<IN>(c, sc, t + 1);
+            }
+        };
+        auto step = [&](float2 (&A)[NS][3], int j) {
+            float2 v[NS];
+#pragma unroll
+            for (int i = 0; i < NS; i++) v[i] = wc_energy_stereo(A[i][0], A[i][1], A[i][2]);
+            if (j + 3 < nT) issue(A, j + 3);
+            while (j >= __atomic_load_n(&flags[NP], __ATOMIC_ACQUIRE) + EF_RT) __builtin_amdgcn_s_sleep(4);     // ring full
+            float *tile = ring + (j % EF_RT) * EF_TILE_FLOATS;
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                const int sl = p + NP * i;
+                if (sl < EF_SPW) {
+                    const bool on = s0 + sl < c.B;
+                    tile[(sl * 2 + 0) * EF_TS + lane] = on ? v[i].x : 0.0f;
+                    tile[(sl * 2 + 1) * EF_TS + lane] = on ? v[i].y : 0.0f;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __atomic_store_n(&flags[p], j + 1, __ATOMIC_RELEASE);
+        };
+        issue(A0, 0);
+        if (nT > 1) issue(A1, 1);
+        if (nT > 2) issue(A2, 2);
+        for (int j = 0; j < nT; j += 3) {
+            step(A0, j);
+            if (j + 1 < nT) step(A1, j + 1);
+            if (j + 2 < nT) step(A2, j + 2);
+        }
+        return;
+    }
+    if (lane >= 2 * EF_SPW) return;                       // the chain: lane = (stream, filter)
+    __builtin_amdgcn_s_setprio(3);
+    const int s = s0 + (lane >> 1), f = lane & 1;
+    const bool live = s < c.B;
+    float env = live ? c.wcs[s].tf[f] : 0.0f;
+    const float cc = f ? c.cBP : c.cHP;
+    constexpr int QS = 512 / 4;                           // float4s between consecutive quads of a stream
+    float4 *wp = (float4 *)((float *)c.env + envq_idx(c, live ? s : 0, k0 * c.BS / 4) + f * 256);
+    for (int j = 0; j < nT; j++) {
+        for (;;) {                                        // every producer wave has finished tile j
+            int m = (lane < NP) ? __atomic_load_n(&flags[lane], __ATOMIC_ACQUIRE) : 0x7fffffff;
+            if (__all(m > j)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const float4 *row = (const float4 *)(ring + (j % EF_RT) * EF_TILE_FLOATS + lane * EF_TS);
+        float4 x[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) x[q] = row[q];
+        // (LDS operations of a wave complete in order: this store lands behind the 16 reads, so the slot is free for the producers)
+        if (lane == 0) __atomic_store_n(&flags[NP], j + 1, __ATOMIC_RELEASE);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            float4 v = x[q];
+            float d;
+            d = v.x - env; env += d * cc; v.x = env;
+            d = v.y - env; env += d * cc; v.y = env;
+            d = v.z - env; env += d * cc; v.z = env;
+            d = v.w - env; env += d * cc; v.w = env;
+            if (live) stnt(wp + (size_t)q * QS, v);
+        }
+        wp += 16 * QS;
+    }
+    if (live) c.wcs[s].tf[f] = env;                       // state for the next call
 }
 
 // WindowControl.c:90-104: backward sweep from each block's forward end state.
@@ -2079,6 +2197,16 @@ static void launch_wc_energy(const UlcxEncCtx &c, unsigned grid, hipStream_t st,
     if (c.pcm16) hipLaunchKernelGGL(k_wc_energy<int16_t>, dim3(grid), dim3(WG), 0, st, c, k0, k1);
     else hipLaunchKernelGGL(k_wc_energy<float>, dim3(grid), dim3(WG), 0, st, c, k0, k1);
 }
+static void launch_wc_ef(const UlcxEncCtx &c, hipStream_t st, int k0, int k1) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void *)k_wc_ef<EF_NW, float>, hipFuncAttributeMaxDynamicSharedMemorySize, EF_LDS_BYTES);
+        hipFuncSetAttribute((const void *)k_wc_ef<EF_NW, int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, EF_LDS_BYTES);
+        attr = true;
+    }
+    if (c.pcm16) hipLaunchKernelGGL((k_wc_ef<EF_NW, int16_t>), dim3((c.B + EF_SPW - 1) / EF_SPW), dim3(EF_NW * 64), EF_LDS_BYTES, st, c, k0, k1);
+    else hipLaunchKernelGGL((k_wc_ef<EF_NW, float>), dim3((c.B + EF_SPW - 1) / EF_SPW), dim3(EF_NW * 64), EF_LDS_BYTES, st, c, k0, k1);
+}
 static void launch_xf(const UlcxEncCtx &c, unsigned grid, size_t lds, hipStream_t st, int k0, int k1) {
     if (c.pcm16) {
         if (c.C == 2) hipLaunchKernelGGL((k_xf<true, int16_t>), dim3(grid), dim3(WG), lds, st, c, k0, k1);
@@ -2128,10 +2256,14 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             CK(hipFuncSetAttribute((const void *)k_xf<true, int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             CK(hipFuncSetAttribute((const void *)k_xf<false, int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
+        const bool wcFuse = c.C == 2 && [] { const char *v = getenv("ULCX_WC_FUSE"); return v && v[0] == '1'; }();   // k_wc_energy + k_wc_forward in one kernel
         auto launch_wc = [&](hipStream_t s2, int k0, int k1, bool marks) -> int {
             int kc = k1 - k0;
+            if (wcFuse) { if (marks) MARK(); launch_wc_ef(c, s2, k0, k1);                                             if (marks) MARK(); }
+            else {
             launch_wc_energy(c, (unsigned)(SG * ((kc * c.BS) / 64)), s2, k0, k1);   if (marks) MARK();
             hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, s2, c, k0, k1);                  if (marks) MARK();
+            }
             hipLaunchKernelGGL(k_wc_backward, dim3(SG * kc), dim3(64), 0, s2, c, k0, k1);                             if (marks) MARK();
             hipLaunchKernelGGL(k_wc_integrate, dim3((c.B + 63) / 64), dim3(64), 0, s2, c, k0, k1);                    if (marks) MARK();
             hipLaunchKernelGGL(k_wc_decide, dim3((c.B * kc + 63) / 64), dim3(64), 0, s2, c, k0, k1);                  if (marks) MARK();
@@ -2171,9 +2303,12 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                 //  chain kernels slow down by more than the time it takes between two links of the chain)
                 hipStream_t es = side4 ? side4 : side;
                 if (side4 && w >= 2) CK(hipStreamWaitEvent(side4, evF[w - 2], 0));      // run ahead of the chain by one step only
+                if (wcFuse && !side4) launch_wc_ef(c, side, k0, k1);
+                else {
                 launch_wc_energy(c, (unsigned)(SG * ((kc * c.BS) / 64)), es, k0, k1);
                 if (side4) { CK(hipEventRecord(evE[w], side4)); CK(hipStreamWaitEvent(side, evE[w], 0)); }
                 hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, side, c, k0, k1);
+                }
                 CK(hipEventRecord(evF[w], side));
                 CK(hipStreamWaitEvent(side2, evF[w], 0));
                 hipLaunchKernelGGL(k_wc_backward, dim3(SG * kc), dim3(64), 0, side2, c, k0, k1);
