@@ -209,9 +209,9 @@ __global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c, int k0, int k1)
 // not by barriers: the chain never waits as long as the producers are ahead, and they have EF_RT tiles of slack
 // for their load latency.
 #define EF_TS 68                                          // floats per (stream, filter) row of a tile: 64 steps + pad (rows stay 16-byte aligned, b128 reads conflict-free)
-#define EF_RT 6                                           // tiles in the ring
-#define EF_SPW 16                                         // streams per workgroup
-#define EF_NW 16                                          // waves per workgroup: the chain + 15 producers
+#define EF_RT 8                                           // tiles in the ring
+#define EF_SPW 8                                          // streams per workgroup
+#define EF_NW 9                                           // waves per workgroup: the chain + 15 producers
 #define EF_TILE_FLOATS (EF_SPW * 2 * EF_TS)
 #define EF_LDS_BYTES (EF_RT * EF_TILE_FLOATS * 4 + 4 * EF_NW)
 // (stereo only: the producers split the envelope computation into its three 8-byte loads, issued tiles ahead,
