@@ -345,6 +345,8 @@ def test_pcm16_ingest_and_output_match_the_wav_io_conversions(bs, ch, rate, call
     {"ULCX_WC_PIPE": "1"},                         # window control not pipelined with the transform
     {"ULCX_WC_PIPE": "3"}, {"ULCX_WC_PIPE": "8"},
     {"ULCX_WC_STEPS": "4"}, {"ULCX_WC_ESTREAM": "1"},
+    {"ULCX_WC_FUSE": "0"},                         # envelope and forward recurrence as two kernels (what non-stereo streams always use)
+    {"ULCX_WC_FUSE": "0", "ULCX_WC_PIPE": "1"},
     {"ULCX_WAVE": "0"},                            # serial lane-per-unit writer as the main path
     {"ULCX_GAPSUMS": "0"},                         # no speculative noise sums
     {"ULCX_ASYNC_FB": "0", "ULCX_WC_PIPE": "1", "ULCX_WAVE": "0", "ULCX_GAPSUMS": "0"},
