@@ -2283,12 +2283,12 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             // main: xf_j behind decide_j.  The first chunk is a single block so the transform starts early.
             hipEvent_t ev0 = evWC[0], *evF = evWC + 1, *evB = evWC + 1 + ULCX_WC_MAXCH, *evD = evWC + 1 + 2 * ULCX_WC_MAXCH, *evE = aux.evE;
             // The window-control kernels advance in uniform steps of a few blocks (ULCX_WC_STEPS; 0 = in the same chunks as
-            // the transform: first chunk one block, then quarters), and a transform chunk is launched as soon as the step
-            // holding its last block is decided.  Measured on the bench shape: 4, 8 or 16 steps 9.57-9.60 ms per step,
-            // the transform's own chunks 9.66-9.73 (every k_wc_backward launch costs a full 2048-step chain whatever
-            // its size, so very fine steps stop paying).
+            // the transform: first chunk one block, then thirds), and a transform chunk is launched as soon as the step
+            // holding its last block is decided.  Measured on the bench shape with the fused envelope/forward kernel:
+            // 4 steps 8.65-8.70 ms per step, 8 steps 8.73-8.81, 16 steps 8.9-9.0 (every launch of a chain kernel costs its
+            // fixed latency, and a step that has to be dispatched beside a transform chunk waits for its workgroup slots).
             int nW = aux.wcSteps;
-            if (nW < 0) nW = (c.K >= 8) ? ((c.K / 2 < 8) ? c.K / 2 : 8) : 0;     // default: up to 8 uniform steps of >= 2 blocks
+            if (nW < 0) nW = (c.K >= 8) ? 4 : 0;                               // default: 4 uniform steps (of >= 2 blocks)
             if (nW > ULCX_WC_MAXCH) nW = ULCX_WC_MAXCH;
             if (nW > c.K) nW = c.K;
             const bool sameCuts = nW < 1;
