@@ -2201,12 +2201,7 @@ static void launch_wc_energy(const UlcxEncCtx &c, unsigned grid, hipStream_t st,
     else hipLaunchKernelGGL(k_wc_energy<float>, dim3(grid), dim3(WG), 0, st, c, k0, k1);
 }
 static void launch_wc_ef(const UlcxEncCtx &c, hipStream_t st, int k0, int k1) {
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute((const void *)k_wc_ef<EF_NW, float>, hipFuncAttributeMaxDynamicSharedMemorySize, EF_LDS_BYTES);
-        hipFuncSetAttribute((const void *)k_wc_ef<EF_NW, int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, EF_LDS_BYTES);
-        attr = true;
-    }
+    static_assert(EF_LDS_BYTES <= 48 * 1024, "k_wc_ef: raise the dynamic LDS limit with hipFuncSetAttribute");
     if (c.pcm16) hipLaunchKernelGGL((k_wc_ef<EF_NW, int16_t>), dim3((c.B + EF_SPW - 1) / EF_SPW), dim3(EF_NW * 64), EF_LDS_BYTES, st, c, k0, k1);
     else hipLaunchKernelGGL((k_wc_ef<EF_NW, float>), dim3((c.B + EF_SPW - 1) / EF_SPW), dim3(EF_NW * 64), EF_LDS_BYTES, st, c, k0, k1);
 }
