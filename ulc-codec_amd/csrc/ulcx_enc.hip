@@ -1745,11 +1745,14 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
 // anything else (and every later run of the gap) is summed here from the pairs in HBM.
 __device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const float *coefU, const float *pairU, float amp0,
                                           unsigned long long &lo, unsigned long long &hi, int &cnt, bool dbgNoSum = false) {
-    auto put = [&](unsigned x) {
-        x &= 0xF;
-        if (cnt < 16) lo |= (unsigned long long)x << (4 * cnt);
-        else if (cnt < 32) hi |= (unsigned long long)x << (4 * (cnt - 16));
-        cnt++;
+    // a trip's nybbles (at most four) are gathered in a 16-bit word and appended once: one 64-bit shift per trip
+    // (nybbles past the 32nd are dropped but counted: the caller treats cnt > 32 as an overflow)
+    auto append = [&](unsigned code, int len) {
+        if (cnt < 16) {
+            lo |= (unsigned long long)code << (4 * cnt);
+            if (cnt + len > 16) hi |= (unsigned long long)code >> (4 * (16 - cnt));
+        } else if (cnt < 32) hi |= (unsigned long long)code << (4 * (cnt - 16));
+        cnt += len;
     };
     while (zr) {
         int n = 0, v = 0;
@@ -1758,8 +1761,8 @@ __device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const flo
             int q2 = 0;
             if (zr >= 2) q2 = quant_coef(coefU[nc + 1] * quant, 7);
             if (abs(q1) > 1 && (zr < 2 || abs(q2) > 1)) {
-                put((unsigned)q1);
-                if (zr >= 2) put((unsigned)q2);
+                if (zr >= 2) append(((unsigned)q1 & 0xF) | (((unsigned)q2 & 0xF) << 4), 2);
+                else append((unsigned)q1 & 0xF, 1);
                 break;
             }
         }
@@ -1771,9 +1774,9 @@ __device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const flo
             else nq = dbgNoSum ? 0 : get_noise_q(pairU, nc, n, quant);
         }
         amp0 = -2.0f;
-        if (nq) { put(0x8); put((unsigned)(v >> 5)); put((unsigned)(v >> 1)); put((unsigned)((v & 1) | ((nq - 1) << 1))); }
-        else if (zr < 33) { v = zr - 1; if (v > 0xF) v = 0xF; n = v + 1; put(0x0); put((unsigned)v); }
-        else { v = zr - 33; if (v > 0xFF) v = 0xFF; n = v + 33; put(0x1); put((unsigned)(v >> 4)); put((unsigned)v); }
+        if (nq) append(0x8u | (((unsigned)(v >> 5) & 0xF) << 4) | (((unsigned)(v >> 1) & 0xF) << 8) | ((((unsigned)(v & 1) | ((unsigned)(nq - 1) << 1)) & 0xF) << 12), 4);
+        else if (zr < 33) { v = zr - 1; if (v > 0xF) v = 0xF; n = v + 1; append((unsigned)v << 4, 2); }
+        else { v = zr - 33; if (v > 0xFF) v = 0xFF; n = v + 33; append(0x1u | (((unsigned)(v >> 4) & 0xF) << 4) | (((unsigned)v & 0xF) << 8), 3); }
         nc += n;
         zr -= n;
     }
