@@ -60,6 +60,15 @@ def test_argument_validation_and_loud_failure_without_gpu(lib):
     for (b, c, bs) in [(1, 0, 2048), (1, 256, 2048), (1, 2, 128), (1, 2, 65536), (1, 2, 3000), (0, 2, 2048)]:
         assert lib.ulcx_encoder_create(C.byref(h), 0, b, c, bs, 44100, 1) == -1
         assert lib.ulcx_decoder_create(C.byref(h), 0, b, c, bs, 1) == -1
+    # a call without a codec object is refused before anything touches the device (both sample formats)
+    for fn in (lib.ulcx_encode_dev, lib.ulcx_encode_dev_pcm16):
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        assert fn(None, 0, 50.0, 0.0, None, 1, None, None, None, None, None) == -1
+    for fn in (lib.ulcx_decode_dev, lib.ulcx_decode_dev_pcm16):
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        assert fn(None, None, 64, 1, None, None, None) == -1
+    lib.ulcx_encoder_last_xf_launches.argtypes = [C.c_void_p]
+    assert lib.ulcx_encoder_last_xf_launches(None) == 0
     if lib.ulcx_device_count() > 0:
         pytest.skip("GPU present: the no-device path is not reachable here")
     assert lib.ulcx_encoder_create(C.byref(h), 0, 1, 2, 2048, 44100, 1) == -2      # ULCX_ERR_NO_DEVICE, never a CPU fallback
