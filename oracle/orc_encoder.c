@@ -52,11 +52,21 @@ static int quant_coef(float v, int limit) {
     return v < 0.0f ? -q : q;
 }
 
+/* exported for the direct pin against the reference's ulcHelper.h (tests/test_oracle_pinned.py) */
+int orc_companded_quantize(float v) { int q = orc_companded_quantize_unsigned(absf(v)); return v < 0.0f ? -q : q; }   /* ulcHelper.h:73-76 */
+int orc_quant_coef_unsigned(float v, int limit) { return quant_coef_unsigned(v, limit); }
+int orc_quant_coef(float v, int limit) { return quant_coef(v, limit); }
+
 /* ulcHelper.h:96-120 */
 static float freq_to_line(float hz, float nyq, uint32_t n) { return (hz * (float)n / nyq) - 0.5f; }
 static float line_to_freq(uint32_t line, float nyq, uint32_t n) { return ((float)line + 0.5f) * nyq / (float)n; }
 static float freq_to_bark(float hz) { return 6.0f * asinhf(hz * (1.0f / 600.0f)); }
 static float bark_to_freq(float bark) { return 600.0f * sinhf(bark * (1.0f / 6.0f)); }
+
+float orc_freq_to_line(float hz, float nyq, uint32_t n) { return freq_to_line(hz, nyq, n); }
+float orc_line_to_freq(uint32_t line, float nyq, uint32_t n) { return line_to_freq(line, nyq, n); }
+float orc_freq_to_bark(float hz) { return freq_to_bark(hz); }
+float orc_bark_to_freq(float bark) { return bark_to_freq(bark); }
 
 /* ========================================================================== */
 /* Window control: /root/reference/libulc/ulcEncoder_WindowControl.c           */

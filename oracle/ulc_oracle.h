@@ -78,6 +78,13 @@ uint16_t orc_decimation_pattern(int WindowCtrl);
 float orc_fastlog(float x);
 int   orc_companded_quantize_unsigned(float v);
 int   orc_build_quantizer(float MaxVal);
+int   orc_companded_quantize(float v);
+int   orc_quant_coef_unsigned(float v, int limit);
+int   orc_quant_coef(float v, int limit);
+float orc_freq_to_line(float hz, float nyq, uint32_t n);
+float orc_line_to_freq(uint32_t line, float nyq, uint32_t n);
+float orc_freq_to_bark(float hz);
+float orc_bark_to_freq(float bark);
 
 /* ---- pinned units (same signatures as the reference's ULCi_* functions) ---- */
 int  orc_get_window_ctrl(const float *BlockData, orc_transient_t *TransientBuffer, float *TransientFilter,

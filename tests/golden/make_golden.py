@@ -34,6 +34,21 @@ def chan_major_ms(pcm, bs, k):
     return np.ascontiguousarray(np.concatenate([blk(k - 1).reshape(-1), blk(k).reshape(-1)]))
 
 
+def helper_inputs():
+    """Seeded float32 inputs for the ulcHelper.h helpers: every binade the codec can see, exact quantiser
+    decision points n^2 - n + 0.5 and their float neighbours, denormals, zeros, both signs."""
+    rng = np.random.default_rng(2718)
+    xs = [np.float32(0.0), np.float32(-0.0), np.float32(2.0 ** -126), np.float32(2.0 ** -149), np.float32(1.0), np.float32(0.5), np.float32(0.25)]
+    for e in range(-140, 40):
+        xs += list((rng.uniform(1.0, 2.0, 6) * 2.0 ** e).astype(np.float32))
+    for n in range(0, 20):
+        t = np.float32(n * n - n + 0.5) if n else np.float32(0.5)
+        xs += [t, np.nextafter(t, np.float32(0)), np.nextafter(t, np.float32(1e9))]
+    xs = np.array(xs, np.float32)
+    sign = np.where(rng.integers(0, 2, xs.size) == 1, np.float32(-1), np.float32(1)).astype(np.float32)
+    return (xs * sign).astype(np.float32)
+
+
 def main():
     REF = ref_partial()
     assert REF is not None, "needs /root/reference (or a prebuilt oracle/_ref)"
@@ -74,6 +89,41 @@ def main():
         REF.ULCi_GetHFExtParams(ptr(pairs, f32p), band, 2048 - band, q, ptr(a, i32p), ptr(b, i32p))
         h_out.append((a[0], b[0]))
     out["nf_in"] = np.array(q_in, np.float64); out["nf_q"] = np.array(q_out, np.int32); out["nf_hf"] = np.array(h_out, np.int32)
+    # --- ulcHelper.h inline helpers through oracle/ref_helper_harness.c (the reference's own header, compiled in place)
+    import ctypes as C
+    REF.ref_FastLog.restype = C.c_float; REF.ref_FastLog.argtypes = [C.c_float]
+    for f in ("ref_CompandedQuantizeUnsigned", "ref_CompandedQuantize"):
+        getattr(REF, f).argtypes = [C.c_float]
+    for f in ("ref_CompandedQuantizeCoefficientUnsigned", "ref_CompandedQuantizeCoefficient"):
+        getattr(REF, f).argtypes = [C.c_float, C.c_int]
+    REF.ref_SubBlockDecimationPattern.restype = C.c_uint
+    for f, at in (("ref_FreqToLine", [C.c_float, C.c_float, C.c_uint32]), ("ref_LineToFreq", [C.c_uint32, C.c_float, C.c_uint32]),
+                  ("ref_FreqToBark", [C.c_float]), ("ref_BarkToFreq", [C.c_float])):
+        getattr(REF, f).restype = C.c_float; getattr(REF, f).argtypes = at
+    x = helper_inputs()
+    out["hlp_x"] = x
+    out["hlp_fastlog"] = np.array([REF.ref_FastLog(float(v)) for v in x], np.float32)
+    out["hlp_qu"] = np.array([REF.ref_CompandedQuantizeUnsigned(float(abs(v))) for v in x], np.int32)
+    out["hlp_q"] = np.array([REF.ref_CompandedQuantize(float(v)) for v in x], np.int32)
+    out["hlp_qc7"] = np.array([REF.ref_CompandedQuantizeCoefficient(float(v), 7) for v in x], np.int32)
+    out["hlp_qcu8"] = np.array([REF.ref_CompandedQuantizeCoefficientUnsigned(float(abs(v)), 8) for v in x], np.int32)
+    out["hlp_qcu16"] = np.array([REF.ref_CompandedQuantizeCoefficientUnsigned(float(abs(v)), 16) for v in x], np.int32)
+    out["hlp_pattern"] = np.array([REF.ref_SubBlockDecimationPattern(w << 4) for w in range(16)], np.uint32)
+    lines = []
+    for n, rate in ((1024, 44100), (128, 48000), (2048, 48000), (16, 32000)):
+        nyq = np.float32(rate) * np.float32(0.5)
+        for line in range(n):
+            f = REF.ref_LineToFreq(line, float(nyq), n)
+            b = REF.ref_FreqToBark(f)
+            lines.append((n, rate, line, f, b))
+    out["hlp_line"] = np.array(lines, np.float64)
+    barks = []
+    for rate in (44100, 48000):
+        nyq = np.float32(rate) * np.float32(0.5)
+        for bi in np.arange(-1.0, 27.0, 0.25, dtype=np.float32):
+            f = REF.ref_BarkToFreq(float(bi))
+            barks.append((rate, float(bi), f, REF.ref_FreqToLine(f, float(nyq), 1024)))
+    out["hlp_bark"] = np.array(barks, np.float64)
     np.savez_compressed(os.path.join(HERE, "ref_units.npz"), **out)
 
     # --- oracle whole-stream regression hashes

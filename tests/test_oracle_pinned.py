@@ -112,3 +112,38 @@ def test_noise_fill_params_match_reference():
     assert nq > 20
     z = np.zeros(64, np.float32)
     assert lib.orc_get_noise_q(ptr(z, f32p), 0, 32, 1024.0) == REF.ULCi_GetNoiseQ(ptr(z, f32p), 0, 32, 1024.0) == 0
+
+
+@needs_ref
+def test_helper_header_matches_reference_directly():
+    """ulcHelper.h:24-136 through oracle/ref_helper_harness.c (the reference's own header compiled in place):
+    FastLog, the companded quantisers, the decimation pattern table and the Bark/line maps, bit for bit."""
+    from golden.make_golden import helper_inputs
+    lib = oracle()
+    if not hasattr(REF, "ref_FastLog"):
+        pytest.skip("prebuilt oracle/_ref predates the helper harness")
+    f32 = lambda v: np.float32(v).tobytes()
+    xs = helper_inputs()
+    rng = np.random.default_rng(99)
+    xs = np.concatenate([xs, (rng.uniform(-60, 60, 20000)).astype(np.float32), (2.0 ** rng.uniform(-40, 8, 20000)).astype(np.float32)])
+    for v in xs:
+        v = float(v)
+        assert f32(lib.orc_fastlog(v)) == f32(REF.ref_FastLog(v)), v
+        assert lib.orc_companded_quantize_unsigned(abs(v)) == REF.ref_CompandedQuantizeUnsigned(abs(v)), v
+        assert lib.orc_companded_quantize(v) == REF.ref_CompandedQuantize(v), v
+        for lim in (7, 8, 16):
+            assert lib.orc_quant_coef_unsigned(abs(v), lim) == REF.ref_CompandedQuantizeCoefficientUnsigned(abs(v), lim)
+            assert lib.orc_quant_coef(v, lim) == REF.ref_CompandedQuantizeCoefficient(v, lim)
+    for w in range(16):
+        assert lib.orc_decimation_pattern(w << 4) == REF.ref_SubBlockDecimationPattern(w << 4)
+        assert lib.orc_decimation_pattern((w << 4) | 0xB) == REF.ref_SubBlockDecimationPattern((w << 4) | 0xB)
+    for n, rate in ((1024, 44100), (128, 48000), (4096, 96000), (16, 8000)):
+        nyq = float(np.float32(rate) * np.float32(0.5))
+        for line in range(n):
+            fo, fr = lib.orc_line_to_freq(line, nyq, n), REF.ref_LineToFreq(line, nyq, n)
+            assert f32(fo) == f32(fr)
+            assert f32(lib.orc_freq_to_bark(fo)) == f32(REF.ref_FreqToBark(fr))
+    for b in np.arange(-1.0, 27.0, 0.125, dtype=np.float32):
+        fo, fr = lib.orc_bark_to_freq(float(b)), REF.ref_BarkToFreq(float(b))
+        assert f32(fo) == f32(fr)
+        assert f32(lib.orc_freq_to_line(fo, 22050.0, 1024)) == f32(REF.ref_FreqToLine(fr, 22050.0, 1024))

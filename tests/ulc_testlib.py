@@ -37,6 +37,12 @@ def oracle():
         lib.orc_fastlog.argtypes = [C.c_float]
         lib.orc_companded_quantize_unsigned.argtypes = [C.c_float]
         lib.orc_build_quantizer.argtypes = [C.c_float]
+        lib.orc_companded_quantize.argtypes = [C.c_float]
+        lib.orc_quant_coef_unsigned.argtypes = [C.c_float, C.c_int]
+        lib.orc_quant_coef.argtypes = [C.c_float, C.c_int]
+        for f, at in (("orc_freq_to_line", [C.c_float, C.c_float, C.c_uint32]), ("orc_line_to_freq", [C.c_uint32, C.c_float, C.c_uint32]),
+                      ("orc_freq_to_bark", [C.c_float]), ("orc_bark_to_freq", [C.c_float])):
+            getattr(lib, f).restype = C.c_float; getattr(lib, f).argtypes = at
         lib.orc_get_noise_q.argtypes = [f32p, C.c_int, C.c_int, C.c_float]
         lib.orc_get_hfext_params.argtypes = [f32p, C.c_int, C.c_int, C.c_float, i32p, i32p]
         lib.orc_get_window_ctrl.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int]
@@ -75,6 +81,16 @@ def ref_partial():
     lib.ULCi_GetWindowCtrl.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int]
     lib.ULCi_CalculatePsychoacoustics.argtypes = [f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_uint32]
     lib.ULCi_CalculateNoiseLogSpectrum.argtypes = [f32p, C.c_void_p, C.c_int, C.c_int]
+    if hasattr(lib, "ref_FastLog"):           # oracle/ref_helper_harness.c: the reference's ulcHelper.h inline helpers
+        lib.ref_FastLog.restype = C.c_float; lib.ref_FastLog.argtypes = [C.c_float]
+        for f in ("ref_CompandedQuantizeUnsigned", "ref_CompandedQuantize"):
+            getattr(lib, f).argtypes = [C.c_float]
+        for f in ("ref_CompandedQuantizeCoefficientUnsigned", "ref_CompandedQuantizeCoefficient"):
+            getattr(lib, f).argtypes = [C.c_float, C.c_int]
+        lib.ref_SubBlockDecimationPattern.restype = C.c_uint
+        for f, at in (("ref_FreqToLine", [C.c_float, C.c_float, C.c_uint32]), ("ref_LineToFreq", [C.c_uint32, C.c_float, C.c_uint32]),
+                      ("ref_FreqToBark", [C.c_float]), ("ref_BarkToFreq", [C.c_float])):
+            getattr(lib, f).restype = C.c_float; getattr(lib, f).argtypes = at
     return lib
 
 
