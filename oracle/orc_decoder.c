@@ -210,3 +210,21 @@ int orc_decode_stream(int nChan, int BlockSize, const uint8_t *in, int slotBytes
     orc_decoder_destroy(&st);
     return rc;
 }
+
+/* as orc_decode_stream, also returning every block's dequantised coefficients [nBlocks][nChan*BlockSize]
+ * (tests/test_spec_decoder.py checks them against a decoder written from FormatSpecs.md alone) */
+int orc_decode_stream_coefs(int nChan, int BlockSize, const uint8_t *in, int slotBytes, int nBlocks, float *pcm, int32_t *bitsRead, float *coefs) {
+    orc_decoder st; memset(&st, 0, sizeof(st));
+    st.nChan = nChan; st.BlockSize = BlockSize;
+    if (orc_decoder_init(&st) < 0) return -1;
+    size_t blk = (size_t)nChan * BlockSize;
+    int rc = 0;
+    for (int k = 0; k < nBlocks; k++) {
+        int b = orc_decode_block(&st, pcm + k * blk, in + (size_t)k * slotBytes);
+        if (bitsRead) bitsRead[k] = b;
+        if (!b) { rc = k + 1; break; }
+        if (coefs) memcpy(coefs + k * blk, st.CoefDbg, sizeof(float) * blk);
+    }
+    orc_decoder_destroy(&st);
+    return rc;
+}

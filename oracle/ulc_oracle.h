@@ -122,6 +122,7 @@ int orc_encode_stream_debug(int mode, int RateHz, int nChan, int BlockSize, cons
                             float *coef, float *noise, float *keys, int32_t *ranks, int32_t *nout);
 /* Decodes nBlocks from per-block slots (fresh state, fresh RNG seed). Returns 0 on success, blockIndex+1 of the first corrupt block otherwise. */
 int orc_decode_stream(int nChan, int BlockSize, const uint8_t *in, int slotBytes, int nBlocks, float *pcm, int32_t *bitsRead);
+int orc_decode_stream_coefs(int nChan, int BlockSize, const uint8_t *in, int slotBytes, int nBlocks, float *pcm, int32_t *bitsRead, float *coefs);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,7 @@ def oracle():
         lib.orc_encode_stream_debug.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_float, C.c_float,
                                                 u8p, C.c_int, i32p, i32p, f32p, f32p, f32p, f32p, i32p, i32p]
         lib.orc_decode_stream.argtypes = [C.c_int, C.c_int, u8p, C.c_int, C.c_int, f32p, i32p]
+        lib.orc_decode_stream_coefs.argtypes = [C.c_int, C.c_int, u8p, C.c_int, C.c_int, f32p, i32p, f32p]
         _oracle = lib
     return _oracle
 
@@ -157,6 +158,18 @@ def oracle_decode_stream(blocks, n_chan, block_size):
     return rc, pcm, bits
 
 
+def oracle_decode_stream_coefs(blocks, n_chan, block_size):
+    """As oracle_decode_stream, plus the dequantised coefficients of every block [nblk][n_chan*block_size]."""
+    lib = oracle()
+    nblk, slot = blocks.shape
+    pcm = np.zeros((nblk * block_size, n_chan), np.float32)
+    bits = np.zeros(nblk, np.int32)
+    coefs = np.zeros((nblk, n_chan * block_size), np.float32)
+    rc = lib.orc_decode_stream_coefs(n_chan, block_size, ptr(np.ascontiguousarray(blocks), u8p), slot, nblk,
+                                     ptr(pcm, f32p), ptr(bits, i32p), ptr(coefs, f32p))
+    return rc, pcm, bits, coefs
+
+
 def oracle_encode_debug(pcm, block_size, rate, mode=0, p0=50.0, p1=0.0, slot=None):
     """Full oracle encode of one stream with intermediates. pcm [n][C]."""
     lib = oracle()
@@ -184,16 +197,20 @@ _PATTERNS = [0x0000, 0x0008, 0x0019, 0x0091, 0x012A, 0x01A2, 0x02A1, 0x0A21,
              0x123B, 0x12B3, 0x13B2, 0x1B32, 0x23B1, 0x2B31, 0x3B21, 0xB321]      # ulcHelper.h:24-46
 
 
-def _gen_unit(rng, S, nyb):
+def _gen_unit(rng, S, nyb, spec_only=False):
+    """spec_only: only codes FormatSpecs.md allocates (no opening Fh, extended quantizers Eh,0h..Ch)."""
     N = S
+    xmax = 13 if spec_only else 15
     r = rng.random()
+    if spec_only and 0.04 <= r < 0.07:
+        r = 0.5
     if r < 0.04:
         nyb += [0xE, 0xF]                                  # unit opens with the stop code: all zeros
         return
     if r < 0.07:
         nyb += [0xF]                                       # opening Fh (no encoder writes it): the reference expands quantizer -2 = 0.0
     elif r < 0.3:
-        nyb += [0xE, int(rng.integers(0, 15))]             # extended quantizer Eh,X
+        nyb += [0xE, int(rng.integers(0, xmax))]           # extended quantizer Eh,X
     else:
         nyb += [int(rng.integers(0, 14))]
     dense = rng.random() < 0.5
@@ -222,7 +239,7 @@ def _gen_unit(rng, S, nyb):
             if rng.random() < 0.7:
                 nyb += [0xF, int(rng.integers(0, 14))]
             else:
-                nyb += [0xF, 0xE, int(rng.integers(0, 15))]
+                nyb += [0xF, 0xE, int(rng.integers(0, xmax))]
         elif r < 0.975:
             nyb += [0xF, 0xE, 0xF]                         # stop: zeros to the end
             return
@@ -231,7 +248,7 @@ def _gen_unit(rng, S, nyb):
             return
 
 
-def synth_block_stream(seed, n_blocks, n_chan, block_size, slot):
+def synth_block_stream(seed, n_blocks, n_chan, block_size, slot, spec_only=False):
     """[n_blocks][slot] uint8: random valid blocks, low nybble first (ulcDecoder.c:82-88)."""
     rng = np.random.default_rng(seed)
     out = np.zeros((n_blocks, slot), np.uint8)
@@ -244,7 +261,7 @@ def synth_block_stream(seed, n_blocks, n_chan, block_size, slot):
         nyb.append(f)
         pat = _PATTERNS[1]
         if f & 8:
-            p = int(rng.integers(0, 16))
+            p = int(rng.integers(2, 16)) if spec_only else int(rng.integers(0, 16))
             nyb.append(p)
             pat = _PATTERNS[p]
         subs = []
@@ -258,7 +275,7 @@ def synth_block_stream(seed, n_blocks, n_chan, block_size, slot):
             subs = subs[:1]                                # ulcDecoder.c:242-245
         for ch in range(n_chan):
             for S in subs:
-                _gen_unit(rng, S, nyb)
+                _gen_unit(rng, S, nyb, spec_only)
         assert len(nyb) <= 2 * (slot - 4), "block does not fit its slot"
         nbits[b] = 4 * len(nyb)
         if len(nyb) & 1:
