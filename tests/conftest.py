@@ -8,3 +8,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_runtime_first():
+    """PyTorch bundles its own HIP runtime; libulc_amd.so links /opt/rocm's.  Both live in one process in the GPU tests,
+    and torch only finds the device when its runtime initialises first - so do that before any test touches the library
+    (no-op on a box without a GPU)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield

@@ -9,7 +9,6 @@
 #include <vector>
 #include "ulcx_internal.h"
 
-size_t ulcx_dec_lds_bytes(int BS, int C);
 
 #define CKR(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)
 
@@ -35,7 +34,6 @@ struct ulcx_decoder {
     hipEvent_t ev[ULCX_DEC_STAGES + 1];
     bool evOk, evRecorded;
     uint8_t *d_in; int d_in_bytes; float *d_pcm; int32_t *d_bits;
-    hipStream_t side; hipEvent_t evFork, evSide; bool sideOk;
 };
 
 extern "C" int ulcx_device_count(void) {
@@ -331,7 +329,6 @@ static void cleanup(ulcx_decoder *e) {
     for (void *p : e->allocs) hipFree(p);
     if (e->tables) hipFree(e->tables);
     if (e->evOk) for (auto &v : e->ev) hipEventDestroy(v);
-    if (e->sideOk) { hipStreamDestroy(e->side); hipEventDestroy(e->evFork); hipEventDestroy(e->evSide); }
     delete e;
 }
 static int dec_reset_state(ulcx_decoder *e) {
@@ -345,69 +342,95 @@ static int dec_reset_state(ulcx_decoder *e) {
     return ULCX_OK;
 }
 
+// Tables of the noise RNG (ulcDecoder.c:75-81).  xorshift32 is linear over GF(2): a matrix is kept as its 32 columns.
+static uint32_t gf2_matvec(const uint32_t *col, uint32_t v) { uint32_t r = 0; for (int b = 0; b < 32; b++) if (v >> b & 1) r ^= col[b]; return r; }
+static void gf2_matmul(uint32_t *out, const uint32_t *A, const uint32_t *Bm) { uint32_t t[32]; for (int b = 0; b < 32; b++) t[b] = gf2_matvec(A, Bm[b]); memcpy(out, t, sizeof(t)); }
+static void build_rng_tables(std::vector<uint32_t> &jumpT, std::vector<uint32_t> &vtab, int BS) {
+    auto step = [](uint32_t s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; };
+    // jumpT[i][d][k][v]: byte k = v of the state, through T^(d * 16^i)
+    jumpT.assign((size_t)8 * 16 * 4 * 256, 0u);
+    uint32_t P[32];                                       // T^(16^i)
+    for (int b = 0; b < 32; b++) P[b] = step(1u << b);
+    for (int i = 0; i < 8; i++) {
+        uint32_t Md[32];                                  // P^d
+        for (int b = 0; b < 32; b++) Md[b] = 1u << b;
+        for (int d = 1; d < 16; d++) {
+            gf2_matmul(Md, P, Md);
+            uint32_t *tab = jumpT.data() + ((size_t)(i * 16 + d) << 10);
+            for (int k = 0; k < 4; k++)
+                for (int v = 0; v < 256; v++) {
+                    uint32_t r = 0;
+                    for (int t = 0; t < 8; t++) if (v >> t & 1) r ^= Md[8 * k + t];
+                    tab[k * 256 + v] = r;
+                }
+        }
+        gf2_matmul(Md, P, Md);                            // P^16 = the next position's unit
+        memcpy(P, Md, sizeof(P));
+    }
+    // vtab[d] = XOR_{t=1..d} row 31 of T^t  (bit b of row 31 of T^t = top bit of T^t e_b)
+    vtab.assign((size_t)BS + 1, 0u);
+    uint32_t colv[32];
+    for (int b = 0; b < 32; b++) colv[b] = 1u << b;
+    uint32_t acc = 0;
+    for (int d = 1; d <= BS; d++) {
+        uint32_t row = 0;
+        for (int b = 0; b < 32; b++) { colv[b] = step(colv[b]); row |= (colv[b] >> 31) << b; }
+        acc ^= row;
+        vtab[d] = acc;
+    }
+}
+
 extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams, int nChan, int BlockSize, int maxBlocksPerCall) {
     if (!out) return ULCX_ERR_ARG;
     *out = nullptr;
     if (!validate(nChan, BlockSize) || nStreams < 1 || maxBlocksPerCall < 1) { ulcx_set_error("invalid decoder geometry"); return ULCX_ERR_ARG; }
-    if (BlockSize > ULCX_MAX_BS_DEVICE) { ulcx_set_error("BlockSize %d > %d not built for the device yet", BlockSize, ULCX_MAX_BS_DEVICE); return ULCX_ERR_UNSUPPORTED; }
-    if (ulcx_dec_lds_bytes(BlockSize, nChan) > 160 * 1024) { ulcx_set_error("nChan*BlockSize too large for the LDS-resident lapping state"); return ULCX_ERR_UNSUPPORTED; }
     int rc = select_device(device);
     if (rc) return rc;
     ulcx_decoder *e = new ulcx_decoder();
     e->device = device; e->B = nStreams; e->C = nChan; e->BS = BlockSize; e->maxK = maxBlocksPerCall;
-    e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->sideOk = false;
+    e->tables = nullptr; e->evOk = false; e->evRecorded = false;
     e->d_in = nullptr; e->d_in_bytes = 0; e->d_pcm = nullptr; e->d_bits = nullptr;
     UlcxDecCtx &c = e->ctx;
     memset(&c, 0, sizeof(c));
     c.B = nStreams; c.C = nChan; c.BS = BlockSize; c.lgBS = ilog2i(BlockSize); c.maxK = maxBlocksPerCall;
     if (const char *ev = getenv("ULCX_DBG_SKIP")) c.dbgSkip = atoi(ev);
+    // stereo streams keep their lapping state and both channels' FFT arrays in LDS (one wave per channel); everything
+    // else takes the general path (one array, state in HBM).  FFT twiddles are LDS-resident when they fit beside that.
+    c.fastOK = (nChan == 2 && ulcx_dec_lds_bytes(BlockSize, nChan, 1, 0) <= (size_t)ULCX_LDS_LIMIT) ? 1 : 0;
+    if (const char *ev = getenv("ULCX_DEC_FAST")) c.fastOK = c.fastOK && (ev[0] != '0');
+    c.twInLds = (ulcx_dec_lds_bytes(BlockSize, nChan, c.fastOK, 1) <= (size_t)ULCX_LDS_LIMIT) ? 1 : 0;
     rc = ulcx_tables_build(&c.T, &e->tables, BlockSize, 44100, false);
     if (rc) { cleanup(e); return rc; }
-    size_t B = nStreams, NB = B * maxBlocksPerCall, cb = (size_t)nChan * BlockSize;
+    size_t B = nStreams, NB = B * maxBlocksPerCall;
     DA(c.lap, B * nChan * (BlockSize / 2), true);
     DA(c.lastSub, B, true);
     DA(c.seed, B, true);
     DA(c.dead, B, true);
-    DA(c.seedNext, B, true);
-    DA(c.deadNext, B, true);
     DA(c.wcScan, NB, true);
-    DA(c.coef, NB * cb, false);
-    DA(c.wc, NB, true);
     DA(c.draws, NB, true);
-    DA(c.blockSeed, NB, true);
     DA(c.packOff, B, true);
     DA(c.blkOff, NB, true);
     DA(c.unitStart, NB * nChan * 4, true);
     DA(c.unitDraws, NB * nChan * 4, true);
-    DA(c.cp, NB * nChan * 4 * 8, true);
-    DA(c.decList, NB, true);
-    DA(c.decCount, 1, true);
+    DA(c.unitTail, NB * nChan * 4, true);
+    // a block of this geometry has at most 2*C*BS + 16 bytes (4 nybbles per coefficient + header): one start bit per nybble
+    c.maskWords = (2 * (2 * nChan * BlockSize + 16) + 63) / 64 + 1;
+    DA(c.startMask, NB * (size_t)c.maskWords, false);
+    c.tailStride = BlockSize / 32;
+    DA(c.tailMag, NB * nChan * 4 * (size_t)c.tailStride, false);
+    DA(c.scratch, B * 4 * (size_t)BlockSize, false);
     {
-        // columns of T^(2^i) for the xorshift32 step T (ulcDecoder.c:75-81): J0[c] = T(e_c), J(i+1) = J(i)*J(i)
-        std::vector<uint32_t> J(32 * 32);
-        auto step = [](uint32_t s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; };
-        for (int cbit = 0; cbit < 32; cbit++) J[cbit] = step(1u << cbit);
-        for (int i = 1; i < 32; i++)
-            for (int cbit = 0; cbit < 32; cbit++) {
-                uint32_t v = J[(i - 1) * 32 + cbit], r = 0;
-                for (int b = 0; b < 32; b++) if (v >> b & 1) r ^= J[(i - 1) * 32 + b];
-                J[i * 32 + cbit] = r;
-            }
-        uint32_t *dj = nullptr;
-        DA(dj, 32 * 32, false);
-        if (hipMemcpy(dj, J.data(), sizeof(uint32_t) * J.size(), hipMemcpyHostToDevice) != hipSuccess) { ulcx_set_error("hipMemcpy(jump)"); cleanup(e); return ULCX_ERR_HIP; }
-        c.jump = dj;
+        std::vector<uint32_t> jt, vt;
+        build_rng_tables(jt, vt, BlockSize);
+        uint32_t *dj = nullptr, *dv = nullptr;
+        DA(dj, jt.size(), false);
+        DA(dv, vt.size(), false);
+        if (hipMemcpy(dj, jt.data(), sizeof(uint32_t) * jt.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dv, vt.data(), sizeof(uint32_t) * vt.size(), hipMemcpyHostToDevice) != hipSuccess) { ulcx_set_error("hipMemcpy(rng tables)"); cleanup(e); return ULCX_ERR_HIP; }
+        c.jumpT = dj; c.vtab = dv;
     }
     for (auto &v : e->ev) { if (hipEventCreate(&v) != hipSuccess) { ulcx_set_error("hipEventCreate failed"); cleanup(e); return ULCX_ERR_HIP; } }
     e->evOk = true;
-    e->sideOk = false;
-    {
-        const char *evs = getenv("ULCX_ASYNC_FB");      // (same switch as the encoder: 0 = everything on the caller's stream)
-        if (!(evs && evs[0] == '0') &&
-            hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&e->evSide, hipEventDisableTiming) == hipSuccess) e->sideOk = true;
-    }
     rc = dec_reset_state(e);
     if (rc) { cleanup(e); return rc; }
     *out = e;
@@ -421,7 +444,10 @@ static int decode_dev_any(ulcx_decoder *e, const uint8_t *d_in, int slotBytes, i
     CKR(hipSetDevice(e->device));
     UlcxDecCtx c = e->ctx;
     c.K = nBlocks; c.slot = slotBytes; c.in = d_in; c.pcm = d_pcm; c.pcm16 = d_pcm16; c.bits = d_bits;
-    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->ev, e->sideOk ? e->side : nullptr, e->evFork, e->evSide);
+    c.inBytes = (long long)e->B * nBlocks * slotBytes;
+    // one start bit per nybble of a slot (slots longer than any block of this geometry: the walk stops where the bits end)
+    if ((2 * (long long)slotBytes + 63) / 64 + 1 < c.maskWords) c.maskWords = (int)((2 * (long long)slotBytes + 63) / 64 + 1);
+    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->ev);
     e->evRecorded = (rc == ULCX_OK);
     return rc;
 }
@@ -494,7 +520,8 @@ extern "C" int ulcx_decode_packed_dev(ulcx_decoder *e, const uint8_t *d_payload,
     UlcxDecCtx c = e->ctx;
     c.K = nBlocks; c.slot = 0; c.in = d_payload; c.pcm = d_pcm; c.pcm16 = nullptr; c.bits = d_bits;
     c.packed = 1; c.payStride = payloadStride; c.payBytes = d_payloadBytes;
-    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->ev, e->sideOk ? e->side : nullptr, e->evFork, e->evSide);
+    c.inBytes = (long long)e->B * payloadStride;
+    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->ev);
     e->evRecorded = (rc == ULCX_OK);
     return rc;
 }
@@ -520,7 +547,7 @@ extern "C" int ulcx_decode_packed_host(ulcx_decoder *e, const uint8_t *h_payload
     return rc;
 }
 
-static const char *kDecStage[ULCX_DEC_STAGES] = { "k_dscan", "k_dseed", "k_dgen", "k_dimdct" };
+static const char *kDecStage[ULCX_DEC_STAGES] = { "k_dscan", "k_dsyn" };
 extern "C" const char *ulcx_decoder_stage_name(int i) { return (i >= 0 && i < ULCX_DEC_STAGES) ? kDecStage[i] : ""; }
 extern "C" int ulcx_decoder_stage_ms(ulcx_decoder *e, float *ms, int maxStages) {
     if (!e || !e->evRecorded) return 0;

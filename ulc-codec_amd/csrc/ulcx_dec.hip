@@ -1,27 +1,23 @@
 // ulcx_dec.hip — batched ulc-codec decoder for gfx950 (MI355X), hand-written HIP.
 //
-//   k_dscan / k_dseed / k_dgen
-//             nybble parser + dequantiser + noise synthesis
-//             (libulc/ulcDecoder.c:75-197; syntax FormatSpecs.md:57-141).  The syntax is a
-//             sequential state machine per (channel, subblock) unit and the noise RNG is one
-//             chain per stream; the chain is cut by counting draws per unit (scan) and
-//             jumping the xorshift state ahead (GF(2) matrix powers), so generation runs
-//             one lane per unit over the whole batch.
-//   k_dimdct  one workgroup per stream, blocks in order, lapping state resident in LDS:
-//             IMDCT (one DCT-IV = complex FFT in LDS), sine-window overlap-add, the
-//             reversed-time centring FIFO, inverse M/S, interleave
+// Two kernels per call; dequantised coefficients never exist in HBM:
+//   k_dscan   one lane per block: the serial syntax walk (libulc/ulcDecoder.c:99-197, syntax
+//             FormatSpecs.md:57-141) reduced to what cannot be done in parallel - where codes START
+//             (one bit per nybble of the block), where each (channel, subblock) unit starts, how many
+//             RNG draws it makes, and the decaying-noise magnitude chain of each unit's tail.
+//   k_dsyn    one workgroup (2 waves) per stream, blocks in order, lapping state in LDS: every nybble
+//             that starts a code is decoded by its own lane (positions, quantizers and draw indices are
+//             wave prefix scans), coefficients are written STRAIGHT INTO the FFT's LDS arrays, noise
+//             runs are synthesised 32 coefficients per lane from a jumped-ahead xorshift state, then
+//             IMDCT (one DCT-IV = complex FFT per channel, one wave per array, no barrier between the
+//             passes), sine-window overlap-add, reversed-time centring FIFO, inverse M/S, interleave
 //             (libulc/ulcDecoder.c:198-302; IMDCT per FormatSpecs.md:150-157).
 // Compiled with -ffp-contract=off (see ulcx_enc.hip).
 #include "ulcx_internal.h"
 
-#define WG 256
+#define WG 128
 #include "ulcx_fft.h"
-#define DPS 4        // FFT array padding of k_dimdct (ulcx_fft.h; 3 measured no faster)
-// Two blocks per trip with one wave per transform (four padded arrays) needs 4.25*BS floats of LDS for z instead of
-// 2.5*BS (two arrays | dec | tmpq) and makes BlockSize 8192 stereo unsupported: measured 1.11 ms vs 1.13 ms for one block per
-// trip at 5 workgroups per CU - kept off.
-#define DIMDCT_PAIRS 0
-#define DIMDCT_ZFLOATS(BS) (DIMDCT_PAIRS ? 4 * FFT_PADDEDS(BS, DPS) : (5 * (BS)) / 2)
+#define DPS 4        // FFT array padding (ulcx_fft.h): one complex after every 16
 
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float expand_quantizer(int q) {        // ulcDecoder.c:96-98
@@ -82,15 +78,13 @@ __device__ __forceinline__ Code decode_code(uint32_t w, bool first) {
 }
 // number of leading nybbles of w (low first, at most 7) that are plain coefficients, i.e. none of 0h 1h 8h Fh
 __device__ __forceinline__ int plain_prefix(uint32_t w) {
-    // a nybble is special iff its low three bits are all equal and ... : {0,1,8,F} = {0000,0001,1000,1111}
-    // zero-nybble detector on w ^ pattern for each of the four values
     auto zn = [](uint32_t x) { return (x - 0x11111111u) & ~x & 0x88888888u; };       // bit 3 of every nybble that is 0 (exact for the lowest such nybble)
     uint32_t sp = zn(w) | zn(w ^ 0x11111111u) | zn(w ^ 0x88888888u) | zn(w ^ 0xFFFFFFFFu);
     sp |= 0x80000000u;                                   // the 8th nybble is not part of the window
     return (__ffs((int)sp) - 1) >> 2;                    // index of the first special nybble
 }
 typedef uint32_t u32_any_align __attribute__((aligned(1)));
-// 32-bit window at bit position pos; bytes at or past readBytes read as 0
+// 32-bit window at bit position pos; bytes at or past readBytes read as 0 (and are not touched)
 __device__ __forceinline__ uint32_t code_window(const uint8_t *p, int pos, int readBytes) {
     int b = pos >> 3;
     uint32_t w;
@@ -107,20 +101,73 @@ __device__ __forceinline__ const uint8_t *block_ptr(const UlcxDecCtx &c, int blk
     if (!c.packed) return c.in + (size_t)blk * c.slot;
     return c.in + (size_t)(blk / c.K) * c.payStride + c.blkOff[blk];
 }
+// bytes of block blk that may be read
+__device__ __forceinline__ int block_read_bytes(const UlcxDecCtx &c, int blk) {
+    if (!c.packed) return c.slot;
+    return c.payBytes[blk / c.K] - c.blkOff[blk];
+}
 
-// Checkpoints: every unit is cut at the first code that starts at or after coefficient q*S/8
-// (q = 0..7), so pass 3 can decode eight pieces of a unit on eight lanes.  {bit position, coefficients
-// still to come, draws so far in the block, quantizer index (-1: the unit's opening code)}; N = 0 = no piece.
-#define DCP_PER_UNIT 8
+// ---------------------------------------------------------------------------
+// The scan's view of the stream: 16-byte aligned chunks kept in registers, the next one always in flight, so a
+// trip of the walk waits for memory once per 32 nybbles instead of once per code.
+// ---------------------------------------------------------------------------
+struct NybWin {
+    const uint8_t *p16;          // 16-byte aligned address at or below the block's first byte
+    int a;                       // bytes between p16 and the block's first byte
+    int readBytes;               // block bytes that may be used (later ones read as 0)
+    const uint8_t *bufBeg, *bufEnd;   // the caller's whole input: nothing outside it is touched
+    uint4 cur, nxt; int chunk;
+
+    __device__ __forceinline__ uint4 load_chunk(int ci) const {
+        const uint8_t *q = p16 + (ptrdiff_t)ci * 16;
+        const int rel = ci * 16 - a;                       // block-relative offset of the chunk's first byte
+        uint32_t d[4];
+        if (q >= bufBeg && q + 16 <= bufEnd) { uint4 v = *(const uint4 *)q; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t w = 0;
+                for (int t = 0; t < 4; t++) { const uint8_t *b = q + 4 * j + t; if (b >= bufBeg && b < bufEnd) w |= (uint32_t)*b << (8 * t); }
+                d[j] = w;
+            }
+        }
+        if (rel + 16 > readBytes) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int keep = readBytes - (rel + 4 * j);
+                uint32_t m = keep >= 4 ? 0xFFFFFFFFu : keep <= 0 ? 0u : ((1u << (8 * keep)) - 1u);
+                d[j] &= m;
+            }
+        }
+        return make_uint4(d[0], d[1], d[2], d[3]);
+    }
+    __device__ __forceinline__ void init(const uint8_t *p, int rb, const uint8_t *b0, const uint8_t *b1) {
+        a = (int)((uintptr_t)p & 15); p16 = p - a; readBytes = rb; bufBeg = b0; bufEnd = b1;
+        chunk = 0; cur = load_chunk(0); nxt = load_chunk(1);
+    }
+    // window at bit position pos of the block (positions only ever advance, by at most 7 nybbles per call)
+    __device__ __forceinline__ uint32_t at(int pos) {
+        const int q = (pos >> 2) + 2 * a;
+        if ((q >> 5) > chunk) { cur = nxt; chunk++; nxt = load_chunk(chunk + 1); }
+        const int di = (q >> 3) & 3, sh = (q & 7) * 4;
+        const uint32_t lo = di == 0 ? cur.x : di == 1 ? cur.y : di == 2 ? cur.z : cur.w;
+        const uint32_t hi = di == 0 ? cur.y : di == 1 ? cur.z : di == 2 ? cur.w : nxt.x;
+        return __builtin_amdgcn_alignbit(hi, lo, sh);
+    }
+};
 
 // Syntax walk of one block starting at p (limit = bits that may be consumed, readBytes = bytes that may be
-// touched): records unit starts / draw counts / checkpoints.  Returns bits consumed (0 = corrupt).
-// One flat loop, one code (or one checkpoint) per trip.
-__device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const uint8_t *p, int limit, int readBytes) {
+// used).  Records: bits / WindowCtrl / draws of the block; nybble index and draws-so-far at each unit's opening
+// code; one bit per nybble of the block that STARTS a code; parameters of each unit's decaying-noise tail.
+// Returns bits consumed (0 = corrupt).  One flat loop, one code (or one run of plain coefficients) per trip.
+__device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const uint8_t *p, int limit, int readBytes,
+                                          const uint8_t *bufBeg, const uint8_t *bufEnd) {
+    NybWin win; win.init(p, readBytes, bufBeg, bufEnd);
+    { const int cap = (c.maskWords * 64 - 8) * 4; limit = limit < cap ? limit : cap; }   // (beyond any block of this geometry: the start bitmap ends there)
     int pos = 0;
     int wc;
     {
-        uint32_t w0 = (limit >= 8) ? code_window(p, 0, readBytes) : 0;     // ulcDecoder.c:211-216
+        uint32_t w0 = (limit >= 8) ? win.at(0) : 0;                 // ulcDecoder.c:211-216
         wc = w0 & 0xF;
         bool dec = (wc & 0x8) != 0;
         wc |= dec ? (int)(w0 & 0xF0) : (1 << 4);
@@ -130,90 +177,111 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
     int nsub = 0; { unsigned q = pat; do nsub++; while (q >>= 4); }
     if ((c.BS >> (pat & 7)) == c.BS) nsub = 1;                      // ulcDecoder.c:242-245
     int total = c.C * nsub;
-    if (nsub > 1) c.decList[atomicAdd(c.decCount, 1)] = blk;        // its units j >= 1 get their own (small) pass-3 launch
     int *ustart = c.unitStart + (size_t)blk * c.C * 4;
     int *udraw  = c.unitDraws + (size_t)blk * c.C * 4;
-    int4 *cp = c.cp + (size_t)blk * c.C * 4 * DCP_PER_UNIT;
-    int u = 0, draws = 0, qidx = 0, nextQ = 0, uslot = 0;
-    ustart[0] = pos; udraw[0] = 0;
+    float4 *utail = c.unitTail + (size_t)blk * c.C * 4;
+    unsigned long long *mw = c.startMask + (size_t)blk * c.maskWords;
+    int cw = 0; unsigned long long macc = 0;                        // mask word being filled
+    // mark nybbles [n0, n0+cnt) as code starts (cnt <= 7; consecutive calls never skip a whole word)
+    auto mark = [&](int n0, int cnt) {
+        const int w = n0 >> 6, b = n0 & 63;
+        if (w != cw) { if (cw < c.maskWords) mw[cw] = macc; macc = 0; cw = w; }
+        const unsigned long long m = (1ull << cnt) - 1ull;
+        macc |= m << b;
+        if (b + cnt > 64) { if (cw < c.maskWords) mw[cw] = macc; macc = m >> (64 - b); cw = w + 1; }
+    };
+    int u = 0, draws = 0, uslot = 0;
+    ustart[0] = pos >> 2; udraw[0] = 0;
+    utail[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     int S = c.BS >> (pat & 7), N = S;
     bool first = true;
     bool fin = (limit < 16), bad = fin;
-    while (!fin) {
-        if (nextQ < DCP_PER_UNIT && (S - N) >= nextQ * (S >> 3)) {
-            cp[uslot * DCP_PER_UNIT + nextQ] = make_int4(pos, N, draws, first ? -1 : qidx);
-            nextQ++;
-            continue;
+    auto next_unit = [&]() {
+        u++;
+        fin = bad | (u >= total);
+        if (!fin) {
+            int ch = u / nsub, j = u - ch * nsub;
+            uslot = ch * 4 + j;
+            ustart[uslot] = pos >> 2; udraw[uslot] = draws;
+            utail[uslot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            S = c.BS >> ((pat >> (4 * j)) & 7); N = S;
+            first = true;
         }
-        const uint32_t w = code_window(p, pos, readBytes);
+    };
+    float quant = 0.0f;
+    while (!fin) {
+        const uint32_t w = win.at(pos);
         if (!first) {
             // a run of plain coefficient nybbles (+-2..+-7) is consumed in one trip: the scan needs nothing
-            // from them but their count.  Never across the next checkpoint position, the unit end or the
-            // 7 nybbles the window holds.
+            // from them but their count.  Never across the unit end or the 7 nybbles the window holds.
             int m = plain_prefix(w);
-            int room = (nextQ < DCP_PER_UNIT) ? nextQ * (S >> 3) - (S - N) : N;
-            m = m < room ? m : room;
             m = m < N ? m : N;
             if (m > 0 && pos + 4 * m <= limit) {
+                mark(pos >> 2, m);
                 pos += 4 * m; N -= m;
-                if (N > 0) continue;
-                // (unit complete: fall through the common end-of-unit code below with a zero-length code)
-                u++;
-                fin = bad | (u >= total);
-                if (!fin) {
-                    int ch = u / nsub, j = u - ch * nsub;
-                    uslot = ch * 4 + j;
-                    ustart[uslot] = pos; udraw[uslot] = draws;
-                    S = c.BS >> ((pat >> (4 * j)) & 7); N = S;
-                    first = true; nextQ = 0;
-                }
+                if (N == 0) next_unit();
                 continue;
             }
         }
         Code k = decode_code(w, first);
+        mark(pos >> 2, 1);
         const bool over = (k.zrun & (k.n > N)) | (k.n8 & (k.np > N));     // ulcDecoder.c:127,139,154
         const bool toEnd = k.stop | k.tail;
         const int used = over ? 0 : (toEnd ? N : k.n + k.np);
+        quant = (k.qnew >= 0) ? expand_quantizer(k.qnew) : quant;          // ulcDecoder.c:89-98
+        if (k.tail & !over) {
+            // ulcDecoder.c:163-186: start amplitude, decay, first coefficient, count; the chain itself runs after the walk
+            const float lev0 = (float)(k.l * k.l) * quant * (1.0f / 16);
+            const float rr = 1.0f + (float)(k.dn * k.dn) * -0x1.0p-19f;
+            utail[uslot] = make_float4(lev0, rr, __int_as_float(S - N), __int_as_float(N));
+        }
         draws += over ? 0 : (k.tail ? N : k.np);
-        qidx = (k.qnew >= 0) ? k.qnew : qidx;
         pos += 4 * k.len;
         N -= used;
         bad |= over;
         first = false;
-        if ((N == 0) | over) {
-            u++;
-            fin = bad | (u >= total);
-            if (!fin) {
-                int ch = u / nsub, j = u - ch * nsub;
-                uslot = ch * 4 + j;
-                ustart[uslot] = pos; udraw[uslot] = draws;
-                S = c.BS >> ((pat >> (4 * j)) & 7); N = S;
-                first = true; nextQ = 0;
-            }
-        }
+        if ((N == 0) | over) next_unit();
         if (pos > limit) { bad = true; fin = true; }               // ran off the readable bytes: corrupt
     }
+    if (cw < c.maskWords) mw[cw] = macc;
+    // (the last code may reach into a word in which no code starts: the synthesis reads that word too)
+    if ((((pos >> 2) - 1) >> 6) > cw && cw + 1 < c.maskWords) mw[cw + 1] = 0ull;
     bool ok = !bad;
     c.bits[blk] = ok ? pos : 0;
     c.wcScan[blk] = ok ? wc : 0;
     c.draws[blk] = draws;
+    // Decaying-noise tails (ulcDecoder.c:176-186: v = p; p *= r per coefficient): the magnitude chain is one serial
+    // float recurrence per unit.  It runs here, 64 units abreast, and leaves the magnitude at every 32nd coefficient
+    // position so that the synthesis can start anywhere.
+    if (ok) {
+        for (int t = 0; t < total; t++) {
+            int ch = t / nsub, j = t - ch * nsub, us = ch * 4 + j;
+            float4 tp = utail[us];
+            int n = __float_as_int(tp.w);
+            if (n <= 0) continue;
+            int p0 = __float_as_int(tp.z);
+            float lev = tp.x; const float rr = tp.y;
+            float *tm = c.tailMag + ((size_t)blk * c.C * 4 + us) * c.tailStride;
+            int i = p0, end = p0 + n;
+            while (i < end && (i & 31)) { lev *= rr; i++; }        // up to the first chunk boundary
+            for (; i < end; i += 32) {
+                tm[i >> 5] = lev;
+#pragma unroll
+                for (int q = 0; q < 32; q++) lev *= rr;
+            }
+        }
+    }
     return ok ? pos : 0;
 }
 
-// Pass 1 — one lane per block: walk the syntax, record where each (channel, subblock)
-// unit starts (nybble offset) and how many RNG draws precede it inside the block.
-// The walk is one long dependent chain per lane, so a full wave per SIMD would sit at ~10 cycles per
-// instruction: only DSCAN_LANES lanes of each wave are used, which puts 64/DSCAN_LANES times the waves
-// (more chains) on every SIMD.
-#define DSCAN_LANES 64
+// Pass 1 - one lane per block.
 __global__ __launch_bounds__(64) void k_dscan(UlcxDecCtx c) {
-    if (threadIdx.x >= DSCAN_LANES) return;
-    int blk = blockIdx.x * DSCAN_LANES + threadIdx.x;
+    int blk = blockIdx.x * 64 + threadIdx.x;
     if (blk >= c.B * c.K) return;
-    scan_block(c, blk, c.in + (size_t)blk * c.slot, c.slot * 8 - 32, c.slot);
+    scan_block(c, blk, c.in + (size_t)blk * c.slot, c.slot * 8, c.slot, c.in, c.in + c.inBytes);
 }
 
-// Pass 1, packed payloads — one lane per stream: a block's start is only known once the previous
+// Pass 1, packed payloads - one lane per stream: a block's start is only known once the previous
 // block has been parsed (the container stores no block lengths, tools/ulcDecodeTool.c:153-165).
 __global__ __launch_bounds__(64) void k_dscan_packed(UlcxDecCtx c) {
     int s = blockIdx.x * 64 + threadIdx.x;
@@ -226,7 +294,7 @@ __global__ __launch_bounds__(64) void k_dscan_packed(UlcxDecCtx c) {
         int blk = s * c.K + k;
         c.blkOff[blk] = off;
         int bits = 0;
-        if (!dead && off < avail) bits = scan_block(c, blk, base + off, (avail - off) * 8, avail - off);
+        if (!dead && off < avail) bits = scan_block(c, blk, base + off, (avail - off) * 8, avail - off, c.in, c.in + c.inBytes);
         else { c.bits[blk] = 0; c.wcScan[blk] = 0; c.draws[blk] = 0; }
         if (!bits) dead = true;
         off += (bits + 7) >> 3;                                     // the tool rounds every block up to a byte
@@ -234,183 +302,299 @@ __global__ __launch_bounds__(64) void k_dscan_packed(UlcxDecCtx c) {
     c.packOff[s] = off;
 }
 
-// xorshift32 is linear over GF(2): state after n draws = T^n * state.  jump[i] holds the
-// 32 columns of T^(2^i) (host-built, ulcx_api.cpp), so a jump costs popcount(n) mat-vecs.
-__device__ __forceinline__ uint32_t rng_jump(const uint32_t *__restrict__ jump, uint32_t s, uint32_t n) {
-    for (int i = 0; n; i++, n >>= 1) {
-        if (n & 1) {
-            const uint32_t *J = jump + i * 32;
-            uint32_t r = 0, t = s;
-            while (t) { int b = __ffs(t) - 1; r ^= J[b]; t &= t - 1; }
-            s = r;
+// ---------------------------------------------------------------------------
+// xorshift32 is linear over GF(2): the state after n draws is T^n * state.  jumpT holds T^(d*16^i) for every
+// hexadecimal digit d of n at every position i, each as four 256-entry byte tables (host-built, ulcx_api.cpp):
+// a jump costs one table-driven mat-vec (4 lookups) per non-zero digit.
+// vtab[d] = XOR over t = 1..d of row 31 of T^t: the parity of popcount(vtab[d] & s) says whether an odd number of
+// the first d draws from state s had their top bit set - the sign a run of noise has reached after d coefficients
+// (ulcDecoder.c:156-160: the sign flips cumulatively on every draw with the top bit set).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rng_jump(const uint32_t *__restrict__ jt, uint32_t s, uint32_t n) {
+    for (int i = 0; n; i++, n >>= 4) {
+        const uint32_t dgt = n & 15u;
+        if (dgt) {
+            const uint32_t *J = jt + ((size_t)(i * 16 + dgt) << 10);
+            s = J[s & 255u] ^ J[256 + ((s >> 8) & 255u)] ^ J[512 + ((s >> 16) & 255u)] ^ J[768 + (s >> 24)];
         }
     }
     return s;
 }
 
-// Pass 2 — the RNG chain across blocks (ulcDecoder.c:75-81 keeps one seed for the life of the stream)
-// and "a corrupt block ends the stream" (ulcDecodeTool.c:154-157).  The chain is linear, so block k's
-// seed is the stream's seed jumped by the draws of blocks 0..k-1: one lane per BLOCK, each summing its
-// predecessors' counts itself (K is small) - no stream-long serial walk.  The stream's state for the
-// next call is staged (seedNext/deadNext) and committed by a second tiny kernel, because every block
-// of the stream reads the old value here.
-__global__ __launch_bounds__(64) void k_dseed(UlcxDecCtx c) {
-    int blk = blockIdx.x * 64 + threadIdx.x;
-    if (blk >= c.B * c.K) return;
-    int s = blk / c.K, k = blk - s * c.K;
-    int dead = c.dead[s];
-    unsigned before = 0;
-    for (int i = 0; i < k; i++) {
-        if (c.wcScan[s * c.K + i] == 0) dead = 1;
-        before += dead ? 0u : (unsigned)c.draws[s * c.K + i];
-    }
-    int wcMine = c.wcScan[blk];
-    if (wcMine == 0) dead = 1;
-    c.wc[blk] = dead ? 0 : wcMine;
-    if (dead) c.bits[blk] = 0;
-    uint32_t seed0 = c.seed[s];
-    if (!dead) c.blockSeed[blk] = rng_jump(c.jump, seed0, before);
-    if (k == c.K - 1) {
-        unsigned total = before + (dead ? 0u : (unsigned)c.draws[blk]);
-        c.seedNext[s] = rng_jump(c.jump, seed0, total);
-        c.deadNext[s] = dead;
-    }
+// wave-wide inclusive prefix sum / prefix maximum of one 32-bit value per lane (row shifts + row broadcasts)
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
 }
-__global__ __launch_bounds__(64) void k_dseed_commit(UlcxDecCtx c) {
-    int s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= c.B) return;
-    c.seed[s] = c.seedNext[s];
-    c.dead[s] = c.deadNext[s];
+__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
+    v = umax32(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));
+    v = umax32(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));
+    v = umax32(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));
+    v = umax32(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));
+    v = umax32(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));
+    v = umax32(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
+    return v;
+}
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// float index inside a padded FFT array (two floats of padding after every 32): complex n sits at FFT_PADS(n, DPS)
+__device__ __forceinline__ int padf(int f) { return f + ((f >> 5) << 1); }
+
+// Noise runs found while decoding a unit, 8 bytes each:
+//   x = first coefficient | count << 16 (count - 1 for a tail, which may span the whole unit) | tail << 31
+//   y = draws made in the unit before the run | level << 16 | quantizer index << 21
+#define NOISE_CAP 128
+struct SynWave {                 // one wave's working set while it synthesises one (channel, subblock) unit
+    float *A;                    // the unit's coefficients = the FFT's input array (LDS, padded)
+    uint2 *list;                 // NOISE_CAP noise runs (LDS)
+    int   *pre;                  // 64 prefix counts (LDS)
+    int lane;
+};
+
+// Noise synthesis of the queued runs: one lane per (run, 32-coefficient chunk) piece.
+__device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &sw, int nE, uint32_t unitSeed, float tailRR, const float *tailMag) {
+    const int lane = sw.lane;
+    for (int e0 = 0; e0 < nE; e0 += 64) {
+        const int e = e0 + lane;
+        const bool have = e < nE;
+        uint2 ent = have ? sw.list[e] : make_uint2(0u, 0u);
+        const int pos = ent.x & 0xFFFF, isTail = (int)(ent.x >> 31);
+        const int np = (int)((ent.x >> 16) & 0x7FFF) + isTail;
+        const int nseg = have ? ((pos + np - 1) >> 5) - (pos >> 5) + 1 : 0;
+        const uint32_t incl = wave_scan_add((uint32_t)nseg);
+        const int total = __builtin_amdgcn_readlane((int)incl, 63);
+        sw.pre[lane] = have ? (int)(incl - nseg) : 0x7FFFFFFF;
+        WAVE_SYNC();
+        for (int sb = 0; sb < total; sb += 64) {
+            const int si = sb + lane;
+            const bool act = si < total;
+            // the run this piece belongs to: the last one whose first piece is at or before si
+            int lo = 0, hi = 63;
+#pragma unroll
+            for (int it = 0; it < 6; it++) { int mid = (lo + hi + 1) >> 1; bool le = sw.pre[mid] <= si; lo = le ? mid : lo; hi = le ? hi : mid - 1; }
+            const int j = act ? lo : 0;
+            const uint32_t ex = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)ent.x);
+            const uint32_t ey = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)ent.y);
+            const int first = __builtin_amdgcn_ds_bpermute(j << 2, (int)(incl - nseg));
+            const int rpos = ex & 0xFFFF, rtail = (int)(ex >> 31), rnp = (int)((ex >> 16) & 0x7FFF) + rtail;
+            const int d0 = ey & 0xFFFF, lvl = (ey >> 16) & 31, qi = (ey >> 21) & 63;
+            const int chunk = (rpos >> 5) + (act ? si - first : 0);          // (idle lanes shadow the first piece of run 0: every address they form is valid)
+            const int plo = rpos > (chunk << 5) ? rpos : (chunk << 5);
+            const int phi = (rpos + rnp) < ((chunk << 5) + 32) ? (rpos + rnp) : ((chunk << 5) + 32);
+            const int n = act ? phi - plo : 0;
+            const int off = plo - rpos;
+            const int d = d0 + off;
+            uint32_t seed = rng_jump(c.jumpT, unitSeed, (uint32_t)d);
+            const int par = (__popc(c.vtab[d] & unitSeed) ^ __popc(c.vtab[d0] & unitSeed)) & 1;
+            const float quant = expand_quantizer(qi);
+            float mag = (float)(lvl * lvl) * quant * (rtail ? (1.0f / 16) : (1.0f / 4));      // ulcDecoder.c:146-150, :166-170
+            if (rtail && off > 0) mag = tailMag[chunk];                                         // the tail's chain at coefficient 32*chunk (k_dscan)
+            float lev = par ? -mag : mag;
+            const float rr = rtail ? tailRR : 1.0f;
+            float *dst = sw.A + padf(plo);                                                      // a piece never crosses a padding gap
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                // ulcDecoder.c:156-160 / :181-184: draw, flip on the top bit (cumulative), store, decay (r = 1 for runs)
+                seed = xorshift32(seed);
+                lev = __uint_as_float(__float_as_uint(lev) ^ (seed & 0x80000000u));
+                if (i < n) dst[i] = lev;
+                lev *= rr;
+            }
+        }
+        WAVE_SYNC();
+    }
 }
 
-// Pass 3 — dequantise + noise synthesis, one lane per PIECE of a (block, channel, subblock) unit:
-// the scan cut every unit at eight checkpoints, so a lane's serial walk is ~1/8 of a unit and there are
-// eight times the lanes (a wave runs as long as its longest lane, and whole units differ several-fold).
-// ONE flat loop, no inner loops: a trip either decodes one whole code or emits up to four noise
-// coefficients - a noise run is a state of the lane (with inner loops every lane of the wave waited for
-// the longest run in flight: measured 460 k wave instructions per wave of 64 units).
-__device__ __forceinline__ void dgen_piece(const UlcxDecCtx &c, int blk, int ch, int j, int q) {
-    int wc = c.wc[blk];
-    if (wc == 0) return;
-    const int4 *cpU = c.cp + ((size_t)(blk * c.C + ch) * 4 + j) * DCP_PER_UNIT;
-    int4 cp = cpU[q];
-    int N = cp.y;
-    if (N == 0) return;                                    // no such piece (unit ended before this checkpoint / no such unit)
-    int Nstop = (q + 1 < DCP_PER_UNIT) ? cpU[q + 1].y : 0;
-    if (N <= Nstop) return;                                // a long run jumped over this piece
-    unsigned pat = ulcx_pattern(wc);
-    int off = 0;
-    for (int i = 0; i < j; i++) { off += c.BS >> (pat & 7); pat >>= 4; }
-    const int S = c.BS >> (pat & 7);
-    const uint8_t *src = block_ptr(c, blk);
-    const int readBytes = c.packed ? (1 << 30) : c.slot;   // (a block the scan accepted is never read past its end)
-    int bitpos = cp.x;
-    uint32_t seed = rng_jump(c.jump, c.blockSeed[blk], (uint32_t)cp.z);
-    float *dst = c.coef + (size_t)blk * c.C * c.BS + (size_t)ch * c.BS + off;       // pre-zeroed: zero runs just skip
-    bool first = cp.w < 0;
-    float quant = first ? 0.0f : expand_quantizer(cp.w);
-    int pos = S - N, pend = 0;
-    float lev = 0.0f, rr = 1.0f;
-    int guard = 2 * c.slot + S + 64;                       // codes of a slot + noise coefficients: cannot be exceeded
-    while (N > Nstop && guard-- > 0) {
-        if (pend > 0) {
-            // ulcDecoder.c:156-160 / :181-184: draw, flip on the MSB (cumulative), store, decay (rr = 1 for runs).
-            // Up to the next multiple of four positions per trip, so the body of a long run goes out as
-            // aligned 16-byte stores (this kernel is bound by the number of store requests, not by arithmetic).
-            const int room = 4 - (pos & 3);
-            const int cnt = pend < room ? pend : room;
-            float v[4];
-            if (cnt == 4) {                                // the body of a run: a full aligned group, nothing predicated
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    seed = xorshift32(seed);
-                    lev = __uint_as_float(__float_as_uint(lev) ^ (seed & 0x80000000u));      // flip on the MSB
-                    v[k] = lev;
-                    lev *= rr;
-                }
-                *(float4 *)(dst + pos) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    if (k < cnt) {
-                        seed = xorshift32(seed);
-                        lev = __uint_as_float(__float_as_uint(lev) ^ (seed & 0x80000000u));
-                        dst[pos + k] = lev;
-                        lev *= rr;
-                    }
-                }
+// Dequantise one (channel, subblock) unit into A[0 .. S) (zeroed by the caller): nybbles [nyb0, nyb1) of the block.
+// Every nybble gets a lane; the lanes whose nybble starts a code (k_dscan's bitmap) decode it; where a code's
+// coefficients go, which quantizer is in force and how many draws precede it are prefix scans over the wave.
+__device__ __forceinline__ void synth_unit(const UlcxDecCtx &c, const SynWave &sw, int S, const uint8_t *src, int readBytes,
+                                           const unsigned long long *mw, int nyb0, int nyb1, uint32_t unitSeed, const float *tailMag) {
+    const int lane = sw.lane;
+    int posBase = 0, drawBase = 0, qcur = 30;       // (the opening code always sets a quantizer; 30 expands to 0)
+    int nE = 0;
+    float tailRR = 1.0f;
+    for (int n0 = nyb0 & ~63; n0 < nyb1; n0 += 64) {
+        const int n = n0 + lane;
+        const bool in = (n >= nyb0) & (n < nyb1);
+        const unsigned long long W = mw[n0 >> 6];                                   // (wave-uniform)
+        const bool isStart = in && ((W >> lane) & 1ull);
+        const uint32_t w = in ? code_window(src, n * 4, readBytes) : 0u;
+        const Code k = decode_code(w, n == nyb0);
+        const int cnt = !isStart ? 0 : k.plain ? 1 : k.zrun ? k.n : k.n8 ? k.np : 0;
+        const int dr = (isStart && k.n8) ? k.np : 0;
+        const uint32_t packed = (uint32_t)cnt | ((uint32_t)dr << 16);
+        const uint32_t incl = wave_scan_add(packed);
+        const uint32_t excl = incl - packed;
+        const int pos = posBase + (int)(excl & 0xFFFFu);
+        const int d0 = drawBase + (int)(excl >> 16);
+        const uint32_t qv = (isStart && k.qnew >= 0) ? (((uint32_t)lane << 8) | (uint32_t)(k.qnew + 1)) : 0u;
+        const uint32_t qs = wave_scan_max(qv);
+        const int qi = (qs & 0xFFu) ? (int)(qs & 0xFFu) - 1 : qcur;
+        const float quant = expand_quantizer(qi);
+        if (isStart && k.plain && pos < S) sw.A[padf(pos)] = (float)k.sv * quant;  // ulcDecoder.c:69-73
+        const bool noisy = isStart && (k.n8 | k.tail) && pos < S;
+        const unsigned long long nm = __ballot(noisy);
+        if (nm) {
+            const int slot = nE + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0));
+            if (noisy && slot < NOISE_CAP) {
+                int np = k.tail ? S - pos : k.np;
+                np = np < S - pos ? np : S - pos;                                   // (cannot exceed it in a block the scan accepted)
+                sw.list[slot] = make_uint2((uint32_t)pos | ((uint32_t)(np - (k.tail ? 1 : 0)) << 16) | (k.tail ? 0x80000000u : 0u),
+                                           (uint32_t)d0 | ((uint32_t)k.l << 16) | ((uint32_t)qi << 21));
             }
-            pos += cnt; pend -= cnt; N -= cnt;
-        } else {
-            const uint32_t w = code_window(src, bitpos, readBytes);
-            if (!first) {
-                // a run of plain coefficients (ulcDecoder.c:69-73): up to the next multiple of four positions in
-                // one trip, an aligned 16-byte store when that is a full group
-                int m = plain_prefix(w);
-                const int room = 4 - (pos & 3);
-                m = m < room ? m : room;
-                m = m < N - Nstop ? m : N - Nstop;
-                if (m > 0) {
-                    float v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        int sv = (int)((w >> (4 * k)) & 0xF);
-                        sv = (sv ^ 0x8) - 0x8;
-                        sv = (sv < 0) ? (-sv * sv) : (+sv * sv);
-                        v[k] = (float)sv * quant;
-                    }
-                    if (m == 4) *(float4 *)(dst + pos) = make_float4(v[0], v[1], v[2], v[3]);
-                    else {
-#pragma unroll
-                        for (int k = 0; k < 3; k++) if (k < m) dst[pos + k] = v[k];
-                    }
-                    bitpos += 4 * m; pos += m; N -= m;
-                    continue;
-                }
+            const unsigned long long tm = __ballot(noisy && k.tail);
+            if (tm) {
+                const float rr = 1.0f + (float)(k.dn * k.dn) * -0x1.0p-19f;           // ulcDecoder.c:171-175
+                tailRR = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rr), __builtin_ctzll(tm)));
             }
-            Code k = decode_code(w, first);
-            if (k.plain) dst[pos] = (float)k.sv * quant;                    // ulcDecoder.c:69-73
-            int n = k.stop ? N : k.n;
-            n = (n > N) ? N : n;                                            // (cannot happen in a block the scan accepted)
-            int np = k.tail ? N : k.np;
-            np = (np > N) ? N : np;
-            // noise run / tail parameters (ulcDecoder.c:95-115, :123-137)
-            const float lvl = (float)(k.l * k.l) * quant * (k.n8 ? (1.0f / 4) : (1.0f / 16));
-            lev = (k.n8 | k.tail) ? lvl : lev;
-            rr = k.tail ? 1.0f + (float)(k.dn * k.dn) * -0x1.0p-19f : (k.n8 ? 1.0f : rr);
-            pend = np;
-            quant = (k.qnew >= 0) ? expand_quantizer(k.qnew) : quant;      // ulcDecoder.c:89-98
-            bitpos += 4 * k.len;
-            pos += n; N -= n;
-            first = false;
+            nE += __popcll(nm);
+        }
+        posBase += (int)(__builtin_amdgcn_readlane((int)incl, 63) & 0xFFFF);
+        drawBase += (int)((uint32_t)__builtin_amdgcn_readlane((int)incl, 63) >> 16);
+        qcur = __builtin_amdgcn_readlane((int)qs, 63) & 0xFF ? (__builtin_amdgcn_readlane((int)qs, 63) & 0xFF) - 1 : qcur;
+        if (nE > NOISE_CAP - 64) {                                                   // the next round could overflow the list
+            WAVE_SYNC();
+            synth_noise(c, sw, nE, unitSeed, tailRR, tailMag);
+            nE = 0;
         }
     }
+    WAVE_SYNC();
+    if (nE) synth_noise(c, sw, nE, unitSeed, tailRR, tailMag);
+    WAVE_SYNC();
 }
-// Units j = 0 of every block: lane = (piece q, channel, block), block fastest.  Units j >= 1 exist only
-// in decimated blocks: the first DGEN_DEC_WGS workgroups of the same launch walk the list the scan made
-// (first, so they start early and run beside the rest instead of after it).
-#define DGEN_DEC_WGS 1024
-__global__ __launch_bounds__(256) void k_dgen(UlcxDecCtx c) {
-    if (blockIdx.x < DGEN_DEC_WGS) {
-        int n = *c.decCount;
-        int per = 3 * c.C * DCP_PER_UNIT;
-        for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < (long long)n * per; t += (long long)DGEN_DEC_WGS * 256) {
-            int e = (int)(t / per), r = (int)(t % per);
-            int q = r % DCP_PER_UNIT, ch = (r / DCP_PER_UNIT) % c.C, j = 1 + r / (DCP_PER_UNIT * c.C);
-            dgen_piece(c, c.decList[e], ch, j, q);
-        }
-        return;
-    }
-    int tid0 = (blockIdx.x - DGEN_DEC_WGS) * 256 + threadIdx.x;
-    int NBd = c.B * c.K;
-    if (tid0 >= NBd * c.C * DCP_PER_UNIT) return;
-    int blk = tid0 % NBd, r = tid0 / NBd, ch = r % c.C, q = r / c.C;
-    dgen_piece(c, blk, ch, 0, q);
-}
+
 
 // ---------------------------------------------------------------------------
-// IMDCT + overlap-add.  LDS carve (floats): lap [C][BS/2] | z [4.25*BS] (four padded arrays of BS/2 complex;
-// the general path uses the first BS floats as one array and keeps dec [BS] | tmpq [BS/2] behind it) | twl [BS/2]
+// One channel of a DECIMATED block of a stereo stream, by one wave, entirely in LDS (ulcDecoder.c:219-273).
+// The channel's FFT array holds its subblocks back to back (subblock offsets are multiples of 32 floats, so the
+// padding of the parts is the padding of the whole).  Per subblock: synthesis, DCT-IV, then - in order, because
+// each subblock overlaps with what the previous one left in the lapping state - windowed overlap-add and the
+// reversed-time centring FIFO; the time samples of subblock j replace its own coefficients.  Every in-place move
+// is "all lanes read into registers, wave barrier, all lanes write".  Returns the size of the last subblock.
+// ---------------------------------------------------------------------------
+// DEC_MAXT = (BlockSize/2)/64 register slots per lane: a template parameter of the kernel (16: BlockSize <= 2048, 32: <= 4096)
+template <int DEC_MAXT>
+__device__ __forceinline__ int dec_channel_wave(const UlcxDecCtx &c, SynWave &sw, float2 *zc, float *L, int ch, int wc, unsigned pat0, int lastSub,
+                                                const uint8_t *src, int readBytes, const unsigned long long *mw, const int *ustart, const int *udraw,
+                                                int blkNyb, uint32_t seed, const float *tmag) {
+    const int BS = c.BS, H2 = BS / 2, lane = sw.lane;
+    int nsub = 0; { unsigned q = pat0; do nsub++; while (q >>= 4); }
+    // ---- coefficients -> spectra of every subblock (independent of each other)
+    {
+        unsigned pat = pat0; int off = 0;
+        for (int j = 0; j < nsub; j++, pat >>= 4) {
+            const int d = pat & 7, S = BS >> d, M = S >> 1, Mp = FFT_PADDEDS(M, DPS);
+            float2 *zj = zc + FFT_PADS(off >> 1, DPS);
+            for (int i = lane; i < Mp; i += 64) zj[i] = make_float2(0.0f, 0.0f);
+            sw.A = (float *)zj;
+            const int nyb1 = (j + 1 < nsub) ? ustart[ch * 4 + j + 1] : (ch + 1 < c.C) ? ustart[(ch + 1) * 4] : blkNyb;
+            const uint32_t unitSeed = rng_jump(c.jumpT, seed, (uint32_t)udraw[ch * 4 + j]);
+            synth_unit(c, sw, S, src, readBytes, mw, ustart[ch * 4 + j], nyb1, unitSeed, tmag + (size_t)(ch * 4 + j) * c.tailStride);
+            const float2 *pre = c.T.pre[d];
+            for (int n = lane; n < M / 2; n += 64) {
+                const int n2 = M - 1 - n;
+                const int pn = FFT_PADS(n, DPS), pn2 = FFT_PADS(n2, DPS);
+                const float2 a = zj[pn], b = zj[pn2];
+                zj[pn]  = cmulc(make_float2(a.x, b.y), pre[n]);
+                zj[pn2] = cmulc(make_float2(b.x, a.y), pre[n2]);
+            }
+            fft_wave_dif(zj, M, c.T.tw[d], lane, DPS);
+            off += S;
+        }
+    }
+    WAVE_SYNC();
+    // ---- time domain, subblock by subblock
+    int last = lastSub;
+    unsigned pat = pat0; int off = 0;
+    for (int j = 0; j < nsub; j++, pat >>= 4) {
+        const int d = pat & 7, S = BS >> d, M = S >> 1;
+        int ov = S;                                              // ulcDecoder.c:234-239
+        if (pat & 8) ov >>= (wc & 7);
+        if (ov > last) ov = last;
+        last = S;
+        float2 *zj = zc + FFT_PADS(off >> 1, DPS);
+        float *tj = (float *)zj;                                 // the subblock's time samples, natural order, padded
+        const float2 *pre = c.T.pre[d];
+        const int a = (S - ov) >> 1;
+        const float *fall = c.T.winFall + ov, *rise = c.T.winRise + ov;
+        const int bits = 31 - __clz(M);
+        // post-twiddle fused with the windowed overlap (oracle/orc_fourier.c orc_imdct): pair p: A = lap[M-1-p], B = zz[M+p]
+        {
+            float o[DEC_MAXT / 4][4], nl[DEC_MAXT / 4][2];
+#pragma unroll
+            for (int t = 0; t < DEC_MAXT / 4; t++) {
+                const int kk = lane + 64 * t;
+                if (kk < M / 2) {
+                    const int k1 = kk, k2 = M - 1 - kk;
+                    const int r1 = FFT_PADS((int)(__brev((unsigned)k1) >> (32 - bits)), DPS);
+                    const int r2 = FFT_PADS((int)(__brev((unsigned)k2) >> (32 - bits)), DPS);
+                    const float2 y1 = cmulc(zj[r1], pre[k1]), y2 = cmulc(zj[r2], pre[k2]);
+                    const float Av[2] = { L[2 * k1], L[2 * k1 + 1] };
+                    const float Bv[2] = { -y1.y, y2.x };
+                    const int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int p = pv[q];
+                        const float A = Av[q], B = Bv[q];
+                        if (p < a) { o[t][2 * q] = A; o[t][2 * q + 1] = B; }
+                        else {
+                            const float cw = fall[p - a], sn = rise[p - a];
+                            const float m0 = cw * A, m1 = sn * B, m2 = sn * A, m3 = cw * B;
+                            o[t][2 * q] = m0 - m1;
+                            o[t][2 * q + 1] = m2 + m3;
+                        }
+                    }
+                    nl[t][0] = y1.x; nl[t][1] = -y2.y;
+                }
+            }
+            WAVE_SYNC();
+#pragma unroll
+            for (int t = 0; t < DEC_MAXT / 4; t++) {
+                const int kk = lane + 64 * t;
+                if (kk < M / 2) {
+                    const int k1 = kk;
+                    const int p0 = M - 1 - 2 * k1, p1 = M - 2 - 2 * k1;
+                    tj[padf(p0)] = o[t][0]; tj[padf(S - 1 - p0)] = o[t][1];
+                    tj[padf(p1)] = o[t][2]; tj[padf(S - 1 - p1)] = o[t][3];
+                    L[2 * k1] = nl[t][0]; L[2 * k1 + 1] = nl[t][1];
+                }
+            }
+            WAVE_SYNC();
+        }
+        // reversed-time centring FIFO in lap[M .. BS/2) (ulcDecoder.c:253-272): queue[q] = lap[BS/2-1-q], q = 0 the oldest
+        {
+            const int avail = (BS - S) >> 1;
+            float dv[DEC_MAXT], qv[DEC_MAXT];
+#pragma unroll
+            for (int t = 0; t < DEC_MAXT; t++) {
+                const int n = lane + 64 * t;
+                if (n < S) dv[t] = (n < avail) ? L[H2 - 1 - n] : tj[padf(n - avail)];
+                if (n < avail) {
+                    if (S <= avail) qv[t] = (n < avail - S) ? L[H2 - 1 - (n + S)] : tj[padf(n - (avail - S))];
+                    else qv[t] = tj[padf(S - avail + n)];
+                }
+            }
+            WAVE_SYNC();
+#pragma unroll
+            for (int t = 0; t < DEC_MAXT; t++) {
+                const int n = lane + 64 * t;
+                if (n < S) tj[padf(n)] = dv[t];
+                if (n < avail) L[H2 - 1 - n] = qv[t];
+            }
+            WAVE_SYNC();
+        }
+        off += S;
+    }
+    return last;
+}
+
 // ---------------------------------------------------------------------------
 // Output samples.  OUT = float: the C API's layout; OUT = int16_t: PCM16 output, converted on store
 // exactly as the reference's WAV writer does (tools/WavIO_Helper.c:9-13,56-63: lrintf(clamp(x * 2^15, -32768, 32767))).
@@ -419,13 +603,12 @@ __device__ __forceinline__ int16_t to_pcm16(float x) {
     v = (v < -32768.0f) ? -32768.0f : (v > 32767.0f) ? 32767.0f : v;
     return (int16_t)__float2int_rn(v);
 }
-// (the decoded samples are written once and not read again by the decoder, the coefficients are read once: non-temporal)
+// (the decoded samples are written once and not read again by the decoder: non-temporal)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void st1(float *p, float a) { __builtin_nontemporal_store(a, p); }
 __device__ __forceinline__ void st2(float *p, float a, float b) { f32x2 w = { a, b }; __builtin_nontemporal_store(w, (f32x2 *)p); }
 __device__ __forceinline__ void st4(float *p, float a, float b, float d, float e) { f32x4 w = { a, b, d, e }; __builtin_nontemporal_store(w, (f32x4 *)p); }
-__device__ __forceinline__ float2 ld2nt(const float *p) { f32x2 v = __builtin_nontemporal_load((const f32x2 *)p); return make_float2(v.x, v.y); }
 __device__ __forceinline__ void st1(int16_t *p, float a) { *p = to_pcm16(a); }
 __device__ __forceinline__ void st2(int16_t *p, float a, float b) { *(short2 *)p = make_short2(to_pcm16(a), to_pcm16(b)); }
 __device__ __forceinline__ void st4(int16_t *p, float a, float b, float d, float e) { *(short4 *)p = make_short4(to_pcm16(a), to_pcm16(b), to_pcm16(d), to_pcm16(e)); }
@@ -433,256 +616,289 @@ template <typename OUT> __device__ __forceinline__ OUT *out_base(const UlcxDecCt
 template <> __device__ __forceinline__ float *out_base<float>(const UlcxDecCtx &c) { return c.pcm; }
 template <> __device__ __forceinline__ int16_t *out_base<int16_t>(const UlcxDecCtx &c) { return c.pcm16; }
 
-template <typename OUT>
-__global__ __launch_bounds__(WG) void k_dimdct(UlcxDecCtx c) {
-    extern __shared__ float lds[];
-    const int BS = c.BS, C = c.C, H2 = BS / 2;
-    int s = blockIdx.x, tid = threadIdx.x;
-    float  *lap   = lds;
-    float2 *z     = (float2 *)(lap + (size_t)C * H2);
-    float  *dec   = (float *)z + BS;
-    float  *tmpq  = dec + BS;
-    float2 *twl   = (float2 *)((float *)z + DIMDCT_ZFLOATS(BS));   // BS/4 complex: FFT twiddles of the full-size transform
-    float *glap = c.lap + (size_t)s * C * H2;
-    for (int i = tid; i < C * H2; i += WG) lap[i] = glap[i];
-    for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
-    int lastSub = c.lastSub[s];
-    __syncthreads();
-
-    // stereo, un-decimated block (the common case): both channels at once, inverse M/S in registers,
-    // interleaved stores.  Post-twiddle fused with the windowed overlap (oracle/orc_fourier.c orc_imdct).
-    auto fast_block = [&](int wcv) { return C == 2 && wcv != 0 && (BS >> (ulcx_pattern(wcv) & 7)) == BS; };
-    auto fast_overlap = [&](int wcv, int last) {
-        int ov = BS;                                                // ulcDecoder.c:234-239
-        if (ulcx_pattern(wcv) & 8) ov >>= (wcv & 7);
-        return ov > last ? last : ov;
-    };
-    auto fast_pre = [&](const float *coefB, float2 *za, float2 *zb, bool padded) {
-        const int S = BS, M = BS >> 1;
-        const float2 *pre = c.T.pre[0];
-        const float *X0 = coefB, *X1 = coefB + BS;
-        // n and M-1-n together: their four inputs are the two aligned pairs (X[2n], X[2n+1]) and (X[S-2-2n], X[S-1-2n])
-        for (int n = tid; n < M / 2; n += WG) {
-            const int n2 = M - 1 - n;
-            float2 P = pre[n], P2 = pre[n2];
-            int pn = padded ? FFT_PADS(n, DPS) : n, pn2 = padded ? FFT_PADS(n2, DPS) : n2;
-            float2 a0 = ld2nt(X0 + 2 * n), b0 = ld2nt(X0 + S - 2 - 2 * n);
-            float2 a1 = ld2nt(X1 + 2 * n), b1 = ld2nt(X1 + S - 2 - 2 * n);
-            za[pn]  = cmulc(make_float2(a0.x, b0.y), P);
-            za[pn2] = cmulc(make_float2(b0.x, a0.y), P2);
-            zb[pn]  = cmulc(make_float2(a1.x, b1.y), P);
-            zb[pn2] = cmulc(make_float2(b1.x, a1.y), P2);
-        }
-    };
-    auto fast_post = [&](const float2 *z0, const float2 *z1, OUT *outp, int ov, bool padded) {
-        const int S = BS, M = BS >> 1;
-        const float2 *pre = c.T.pre[0];
-        int a = (S - ov) >> 1;
-        const float *fall = c.T.winFall + ov, *rise = c.T.winRise + ov;
-        int bits = 31 - __clz(M);
-        float *L0 = lap, *L1 = lap + H2;
-        for (int kk = tid; kk < M / 2; kk += WG) {
-            int k1 = kk, k2 = M - 1 - kk;
-            int r1 = (int)(__brev((unsigned)k1) >> (32 - bits));
-            int r2 = (int)(__brev((unsigned)k2) >> (32 - bits));
-            if (padded) { r1 = FFT_PADS(r1, DPS); r2 = FFT_PADS(r2, DPS); }
-            float2 P1 = pre[k1], P2 = pre[k2];
-            float2 ya1 = cmulc(z0[r1], P1), ya2 = cmulc(z0[r2], P2);     // channel 0 (M)
-            float2 yb1 = cmulc(z1[r1], P1), yb2 = cmulc(z1[r2], P2);     // channel 1 (S)
-            float A0m = L0[2 * k1], A1m = L0[2 * k1 + 1], A0s = L1[2 * k1], A1s = L1[2 * k1 + 1];
-            float Bm[2] = { -ya1.y, ya2.x }, Bs[2] = { -yb1.y, yb2.x };
-            float Am[2] = { A0m, A1m }, As[2] = { A0s, A1s };
-            int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
-            float2 lo2[2], hi2[2];                                         // interleaved L/R at positions p and S-1-p
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                int p = pv[q];
-                float mLo, mHi, sLo, sHi;                                  // outputs at positions p and S-1-p
-                if (p < a) { mLo = Am[q]; mHi = Bm[q]; sLo = As[q]; sHi = Bs[q]; }
-                else {
-                    float cw = fall[p - a], sw = rise[p - a];
-                    float m0 = cw * Am[q], m1 = sw * Bm[q], m2 = sw * Am[q], m3 = cw * Bm[q];
-                    mLo = m0 - m1; mHi = m2 + m3;
-                    float s0 = cw * As[q], s1 = sw * Bs[q], s2 = sw * As[q], s3 = cw * Bs[q];
-                    sLo = s0 - s1; sHi = s2 + s3;
-                }
-                // inverse M/S (ulcDecoder.c:281-289) + interleave (:292-297)
-                lo2[q] = make_float2(mLo + sLo, mLo - sLo);
-                hi2[q] = make_float2(mHi + sHi, mHi - sHi);
-            }
-            // positions pv[1] = pv[0]-1 and S-1-pv[0], S-pv[0] are neighbours: two aligned 16-byte stores
-            st4(outp + 2 * pv[1], lo2[1].x, lo2[1].y, lo2[0].x, lo2[0].y);
-            st4(outp + 2 * (S - 1 - pv[0]), hi2[0].x, hi2[0].y, hi2[1].x, hi2[1].y);
-            L0[2 * k1] = ya1.x; L0[2 * k1 + 1] = -ya2.y;
-            L1[2 * k1] = yb1.x; L1[2 * k1 + 1] = -yb2.y;
-        }
-    };
-
-    for (int k = 0; k < c.K; k++) {
-        int blk = s * c.K + k;
-        int wc = c.wc[blk];
-        OUT *outp = out_base<OUT>(c) + (size_t)blk * C * BS;
-        if (wc == 0) {                                              // corrupt block / dead stream
-            for (int i = tid; i < C * BS; i += WG) st1(outp + i, 0.0f);
-            continue;
-        }
-        const float *coefB = c.coef + (size_t)blk * C * BS;
-        int newLast = lastSub;
-        if (fast_block(wc)) {
-            const int M = BS >> 1, Mp = FFT_PADDEDS(M, DPS);
-            int wc2 = (k + 1 < c.K) ? c.wc[blk + 1] : 0;
-            if (DIMDCT_PAIRS && fast_block(wc2)) {
-                // ---- two consecutive blocks: four transforms, ONE WAVE PER ARRAY (16 points per lane through
-                //      four radix-2 stages in registers, no barrier between passes), then the two overlap-adds in order
-                if (!(c.dbgSkip & 1)) { fast_pre(coefB, z, z + Mp, true);
-                fast_pre(coefB + (size_t)C * BS, z + 2 * Mp, z + 3 * Mp, true); }
-                __syncthreads();
-                if (!(c.dbgSkip & 2)) fft_wave_dif(z + __builtin_amdgcn_readfirstlane(tid >> 6) * Mp, M, twl, tid & 63, DPS);
-                __syncthreads();
-                if (!(c.dbgSkip & 4)) fast_post(z, z + Mp, outp, fast_overlap(wc, lastSub), true);
-                __syncthreads();
-                if (!(c.dbgSkip & 4)) fast_post(z + 2 * Mp, z + 3 * Mp, outp + (size_t)C * BS, fast_overlap(wc2, BS), true);
-                __syncthreads();
-                lastSub = BS;
-                k++;
-                continue;
-            }
-            fast_pre(coefB, z, z + M, false);
-            __syncthreads();
-            fftn_dif(z, 2, M, twl, tid);
-            fast_post(z, z + M, outp, fast_overlap(wc, lastSub), false);
-            __syncthreads();
-            lastSub = BS;
-            continue;
-        }
-        for (int ch = 0; ch < C; ch++) {
-            int last = lastSub;                                     // ulcDecoder.c:219
-            // the channel's time samples are staged over its own (already consumed) coefficients in global memory:
-            // keeps 2*BS floats out of LDS (occupancy of the common path) - only mono/odd/decimated blocks come here
-            float *dst = c.coef + (size_t)blk * C * BS + (size_t)ch * BS;
-            float *L = lap + (size_t)ch * H2;
-            unsigned pat = ulcx_pattern(wc);
-            int off = 0, dpos = 0;
-            do {
-                int d = pat & 7, S = BS >> d, M = S >> 1;
-                int ov = S;                                         // ulcDecoder.c:234-239
-                if (pat & 8) ov >>= (wc & 7);
-                if (ov > last) ov = last;
-                last = S;
-                const float *X = coefB + (size_t)ch * BS + off;
-                const float2 *pre = c.T.pre[d];
-                // DCT-IV pre-twiddle
-                for (int n = tid; n < M; n += WG) z[n] = cmulc(make_float2(X[2 * n], X[S - 1 - 2 * n]), pre[n]);
-                __syncthreads();
-                fft1_dif(z, M, c.T.tw[d], tid);
-                // post-twiddle fused with the windowed overlap (oracle/orc_fourier.c orc_imdct):
-                //   zz[2k] = Re y[k], zz[S-1-2k] = -Im y[k];  pair p: A = lap[M-1-p], B = zz[M+p]
-                float *out = (S == BS) ? dst : dec;
-                int a = (S - ov) >> 1;
-                const float *fall = c.T.winFall + ov, *rise = c.T.winRise + ov;
-                int bits = 31 - __clz(M);
-                for (int kk = tid; kk < M / 2; kk += WG) {
-                    int k1 = kk, k2 = M - 1 - kk;
-                    int r1 = (int)(__brev((unsigned)k1) >> (32 - bits));
-                    int r2 = (int)(__brev((unsigned)k2) >> (32 - bits));
-                    float2 y1 = cmulc(z[r1], pre[k1]), y2 = cmulc(z[r2], pre[k2]);
-                    // zz[2k1] = y1.x, zz[2k1+1] = -y2.y (new lap);  zz[S-1-2k1] = -y1.y, zz[S-2-2k1] = y2.x (B values)
-                    float A0 = L[2 * k1], A1 = L[2 * k1 + 1];
-                    float Bv[2] = { -y1.y, y2.x };
-                    float Av[2] = { A0, A1 };
-                    int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        int p = pv[q];
-                        float A = Av[q], B = Bv[q];
-                        if (p < a) { out[p] = A; out[S - 1 - p] = B; }
-                        else {
-                            float cw = fall[p - a], sw = rise[p - a];
-                            float m0 = cw * A, m1 = sw * B, m2 = sw * A, m3 = cw * B;
-                            out[p] = m0 - m1;
-                            out[S - 1 - p] = m2 + m3;
-                        }
-                    }
-                    L[2 * k1] = y1.x;
-                    L[2 * k1 + 1] = -y2.y;
-                }
-                __syncthreads();
-                if (S == BS) break;                                 // ulcDecoder.c:242-245
-                // reversed-time centring FIFO in lap[M .. BS/2) (ulcDecoder.c:253-272)
-                int avail = (BS - S) >> 1;
-                for (int q = tid; q < avail; q += WG) tmpq[q] = L[H2 - 1 - q];      // queue[q], q = 0 is the oldest
-                __syncthreads();
-                for (int n = tid; n < S; n += WG)
-                    dst[dpos + n] = (n < avail) ? tmpq[n] : dec[n - avail];
-                if (S <= avail) {
-                    for (int q = tid; q < avail; q += WG)
-                        L[H2 - 1 - q] = (q < avail - S) ? tmpq[q + S] : dec[q - (avail - S)];
-                } else {
-                    for (int q = tid; q < avail; q += WG) L[H2 - 1 - q] = dec[S - avail + q];
-                }
-                __syncthreads();
-                dpos += S; off += S;
-            } while (pat >>= 4);
-            newLast = last;
-            // inverse M/S + interleave once both members of a pair (or a trailing single) are staged
-            bool pairDone = (ch & 1) || (ch == C - 1);
-            if (pairDone) {
-                __syncthreads();
-                if (ch & 1) {
-                    for (int n = tid; n < BS; n += WG) {
-                        float m = dst[(ptrdiff_t)n - BS], sd = dst[n];                 // ulcDecoder.c:281-289
-                        float l = m + sd, r = m - sd;
-                        if (C == 2) st2(outp + 2 * n, l, r);
-                        else { st1(outp + (size_t)n * C + ch - 1, l); st1(outp + (size_t)n * C + ch, r); }
-                    }
-                } else {
-                    for (int n = tid; n < BS; n += WG) st1(outp + (size_t)n * C + ch, dst[n]);
-                }
-                __syncthreads();
-            }
-        }
-        lastSub = newLast;
-    }
-    for (int i = tid; i < C * H2; i += WG) glap[i] = lap[i];
-    if (tid == 0) c.lastSub[s] = lastSub;
+// LDS carve of k_dsyn, in floats:  z [2 (stereo fast path) or 1 padded array(s) of BS/2 complex] |
+//   lap [2][BS/2] (fast path only) | twl [BS/4 complex] (when it fits) | per wave: noise list + prefix counts
+struct DsynLds { int zFloats, lapFloats, twFloats, listFloats; };
+__host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int twInLds) {
+    DsynLds l;
+    l.zFloats = (fast ? 2 : 1) * 2 * FFT_PADDEDS(BS / 2, DPS);
+    l.lapFloats = fast ? 2 * (BS / 2) : 0;
+    l.twFloats = twInLds ? BS / 2 : 0;
+    l.listFloats = 2 * (2 * NOISE_CAP + 64);
+    (void)C;
+    return l;
 }
 
-size_t ulcx_dec_lds_bytes(int BS, int C) {
-    return sizeof(float) * ((size_t)C * (BS / 2) + (size_t)DIMDCT_ZFLOATS(BS) + BS / 2);
+template <typename OUT, int DEC_MAXT>
+__global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
+    extern __shared__ float lds[];
+    const int BS = c.BS, C = c.C, H2 = BS / 2;
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const DsynLds L = dsyn_lds(BS, C, c.fastOK, c.twInLds);
+    float2 *z    = (float2 *)lds;
+    float  *lap  = lds + L.zFloats;                                  // (fast path only)
+    float2 *twl  = (float2 *)(lds + L.zFloats + L.lapFloats);        // FFT twiddles of the full-size transform
+    SynWave sw;
+    sw.list = (uint2 *)(lds + L.zFloats + L.lapFloats + L.twFloats) + wv * (NOISE_CAP + 32);
+    sw.pre  = (int *)(sw.list + NOISE_CAP);
+    sw.lane = lane;
+    float *glap = c.lap + (size_t)s * C * H2;
+    const bool fastStream = c.fastOK != 0;
+    if (fastStream) for (int i = tid; i < 2 * H2; i += WG) lap[i] = glap[i];
+    if (c.twInLds) for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
+    int lastSub = c.lastSub[s];
+    int dead = c.dead[s];
+    uint32_t seed = c.seed[s];
+    float *scr = c.scratch + (size_t)s * 4 * BS;                     // slow path staging: dst[2][BS] | dec[BS] | tmpq[BS/2]
+    __syncthreads();
+
+    const int M0 = BS >> 1, Mp0 = FFT_PADDEDS(M0, DPS);
+    for (int k = 0; k < c.K; k++) {
+        const int blk = s * c.K + k;
+        int wc = c.wcScan[blk];
+        if (wc == 0) dead = 1;                                       // a corrupt block ends the stream (ulcDecodeTool.c:154-157)
+        OUT *outp = out_base<OUT>(c) + (size_t)blk * C * BS;
+        if (dead) {
+            for (int i = tid; i < C * BS; i += WG) st1(outp + i, 0.0f);
+            if (tid == 0) c.bits[blk] = 0;
+            continue;
+        }
+        const uint8_t *src = block_ptr(c, blk);
+        const int readBytes = block_read_bytes(c, blk);
+        const int blkNyb = c.bits[blk] >> 2;
+        const int *ustart = c.unitStart + (size_t)blk * C * 4;
+        const int *udraw = c.unitDraws + (size_t)blk * C * 4;
+        const unsigned long long *mw = c.startMask + (size_t)blk * c.maskWords;
+        const float *tmag = c.tailMag + (size_t)blk * C * 4 * c.tailStride;
+        const unsigned pat0 = ulcx_pattern(wc);
+        const bool whole = (BS >> (pat0 & 7)) == BS;                 // one subblock per channel (ulcDecoder.c:242-245)
+        int nsub = 1;
+        if (!whole) { nsub = 0; unsigned q = pat0; do nsub++; while (q >>= 4); }
+        // nybble at which unit (ch, j) ends = where the next unit starts, or the end of the block's codes
+        auto unit_end = [&](int ch, int j) {
+            if (j + 1 < nsub) return ustart[ch * 4 + j + 1];
+            if (ch + 1 < C) return ustart[(ch + 1) * 4];
+            return blkNyb;
+        };
+
+        if (fastStream && whole) {
+            // ---- stereo, un-decimated block (the common case): one wave per channel up to the end of the FFT,
+            //      then both channels together: windowed overlap-add, inverse M/S in registers, interleaved stores
+            float2 *zw = z + wv * Mp0;
+            sw.A = (float *)zw;
+            for (int i = lane; i < Mp0; i += 64) zw[i] = make_float2(0.0f, 0.0f);
+            const uint32_t unitSeed = rng_jump(c.jumpT, seed, (uint32_t)udraw[wv * 4]);
+            if (!(c.dbgSkip & 1)) synth_unit(c, sw, BS, src, readBytes, mw, ustart[wv * 4], unit_end(wv, 0), unitSeed, tmag + (size_t)wv * 4 * c.tailStride);
+            // DCT-IV pre-twiddle in place: n and M-1-n together read and write the same two complex slots
+            const float2 *pre = c.T.pre[0];
+            if (!(c.dbgSkip & 2)) {
+            for (int n = lane; n < M0 / 2; n += 64) {
+                const int n2 = M0 - 1 - n;
+                const int pn = FFT_PADS(n, DPS), pn2 = FFT_PADS(n2, DPS);
+                const float2 a = zw[pn], b = zw[pn2];                // (X[2n], X[2n+1]), (X[S-2-2n], X[S-1-2n])
+                zw[pn]  = cmulc(make_float2(a.x, b.y), pre[n]);
+                zw[pn2] = cmulc(make_float2(b.x, a.y), pre[n2]);
+            }
+            if (c.twInLds) fft_wave_dif(zw, M0, twl, lane, DPS);      // (two call sites: the LDS pointer keeps its address space)
+            else fft_wave_dif(zw, M0, c.T.tw[0], lane, DPS);
+            }
+            __syncthreads();
+            int ov = BS;                                             // ulcDecoder.c:234-239
+            if (pat0 & 8) ov >>= (wc & 7);
+            if (ov > lastSub) ov = lastSub;
+            if (!(c.dbgSkip & 4)) {
+                const int S = BS, M = M0;
+                const float2 *z0 = z, *z1 = z + Mp0;
+                const int a = (S - ov) >> 1;
+                const float *fall = c.T.winFall + ov, *rise = c.T.winRise + ov;
+                const int bits = 31 - __clz(M);
+                float *L0 = lap, *L1 = lap + H2;
+                for (int kk = tid; kk < M / 2; kk += WG) {
+                    const int k1 = kk, k2 = M - 1 - kk;
+                    int r1 = (int)(__brev((unsigned)k1) >> (32 - bits));
+                    int r2 = (int)(__brev((unsigned)k2) >> (32 - bits));
+                    r1 = FFT_PADS(r1, DPS); r2 = FFT_PADS(r2, DPS);
+                    const float2 P1 = pre[k1], P2 = pre[k2];
+                    const float2 ya1 = cmulc(z0[r1], P1), ya2 = cmulc(z0[r2], P2);     // channel 0 (M)
+                    const float2 yb1 = cmulc(z1[r1], P1), yb2 = cmulc(z1[r2], P2);     // channel 1 (S)
+                    const float A0m = L0[2 * k1], A1m = L0[2 * k1 + 1], A0s = L1[2 * k1], A1s = L1[2 * k1 + 1];
+                    const float Bm[2] = { -ya1.y, ya2.x }, Bs[2] = { -yb1.y, yb2.x };
+                    const float Am[2] = { A0m, A1m }, As[2] = { A0s, A1s };
+                    const int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
+                    float2 lo2[2], hi2[2];                                             // interleaved L/R at positions p and S-1-p
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int p = pv[q];
+                        float mLo, mHi, sLo, sHi;                                      // outputs at positions p and S-1-p
+                        if (p < a) { mLo = Am[q]; mHi = Bm[q]; sLo = As[q]; sHi = Bs[q]; }
+                        else {
+                            const float cw = fall[p - a], sn = rise[p - a];
+                            const float m0 = cw * Am[q], m1 = sn * Bm[q], m2 = sn * Am[q], m3 = cw * Bm[q];
+                            mLo = m0 - m1; mHi = m2 + m3;
+                            const float s0 = cw * As[q], s1 = sn * Bs[q], s2 = sn * As[q], s3 = cw * Bs[q];
+                            sLo = s0 - s1; sHi = s2 + s3;
+                        }
+                        // inverse M/S (ulcDecoder.c:281-289) + interleave (:292-297)
+                        lo2[q] = make_float2(mLo + sLo, mLo - sLo);
+                        hi2[q] = make_float2(mHi + sHi, mHi - sHi);
+                    }
+                    // positions pv[1] = pv[0]-1 and S-1-pv[0], S-pv[0] are neighbours: two aligned 16-byte stores
+                    st4(outp + 2 * pv[1], lo2[1].x, lo2[1].y, lo2[0].x, lo2[0].y);
+                    st4(outp + 2 * (S - 1 - pv[0]), hi2[0].x, hi2[0].y, hi2[1].x, hi2[1].y);
+                    L0[2 * k1] = ya1.x; L0[2 * k1 + 1] = -ya2.y;
+                    L1[2 * k1] = yb1.x; L1[2 * k1 + 1] = -yb2.y;
+                }
+            }
+            __syncthreads();
+            lastSub = BS;
+        } else if (fastStream && BS <= 64 * DEC_MAXT * 2) {
+            // ---- stereo, decimated block: one wave per channel, everything in LDS, then both channels together:
+            //      inverse M/S (ulcDecoder.c:281-289) + interleave (:292-297)
+            const int newLast = dec_channel_wave<DEC_MAXT>(c, sw, z + wv * Mp0, lap + wv * H2, wv, wc, pat0, lastSub, src, readBytes, mw, ustart, udraw, blkNyb, seed, tmag);
+            __syncthreads();
+            const float *t0 = (const float *)z, *t1 = (const float *)(z + Mp0);
+            for (int n = 2 * tid; n < BS; n += 2 * WG) {
+                const float2 m = *(const float2 *)(t0 + padf(n)), sd = *(const float2 *)(t1 + padf(n));
+                st4(outp + 2 * n, m.x + sd.x, m.x - sd.x, m.y + sd.y, m.y - sd.y);
+            }
+            __syncthreads();
+            lastSub = newLast;
+        } else {
+            // ---- general path (mono / multichannel / decimated blocks / large BlockSize): one (channel, subblock) at a time
+            //      through ONE LDS array, the lapping state and the staging of the time samples in global memory
+            if (fastStream) { for (int i = tid; i < 2 * H2; i += WG) glap[i] = lap[i]; __syncthreads(); }
+            float *dec = scr + 2 * BS, *tmpq = scr + 3 * BS;
+            int newLast = lastSub;
+            for (int ch = 0; ch < C; ch++) {
+                int last = lastSub;                                  // ulcDecoder.c:219
+                float *dst = scr + (size_t)(ch & 1) * BS;
+                float *Lp = glap + (size_t)ch * H2;
+                unsigned pat = pat0;
+                int dpos = 0, j = 0;
+                do {
+                    const int d = pat & 7, S = BS >> d, M = S >> 1, Mp = FFT_PADDEDS(M, DPS);
+                    int ov = S;                                      // ulcDecoder.c:234-239
+                    if (pat & 8) ov >>= (wc & 7);
+                    if (ov > last) ov = last;
+                    last = S;
+                    for (int i = tid; i < Mp; i += WG) z[i] = make_float2(0.0f, 0.0f);
+                    __syncthreads();
+                    if (wv == 0) {
+                        sw.A = (float *)z;
+                        const uint32_t unitSeed = rng_jump(c.jumpT, seed, (uint32_t)udraw[ch * 4 + j]);
+                        synth_unit(c, sw, S, src, readBytes, mw, ustart[ch * 4 + j], unit_end(ch, j), unitSeed, tmag + (size_t)(ch * 4 + j) * c.tailStride);
+                    }
+                    __syncthreads();
+                    const float2 *pre = c.T.pre[d];
+                    for (int n = tid; n < M / 2; n += WG) {
+                        const int n2 = M - 1 - n;
+                        const int pn = FFT_PADS(n, DPS), pn2 = FFT_PADS(n2, DPS);
+                        const float2 a = z[pn], b = z[pn2];
+                        z[pn]  = cmulc(make_float2(a.x, b.y), pre[n]);
+                        z[pn2] = cmulc(make_float2(b.x, a.y), pre[n2]);
+                    }
+                    __syncthreads();
+                    if (wv == 0) fft_wave_dif(z, M, c.T.tw[d], lane, DPS);
+                    __syncthreads();
+                    // post-twiddle fused with the windowed overlap (oracle/orc_fourier.c orc_imdct):
+                    //   zz[2k] = Re y[k], zz[S-1-2k] = -Im y[k];  pair p: A = lap[M-1-p], B = zz[M+p]
+                    float *out = (S == BS) ? dst : dec;
+                    const int a = (S - ov) >> 1;
+                    const float *fall = c.T.winFall + ov, *rise = c.T.winRise + ov;
+                    const int bits = 31 - __clz(M);
+                    for (int kk = tid; kk < M / 2; kk += WG) {
+                        const int k1 = kk, k2 = M - 1 - kk;
+                        const int r1 = FFT_PADS((int)(__brev((unsigned)k1) >> (32 - bits)), DPS);
+                        const int r2 = FFT_PADS((int)(__brev((unsigned)k2) >> (32 - bits)), DPS);
+                        const float2 y1 = cmulc(z[r1], pre[k1]), y2 = cmulc(z[r2], pre[k2]);
+                        // zz[2k1] = y1.x, zz[2k1+1] = -y2.y (new lap);  zz[S-1-2k1] = -y1.y, zz[S-2-2k1] = y2.x (B values)
+                        const float A0 = Lp[2 * k1], A1 = Lp[2 * k1 + 1];
+                        const float Bv[2] = { -y1.y, y2.x };
+                        const float Av[2] = { A0, A1 };
+                        const int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
+#pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            const int p = pv[q];
+                            const float A = Av[q], B = Bv[q];
+                            if (p < a) { out[p] = A; out[S - 1 - p] = B; }
+                            else {
+                                const float cw = fall[p - a], sn = rise[p - a];
+                                const float m0 = cw * A, m1 = sn * B, m2 = sn * A, m3 = cw * B;
+                                out[p] = m0 - m1;
+                                out[S - 1 - p] = m2 + m3;
+                            }
+                        }
+                        Lp[2 * k1] = y1.x;
+                        Lp[2 * k1 + 1] = -y2.y;
+                    }
+                    __syncthreads();
+                    if (S == BS) break;                              // ulcDecoder.c:242-245
+                    // reversed-time centring FIFO in lap[M .. BS/2) (ulcDecoder.c:253-272)
+                    const int avail = (BS - S) >> 1;
+                    for (int q = tid; q < avail; q += WG) tmpq[q] = Lp[H2 - 1 - q];      // queue[q], q = 0 is the oldest
+                    __syncthreads();
+                    for (int n = tid; n < S; n += WG)
+                        dst[dpos + n] = (n < avail) ? tmpq[n] : dec[n - avail];
+                    if (S <= avail) {
+                        for (int q = tid; q < avail; q += WG)
+                            Lp[H2 - 1 - q] = (q < avail - S) ? tmpq[q + S] : dec[q - (avail - S)];
+                    } else {
+                        for (int q = tid; q < avail; q += WG) Lp[H2 - 1 - q] = dec[S - avail + q];
+                    }
+                    __syncthreads();
+                    dpos += S; j++;
+                } while (pat >>= 4);
+                newLast = last;
+                // inverse M/S + interleave once both members of a pair (or a trailing single) are staged
+                const bool pairDone = (ch & 1) || (ch == C - 1);
+                if (pairDone) {
+                    __syncthreads();
+                    if (ch & 1) {
+                        const float *dm = scr, *ds = scr + BS;
+                        for (int n = tid; n < BS; n += WG) {
+                            const float m = dm[n], sd = ds[n];                            // ulcDecoder.c:281-289
+                            const float l = m + sd, r = m - sd;
+                            if (C == 2) st2(outp + 2 * n, l, r);
+                            else { st1(outp + (size_t)n * C + ch - 1, l); st1(outp + (size_t)n * C + ch, r); }
+                        }
+                    } else {
+                        for (int n = tid; n < BS; n += WG) st1(outp + (size_t)n * C + ch, dst[n]);
+                    }
+                    __syncthreads();
+                }
+            }
+            lastSub = newLast;
+            if (fastStream) { for (int i = tid; i < 2 * H2; i += WG) lap[i] = glap[i]; __syncthreads(); }
+        }
+        seed = rng_jump(c.jumpT, seed, (uint32_t)c.draws[blk]);      // the one RNG chain of the stream (ulcDecoder.c:75-81)
+    }
+    if (fastStream) for (int i = tid; i < 2 * H2; i += WG) glap[i] = lap[i];
+    if (tid == 0) { c.lastSub[s] = lastSub; c.seed[s] = seed; c.dead[s] = dead; }
+}
+
+size_t ulcx_dec_lds_bytes(int BS, int C, int fast, int twInLds) {
+    DsynLds l = dsyn_lds(BS, C, fast, twInLds);
+    return sizeof(float) * ((size_t)l.zFloats + l.lapFloats + l.twFloats + l.listFloats);
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)
 
-int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev, hipStream_t side, hipEvent_t evFork, hipEvent_t evSide) {
+int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev) {
     int stage = 0;
     if (ev) CK(hipEventRecord(ev[stage++], st));
     int NB = c.B * c.K;
-    // zero runs are not written by pass 3: the coefficient buffer is cleared beside the (latency-bound) scan
-    if (side) {
-        CK(hipEventRecord(evFork, st));
-        CK(hipStreamWaitEvent(side, evFork, 0));
-        CK(hipMemsetAsync(c.coef, 0, sizeof(float) * (size_t)NB * c.C * c.BS, side));
-        CK(hipEventRecord(evSide, side));
-    }
-    CK(hipMemsetAsync(c.cp, 0, sizeof(int4) * (size_t)NB * c.C * 4 * DCP_PER_UNIT, st));   // N = 0: no piece
-    CK(hipMemsetAsync(c.decCount, 0, sizeof(int), st));
     if (c.packed) hipLaunchKernelGGL(k_dscan_packed, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
-    else hipLaunchKernelGGL(k_dscan, dim3((NB + DSCAN_LANES - 1) / DSCAN_LANES), dim3(64), 0, st, c);
+    else hipLaunchKernelGGL(k_dscan, dim3((NB + 63) / 64), dim3(64), 0, st, c);
     if (ev) CK(hipEventRecord(ev[stage++], st));
-    hipLaunchKernelGGL(k_dseed, dim3((NB + 63) / 64), dim3(64), 0, st, c);
-    hipLaunchKernelGGL(k_dseed_commit, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
-    if (ev) CK(hipEventRecord(ev[stage++], st));
-    if (!side) CK(hipMemsetAsync(c.coef, 0, sizeof(float) * (size_t)NB * c.C * c.BS, st));
-    if (side) CK(hipStreamWaitEvent(st, evSide, 0));                                   // the coefficient buffer is zeroed
-    hipLaunchKernelGGL(k_dgen, dim3(DGEN_DEC_WGS + (NB * c.C * DCP_PER_UNIT + 255) / 256), dim3(256), 0, st, c);
-    if (ev) CK(hipEventRecord(ev[stage++], st));
-    size_t lds = ulcx_dec_lds_bytes(c.BS, c.C);
-    if (lds > 48 * 1024) {
-        CK(hipFuncSetAttribute((const void *)k_dimdct<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CK(hipFuncSetAttribute((const void *)k_dimdct<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    if (c.pcm16) hipLaunchKernelGGL(k_dimdct<int16_t>, dim3(c.B), dim3(WG), lds, st, c);
-    else hipLaunchKernelGGL(k_dimdct<float>, dim3(c.B), dim3(WG), lds, st, c);
+    size_t lds = ulcx_dec_lds_bytes(c.BS, c.C, c.fastOK, c.twInLds);
+    const bool small = c.BS <= 2048;                      // register slots of the decimated-block path (dec_channel_wave)
+    const void *fn = c.pcm16 ? (small ? (const void *)k_dsyn<int16_t, 16> : (const void *)k_dsyn<int16_t, 32>)
+                             : (small ? (const void *)k_dsyn<float, 16> : (const void *)k_dsyn<float, 32>);
+    if (lds > 48 * 1024) CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (c.dbgSkip & 8) {}
+    else if (c.pcm16) { if (small) hipLaunchKernelGGL((k_dsyn<int16_t, 16>), dim3(c.B), dim3(WG), lds, st, c); else hipLaunchKernelGGL((k_dsyn<int16_t, 32>), dim3(c.B), dim3(WG), lds, st, c); }
+    else { if (small) hipLaunchKernelGGL((k_dsyn<float, 16>), dim3(c.B), dim3(WG), lds, st, c); else hipLaunchKernelGGL((k_dsyn<float, 32>), dim3(c.B), dim3(WG), lds, st, c); }
     if (ev) CK(hipEventRecord(ev[stage++], st));
     CK(hipGetLastError());
     return ULCX_OK;
@@ -693,7 +909,6 @@ int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev, hipStre
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_streams(int nBlocks, int slotBytes, const uint8_t *slots, const int32_t *bits,
                                                        uint8_t *payload, long long stride, int32_t *payloadBytes, int32_t *maxBlock) {
-    __shared__ int s_off, s_len;
     int s = blockIdx.x, tid = threadIdx.x;
     uint8_t *dst = payload + (size_t)s * stride;
     int off = 0, mx = 0;
@@ -704,7 +919,6 @@ __global__ __launch_bounds__(256) void k_pack_streams(int nBlocks, int slotBytes
         off += n;
         mx = n > mx ? n : mx;
     }
-    (void)s_off; (void)s_len;
     if (tid == 0) { payloadBytes[s] = off; if (maxBlock) maxBlock[s] = mx; }
 }
 int ulcx_pack_launch(int nStreams, int nBlocks, int slotBytes, const uint8_t *d_slots, const int32_t *d_bits, uint8_t *d_payload,

@@ -97,23 +97,26 @@ struct UlcxDecCtx {
     int dbgSkip;                         // timing experiments only (ULCX_DBG_SKIP)
     UlcxTables T;
     const uint8_t *in; float *pcm; int16_t *pcm16;   // exactly one of pcm / pcm16 is set (f32 as the C API, or PCM16 output)
+    long long inBytes;                   // readable extent of `in`: nothing outside [in, in + inBytes) is touched
     int32_t *bits;
     // persistent
     float *lap;                          // [B][C][BS/2] TransformInvLap
     int   *lastSub;                      // [B] LastSubBlockSize
     uint32_t *seed;                      // [B] noise RNG state (ulcDecoder.c:75-81)
     int   *dead;                         // [B] stream hit a corrupt block
-    uint32_t *seedNext; int *deadNext;   // [B] staged by k_dseed, committed by k_dseed_commit
-    int   *wcScan;                       // [NB] WindowCtrl as the scan saw it (0 = corrupt); wc[] also carries "stream already dead"
-    // per-call scratch
-    float *coef;                         // [NB][C*BS] dequantised coefficients
-    int   *wc;                           // [NB] WindowCtrl per block (0 = corrupt)
+    // per-call scratch: what the scan leaves for the synthesis (ulcx_dec.hip)
+    int   *wcScan;                       // [NB] WindowCtrl as the scan saw it (0 = corrupt)
     int   *draws;                        // [NB] RNG draws consumed by the block
-    uint32_t *blockSeed;                 // [NB] RNG state at the start of the block
-    int   *unitStart, *unitDraws;        // [NB][C*4] nybble offset / draws before each (chan,subblock) unit
-    int4  *cp;                           // [NB][C*4][8] checkpoints inside each unit (ulcx_dec.hip DCP_PER_UNIT)
-    int   *decList, *decCount;           // blocks with more than one subblock, found by the scan
-    const uint32_t *jump;                // [32][32] columns of T^(2^i), T = one xorshift32 step
+    int   *unitStart, *unitDraws;        // [NB][C*4] nybble index of / draws before each (chan,subblock) unit's opening code
+    float4 *unitTail;                    // [NB][C*4] decaying-noise tail of the unit: {start level, decay, first coefficient, count}
+    unsigned long long *startMask;       // [NB][maskWords] one bit per nybble of the block: a code starts here
+    int    maskWords;
+    float *tailMag;                      // [NB][C*4][tailStride] tail level at every 32nd coefficient of the unit
+    int    tailStride;                   // BS/32
+    float *scratch;                      // [B][4*BS] general-path staging of time samples (decimated / non-stereo blocks)
+    const uint32_t *jumpT;               // [8][16][4][256] byte tables of T^(d*16^i), T = one xorshift32 step
+    const uint32_t *vtab;                // [BS+1] sign-parity functionals (ulcx_dec.hip)
+    int    fastOK, twInLds;              // stereo fast path / FFT twiddles resident in LDS
     // packed-stream mode (.ulc payloads): blocks are located by parsing, not by slot
     int   packed;
     long long payStride;                 // bytes between stream payloads
@@ -141,7 +144,7 @@ void ulcx_set_error(const char *fmt, ...);
 #define ULCX_ENC_STAGES 20
 #define ULCX_ENC_STAGES_REPORTED (ULCX_ENC_STAGES + 1)   // + "wc_pipeline_exposed" (computed, not an event interval)
 extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES_REPORTED];
-#define ULCX_DEC_STAGES 4
+#define ULCX_DEC_STAGES 2
 #define ULCX_WC_MAXCH 32    // fine steps of the window-control pipeline per call
 #define ULCX_XF_MAXCH 8     // coarse transform chunks per call
 #define ULCX_LDS_LIMIT (160 * 1024)     // LDS per workgroup on gfx950
@@ -158,7 +161,8 @@ struct UlcxEncAux {
     int *nXf;                            // out: transform chunk launches this call
 };
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, const UlcxEncAux &aux);
-int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev, hipStream_t side /* or NULL */, hipEvent_t evFork, hipEvent_t evSide);
+int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev);
+size_t ulcx_dec_lds_bytes(int BS, int C, int fast, int twInLds);
 int ulcx_pack_launch(int nStreams, int nBlocks, int slotBytes, const uint8_t *d_slots, const int32_t *d_bits, uint8_t *d_payload,
                      long long stride, int32_t *d_payloadBytes, int32_t *d_maxBlock, hipStream_t st);
 size_t ulcx_enc_xf_lds_bytes(int BS, int C);
