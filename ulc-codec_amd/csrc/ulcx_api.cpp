@@ -394,11 +394,11 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     memset(&c, 0, sizeof(c));
     c.B = nStreams; c.C = nChan; c.BS = BlockSize; c.lgBS = ilog2i(BlockSize); c.maxK = maxBlocksPerCall;
     if (const char *ev = getenv("ULCX_DBG_SKIP")) c.dbgSkip = atoi(ev);
-    // stereo streams keep their lapping state and both channels' FFT arrays in LDS (one wave per channel); everything
-    // else takes the general path (one array, state in HBM).  FFT twiddles are LDS-resident when they fit beside that.
-    c.fastOK = (nChan == 2 && ulcx_dec_lds_bytes(BlockSize, nChan, 1, 0) <= (size_t)ULCX_LDS_LIMIT) ? 1 : 0;
+    // stereo streams up to BlockSize 4096 keep their lapping state, both channels' FFT arrays and the twiddles in LDS, one wave
+    // per channel (k_dsyn); everything else takes the general kernel (k_dgen: one array, state in HBM)
+    c.fastOK = (nChan == 2 && BlockSize <= 4096) ? 1 : 0;
     if (const char *ev = getenv("ULCX_DEC_FAST")) c.fastOK = c.fastOK && (ev[0] != '0');
-    c.twInLds = (ulcx_dec_lds_bytes(BlockSize, nChan, c.fastOK, 1) <= (size_t)ULCX_LDS_LIMIT) ? 1 : 0;
+    c.twInLds = c.fastOK;
     rc = ulcx_tables_build(&c.T, &e->tables, BlockSize, 44100, false);
     if (rc) { cleanup(e); return rc; }
     size_t B = nStreams, NB = B * maxBlocksPerCall;
@@ -547,6 +547,15 @@ extern "C" int ulcx_decode_packed_host(ulcx_decoder *e, const uint8_t *h_payload
     return rc;
 }
 
+// diagnostic: first nBytes of the general-path staging buffer (a -DULCX_DSYN_STAMPS build leaves per-phase cycle counts there)
+extern "C" int ulcx_decoder_debug_scratch(ulcx_decoder *e, void *h_out, size_t strideBytes, size_t nBytes, int nStreams) {
+    if (!e || !h_out) return ULCX_ERR_ARG;
+    CKR(hipSetDevice(e->device));
+    CKR(hipDeviceSynchronize());
+    for (int s = 0; s < nStreams && s < e->B; s++)
+        CKR(hipMemcpy((char *)h_out + (size_t)s * nBytes, (const char *)e->ctx.scratch + (size_t)s * strideBytes, nBytes, hipMemcpyDeviceToHost));
+    return ULCX_OK;
+}
 static const char *kDecStage[ULCX_DEC_STAGES] = { "k_dscan", "k_dsyn" };
 extern "C" const char *ulcx_decoder_stage_name(int i) { return (i >= 0 && i < ULCX_DEC_STAGES) ? kDecStage[i] : ""; }
 extern "C" int ulcx_decoder_stage_ms(ulcx_decoder *e, float *ms, int maxStages) {

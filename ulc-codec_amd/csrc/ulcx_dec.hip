@@ -349,13 +349,31 @@ __device__ __forceinline__ int padf(int f) { return f + ((f >> 5) << 1); }
 // Noise runs found while decoding a unit, 8 bytes each:
 //   x = first coefficient | count << 16 (count - 1 for a tail, which may span the whole unit) | tail << 31
 //   y = draws made in the unit before the run | level << 16 | quantizer index << 21
-#define NOISE_CAP 128
+#define NOISE_CAP 96
+#ifdef ULCX_DSYN_STAMPS
+struct DsynStamps { unsigned long long t[12], t0; };
+#define SSTAMP(sw, i) do { if ((sw).stp) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); (sw).stp->t[i] += t_ - (sw).stp->t0; (sw).stp->t0 = t_; } } while (0)
+#else
+#define SSTAMP(sw, i) do {} while (0)
+#endif
 struct SynWave {                 // one wave's working set while it synthesises one (channel, subblock) unit
     float *A;                    // the unit's coefficients = the FFT's input array (LDS, padded)
     uint2 *list;                 // NOISE_CAP noise runs (LDS)
     int   *pre;                  // 64 prefix counts (LDS)
+    uint32_t *seedTab;           // RNG state of the unit after every 32nd draw, 64 entries (LDS)
     int lane;
+#ifdef ULCX_DSYN_STAMPS
+    DsynStamps *stp;
+#endif
 };
+#define SEEDTAB_DRAWS 2048       // draws of a unit the table covers; pieces beyond it jump on their own
+
+// one table-driven step of a jump: s through T^(dgt * 16^i)
+__device__ __forceinline__ uint32_t rng_jump_digit(const uint32_t *__restrict__ jt, uint32_t s, int i, uint32_t dgt) {
+    const uint32_t *J = jt + ((size_t)(i * 16 + (dgt ? dgt : 1u)) << 10);
+    const uint32_t r = J[s & 255u] ^ J[256 + ((s >> 8) & 255u)] ^ J[512 + ((s >> 16) & 255u)] ^ J[768 + (s >> 24)];
+    return dgt ? r : s;
+}
 
 // Noise synthesis of the queued runs: one lane per (run, 32-coefficient chunk) piece.
 __device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &sw, int nE, uint32_t unitSeed, float tailRR, const float *tailMag) {
@@ -390,7 +408,12 @@ __device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &
             const int n = act ? phi - plo : 0;
             const int off = plo - rpos;
             const int d = d0 + off;
-            uint32_t seed = rng_jump(c.jumpT, unitSeed, (uint32_t)d);
+            // state after d draws: the table entry at or below d, then d % 32 single steps
+            uint32_t seed;
+            if (d < SEEDTAB_DRAWS) {
+                seed = sw.seedTab[d >> 5];
+                for (int st = d & 31; __any(st > 0); st--) seed = (st > 0) ? xorshift32(seed) : seed;
+            } else seed = rng_jump(c.jumpT, unitSeed, (uint32_t)d);
             const int par = (__popc(c.vtab[d] & unitSeed) ^ __popc(c.vtab[d0] & unitSeed)) & 1;
             const float quant = expand_quantizer(qi);
             float mag = (float)(lvl * lvl) * quant * (rtail ? (1.0f / 16) : (1.0f / 4));      // ulcDecoder.c:146-150, :166-170
@@ -414,102 +437,94 @@ __device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &
 // Dequantise one (channel, subblock) unit into A[0 .. S) (zeroed by the caller): nybbles [nyb0, nyb1) of the block.
 // Every nybble gets a lane; the lanes whose nybble starts a code (k_dscan's bitmap) decode it; where a code's
 // coefficients go, which quantizer is in force and how many draws precede it are prefix scans over the wave.
+// ONE round body and ONE noise-synthesis site in a rolled loop (the kernel has to stay inside the instruction cache);
+// the loads of a round (start bitmap word, the lane's code window) are issued two rounds ahead.
 __device__ __forceinline__ void synth_unit(const UlcxDecCtx &c, const SynWave &sw, int S, const uint8_t *src, int readBytes,
                                            const unsigned long long *mw, int nyb0, int nyb1, uint32_t unitSeed, const float *tailMag) {
     const int lane = sw.lane;
     int posBase = 0, drawBase = 0, qcur = 30;       // (the opening code always sets a quantizer; 30 expands to 0)
     int nE = 0;
     float tailRR = 1.0f;
-    for (int n0 = nyb0 & ~63; n0 < nyb1; n0 += 64) {
-        const int n = n0 + lane;
-        const bool in = (n >= nyb0) & (n < nyb1);
-        const unsigned long long W = mw[n0 >> 6];                                   // (wave-uniform)
-        const bool isStart = in && ((W >> lane) & 1ull);
-        const uint32_t w = in ? code_window(src, n * 4, readBytes) : 0u;
-        const Code k = decode_code(w, n == nyb0);
-        const int cnt = !isStart ? 0 : k.plain ? 1 : k.zrun ? k.n : k.n8 ? k.np : 0;
-        const int dr = (isStart && k.n8) ? k.np : 0;
-        const uint32_t packed = (uint32_t)cnt | ((uint32_t)dr << 16);
-        const uint32_t incl = wave_scan_add(packed);
-        const uint32_t excl = incl - packed;
-        const int pos = posBase + (int)(excl & 0xFFFFu);
-        const int d0 = drawBase + (int)(excl >> 16);
-        const uint32_t qv = (isStart && k.qnew >= 0) ? (((uint32_t)lane << 8) | (uint32_t)(k.qnew + 1)) : 0u;
-        const uint32_t qs = wave_scan_max(qv);
-        const int qi = (qs & 0xFFu) ? (int)(qs & 0xFFu) - 1 : qcur;
-        const float quant = expand_quantizer(qi);
-        if (isStart && k.plain && pos < S) sw.A[padf(pos)] = (float)k.sv * quant;  // ulcDecoder.c:69-73
-        const bool noisy = isStart && (k.n8 | k.tail) && pos < S;
-        const unsigned long long nm = __ballot(noisy);
-        if (nm) {
-            const int slot = nE + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0));
-            if (noisy && slot < NOISE_CAP) {
-                int np = k.tail ? S - pos : k.np;
-                np = np < S - pos ? np : S - pos;                                   // (cannot exceed it in a block the scan accepted)
-                sw.list[slot] = make_uint2((uint32_t)pos | ((uint32_t)(np - (k.tail ? 1 : 0)) << 16) | (k.tail ? 0x80000000u : 0u),
-                                           (uint32_t)d0 | ((uint32_t)k.l << 16) | ((uint32_t)qi << 21));
+    // seedTab[l] = RNG state after 32*l draws of the unit = unitSeed through T^(32 l): two table-driven steps per lane
+    // (hex digits 1 and 2 of 32*l); the second is taken after the first round so that both fly behind the decoding
+    uint32_t sj = rng_jump_digit(c.jumpT, unitSeed, 1, (uint32_t)(lane & 7) << 1);
+    const int nFirst = nyb0 & ~63;
+    auto ld_mask = [&](int n0) -> unsigned long long { return (n0 < nyb1) ? mw[n0 >> 6] : 0ull; };                       // (wave-uniform)
+    auto ld_win  = [&](int n0) -> uint32_t { const int n = n0 + lane; return ((n >= nyb0) & (n < nyb1)) ? code_window(src, n * 4, readBytes) : 0u; };
+    unsigned long long W0 = ld_mask(nFirst), W1 = ld_mask(nFirst + 64);
+    uint32_t w0 = ld_win(nFirst), w1 = ld_win(nFirst + 64);
+    bool more = true;
+    for (int n0 = nFirst; more; n0 += 64) {
+        const bool rounds = n0 < nyb1;                                               // (wave-uniform) false: only the final flush is left
+        if (rounds) {
+            const unsigned long long W = W0; const uint32_t w = w0;
+            W0 = W1; w0 = w1;
+            W1 = ld_mask(n0 + 128); w1 = ld_win(n0 + 128);
+            if (n0 == nFirst) sj = rng_jump_digit(c.jumpT, sj, 2, (uint32_t)lane >> 3);
+            const int n = n0 + lane;
+            const bool in = (n >= nyb0) & (n < nyb1);
+            const bool isStart = in && ((W >> lane) & 1ull);
+            const Code k = decode_code(w, n == nyb0);
+            const int cnt = !isStart ? 0 : k.plain ? 1 : k.zrun ? k.n : k.n8 ? k.np : 0;
+            const int dr = (isStart && k.n8) ? k.np : 0;
+            const uint32_t packed = (uint32_t)cnt | ((uint32_t)dr << 16);
+            const uint32_t incl = wave_scan_add(packed);
+            const uint32_t excl = incl - packed;
+            const int pos = posBase + (int)(excl & 0xFFFFu);
+            const int d0 = drawBase + (int)(excl >> 16);
+            const uint32_t qv = (isStart && k.qnew >= 0) ? (((uint32_t)lane << 8) | (uint32_t)(k.qnew + 1)) : 0u;
+            const uint32_t qs = wave_scan_max(qv);
+            const int qi = (qs & 0xFFu) ? (int)(qs & 0xFFu) - 1 : qcur;
+            const float quant = expand_quantizer(qi);
+            if (isStart && k.plain && pos < S) sw.A[padf(pos)] = (float)k.sv * quant;  // ulcDecoder.c:69-73
+            const bool noisy = isStart && (k.n8 | k.tail) && pos < S;
+            const unsigned long long nm = __ballot(noisy);
+            if (nm) {
+                const int slot = nE + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0));
+                if (noisy && slot < NOISE_CAP) {
+                    int np = k.tail ? S - pos : k.np;
+                    np = np < S - pos ? np : S - pos;                                   // (cannot exceed it in a block the scan accepted)
+                    sw.list[slot] = make_uint2((uint32_t)pos | ((uint32_t)(np - (k.tail ? 1 : 0)) << 16) | (k.tail ? 0x80000000u : 0u),
+                                               (uint32_t)d0 | ((uint32_t)k.l << 16) | ((uint32_t)qi << 21));
+                }
+                const unsigned long long tm = __ballot(noisy && k.tail);
+                if (tm) {
+                    const float rr = 1.0f + (float)(k.dn * k.dn) * -0x1.0p-19f;           // ulcDecoder.c:171-175
+                    tailRR = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rr), __builtin_ctzll(tm)));
+                }
+                nE += __popcll(nm);
             }
-            const unsigned long long tm = __ballot(noisy && k.tail);
-            if (tm) {
-                const float rr = 1.0f + (float)(k.dn * k.dn) * -0x1.0p-19f;           // ulcDecoder.c:171-175
-                tailRR = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rr), __builtin_ctzll(tm)));
-            }
-            nE += __popcll(nm);
+            const int inclLast = __builtin_amdgcn_readlane((int)incl, 63), qsLast = __builtin_amdgcn_readlane((int)qs, 63);
+            posBase += inclLast & 0xFFFF;
+            drawBase += (int)((uint32_t)inclLast >> 16);
+            qcur = (qsLast & 0xFF) ? (qsLast & 0xFF) - 1 : qcur;
         }
-        posBase += (int)(__builtin_amdgcn_readlane((int)incl, 63) & 0xFFFF);
-        drawBase += (int)((uint32_t)__builtin_amdgcn_readlane((int)incl, 63) >> 16);
-        qcur = __builtin_amdgcn_readlane((int)qs, 63) & 0xFF ? (__builtin_amdgcn_readlane((int)qs, 63) & 0xFF) - 1 : qcur;
-        if (nE > NOISE_CAP - 64) {                                                   // the next round could overflow the list
+        more = rounds;
+        // the queued noise runs: when the next round could overflow the list, and once after the last round
+        if (nE > NOISE_CAP - 64 || (!rounds && nE)) {
+            SSTAMP(sw, 8);
+            sw.seedTab[lane] = sj;
             WAVE_SYNC();
             synth_noise(c, sw, nE, unitSeed, tailRR, tailMag);
             nE = 0;
+            SSTAMP(sw, 10);
         }
     }
-    WAVE_SYNC();
-    if (nE) synth_noise(c, sw, nE, unitSeed, tailRR, tailMag);
     WAVE_SYNC();
 }
 
-
 // ---------------------------------------------------------------------------
-// One channel of a DECIMATED block of a stereo stream, by one wave, entirely in LDS (ulcDecoder.c:219-273).
-// The channel's FFT array holds its subblocks back to back (subblock offsets are multiples of 32 floats, so the
-// padding of the parts is the padding of the whole).  Per subblock: synthesis, DCT-IV, then - in order, because
-// each subblock overlaps with what the previous one left in the lapping state - windowed overlap-add and the
-// reversed-time centring FIFO; the time samples of subblock j replace its own coefficients.  Every in-place move
-// is "all lanes read into registers, wave barrier, all lanes write".  Returns the size of the last subblock.
-// ---------------------------------------------------------------------------
+// Time domain of one channel of a DECIMATED block of a stereo stream, by one wave, entirely in LDS
+// (ulcDecoder.c:219-273).  The channel's array holds the spectra of its subblocks back to back (subblock offsets are
+// multiples of 32 floats, so the padding of the parts is the padding of the whole).  In order - each subblock
+// overlaps with what the previous one left in the lapping state - windowed overlap-add and the reversed-time
+// centring FIFO; the time samples of subblock j replace its own spectrum.  Every in-place move is "all lanes read
+// into registers, wave barrier, all lanes write".  Returns the size of the last subblock.
 // DEC_MAXT = (BlockSize/2)/64 register slots per lane: a template parameter of the kernel (16: BlockSize <= 2048, 32: <= 4096)
+// ---------------------------------------------------------------------------
 template <int DEC_MAXT>
-__device__ __forceinline__ int dec_channel_wave(const UlcxDecCtx &c, SynWave &sw, float2 *zc, float *L, int ch, int wc, unsigned pat0, int lastSub,
-                                                const uint8_t *src, int readBytes, const unsigned long long *mw, const int *ustart, const int *udraw,
-                                                int blkNyb, uint32_t seed, const float *tmag) {
-    const int BS = c.BS, H2 = BS / 2, lane = sw.lane;
-    int nsub = 0; { unsigned q = pat0; do nsub++; while (q >>= 4); }
-    // ---- coefficients -> spectra of every subblock (independent of each other)
-    {
-        unsigned pat = pat0; int off = 0;
-        for (int j = 0; j < nsub; j++, pat >>= 4) {
-            const int d = pat & 7, S = BS >> d, M = S >> 1, Mp = FFT_PADDEDS(M, DPS);
-            float2 *zj = zc + FFT_PADS(off >> 1, DPS);
-            for (int i = lane; i < Mp; i += 64) zj[i] = make_float2(0.0f, 0.0f);
-            sw.A = (float *)zj;
-            const int nyb1 = (j + 1 < nsub) ? ustart[ch * 4 + j + 1] : (ch + 1 < c.C) ? ustart[(ch + 1) * 4] : blkNyb;
-            const uint32_t unitSeed = rng_jump(c.jumpT, seed, (uint32_t)udraw[ch * 4 + j]);
-            synth_unit(c, sw, S, src, readBytes, mw, ustart[ch * 4 + j], nyb1, unitSeed, tmag + (size_t)(ch * 4 + j) * c.tailStride);
-            const float2 *pre = c.T.pre[d];
-            for (int n = lane; n < M / 2; n += 64) {
-                const int n2 = M - 1 - n;
-                const int pn = FFT_PADS(n, DPS), pn2 = FFT_PADS(n2, DPS);
-                const float2 a = zj[pn], b = zj[pn2];
-                zj[pn]  = cmulc(make_float2(a.x, b.y), pre[n]);
-                zj[pn2] = cmulc(make_float2(b.x, a.y), pre[n2]);
-            }
-            fft_wave_dif(zj, M, c.T.tw[d], lane, DPS);
-            off += S;
-        }
-    }
-    WAVE_SYNC();
+__device__ __forceinline__ int dec_time_wave(const UlcxDecCtx &c, float2 *zc, float *L, int wc, unsigned pat0, int nsub, int lastSub, int lane) {
+    const int BS = c.BS, H2 = BS / 2;
     // ---- time domain, subblock by subblock
     int last = lastSub;
     unsigned pat = pat0; int off = 0;
@@ -616,47 +631,78 @@ template <typename OUT> __device__ __forceinline__ OUT *out_base(const UlcxDecCt
 template <> __device__ __forceinline__ float *out_base<float>(const UlcxDecCtx &c) { return c.pcm; }
 template <> __device__ __forceinline__ int16_t *out_base<int16_t>(const UlcxDecCtx &c) { return c.pcm16; }
 
-// LDS carve of k_dsyn, in floats:  z [2 (stereo fast path) or 1 padded array(s) of BS/2 complex] |
-//   lap [2][BS/2] (fast path only) | twl [BS/4 complex] (when it fits) | per wave: noise list + prefix counts
+// LDS carve, in floats.  Stereo kernel (k_dsyn):  z [2 padded arrays of BS/2 complex] | lap [2][BS/2] | twl [BS/4 complex] |
+//   per wave: noise runs, prefix counts, seed table | 128 block / unit seeds.  General kernel (k_dgen): z [1 array] | per-wave lists.
 struct DsynLds { int zFloats, lapFloats, twFloats, listFloats; };
 __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int twInLds) {
     DsynLds l;
     l.zFloats = (fast ? 2 : 1) * 2 * FFT_PADDEDS(BS / 2, DPS);
     l.lapFloats = fast ? 2 * (BS / 2) : 0;
-    l.twFloats = twInLds ? BS / 2 : 0;
-    l.listFloats = 2 * (2 * NOISE_CAP + 64);
-    (void)C;
+    l.twFloats = fast ? BS / 2 : 0;
+    l.listFloats = 2 * (2 * NOISE_CAP + 64 + 64) + 128;
+    (void)C; (void)twInLds;
     return l;
 }
 
+// ---------------------------------------------------------------------------
+// Stereo streams (BlockSize <= 4096): one workgroup = one stream, one wave per channel up to the end of the FFTs.
+// ---------------------------------------------------------------------------
 template <typename OUT, int DEC_MAXT>
 __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
     extern __shared__ float lds[];
-    const int BS = c.BS, C = c.C, H2 = BS / 2;
+    const int BS = c.BS, H2 = BS / 2;
+    constexpr int C = 2;
     const int s = blockIdx.x, tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const DsynLds L = dsyn_lds(BS, C, c.fastOK, c.twInLds);
+    const DsynLds L = dsyn_lds(BS, C, 1, 1);
     float2 *z    = (float2 *)lds;
-    float  *lap  = lds + L.zFloats;                                  // (fast path only)
-    float2 *twl  = (float2 *)(lds + L.zFloats + L.lapFloats);        // FFT twiddles of the full-size transform
+    float  *lap  = lds + L.zFloats;
+    float2 *twl  = (float2 *)(lds + L.zFloats + L.lapFloats);        // FFT twiddles: the full-size table, or the three of a decimated block's sizes
     SynWave sw;
-    sw.list = (uint2 *)(lds + L.zFloats + L.lapFloats + L.twFloats) + wv * (NOISE_CAP + 32);
+    sw.list = (uint2 *)(lds + L.zFloats + L.lapFloats + L.twFloats) + wv * (NOISE_CAP + 64);
     sw.pre  = (int *)(sw.list + NOISE_CAP);
+    sw.seedTab = (uint32_t *)(sw.pre + 64);
+    uint32_t *bseed = (uint32_t *)(lds + L.zFloats + L.lapFloats + L.twFloats + 2 * (2 * NOISE_CAP + 64 + 64));   // [0,64): RNG state at each block's start, [64,128): at its second channel
     sw.lane = lane;
     float *glap = c.lap + (size_t)s * C * H2;
-    const bool fastStream = c.fastOK != 0;
-    if (fastStream) for (int i = tid; i < 2 * H2; i += WG) lap[i] = glap[i];
-    if (c.twInLds) for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
+    for (int i = tid; i < 2 * H2; i += WG) lap[i] = glap[i];
+    for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
+    bool twFull = true;
     int lastSub = c.lastSub[s];
     int dead = c.dead[s];
     uint32_t seed = c.seed[s];
-    float *scr = c.scratch + (size_t)s * 4 * BS;                     // slow path staging: dst[2][BS] | dec[BS] | tmpq[BS/2]
+    const int M0 = BS >> 1, Mp0 = FFT_PADDEDS(M0, DPS);
+    float2 *zc = z + wv * Mp0;                                       // this wave's channel
+#ifdef ULCX_DSYN_STAMPS
+    // diagnostic build only: shader cycles per phase, summed over the stream's blocks
+    DsynStamps stq; for (int i = 0; i < 12; i++) stq.t[i] = 0; stq.t0 = __builtin_amdgcn_s_memtime();
+    sw.stp = &stq;
+#define STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stq.t[i] += t_ - stq.t0; stq.t0 = t_; } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
     __syncthreads();
 
-    const int M0 = BS >> 1, Mp0 = FFT_PADDEDS(M0, DPS);
     for (int k = 0; k < c.K; k++) {
         const int blk = s * c.K + k;
-        int wc = c.wcScan[blk];
+        if ((k & 63) == 0) {
+            // The stream's one RNG chain (ulcDecoder.c:75-81) for the next 64 blocks at once: a block starts draws-of-its-
+            // predecessors after the chunk's first state - one lane per block, prefix sum, one jump each (wave 1: the
+            // state at each block's second channel).  A corrupt block ends the stream: it and its successors draw nothing.
+            __syncthreads();
+            const int kk = k + lane, bk = s * c.K + (kk < c.K ? kk : k);
+            const bool on = kk < c.K;
+            int dr = on ? c.draws[bk] : 0;
+            const unsigned long long badm = __ballot(on && c.wcScan[bk] == 0);
+            if (badm && lane >= __builtin_ctzll(badm)) dr = 0;
+            const uint32_t incl = wave_scan_add((uint32_t)dr);
+            const uint32_t before = incl - (uint32_t)dr + (wv ? (uint32_t)c.unitDraws[(size_t)bk * C * 4 + 4] : 0u);
+            bseed[wv * 64 + lane] = rng_jump(c.jumpT, seed, before);
+            const uint32_t chunkDraws = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            __syncthreads();
+            seed = rng_jump(c.jumpT, seed, chunkDraws);            // state after the chunk: the next chunk's start / the stream's state for the next call
+        }
+        const int wc = c.wcScan[blk];
         if (wc == 0) dead = 1;                                       // a corrupt block ends the stream (ulcDecodeTool.c:154-157)
         OUT *outp = out_base<OUT>(c) + (size_t)blk * C * BS;
         if (dead) {
@@ -675,40 +721,57 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
         const bool whole = (BS >> (pat0 & 7)) == BS;                 // one subblock per channel (ulcDecoder.c:242-245)
         int nsub = 1;
         if (!whole) { nsub = 0; unsigned q = pat0; do nsub++; while (q >>= 4); }
-        // nybble at which unit (ch, j) ends = where the next unit starts, or the end of the block's codes
-        auto unit_end = [&](int ch, int j) {
-            if (j + 1 < nsub) return ustart[ch * 4 + j + 1];
-            if (ch + 1 < C) return ustart[(ch + 1) * 4];
-            return blkNyb;
-        };
-
-        if (fastStream && whole) {
-            // ---- stereo, un-decimated block (the common case): one wave per channel up to the end of the FFT,
-            //      then both channels together: windowed overlap-add, inverse M/S in registers, interleaved stores
-            float2 *zw = z + wv * Mp0;
-            sw.A = (float *)zw;
-            for (int i = lane; i < Mp0; i += 64) zw[i] = make_float2(0.0f, 0.0f);
-            const uint32_t unitSeed = rng_jump(c.jumpT, seed, (uint32_t)udraw[wv * 4]);
-            if (!(c.dbgSkip & 1)) synth_unit(c, sw, BS, src, readBytes, mw, ustart[wv * 4], unit_end(wv, 0), unitSeed, tmag + (size_t)wv * 4 * c.tailStride);
-            // DCT-IV pre-twiddle in place: n and M-1-n together read and write the same two complex slots
-            const float2 *pre = c.T.pre[0];
-            if (!(c.dbgSkip & 2)) {
-            for (int n = lane; n < M0 / 2; n += 64) {
-                const int n2 = M0 - 1 - n;
-                const int pn = FFT_PADS(n, DPS), pn2 = FFT_PADS(n2, DPS);
-                const float2 a = zw[pn], b = zw[pn2];                // (X[2n], X[2n+1]), (X[S-2-2n], X[S-1-2n])
-                zw[pn]  = cmulc(make_float2(a.x, b.y), pre[n]);
-                zw[pn2] = cmulc(make_float2(b.x, a.y), pre[n2]);
+        if (whole != twFull) {
+            // twiddle tables for this block's transform sizes: the full-size one, or those of N/2, N/4, N/8 back to back
+            if (whole) for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
+            else for (int i = tid; i < 7 * BS / 32; i += WG) {
+                const int dd = i < BS / 8 ? 1 : i < 3 * BS / 16 ? 2 : 3;
+                twl[i] = c.T.tw[dd][i - (dd == 1 ? 0 : dd == 2 ? BS / 8 : 3 * BS / 16)];
             }
-            if (c.twInLds) fft_wave_dif(zw, M0, twl, lane, DPS);      // (two call sites: the LDS pointer keeps its address space)
-            else fft_wave_dif(zw, M0, c.T.tw[0], lane, DPS);
-            }
+            twFull = whole;
             __syncthreads();
+        }
+        STAMP(0);
+        // ---- coefficients -> spectra, this wave's channel, subblock by subblock (independent of each other)
+        {
+            unsigned pat = pat0; int off = 0;
+            for (int j = 0; j < nsub; j++, pat >>= 4) {
+                const int d = pat & 7, S = BS >> d, M = S >> 1, Mp = FFT_PADDEDS(M, DPS);
+                float2 *zj = zc + FFT_PADS(off >> 1, DPS);
+                for (int i = lane; i < Mp; i += 64) zj[i] = make_float2(0.0f, 0.0f);
+                sw.A = (float *)zj;
+                const int nyb1 = (j + 1 < nsub) ? ustart[wv * 4 + j + 1] : (wv + 1 < C) ? ustart[(wv + 1) * 4] : blkNyb;
+                const uint32_t unitSeed = (j == 0) ? bseed[wv * 64 + (k & 63)] : rng_jump(c.jumpT, bseed[k & 63], (uint32_t)udraw[wv * 4 + j]);
+                STAMP(1);
+                if (!(c.dbgSkip & 1)) synth_unit(c, sw, S, src, readBytes, mw, ustart[wv * 4 + j], nyb1, unitSeed, tmag + (size_t)(wv * 4 + j) * c.tailStride);
+                STAMP(2);
+                // DCT-IV pre-twiddle in place: n and M-1-n together read and write the same two complex slots
+                const float2 *pre = c.T.pre[d];
+                if (!(c.dbgSkip & 2)) {
+                for (int n = lane; n < M / 2; n += 64) {
+                    const int n2 = M - 1 - n;
+                    const int pn = FFT_PADS(n, DPS), pn2 = FFT_PADS(n2, DPS);
+                    const float2 a = zj[pn], b = zj[pn2];            // (X[2n], X[2n+1]), (X[S-2-2n], X[S-1-2n])
+                    zj[pn]  = cmulc(make_float2(a.x, b.y), pre[n]);
+                    zj[pn2] = cmulc(make_float2(b.x, a.y), pre[n2]);
+                }
+                fft_wave_dif(zj, M, twl + (d <= 1 ? 0 : d == 2 ? BS / 8 : 3 * BS / 16), lane, DPS);
+                }
+                STAMP(3);
+                off += S;
+            }
+        }
+        if (whole) {
+            // ---- un-decimated block (the common case), both channels together: post-twiddle fused with the windowed
+            //      overlap-add (oracle/orc_fourier.c orc_imdct), inverse M/S in registers, interleaved stores
+            __syncthreads();
+            STAMP(4);
             int ov = BS;                                             // ulcDecoder.c:234-239
             if (pat0 & 8) ov >>= (wc & 7);
             if (ov > lastSub) ov = lastSub;
             if (!(c.dbgSkip & 4)) {
                 const int S = BS, M = M0;
+                const float2 *pre = c.T.pre[0];
                 const float2 *z0 = z, *z1 = z + Mp0;
                 const int a = (S - ov) >> 1;
                 const float *fall = c.T.winFall + ov, *rise = c.T.winRise + ov;
@@ -750,12 +813,15 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                     L1[2 * k1] = yb1.x; L1[2 * k1 + 1] = -yb2.y;
                 }
             }
+            STAMP(5);
             __syncthreads();
+            STAMP(6);
             lastSub = BS;
-        } else if (fastStream && BS <= 64 * DEC_MAXT * 2) {
-            // ---- stereo, decimated block: one wave per channel, everything in LDS, then both channels together:
+        } else {
+            // ---- decimated block: each wave finishes its channel in LDS, then both channels together:
             //      inverse M/S (ulcDecoder.c:281-289) + interleave (:292-297)
-            const int newLast = dec_channel_wave<DEC_MAXT>(c, sw, z + wv * Mp0, lap + wv * H2, wv, wc, pat0, lastSub, src, readBytes, mw, ustart, udraw, blkNyb, seed, tmag);
+            WAVE_SYNC();
+            const int newLast = dec_time_wave<DEC_MAXT>(c, zc, lap + wv * H2, wc, pat0, nsub, lastSub, lane);
             __syncthreads();
             const float *t0 = (const float *)z, *t1 = (const float *)(z + Mp0);
             for (int n = 2 * tid; n < BS; n += 2 * WG) {
@@ -764,10 +830,70 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
             }
             __syncthreads();
             lastSub = newLast;
-        } else {
-            // ---- general path (mono / multichannel / decimated blocks / large BlockSize): one (channel, subblock) at a time
-            //      through ONE LDS array, the lapping state and the staging of the time samples in global memory
-            if (fastStream) { for (int i = tid; i < 2 * H2; i += WG) glap[i] = lap[i]; __syncthreads(); }
+            STAMP(7);
+        }
+    }
+#ifdef ULCX_DSYN_STAMPS
+    if (lane == 0) for (int i = 0; i < 12; i++) ((unsigned long long *)(c.scratch + (size_t)s * 4 * BS))[wv * 12 + i] = stq.t[i];
+#endif
+    for (int i = tid; i < 2 * H2; i += WG) glap[i] = lap[i];
+    if (tid == 0) { c.lastSub[s] = lastSub; c.seed[s] = seed; c.dead[s] = dead; }
+}
+
+// ---------------------------------------------------------------------------
+// Everything else (mono / multichannel / BlockSize > 4096): one (channel, subblock) at a time through ONE LDS array,
+// the lapping state and the staging of the time samples in global memory.  Correct for every geometry the
+// reference accepts (ulcDecoder.c:33-35: up to 255 channels, BlockSize up to 32768), not tuned.
+// ---------------------------------------------------------------------------
+template <typename OUT>
+__global__ __launch_bounds__(WG) void k_dgen(UlcxDecCtx c) {
+    extern __shared__ float lds[];
+    const int BS = c.BS, C = c.C, H2 = BS / 2;
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const DsynLds L = dsyn_lds(BS, C, 0, 0);
+    float2 *z = (float2 *)lds;
+    SynWave sw;
+    sw.list = (uint2 *)(lds + L.zFloats) + wv * (NOISE_CAP + 64);
+    sw.pre  = (int *)(sw.list + NOISE_CAP);
+    sw.seedTab = (uint32_t *)(sw.pre + 64);
+    sw.lane = lane;
+#ifdef ULCX_DSYN_STAMPS
+    sw.stp = nullptr;
+#endif
+    float *glap = c.lap + (size_t)s * C * H2;
+    int lastSub = c.lastSub[s];
+    int dead = c.dead[s];
+    uint32_t seed = c.seed[s];
+    float *scr = c.scratch + (size_t)s * 4 * BS;                     // staging: dst[2][BS] | dec[BS] | tmpq[BS/2]
+    for (int k = 0; k < c.K; k++) {
+        const int blk = s * c.K + k;
+        const int wc = c.wcScan[blk];
+        if (wc == 0) dead = 1;                                       // a corrupt block ends the stream (ulcDecodeTool.c:154-157)
+        OUT *outp = out_base<OUT>(c) + (size_t)blk * C * BS;
+        if (dead) {
+            for (int i = tid; i < C * BS; i += WG) st1(outp + i, 0.0f);
+            if (tid == 0) c.bits[blk] = 0;
+            continue;
+        }
+        const uint8_t *src = block_ptr(c, blk);
+        const int readBytes = block_read_bytes(c, blk);
+        const int blkNyb = c.bits[blk] >> 2;
+        const int *ustart = c.unitStart + (size_t)blk * C * 4;
+        const int *udraw = c.unitDraws + (size_t)blk * C * 4;
+        const unsigned long long *mw = c.startMask + (size_t)blk * c.maskWords;
+        const float *tmag = c.tailMag + (size_t)blk * C * 4 * c.tailStride;
+        const unsigned pat0 = ulcx_pattern(wc);
+        const bool whole = (BS >> (pat0 & 7)) == BS;                 // one subblock per channel (ulcDecoder.c:242-245)
+        int nsub = 1;
+        if (!whole) { nsub = 0; unsigned q = pat0; do nsub++; while (q >>= 4); }
+        // nybble at which unit (ch, j) ends = where the next unit starts, or the end of the block's codes
+        auto unit_end = [&](int ch, int j) {
+            if (j + 1 < nsub) return ustart[ch * 4 + j + 1];
+            if (ch + 1 < C) return ustart[(ch + 1) * 4];
+            return blkNyb;
+        };
+        {
             float *dec = scr + 2 * BS, *tmpq = scr + 3 * BS;
             int newLast = lastSub;
             for (int ch = 0; ch < C; ch++) {
@@ -869,11 +995,9 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                 }
             }
             lastSub = newLast;
-            if (fastStream) { for (int i = tid; i < 2 * H2; i += WG) lap[i] = glap[i]; __syncthreads(); }
         }
         seed = rng_jump(c.jumpT, seed, (uint32_t)c.draws[blk]);      // the one RNG chain of the stream (ulcDecoder.c:75-81)
     }
-    if (fastStream) for (int i = tid; i < 2 * H2; i += WG) glap[i] = lap[i];
     if (tid == 0) { c.lastSub[s] = lastSub; c.seed[s] = seed; c.dead[s] = dead; }
 }
 
@@ -892,11 +1016,13 @@ int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev) {
     else hipLaunchKernelGGL(k_dscan, dim3((NB + 63) / 64), dim3(64), 0, st, c);
     if (ev) CK(hipEventRecord(ev[stage++], st));
     size_t lds = ulcx_dec_lds_bytes(c.BS, c.C, c.fastOK, c.twInLds);
-    const bool small = c.BS <= 2048;                      // register slots of the decimated-block path (dec_channel_wave)
-    const void *fn = c.pcm16 ? (small ? (const void *)k_dsyn<int16_t, 16> : (const void *)k_dsyn<int16_t, 32>)
+    const bool small = c.BS <= 2048;                      // register slots of the decimated-block path (dec_time_wave)
+    const void *fn = !c.fastOK ? (c.pcm16 ? (const void *)k_dgen<int16_t> : (const void *)k_dgen<float>)
+                   : c.pcm16 ? (small ? (const void *)k_dsyn<int16_t, 16> : (const void *)k_dsyn<int16_t, 32>)
                              : (small ? (const void *)k_dsyn<float, 16> : (const void *)k_dsyn<float, 32>);
     if (lds > 48 * 1024) CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (c.dbgSkip & 8) {}
+    else if (!c.fastOK) { if (c.pcm16) hipLaunchKernelGGL(k_dgen<int16_t>, dim3(c.B), dim3(WG), lds, st, c); else hipLaunchKernelGGL(k_dgen<float>, dim3(c.B), dim3(WG), lds, st, c); }
     else if (c.pcm16) { if (small) hipLaunchKernelGGL((k_dsyn<int16_t, 16>), dim3(c.B), dim3(WG), lds, st, c); else hipLaunchKernelGGL((k_dsyn<int16_t, 32>), dim3(c.B), dim3(WG), lds, st, c); }
     else { if (small) hipLaunchKernelGGL((k_dsyn<float, 16>), dim3(c.B), dim3(WG), lds, st, c); else hipLaunchKernelGGL((k_dsyn<float, 32>), dim3(c.B), dim3(WG), lds, st, c); }
     if (ev) CK(hipEventRecord(ev[stage++], st));
