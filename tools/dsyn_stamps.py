@@ -21,7 +21,7 @@ print("decimated blocks: %.1f %%" % (100.0 * np.mean((wc & 8) != 0)))
 out = np.zeros((B, 24), np.uint64)
 l = ulc_amd.lib(); l.ulcx_decoder_debug_scratch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
 rc = l.ulcx_decoder_debug_scratch(dec.h, out.ctypes.data, 4 * 2048 * 4, 192, B)
-names = ["hdr loads", "zero+seed", "synth tail", "pretw+fft", "barrier A", "post", "barrier B", "other blocks", "decode rounds", "sync", "noise", "-"]
+names = ["hdr", "zero+seed", "synth-tail", "fft", "barrierA", "post", "barrierB", "dec-time", "decode-rounds", "noise-setup", "noise-draws", "pretw"]
 tot = out.astype(np.float64).mean(axis=0)
 for w in range(2):
-    print("wave", w, "  ".join("%s %.0f" % (names[i], tot[w * 12 + i] / K) for i in range(11)), " sum/blk %.0f cycles" % (tot[w * 12: w * 12 + 12].sum() / K))
+    print("wave", w, "  ".join("%s %.0f" % (names[i], tot[w * 12 + i] / K) for i in range(12)), " sum/blk %.0f cycles" % (tot[w * 12: w * 12 + 12].sum() / K))

@@ -410,12 +410,14 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     DA(c.draws, NB, true);
     DA(c.packOff, B, true);
     DA(c.blkOff, NB, true);
-    DA(c.unitStart, NB * nChan * 4, true);
     DA(c.unitDraws, NB * nChan * 4, true);
     DA(c.unitTail, NB * nChan * 4, true);
-    // a block of this geometry has at most 2*C*BS + 16 bytes (4 nybbles per coefficient + header): one start bit per nybble
-    c.maskWords = (2 * (2 * nChan * BlockSize + 16) + 63) / 64 + 1;
-    DA(c.startMask, NB * (size_t)c.maskWords, false);
+    DA(c.unitRec, NB * nChan * 4, true);
+    // what the scan leaves for the synthesis: at most one plain-run record per coefficient, one noise record per 16 (+ a tail per unit)
+    c.precStride = nChan * BlockSize;
+    c.nrecStride = nChan * BlockSize / 16 + nChan * 4;
+    DA(c.prec, NB * (size_t)c.precStride, false);
+    DA(c.nrec, NB * (size_t)c.nrecStride, false);
     c.tailStride = BlockSize / 32;
     DA(c.tailMag, NB * nChan * 4 * (size_t)c.tailStride, false);
     DA(c.scratch, B * 4 * (size_t)BlockSize, false);
@@ -445,8 +447,6 @@ static int decode_dev_any(ulcx_decoder *e, const uint8_t *d_in, int slotBytes, i
     UlcxDecCtx c = e->ctx;
     c.K = nBlocks; c.slot = slotBytes; c.in = d_in; c.pcm = d_pcm; c.pcm16 = d_pcm16; c.bits = d_bits;
     c.inBytes = (long long)e->B * nBlocks * slotBytes;
-    // one start bit per nybble of a slot (slots longer than any block of this geometry: the walk stops where the bits end)
-    if ((2 * (long long)slotBytes + 63) / 64 + 1 < c.maskWords) c.maskWords = (int)((2 * (long long)slotBytes + 63) / 64 + 1);
     int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->ev);
     e->evRecorded = (rc == ULCX_OK);
     return rc;

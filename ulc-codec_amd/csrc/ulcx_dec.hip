@@ -2,16 +2,17 @@
 //
 // Two kernels per call; dequantised coefficients never exist in HBM:
 //   k_dscan   one lane per block: the serial syntax walk (libulc/ulcDecoder.c:99-197, syntax
-//             FormatSpecs.md:57-141) reduced to what cannot be done in parallel - where codes START
-//             (one bit per nybble of the block), where each (channel, subblock) unit starts, how many
-//             RNG draws it makes, and the decaying-noise magnitude chain of each unit's tail.
-//   k_dsyn    one workgroup (2 waves) per stream, blocks in order, lapping state in LDS: every nybble
-//             that starts a code is decoded by its own lane (positions, quantizers and draw indices are
-//             wave prefix scans), coefficients are written STRAIGHT INTO the FFT's LDS arrays, noise
-//             runs are synthesised 32 coefficients per lane from a jumped-ahead xorshift state, then
-//             IMDCT (one DCT-IV = complex FFT per channel, one wave per array, no barrier between the
-//             passes), sine-window overlap-add, reversed-time centring FIFO, inverse M/S, interleave
+//             FormatSpecs.md:57-141).  It is the one thing that cannot be done in parallel, so it does
+//             nothing but walk and take notes: 8-byte records of the runs of coded coefficients and of
+//             the noise runs (about 1 KB per block instead of 16 KB of coefficients), RNG draw counts,
+//             and the decaying-noise level chain of each unit's tail.
+//   k_dsyn    stereo streams: one workgroup (2 waves) per stream, blocks in order, one wave per channel:
+//             the records are scattered STRAIGHT INTO the FFT's LDS arrays, noise runs are synthesised
+//             32 coefficients per lane from a jumped-ahead xorshift state, then IMDCT (one DCT-IV =
+//             complex FFT per channel, one wave per array, no barrier between the passes), sine-window
+//             overlap-add, reversed-time centring FIFO, inverse M/S, interleave
 //             (libulc/ulcDecoder.c:198-302; IMDCT per FormatSpecs.md:150-157).
+//   k_dgen    every other geometry (mono, multichannel, BlockSize > 4096): same pieces, one array.
 // Compiled with -ffp-contract=off (see ulcx_enc.hip).
 #include "ulcx_internal.h"
 
@@ -83,30 +84,6 @@ __device__ __forceinline__ int plain_prefix(uint32_t w) {
     sp |= 0x80000000u;                                   // the 8th nybble is not part of the window
     return (__ffs((int)sp) - 1) >> 2;                    // index of the first special nybble
 }
-typedef uint32_t u32_any_align __attribute__((aligned(1)));
-// 32-bit window at bit position pos; bytes at or past readBytes read as 0 (and are not touched)
-__device__ __forceinline__ uint32_t code_window(const uint8_t *p, int pos, int readBytes) {
-    int b = pos >> 3;
-    uint32_t w;
-    if (b + 4 <= readBytes) w = *(const u32_any_align *)(p + b);
-    else {
-        w = 0;
-        for (int i = 0; i < 4; i++) if (b + i < readBytes) w |= (uint32_t)p[b + i] << (8 * i);
-    }
-    return w >> (pos & 4);
-}
-
-// base pointer of block blk's bytes: its slot, or (packed mode) its parsed offset inside the stream payload
-__device__ __forceinline__ const uint8_t *block_ptr(const UlcxDecCtx &c, int blk) {
-    if (!c.packed) return c.in + (size_t)blk * c.slot;
-    return c.in + (size_t)(blk / c.K) * c.payStride + c.blkOff[blk];
-}
-// bytes of block blk that may be read
-__device__ __forceinline__ int block_read_bytes(const UlcxDecCtx &c, int blk) {
-    if (!c.packed) return c.slot;
-    return c.payBytes[blk / c.K] - c.blkOff[blk];
-}
-
 // ---------------------------------------------------------------------------
 // The scan's view of the stream: 16-byte aligned chunks kept in registers, the next one always in flight, so a
 // trip of the walk waits for memory once per 32 nybbles instead of once per code.
@@ -157,13 +134,18 @@ struct NybWin {
 };
 
 // Syntax walk of one block starting at p (limit = bits that may be consumed, readBytes = bytes that may be
-// used).  Records: bits / WindowCtrl / draws of the block; nybble index and draws-so-far at each unit's opening
-// code; one bit per nybble of the block that STARTS a code; parameters of each unit's decaying-noise tail.
-// Returns bits consumed (0 = corrupt).  One flat loop, one code (or one run of plain coefficients) per trip.
+// used).  The walk is the one thing that cannot be done in parallel; everything it learns on the way is left for the
+// synthesis in a form that can: per (channel, subblock) unit
+//   * PLAIN-RUN records, 8 bytes: up to seven consecutive coded coefficients {first coefficient | quantizer index << 15 |
+//     count << 20, their nybbles};
+//   * NOISE records, 8 bytes (the layout synth_noise reads): {first coefficient | count << 16 | tail << 31,
+//     draws made in the unit before the run | level << 16 | quantizer index << 21};
+//   * the unit's draws-so-far, its decaying-noise tail's parameters and (after the walk) the tail's level chain;
+// and bits / WindowCtrl / draws of the block.  Returns bits consumed (0 = corrupt).  One flat loop, one code (or one
+// run of plain coefficients) per trip.
 __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const uint8_t *p, int limit, int readBytes,
                                           const uint8_t *bufBeg, const uint8_t *bufEnd) {
     NybWin win; win.init(p, readBytes, bufBeg, bufEnd);
-    { const int cap = (c.maskWords * 64 - 8) * 4; limit = limit < cap ? limit : cap; }   // (beyond any block of this geometry: the start bitmap ends there)
     int pos = 0;
     int wc;
     {
@@ -177,61 +159,66 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
     int nsub = 0; { unsigned q = pat; do nsub++; while (q >>= 4); }
     if ((c.BS >> (pat & 7)) == c.BS) nsub = 1;                      // ulcDecoder.c:242-245
     int total = c.C * nsub;
-    int *ustart = c.unitStart + (size_t)blk * c.C * 4;
     int *udraw  = c.unitDraws + (size_t)blk * c.C * 4;
+    int4 *urec = c.unitRec + (size_t)blk * c.C * 4;
     float4 *utail = c.unitTail + (size_t)blk * c.C * 4;
-    unsigned long long *mw = c.startMask + (size_t)blk * c.maskWords;
-    int cw = 0; unsigned long long macc = 0;                        // mask word being filled
-    // mark nybbles [n0, n0+cnt) as code starts (cnt <= 7; consecutive calls never skip a whole word)
-    auto mark = [&](int n0, int cnt) {
-        const int w = n0 >> 6, b = n0 & 63;
-        if (w != cw) { if (cw < c.maskWords) mw[cw] = macc; macc = 0; cw = w; }
-        const unsigned long long m = (1ull << cnt) - 1ull;
-        macc |= m << b;
-        if (b + cnt > 64) { if (cw < c.maskWords) mw[cw] = macc; macc = m >> (64 - b); cw = w + 1; }
-    };
-    int u = 0, draws = 0, uslot = 0;
-    ustart[0] = pos >> 2; udraw[0] = 0;
+    uint2 *prec = c.prec + (size_t)blk * c.precStride;
+    uint2 *nrec = c.nrec + (size_t)blk * c.nrecStride;
+    int nP = 0, nN = 0, uP0 = 0, uN0 = 0;                           // records written so far in the block / at the current unit's start
+    int u = 0, draws = 0, uslot = 0, uDraw0 = 0;
+    udraw[0] = 0;
     utail[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     int S = c.BS >> (pat & 7), N = S;
     bool first = true;
     bool fin = (limit < 16), bad = fin;
     auto next_unit = [&]() {
+        urec[uslot] = make_int4(uP0, nP - uP0, uN0, nN - uN0);
         u++;
         fin = bad | (u >= total);
         if (!fin) {
             int ch = u / nsub, j = u - ch * nsub;
             uslot = ch * 4 + j;
-            ustart[uslot] = pos >> 2; udraw[uslot] = draws;
+            udraw[uslot] = draws; uDraw0 = draws;
             utail[uslot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            uP0 = nP; uN0 = nN;
             S = c.BS >> ((pat >> (4 * j)) & 7); N = S;
             first = true;
         }
     };
-    float quant = 0.0f;
+    int qidx = 30;                                                  // (index 30 expands to 0.0; every unit opens with a quantizer code)
     while (!fin) {
         const uint32_t w = win.at(pos);
         if (!first) {
-            // a run of plain coefficient nybbles (+-2..+-7) is consumed in one trip: the scan needs nothing
-            // from them but their count.  Never across the unit end or the 7 nybbles the window holds.
+            // a run of plain coefficient nybbles (+-2..+-7) is consumed in one trip.  Never across the unit end or the
+            // 7 nybbles the window holds.
             int m = plain_prefix(w);
             m = m < N ? m : N;
             if (m > 0 && pos + 4 * m <= limit) {
-                mark(pos >> 2, m);
+                if (nP < c.precStride) prec[nP] = make_uint2((uint32_t)(S - N) | ((uint32_t)qidx << 15) | ((uint32_t)m << 20), w & (0xFFFFFFFFu >> (32 - 4 * m)));
+                nP++;
                 pos += 4 * m; N -= m;
                 if (N == 0) next_unit();
                 continue;
             }
         }
         Code k = decode_code(w, first);
-        mark(pos >> 2, 1);
         const bool over = (k.zrun & (k.n > N)) | (k.n8 & (k.np > N));     // ulcDecoder.c:127,139,154
         const bool toEnd = k.stop | k.tail;
         const int used = over ? 0 : (toEnd ? N : k.n + k.np);
-        quant = (k.qnew >= 0) ? expand_quantizer(k.qnew) : quant;          // ulcDecoder.c:89-98
+        qidx = (k.qnew >= 0) ? k.qnew : qidx;                              // ulcDecoder.c:89-98
+        if (k.plain) {                                                     // (a plain coefficient the run path left: the block's bits end inside the run)
+            if (nP < c.precStride) prec[nP] = make_uint2((uint32_t)(S - N) | ((uint32_t)qidx << 15) | (1u << 20), w & 0xFu);
+            nP++;
+        }
+        if ((k.n8 | k.tail) & !over) {
+            const int np = k.tail ? N : k.np;
+            if (nN < c.nrecStride) nrec[nN] = make_uint2((uint32_t)(S - N) | ((uint32_t)(np - (k.tail ? 1 : 0)) << 16) | (k.tail ? 0x80000000u : 0u),
+                                                         (uint32_t)(draws - uDraw0) | ((uint32_t)k.l << 16) | ((uint32_t)qidx << 21));
+            nN++;
+        }
         if (k.tail & !over) {
             // ulcDecoder.c:163-186: start amplitude, decay, first coefficient, count; the chain itself runs after the walk
-            const float lev0 = (float)(k.l * k.l) * quant * (1.0f / 16);
+            const float lev0 = (float)(k.l * k.l) * expand_quantizer(qidx) * (1.0f / 16);
             const float rr = 1.0f + (float)(k.dn * k.dn) * -0x1.0p-19f;
             utail[uslot] = make_float4(lev0, rr, __int_as_float(S - N), __int_as_float(N));
         }
@@ -243,9 +230,6 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
         if ((N == 0) | over) next_unit();
         if (pos > limit) { bad = true; fin = true; }               // ran off the readable bytes: corrupt
     }
-    if (cw < c.maskWords) mw[cw] = macc;
-    // (the last code may reach into a word in which no code starts: the synthesis reads that word too)
-    if ((((pos >> 2) - 1) >> 6) > cw && cw + 1 < c.maskWords) mw[cw + 1] = 0ull;
     bool ok = !bad;
     c.bits[blk] = ok ? pos : 0;
     c.wcScan[blk] = ok ? wc : 0;
@@ -349,7 +333,6 @@ __device__ __forceinline__ int padf(int f) { return f + ((f >> 5) << 1); }
 // Noise runs found while decoding a unit, 8 bytes each:
 //   x = first coefficient | count << 16 (count - 1 for a tail, which may span the whole unit) | tail << 31
 //   y = draws made in the unit before the run | level << 16 | quantizer index << 21
-#define NOISE_CAP 96
 #ifdef ULCX_DSYN_STAMPS
 struct DsynStamps { unsigned long long t[12], t0; };
 #define SSTAMP(sw, i) do { if ((sw).stp) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); (sw).stp->t[i] += t_ - (sw).stp->t0; (sw).stp->t0 = t_; } } while (0)
@@ -358,7 +341,6 @@ struct DsynStamps { unsigned long long t[12], t0; };
 #endif
 struct SynWave {                 // one wave's working set while it synthesises one (channel, subblock) unit
     float *A;                    // the unit's coefficients = the FFT's input array (LDS, padded)
-    uint2 *list;                 // NOISE_CAP noise runs (LDS)
     int   *pre;                  // 64 prefix counts (LDS)
     uint32_t *seedTab;           // RNG state of the unit after every 32nd draw, 64 entries (LDS)
     int lane;
@@ -376,12 +358,12 @@ __device__ __forceinline__ uint32_t rng_jump_digit(const uint32_t *__restrict__ 
 }
 
 // Noise synthesis of the queued runs: one lane per (run, 32-coefficient chunk) piece.
-__device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &sw, int nE, uint32_t unitSeed, float tailRR, const float *tailMag) {
+__device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &sw, const uint2 *__restrict__ list, int nE, uint32_t unitSeed, float tailRR, const float *tailMag) {
     const int lane = sw.lane;
     for (int e0 = 0; e0 < nE; e0 += 64) {
         const int e = e0 + lane;
         const bool have = e < nE;
-        uint2 ent = have ? sw.list[e] : make_uint2(0u, 0u);
+        uint2 ent = have ? list[e] : make_uint2(0u, 0u);
         const int pos = ent.x & 0xFFFF, isTail = (int)(ent.x >> 31);
         const int np = (int)((ent.x >> 16) & 0x7FFF) + isTail;
         const int nseg = have ? ((pos + np - 1) >> 5) - (pos >> 5) + 1 : 0;
@@ -421,6 +403,7 @@ __device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &
             float lev = par ? -mag : mag;
             const float rr = rtail ? tailRR : 1.0f;
             float *dst = sw.A + padf(plo);                                                      // a piece never crosses a padding gap
+            SSTAMP(sw, 9);
 #pragma unroll
             for (int i = 0; i < 32; i++) {
                 // ulcDecoder.c:156-160 / :181-184: draw, flip on the top bit (cumulative), store, decay (r = 1 for runs)
@@ -434,82 +417,42 @@ __device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &
     }
 }
 
-// Dequantise one (channel, subblock) unit into A[0 .. S) (zeroed by the caller): nybbles [nyb0, nyb1) of the block.
-// Every nybble gets a lane; the lanes whose nybble starts a code (k_dscan's bitmap) decode it; where a code's
-// coefficients go, which quantizer is in force and how many draws precede it are prefix scans over the wave.
-// ONE round body and ONE noise-synthesis site in a rolled loop (the kernel has to stay inside the instruction cache);
-// the loads of a round (start bitmap word, the lane's code window) are issued two rounds ahead.
-__device__ __forceinline__ void synth_unit(const UlcxDecCtx &c, const SynWave &sw, int S, const uint8_t *src, int readBytes,
-                                           const unsigned long long *mw, int nyb0, int nyb1, uint32_t unitSeed, const float *tailMag) {
+// Dequantise one (channel, subblock) unit into A[0 .. S) (zeroed by the caller) from what the scan left: one lane per
+// plain-run record (up to seven coefficients each, ulcDecoder.c:69-73), then the noise runs (synth_noise).
+// ur = {first plain-run record, their count, first noise record, their count} of the unit.
+__device__ __forceinline__ void synth_unit(const UlcxDecCtx &c, const SynWave &sw, int S, const uint2 *__restrict__ prec, const uint2 *__restrict__ nrec,
+                                           int4 ur, uint32_t unitSeed, float tailRR, const float *tailMag) {
     const int lane = sw.lane;
-    int posBase = 0, drawBase = 0, qcur = 30;       // (the opening code always sets a quantizer; 30 expands to 0)
-    int nE = 0;
-    float tailRR = 1.0f;
     // seedTab[l] = RNG state after 32*l draws of the unit = unitSeed through T^(32 l): two table-driven steps per lane
-    // (hex digits 1 and 2 of 32*l); the second is taken after the first round so that both fly behind the decoding
+    // (hex digits 1 and 2 of 32*l), their loads in flight behind the coefficient scatter
     uint32_t sj = rng_jump_digit(c.jumpT, unitSeed, 1, (uint32_t)(lane & 7) << 1);
-    const int nFirst = nyb0 & ~63;
-    auto ld_mask = [&](int n0) -> unsigned long long { return (n0 < nyb1) ? mw[n0 >> 6] : 0ull; };                       // (wave-uniform)
-    auto ld_win  = [&](int n0) -> uint32_t { const int n = n0 + lane; return ((n >= nyb0) & (n < nyb1)) ? code_window(src, n * 4, readBytes) : 0u; };
-    unsigned long long W0 = ld_mask(nFirst), W1 = ld_mask(nFirst + 64);
-    uint32_t w0 = ld_win(nFirst), w1 = ld_win(nFirst + 64);
-    bool more = true;
-    for (int n0 = nFirst; more; n0 += 64) {
-        const bool rounds = n0 < nyb1;                                               // (wave-uniform) false: only the final flush is left
-        if (rounds) {
-            const unsigned long long W = W0; const uint32_t w = w0;
-            W0 = W1; w0 = w1;
-            W1 = ld_mask(n0 + 128); w1 = ld_win(n0 + 128);
-            if (n0 == nFirst) sj = rng_jump_digit(c.jumpT, sj, 2, (uint32_t)lane >> 3);
-            const int n = n0 + lane;
-            const bool in = (n >= nyb0) & (n < nyb1);
-            const bool isStart = in && ((W >> lane) & 1ull);
-            const Code k = decode_code(w, n == nyb0);
-            const int cnt = !isStart ? 0 : k.plain ? 1 : k.zrun ? k.n : k.n8 ? k.np : 0;
-            const int dr = (isStart && k.n8) ? k.np : 0;
-            const uint32_t packed = (uint32_t)cnt | ((uint32_t)dr << 16);
-            const uint32_t incl = wave_scan_add(packed);
-            const uint32_t excl = incl - packed;
-            const int pos = posBase + (int)(excl & 0xFFFFu);
-            const int d0 = drawBase + (int)(excl >> 16);
-            const uint32_t qv = (isStart && k.qnew >= 0) ? (((uint32_t)lane << 8) | (uint32_t)(k.qnew + 1)) : 0u;
-            const uint32_t qs = wave_scan_max(qv);
-            const int qi = (qs & 0xFFu) ? (int)(qs & 0xFFu) - 1 : qcur;
+    const uint2 *pr = prec + ur.x;
+    for (int r0 = 0; r0 < ur.y; r0 += 64) {
+        const int r = r0 + lane;
+        if (r < ur.y) {
+            const uint2 rec = pr[r];
+            const int pos = rec.x & 0x7FFF, qi = (rec.x >> 15) & 31, m = (rec.x >> 20) & 7;
             const float quant = expand_quantizer(qi);
-            if (isStart && k.plain && pos < S) sw.A[padf(pos)] = (float)k.sv * quant;  // ulcDecoder.c:69-73
-            const bool noisy = isStart && (k.n8 | k.tail) && pos < S;
-            const unsigned long long nm = __ballot(noisy);
-            if (nm) {
-                const int slot = nE + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0));
-                if (noisy && slot < NOISE_CAP) {
-                    int np = k.tail ? S - pos : k.np;
-                    np = np < S - pos ? np : S - pos;                                   // (cannot exceed it in a block the scan accepted)
-                    sw.list[slot] = make_uint2((uint32_t)pos | ((uint32_t)(np - (k.tail ? 1 : 0)) << 16) | (k.tail ? 0x80000000u : 0u),
-                                               (uint32_t)d0 | ((uint32_t)k.l << 16) | ((uint32_t)qi << 21));
-                }
-                const unsigned long long tm = __ballot(noisy && k.tail);
-                if (tm) {
-                    const float rr = 1.0f + (float)(k.dn * k.dn) * -0x1.0p-19f;           // ulcDecoder.c:171-175
-                    tailRR = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rr), __builtin_ctzll(tm)));
-                }
-                nE += __popcll(nm);
+            float *dst = sw.A + padf(pos);
+            const int gap = 32 - (pos & 31);                         // coefficients before the next padding gap
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                int sv = (int)((rec.y >> (4 * i)) & 0xF);
+                sv = (sv ^ 0x8) - 0x8;
+                sv = (sv < 0) ? (-sv * sv) : (+sv * sv);
+                if (i < m && pos + i < S) dst[i + (i >= gap ? 2 : 0)] = (float)sv * quant;
             }
-            const int inclLast = __builtin_amdgcn_readlane((int)incl, 63), qsLast = __builtin_amdgcn_readlane((int)qs, 63);
-            posBase += inclLast & 0xFFFF;
-            drawBase += (int)((uint32_t)inclLast >> 16);
-            qcur = (qsLast & 0xFF) ? (qsLast & 0xFF) - 1 : qcur;
         }
-        more = rounds;
-        // the queued noise runs: when the next round could overflow the list, and once after the last round
-        if (nE > NOISE_CAP - 64 || (!rounds && nE)) {
-            SSTAMP(sw, 8);
-            sw.seedTab[lane] = sj;
-            WAVE_SYNC();
-            synth_noise(c, sw, nE, unitSeed, tailRR, tailMag);
-            nE = 0;
-            SSTAMP(sw, 10);
-        }
+        if (r0 == 0) sj = rng_jump_digit(c.jumpT, sj, 2, (uint32_t)lane >> 3);
     }
+    if (ur.y <= 0) sj = rng_jump_digit(c.jumpT, sj, 2, (uint32_t)lane >> 3);
+    SSTAMP(sw, 8);
+    if (ur.w > 0) {
+        sw.seedTab[lane] = sj;
+        WAVE_SYNC();
+        synth_noise(c, sw, nrec + ur.z, ur.w, unitSeed, tailRR, tailMag);
+    }
+    SSTAMP(sw, 10);
     WAVE_SYNC();
 }
 
@@ -639,7 +582,7 @@ __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int 
     l.zFloats = (fast ? 2 : 1) * 2 * FFT_PADDEDS(BS / 2, DPS);
     l.lapFloats = fast ? 2 * (BS / 2) : 0;
     l.twFloats = fast ? BS / 2 : 0;
-    l.listFloats = 2 * (2 * NOISE_CAP + 64 + 64) + 128;
+    l.listFloats = 2 * (64 + 64) + 128;
     (void)C; (void)twInLds;
     return l;
 }
@@ -659,10 +602,9 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
     float  *lap  = lds + L.zFloats;
     float2 *twl  = (float2 *)(lds + L.zFloats + L.lapFloats);        // FFT twiddles: the full-size table, or the three of a decimated block's sizes
     SynWave sw;
-    sw.list = (uint2 *)(lds + L.zFloats + L.lapFloats + L.twFloats) + wv * (NOISE_CAP + 64);
-    sw.pre  = (int *)(sw.list + NOISE_CAP);
+    sw.pre  = (int *)(lds + L.zFloats + L.lapFloats + L.twFloats) + wv * 128;
     sw.seedTab = (uint32_t *)(sw.pre + 64);
-    uint32_t *bseed = (uint32_t *)(lds + L.zFloats + L.lapFloats + L.twFloats + 2 * (2 * NOISE_CAP + 64 + 64));   // [0,64): RNG state at each block's start, [64,128): at its second channel
+    uint32_t *bseed = (uint32_t *)(lds + L.zFloats + L.lapFloats + L.twFloats + 2 * (64 + 64));   // [0,64): RNG state at each block's start, [64,128): at its second channel
     sw.lane = lane;
     float *glap = c.lap + (size_t)s * C * H2;
     for (int i = tid; i < 2 * H2; i += WG) lap[i] = glap[i];
@@ -710,12 +652,10 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
             if (tid == 0) c.bits[blk] = 0;
             continue;
         }
-        const uint8_t *src = block_ptr(c, blk);
-        const int readBytes = block_read_bytes(c, blk);
-        const int blkNyb = c.bits[blk] >> 2;
-        const int *ustart = c.unitStart + (size_t)blk * C * 4;
         const int *udraw = c.unitDraws + (size_t)blk * C * 4;
-        const unsigned long long *mw = c.startMask + (size_t)blk * c.maskWords;
+        const int4 *urec = c.unitRec + (size_t)blk * C * 4;
+        const float4 *utail = c.unitTail + (size_t)blk * C * 4;
+        const uint2 *prec = c.prec + (size_t)blk * c.precStride, *nrec = c.nrec + (size_t)blk * c.nrecStride;
         const float *tmag = c.tailMag + (size_t)blk * C * 4 * c.tailStride;
         const unsigned pat0 = ulcx_pattern(wc);
         const bool whole = (BS >> (pat0 & 7)) == BS;                 // one subblock per channel (ulcDecoder.c:242-245)
@@ -740,10 +680,9 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                 float2 *zj = zc + FFT_PADS(off >> 1, DPS);
                 for (int i = lane; i < Mp; i += 64) zj[i] = make_float2(0.0f, 0.0f);
                 sw.A = (float *)zj;
-                const int nyb1 = (j + 1 < nsub) ? ustart[wv * 4 + j + 1] : (wv + 1 < C) ? ustart[(wv + 1) * 4] : blkNyb;
                 const uint32_t unitSeed = (j == 0) ? bseed[wv * 64 + (k & 63)] : rng_jump(c.jumpT, bseed[k & 63], (uint32_t)udraw[wv * 4 + j]);
                 STAMP(1);
-                if (!(c.dbgSkip & 1)) synth_unit(c, sw, S, src, readBytes, mw, ustart[wv * 4 + j], nyb1, unitSeed, tmag + (size_t)(wv * 4 + j) * c.tailStride);
+                if (!(c.dbgSkip & 1)) synth_unit(c, sw, S, prec, nrec, urec[wv * 4 + j], unitSeed, utail[wv * 4 + j].y, tmag + (size_t)(wv * 4 + j) * c.tailStride);
                 STAMP(2);
                 // DCT-IV pre-twiddle in place: n and M-1-n together read and write the same two complex slots
                 const float2 *pre = c.T.pre[d];
@@ -755,6 +694,7 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                     zj[pn]  = cmulc(make_float2(a.x, b.y), pre[n]);
                     zj[pn2] = cmulc(make_float2(b.x, a.y), pre[n2]);
                 }
+                STAMP(11);
                 fft_wave_dif(zj, M, twl + (d <= 1 ? 0 : d == 2 ? BS / 8 : 3 * BS / 16), lane, DPS);
                 }
                 STAMP(3);
@@ -854,8 +794,7 @@ __global__ __launch_bounds__(WG) void k_dgen(UlcxDecCtx c) {
     const DsynLds L = dsyn_lds(BS, C, 0, 0);
     float2 *z = (float2 *)lds;
     SynWave sw;
-    sw.list = (uint2 *)(lds + L.zFloats) + wv * (NOISE_CAP + 64);
-    sw.pre  = (int *)(sw.list + NOISE_CAP);
+    sw.pre  = (int *)(lds + L.zFloats) + wv * 128;
     sw.seedTab = (uint32_t *)(sw.pre + 64);
     sw.lane = lane;
 #ifdef ULCX_DSYN_STAMPS
@@ -876,23 +815,12 @@ __global__ __launch_bounds__(WG) void k_dgen(UlcxDecCtx c) {
             if (tid == 0) c.bits[blk] = 0;
             continue;
         }
-        const uint8_t *src = block_ptr(c, blk);
-        const int readBytes = block_read_bytes(c, blk);
-        const int blkNyb = c.bits[blk] >> 2;
-        const int *ustart = c.unitStart + (size_t)blk * C * 4;
         const int *udraw = c.unitDraws + (size_t)blk * C * 4;
-        const unsigned long long *mw = c.startMask + (size_t)blk * c.maskWords;
+        const int4 *urec = c.unitRec + (size_t)blk * C * 4;
+        const float4 *utail = c.unitTail + (size_t)blk * C * 4;
+        const uint2 *prec = c.prec + (size_t)blk * c.precStride, *nrec = c.nrec + (size_t)blk * c.nrecStride;
         const float *tmag = c.tailMag + (size_t)blk * C * 4 * c.tailStride;
         const unsigned pat0 = ulcx_pattern(wc);
-        const bool whole = (BS >> (pat0 & 7)) == BS;                 // one subblock per channel (ulcDecoder.c:242-245)
-        int nsub = 1;
-        if (!whole) { nsub = 0; unsigned q = pat0; do nsub++; while (q >>= 4); }
-        // nybble at which unit (ch, j) ends = where the next unit starts, or the end of the block's codes
-        auto unit_end = [&](int ch, int j) {
-            if (j + 1 < nsub) return ustart[ch * 4 + j + 1];
-            if (ch + 1 < C) return ustart[(ch + 1) * 4];
-            return blkNyb;
-        };
         {
             float *dec = scr + 2 * BS, *tmpq = scr + 3 * BS;
             int newLast = lastSub;
@@ -913,7 +841,7 @@ __global__ __launch_bounds__(WG) void k_dgen(UlcxDecCtx c) {
                     if (wv == 0) {
                         sw.A = (float *)z;
                         const uint32_t unitSeed = rng_jump(c.jumpT, seed, (uint32_t)udraw[ch * 4 + j]);
-                        synth_unit(c, sw, S, src, readBytes, mw, ustart[ch * 4 + j], unit_end(ch, j), unitSeed, tmag + (size_t)(ch * 4 + j) * c.tailStride);
+                        synth_unit(c, sw, S, prec, nrec, urec[ch * 4 + j], unitSeed, utail[ch * 4 + j].y, tmag + (size_t)(ch * 4 + j) * c.tailStride);
                     }
                     __syncthreads();
                     const float2 *pre = c.T.pre[d];

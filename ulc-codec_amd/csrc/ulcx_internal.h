@@ -107,10 +107,11 @@ struct UlcxDecCtx {
     // per-call scratch: what the scan leaves for the synthesis (ulcx_dec.hip)
     int   *wcScan;                       // [NB] WindowCtrl as the scan saw it (0 = corrupt)
     int   *draws;                        // [NB] RNG draws consumed by the block
-    int   *unitStart, *unitDraws;        // [NB][C*4] nybble index of / draws before each (chan,subblock) unit's opening code
+    int   *unitDraws;                    // [NB][C*4] draws made in the block before each (chan,subblock) unit
     float4 *unitTail;                    // [NB][C*4] decaying-noise tail of the unit: {start level, decay, first coefficient, count}
-    unsigned long long *startMask;       // [NB][maskWords] one bit per nybble of the block: a code starts here
-    int    maskWords;
+    int4  *unitRec;                      // [NB][C*4] {first plain-run record, count, first noise record, count} of the unit
+    uint2 *prec; int precStride;         // [NB][C*BS] plain-run records of the block (ulcx_dec.hip scan_block)
+    uint2 *nrec; int nrecStride;         // [NB][C*BS/16 + C*4] noise records
     float *tailMag;                      // [NB][C*4][tailStride] tail level at every 32nd coefficient of the unit
     int    tailStride;                   // BS/32
     float *scratch;                      // [B][4*BS] general-path staging of time samples (decimated / non-stereo blocks)
