@@ -345,7 +345,7 @@ static int dec_reset_state(ulcx_decoder *e) {
 // Tables of the noise RNG (ulcDecoder.c:75-81).  xorshift32 is linear over GF(2): a matrix is kept as its 32 columns.
 static uint32_t gf2_matvec(const uint32_t *col, uint32_t v) { uint32_t r = 0; for (int b = 0; b < 32; b++) if (v >> b & 1) r ^= col[b]; return r; }
 static void gf2_matmul(uint32_t *out, const uint32_t *A, const uint32_t *Bm) { uint32_t t[32]; for (int b = 0; b < 32; b++) t[b] = gf2_matvec(A, Bm[b]); memcpy(out, t, sizeof(t)); }
-static void build_rng_tables(std::vector<uint32_t> &jumpT, std::vector<uint32_t> &vtab, int BS) {
+static void build_rng_tables(std::vector<uint32_t> &jumpT) {
     auto step = [](uint32_t s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; };
     // jumpT[i][d][k][v]: byte k = v of the state, through T^(d * 16^i)
     jumpT.assign((size_t)8 * 16 * 4 * 256, 0u);
@@ -366,17 +366,6 @@ static void build_rng_tables(std::vector<uint32_t> &jumpT, std::vector<uint32_t>
         }
         gf2_matmul(Md, P, Md);                            // P^16 = the next position's unit
         memcpy(P, Md, sizeof(P));
-    }
-    // vtab[d] = XOR_{t=1..d} row 31 of T^t  (bit b of row 31 of T^t = top bit of T^t e_b)
-    vtab.assign((size_t)BS + 1, 0u);
-    uint32_t colv[32];
-    for (int b = 0; b < 32; b++) colv[b] = 1u << b;
-    uint32_t acc = 0;
-    for (int d = 1; d <= BS; d++) {
-        uint32_t row = 0;
-        for (int b = 0; b < 32; b++) { colv[b] = step(colv[b]); row |= (colv[b] >> 31) << b; }
-        acc ^= row;
-        vtab[d] = acc;
     }
 }
 
@@ -422,14 +411,12 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     DA(c.tailMag, NB * nChan * 4 * (size_t)c.tailStride, false);
     DA(c.scratch, B * 4 * (size_t)BlockSize, false);
     {
-        std::vector<uint32_t> jt, vt;
-        build_rng_tables(jt, vt, BlockSize);
-        uint32_t *dj = nullptr, *dv = nullptr;
+        std::vector<uint32_t> jt;
+        build_rng_tables(jt);
+        uint32_t *dj = nullptr;
         DA(dj, jt.size(), false);
-        DA(dv, vt.size(), false);
-        if (hipMemcpy(dj, jt.data(), sizeof(uint32_t) * jt.size(), hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(dv, vt.data(), sizeof(uint32_t) * vt.size(), hipMemcpyHostToDevice) != hipSuccess) { ulcx_set_error("hipMemcpy(rng tables)"); cleanup(e); return ULCX_ERR_HIP; }
-        c.jumpT = dj; c.vtab = dv;
+        if (hipMemcpy(dj, jt.data(), sizeof(uint32_t) * jt.size(), hipMemcpyHostToDevice) != hipSuccess) { ulcx_set_error("hipMemcpy(rng tables)"); cleanup(e); return ULCX_ERR_HIP; }
+        c.jumpT = dj;
     }
     for (auto &v : e->ev) { if (hipEventCreate(&v) != hipSuccess) { ulcx_set_error("hipEventCreate failed"); cleanup(e); return ULCX_ERR_HIP; } }
     e->evOk = true;

@@ -290,9 +290,6 @@ __global__ __launch_bounds__(64) void k_dscan_packed(UlcxDecCtx c) {
 // xorshift32 is linear over GF(2): the state after n draws is T^n * state.  jumpT holds T^(d*16^i) for every
 // hexadecimal digit d of n at every position i, each as four 256-entry byte tables (host-built, ulcx_api.cpp):
 // a jump costs one table-driven mat-vec (4 lookups) per non-zero digit.
-// vtab[d] = XOR over t = 1..d of row 31 of T^t: the parity of popcount(vtab[d] & s) says whether an odd number of
-// the first d draws from state s had their top bit set - the sign a run of noise has reached after d coefficients
-// (ulcDecoder.c:156-160: the sign flips cumulatively on every draw with the top bit set).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t rng_jump(const uint32_t *__restrict__ jt, uint32_t s, uint32_t n) {
     for (int i = 0; n; i++, n >>= 4) {
@@ -342,7 +339,7 @@ struct DsynStamps { unsigned long long t[12], t0; };
 struct SynWave {                 // one wave's working set while it synthesises one (channel, subblock) unit
     float *A;                    // the unit's coefficients = the FFT's input array (LDS, padded)
     int   *pre;                  // 64 prefix counts (LDS)
-    uint32_t *seedTab;           // RNG state of the unit after every 32nd draw, 64 entries (LDS)
+    uint32_t *seedTab;           // the unit's sign-parity stream P (LDS, synth_noise)
     int lane;
 #ifdef ULCX_DSYN_STAMPS
     DsynStamps *stp;
@@ -357,63 +354,91 @@ __device__ __forceinline__ uint32_t rng_jump_digit(const uint32_t *__restrict__ 
     return dgt ? r : s;
 }
 
-// Noise synthesis of the queued runs: one lane per (run, 32-coefficient chunk) piece.
-__device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &sw, const uint2 *__restrict__ list, int nE, uint32_t unitSeed, float tailRR, const float *tailMag) {
+// Noise synthesis (ulcDecoder.c:146-160, :166-186).  The decoder draws one xorshift value per noise coefficient and
+// only ever looks at its top bit: the sign of the run's level flips, cumulatively, on every draw with the top bit set.
+//   1. the unit's draws, densely: lane l makes draws 32l+1 .. 32l+32 from the state its jump gave it (sj = T^(32l) * unit
+//      seed) and keeps their top bits; a prefix XOR inside the word and a parity carry across the lanes turn them into
+//      P: bit n of the stream = parity of the top bits of draws 1 .. n+1.  P goes to LDS (2048 bits per pass).
+//   2. one lane per (run, 32-coefficient chunk) piece: 32 sign bits are a window of P (xor the parity at the run's
+//      start), the level is the run's constant or the tail's chain value at the chunk (k_dscan) decaying from there.
+// No sequential generator in step 2, no jumps, and every coefficient is written exactly once.
+__device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &sw, const uint2 *__restrict__ list, int nE, uint32_t sj, int unitDraws,
+                                            float tailRR, const float *tailMag) {
     const int lane = sw.lane;
-    for (int e0 = 0; e0 < nE; e0 += 64) {
-        const int e = e0 + lane;
-        const bool have = e < nE;
-        uint2 ent = have ? list[e] : make_uint2(0u, 0u);
-        const int pos = ent.x & 0xFFFF, isTail = (int)(ent.x >> 31);
-        const int np = (int)((ent.x >> 16) & 0x7FFF) + isTail;
-        const int nseg = have ? ((pos + np - 1) >> 5) - (pos >> 5) + 1 : 0;
-        const uint32_t incl = wave_scan_add((uint32_t)nseg);
-        const int total = __builtin_amdgcn_readlane((int)incl, 63);
-        sw.pre[lane] = have ? (int)(incl - nseg) : 0x7FFFFFFF;
-        WAVE_SYNC();
-        for (int sb = 0; sb < total; sb += 64) {
-            const int si = sb + lane;
-            const bool act = si < total;
-            // the run this piece belongs to: the last one whose first piece is at or before si
-            int lo = 0, hi = 63;
+    uint32_t *P = sw.seedTab;                                 // the unit's whole stream: max(64, BS/32) words + a zero word
+    // ---- 1. sign-parity stream, 2048 draws per pass (one pass unless the unit has more than 2048 noise coefficients)
+    uint32_t passPar = 0;                                     // parity of the top bits of all earlier passes
+    for (int dbase = 0; dbase < unitDraws; dbase += 2048) {
+        uint32_t seed = sj, W = 0;
 #pragma unroll
-            for (int it = 0; it < 6; it++) { int mid = (lo + hi + 1) >> 1; bool le = sw.pre[mid] <= si; lo = le ? mid : lo; hi = le ? hi : mid - 1; }
-            const int j = act ? lo : 0;
-            const uint32_t ex = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)ent.x);
-            const uint32_t ey = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)ent.y);
-            const int first = __builtin_amdgcn_ds_bpermute(j << 2, (int)(incl - nseg));
-            const int rpos = ex & 0xFFFF, rtail = (int)(ex >> 31), rnp = (int)((ex >> 16) & 0x7FFF) + rtail;
-            const int d0 = ey & 0xFFFF, lvl = (ey >> 16) & 31, qi = (ey >> 21) & 63;
-            const int chunk = (rpos >> 5) + (act ? si - first : 0);          // (idle lanes shadow the first piece of run 0: every address they form is valid)
-            const int plo = rpos > (chunk << 5) ? rpos : (chunk << 5);
-            const int phi = (rpos + rnp) < ((chunk << 5) + 32) ? (rpos + rnp) : ((chunk << 5) + 32);
-            const int n = act ? phi - plo : 0;
-            const int off = plo - rpos;
-            const int d = d0 + off;
-            // state after d draws: the table entry at or below d, then d % 32 single steps
-            uint32_t seed;
-            if (d < SEEDTAB_DRAWS) {
-                seed = sw.seedTab[d >> 5];
-                for (int st = d & 31; __any(st > 0); st--) seed = (st > 0) ? xorshift32(seed) : seed;
-            } else seed = rng_jump(c.jumpT, unitSeed, (uint32_t)d);
-            const int par = (__popc(c.vtab[d] & unitSeed) ^ __popc(c.vtab[d0] & unitSeed)) & 1;
-            const float quant = expand_quantizer(qi);
-            float mag = (float)(lvl * lvl) * quant * (rtail ? (1.0f / 16) : (1.0f / 4));      // ulcDecoder.c:146-150, :166-170
-            if (rtail && off > 0) mag = tailMag[chunk];                                         // the tail's chain at coefficient 32*chunk (k_dscan)
-            float lev = par ? -mag : mag;
-            const float rr = rtail ? tailRR : 1.0f;
-            float *dst = sw.A + padf(plo);                                                      // a piece never crosses a padding gap
-            SSTAMP(sw, 9);
-#pragma unroll
-            for (int i = 0; i < 32; i++) {
-                // ulcDecoder.c:156-160 / :181-184: draw, flip on the top bit (cumulative), store, decay (r = 1 for runs)
-                seed = xorshift32(seed);
-                lev = __uint_as_float(__float_as_uint(lev) ^ (seed & 0x80000000u));
-                if (i < n) dst[i] = lev;
-                lev *= rr;
-            }
+        for (int i = 0; i < 32; i++) { seed = xorshift32(seed); W = (W >> 1) | (seed & 0x80000000u); }   // bit i = top bit of draw dbase+32*lane+i+1
+        uint32_t x = W;
+        x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16;                                 // bit i = parity of bits 0..i
+        const unsigned long long odd = __ballot((__popc(W) & 1) != 0);
+        const uint32_t carry = ((uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(odd >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)odd, 0)) + passPar) & 1u;
+        P[(dbase >> 5) + lane] = carry ? ~x : x;
+        passPar ^= (uint32_t)__popcll(odd) & 1u;
+        if (dbase + 2048 < unitDraws) {
+            // next pass: lane l needs the state 2048 + 32 l draws on = T^(32 l) of lane 63's end state
+            const uint32_t endState = (uint32_t)__builtin_amdgcn_readlane((int)seed, 63);
+            sj = rng_jump(c.jumpT, endState, (uint32_t)lane << 5);
         }
-        WAVE_SYNC();
+    }
+    if (lane == 0) P[((unitDraws + 2047) >> 11) << 6] = 0u;   // the word behind the last pass: windows at the very end read it
+    WAVE_SYNC();
+    {
+        // ---- 2. pieces
+        for (int e0 = 0; e0 < nE; e0 += 64) {
+            const int e = e0 + lane;
+            const bool have = e < nE;
+            const uint2 ent = have ? list[e] : make_uint2(0u, 0u);
+            const int pos = ent.x & 0xFFFF, isTail = (int)(ent.x >> 31);
+            const int np = (int)((ent.x >> 16) & 0x7FFF) + isTail;
+            const int nseg = have ? ((pos + np - 1) >> 5) - (pos >> 5) + 1 : 0;
+            const uint32_t incl = wave_scan_add((uint32_t)nseg);
+            const int total = __builtin_amdgcn_readlane((int)incl, 63);
+            sw.pre[lane] = have ? (int)(incl - nseg) : 0x7FFFFFFF;
+            WAVE_SYNC();
+            for (int sb = 0; sb < total; sb += 64) {
+                const int si = sb + lane;
+                const bool act = si < total;
+                // the run this piece belongs to: the last one whose first piece is at or before si
+                int lo = 0, hi = 63;
+#pragma unroll
+                for (int it = 0; it < 6; it++) { int mid = (lo + hi + 1) >> 1; bool le = sw.pre[mid] <= si; lo = le ? mid : lo; hi = le ? hi : mid - 1; }
+                const int j = act ? lo : 0;
+                const uint32_t ex = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)ent.x);
+                const uint32_t ey = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)ent.y);
+                const int first = __builtin_amdgcn_ds_bpermute(j << 2, (int)(incl - nseg));
+                const int rpos = ex & 0xFFFF, rtail = (int)(ex >> 31), rnp = (int)((ex >> 16) & 0x7FFF) + rtail;
+                const int d0 = ey & 0xFFFF, lvl = (ey >> 16) & 31, qi = (ey >> 21) & 63;
+                const int chunk = (rpos >> 5) + (act ? si - first : 0);          // (idle lanes shadow the first piece of run 0: every address they form is valid)
+                const int plo = rpos > (chunk << 5) ? rpos : (chunk << 5);
+                const int phi = (rpos + rnp) < ((chunk << 5) + 32) ? (rpos + rnp) : ((chunk << 5) + 32);
+                const int off = plo - rpos;
+                const int dc = d0 + off;                                         // draws of the unit in front of the piece's first coefficient
+                const int n = act ? phi - plo : 0;
+                // sign bits of the piece: P bits dc .. dc+31 (parity after its i-th draw), relative to the parity where the run began
+                uint32_t win = __builtin_amdgcn_alignbit(P[(dc >> 5) + 1], P[dc >> 5], dc & 31);
+                uint32_t s0 = 0;                                                 // parity where the run began
+                if (d0 > 0) s0 = (P[(d0 - 1) >> 5] >> ((d0 - 1) & 31)) & 1u;
+                win ^= 0u - s0;
+                const float quant = expand_quantizer(qi);
+                float mag = (float)(lvl * lvl) * quant * (rtail ? (1.0f / 16) : (1.0f / 4));      // ulcDecoder.c:146-150, :166-170
+                if (rtail && off > 0) mag = tailMag[chunk];                                         // the tail's chain at coefficient 32*chunk (k_dscan)
+                const float rr = rtail ? tailRR : 1.0f;
+                float *dst = sw.A + padf(plo);                                                      // a piece never crosses a padding gap
+                SSTAMP(sw, 9);
+#pragma unroll
+                for (int i = 0; i < 32; i++) {
+                    // ulcDecoder.c:156-160 / :181-184: flip on the draw's top bit (cumulative), store, decay (r = 1 for runs)
+                    const float v = __uint_as_float(__float_as_uint(mag) | ((win << (31 - i)) & 0x80000000u));
+                    if (i < n) dst[i] = v;
+                    mag *= rr;
+                }
+            }
+            WAVE_SYNC();
+        }
     }
 }
 
@@ -421,7 +446,7 @@ __device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &
 // plain-run record (up to seven coefficients each, ulcDecoder.c:69-73), then the noise runs (synth_noise).
 // ur = {first plain-run record, their count, first noise record, their count} of the unit.
 __device__ __forceinline__ void synth_unit(const UlcxDecCtx &c, const SynWave &sw, int S, const uint2 *__restrict__ prec, const uint2 *__restrict__ nrec,
-                                           int4 ur, uint32_t unitSeed, float tailRR, const float *tailMag) {
+                                           int4 ur, uint32_t unitSeed, int unitDraws, float tailRR, const float *tailMag) {
     const int lane = sw.lane;
     // seedTab[l] = RNG state after 32*l draws of the unit = unitSeed through T^(32 l): two table-driven steps per lane
     // (hex digits 1 and 2 of 32*l), their loads in flight behind the coefficient scatter
@@ -448,9 +473,7 @@ __device__ __forceinline__ void synth_unit(const UlcxDecCtx &c, const SynWave &s
     if (ur.y <= 0) sj = rng_jump_digit(c.jumpT, sj, 2, (uint32_t)lane >> 3);
     SSTAMP(sw, 8);
     if (ur.w > 0) {
-        sw.seedTab[lane] = sj;
-        WAVE_SYNC();
-        synth_noise(c, sw, nrec + ur.z, ur.w, unitSeed, tailRR, tailMag);
+        synth_noise(c, sw, nrec + ur.z, ur.w, sj, unitDraws, tailRR, tailMag);
     }
     SSTAMP(sw, 10);
     WAVE_SYNC();
@@ -576,13 +599,14 @@ template <> __device__ __forceinline__ int16_t *out_base<int16_t>(const UlcxDecC
 
 // LDS carve, in floats.  Stereo kernel (k_dsyn):  z [2 padded arrays of BS/2 complex] | lap [2][BS/2] | twl [BS/4 complex] |
 //   per wave: noise runs, prefix counts, seed table | 128 block / unit seeds.  General kernel (k_dgen): z [1 array] | per-wave lists.
+#define DSYN_PWORDS(BS) (((BS) / 32 > 64 ? (BS) / 32 : 64) + 2)
 struct DsynLds { int zFloats, lapFloats, twFloats, listFloats; };
 __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int twInLds) {
     DsynLds l;
     l.zFloats = (fast ? 2 : 1) * 2 * FFT_PADDEDS(BS / 2, DPS);
     l.lapFloats = fast ? 2 * (BS / 2) : 0;
     l.twFloats = fast ? BS / 2 : 0;
-    l.listFloats = 2 * (64 + 64) + 128;
+    l.listFloats = 2 * (64 + DSYN_PWORDS(BS)) + 128;             // per wave: prefix counts, sign-parity stream; per workgroup: 128 block / channel RNG states
     (void)C; (void)twInLds;
     return l;
 }
@@ -602,9 +626,9 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
     float  *lap  = lds + L.zFloats;
     float2 *twl  = (float2 *)(lds + L.zFloats + L.lapFloats);        // FFT twiddles: the full-size table, or the three of a decimated block's sizes
     SynWave sw;
-    sw.pre  = (int *)(lds + L.zFloats + L.lapFloats + L.twFloats) + wv * 128;
+    sw.pre  = (int *)(lds + L.zFloats + L.lapFloats + L.twFloats) + wv * (64 + DSYN_PWORDS(BS));
     sw.seedTab = (uint32_t *)(sw.pre + 64);
-    uint32_t *bseed = (uint32_t *)(lds + L.zFloats + L.lapFloats + L.twFloats + 2 * (64 + 64));   // [0,64): RNG state at each block's start, [64,128): at its second channel
+    uint32_t *bseed = (uint32_t *)(lds + L.zFloats + L.lapFloats + L.twFloats + 2 * (64 + DSYN_PWORDS(BS)));   // [0,64): RNG state at each block's start, [64,128): at its second channel
     sw.lane = lane;
     float *glap = c.lap + (size_t)s * C * H2;
     for (int i = tid; i < 2 * H2; i += WG) lap[i] = glap[i];
@@ -661,6 +685,7 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
         const bool whole = (BS >> (pat0 & 7)) == BS;                 // one subblock per channel (ulcDecoder.c:242-245)
         int nsub = 1;
         if (!whole) { nsub = 0; unsigned q = pat0; do nsub++; while (q >>= 4); }
+        auto unit_draws = [&](int ch, int j) { return ((j + 1 < nsub) ? udraw[ch * 4 + j + 1] : (ch + 1 < C) ? udraw[(ch + 1) * 4] : c.draws[blk]) - udraw[ch * 4 + j]; };
         if (whole != twFull) {
             // twiddle tables for this block's transform sizes: the full-size one, or those of N/2, N/4, N/8 back to back
             if (whole) for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
@@ -682,7 +707,7 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                 sw.A = (float *)zj;
                 const uint32_t unitSeed = (j == 0) ? bseed[wv * 64 + (k & 63)] : rng_jump(c.jumpT, bseed[k & 63], (uint32_t)udraw[wv * 4 + j]);
                 STAMP(1);
-                if (!(c.dbgSkip & 1)) synth_unit(c, sw, S, prec, nrec, urec[wv * 4 + j], unitSeed, utail[wv * 4 + j].y, tmag + (size_t)(wv * 4 + j) * c.tailStride);
+                if (!(c.dbgSkip & 1)) synth_unit(c, sw, S, prec, nrec, urec[wv * 4 + j], unitSeed, unit_draws(wv, j), utail[wv * 4 + j].y, tmag + (size_t)(wv * 4 + j) * c.tailStride);
                 STAMP(2);
                 // DCT-IV pre-twiddle in place: n and M-1-n together read and write the same two complex slots
                 const float2 *pre = c.T.pre[d];
@@ -794,7 +819,7 @@ __global__ __launch_bounds__(WG) void k_dgen(UlcxDecCtx c) {
     const DsynLds L = dsyn_lds(BS, C, 0, 0);
     float2 *z = (float2 *)lds;
     SynWave sw;
-    sw.pre  = (int *)(lds + L.zFloats) + wv * 128;
+    sw.pre  = (int *)(lds + L.zFloats) + wv * (64 + DSYN_PWORDS(BS));
     sw.seedTab = (uint32_t *)(sw.pre + 64);
     sw.lane = lane;
 #ifdef ULCX_DSYN_STAMPS
@@ -821,6 +846,10 @@ __global__ __launch_bounds__(WG) void k_dgen(UlcxDecCtx c) {
         const uint2 *prec = c.prec + (size_t)blk * c.precStride, *nrec = c.nrec + (size_t)blk * c.nrecStride;
         const float *tmag = c.tailMag + (size_t)blk * C * 4 * c.tailStride;
         const unsigned pat0 = ulcx_pattern(wc);
+        const bool whole = (BS >> (pat0 & 7)) == BS;                 // one subblock per channel (ulcDecoder.c:242-245)
+        int nsub = 1;
+        if (!whole) { nsub = 0; unsigned q = pat0; do nsub++; while (q >>= 4); }
+        auto unit_draws = [&](int ch, int j) { return ((j + 1 < nsub) ? udraw[ch * 4 + j + 1] : (ch + 1 < C) ? udraw[(ch + 1) * 4] : c.draws[blk]) - udraw[ch * 4 + j]; };
         {
             float *dec = scr + 2 * BS, *tmpq = scr + 3 * BS;
             int newLast = lastSub;
@@ -841,7 +870,7 @@ __global__ __launch_bounds__(WG) void k_dgen(UlcxDecCtx c) {
                     if (wv == 0) {
                         sw.A = (float *)z;
                         const uint32_t unitSeed = rng_jump(c.jumpT, seed, (uint32_t)udraw[ch * 4 + j]);
-                        synth_unit(c, sw, S, prec, nrec, urec[ch * 4 + j], unitSeed, utail[ch * 4 + j].y, tmag + (size_t)(ch * 4 + j) * c.tailStride);
+                        synth_unit(c, sw, S, prec, nrec, urec[ch * 4 + j], unitSeed, unit_draws(ch, j), utail[ch * 4 + j].y, tmag + (size_t)(ch * 4 + j) * c.tailStride);
                     }
                     __syncthreads();
                     const float2 *pre = c.T.pre[d];

@@ -116,7 +116,6 @@ struct UlcxDecCtx {
     int    tailStride;                   // BS/32
     float *scratch;                      // [B][4*BS] general-path staging of time samples (decimated / non-stereo blocks)
     const uint32_t *jumpT;               // [8][16][4][256] byte tables of T^(d*16^i), T = one xorshift32 step
-    const uint32_t *vtab;                // [BS+1] sign-parity functionals (ulcx_dec.hip)
     int    fastOK, twInLds;              // stereo fast path / FFT twiddles resident in LDS
     // packed-stream mode (.ulc payloads): blocks are located by parsing, not by slot
     int   packed;
