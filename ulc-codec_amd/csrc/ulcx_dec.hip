@@ -17,6 +17,7 @@
 #include "ulcx_internal.h"
 
 #define WG 128
+#define FFT_PACKED
 #include "ulcx_fft.h"
 #define DPS 4        // FFT array padding (ulcx_fft.h): one complex after every 16
 
@@ -186,27 +187,30 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
         }
     };
     int qidx = 30;                                                  // (index 30 expands to 0.0; every unit opens with a quantizer code)
+    // One trip = a run of plain coefficient nybbles (possibly empty), then ONE other code: every lane does both parts every
+    // trip, so lanes that alternate between the two kinds (the usual stream) do not wait for each other's other half.
     while (!fin) {
-        const uint32_t w = win.at(pos);
-        if (!first) {
-            // a run of plain coefficient nybbles (+-2..+-7) is consumed in one trip.  Never across the unit end or the
-            // 7 nybbles the window holds.
-            int m = plain_prefix(w);
-            m = m < N ? m : N;
-            if (m > 0 && pos + 4 * m <= limit) {
-                if (nP < c.precStride) prec[nP] = make_uint2((uint32_t)(S - N) | ((uint32_t)qidx << 15) | ((uint32_t)m << 20), w & (0xFFFFFFFFu >> (32 - 4 * m)));
-                nP++;
-                pos += 4 * m; N -= m;
-                if (N == 0) next_unit();
-                continue;
-            }
+        uint32_t w = win.at(pos);
+        // 1. plain coefficients (+-2..+-7), up to the seven the window holds.  Never across the unit end or the block's bits;
+        //    not at a unit's opening code.
+        int m = first ? 0 : plain_prefix(w);
+        m = m < N ? m : N;
+        m = (pos + 4 * m <= limit) ? m : 0;
+        if (m > 0) {
+            if (nP < c.precStride) prec[nP] = make_uint2((uint32_t)(S - N) | ((uint32_t)qidx << 15) | ((uint32_t)m << 20), w & (0xFFFFFFFFu >> (32 - 4 * m)));
+            nP++;
+            pos += 4 * m; N -= m;
+            if (N == 0) next_unit();
+            w = win.at(pos);
         }
+        if (fin) break;
+        // 2. one code
         Code k = decode_code(w, first);
         const bool over = (k.zrun & (k.n > N)) | (k.n8 & (k.np > N));     // ulcDecoder.c:127,139,154
         const bool toEnd = k.stop | k.tail;
         const int used = over ? 0 : (toEnd ? N : k.n + k.np);
         qidx = (k.qnew >= 0) ? k.qnew : qidx;                              // ulcDecoder.c:89-98
-        if (k.plain) {                                                     // (a plain coefficient the run path left: the block's bits end inside the run)
+        if (k.plain) {                                                     // (a plain coefficient part 1 left: the block's bits end inside the run)
             if (nP < c.precStride) prec[nP] = make_uint2((uint32_t)(S - N) | ((uint32_t)qidx << 15) | (1u << 20), w & 0xFu);
             nP++;
         }

@@ -155,9 +155,49 @@ __device__ void fftn_dif(float2 *z0, int nArr, int M, const float2 *__restrict__
 #define FFT_PADS(p, ps) ((p) + ((p) >> (ps)))
 #define FFT_PADDEDS(M, ps) ((M) + ((M) >> (ps)))
 
+// Packed binary32 arithmetic (v_pk_add_f32 / v_pk_mul_f32: both components of a complex number per instruction, each
+// component rounded exactly as the scalar instruction rounds it - no fusion, so the spec's operation order and results are
+// unchanged).  A radix-2 butterfly is 5 instructions instead of 10: sum, difference, two products (d * w.xx, d.yx * w.yy)
+// and one add whose high half is negated (m0 + m1, m2 - m3).
+typedef float fft_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fft_v2f fft_cmulc_pk(fft_v2f d, fft_v2f w) {      // d * conj(w), as cmulc
+    const fft_v2f p = d * __builtin_shufflevector(w, w, 0, 0);                                 // (d.x w.x, d.y w.x)
+    const fft_v2f q = __builtin_shufflevector(d, d, 1, 0) * __builtin_shufflevector(w, w, 1, 1);   // (d.y w.y, d.x w.y)
+    fft_v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(p), "v"(q));                     // (p.x + q.x, p.y - q.y)
+    return r;
+}
+
 template <int R>
 __device__ __forceinline__ void fft_wave_pass(float2 *z, int M, int h, const float2 *__restrict__ tw, int lane, int ps) {
     constexpr int NP = 1 << R;
+#ifdef FFT_PACKED
+    const int q = h >> (R - 1);                    // spacing of one lane's points
+    const int stepA = M / (2 * h);
+    fft_v2f *zv = (fft_v2f *)z; const fft_v2f *twv = (const fft_v2f *)tw;
+    for (int gg = lane; gg < (M >> R); gg += 64) {
+        int j = gg & (q - 1);
+        int p0 = ((gg - j) << R) + j;
+        fft_v2f x[NP];
+#pragma unroll
+        for (int m = 0; m < NP; m++) x[m] = zv[FFT_PADS(p0 + m * q, ps)];
+#pragma unroll
+        for (int s = 0; s < R; s++) {
+            const int half = NP >> (s + 1);
+#pragma unroll
+            for (int m = 0; m < NP; m++) {
+                if (m & half) continue;
+                int t = m & (half - 1);
+                const fft_v2f w = twv[(j + t * q) * (stepA << s)];
+                const fft_v2f a = x[m], b = x[m + half];
+                x[m] = a + b;
+                x[m + half] = fft_cmulc_pk(a - b, w);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NP; m++) zv[FFT_PADS(p0 + m * q, ps)] = x[m];
+    }
+#else
     const int q = h >> (R - 1);                    // spacing of one lane's points
     const int stepA = M / (2 * h);
     for (int gg = lane; gg < (M >> R); gg += 64) {
@@ -183,6 +223,7 @@ __device__ __forceinline__ void fft_wave_pass(float2 *z, int M, int h, const flo
 #pragma unroll
         for (int m = 0; m < NP; m++) z[FFT_PADS(p0 + m * q, ps)] = x[m];
     }
+#endif
 }
 
 // whole M-point transform of one padded array by one wave (M = 16 .. 4096)
