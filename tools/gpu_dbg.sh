@@ -1,4 +1,4 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 300 python tools/dsyn_stamps.py 256 2>&1 | grep -v amdgpu.ids
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | grep -v "^  \|^$" | tail -30

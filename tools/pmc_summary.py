@@ -5,7 +5,7 @@ Per kernel and per bench step (a kernel launched several times per step, e.g. th
   hbm_bytes = 2 * FETCH_SIZE + WRITE_SIZE      (both counters are in KiB)
 FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (it tallies 128-byte
 requests at 64 bytes for wide coalesced reads; other access widths are uncalibrated - the same guide).
-The number of steps in a run = launches of k_state_update<float> (encoder) / k_dimdct (decoder)."""
+The number of steps in a run = launches of k_state_update<float> (encoder) / k_dsyn (decoder)."""
 import csv, json, sys, collections
 
 def load(path, counter):

@@ -4,7 +4,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last step: find last k_wc_energy
-ends = [i for i, r in enumerate(rows) if "k_dimdct" in r["Kernel_Name"]]
+ends = [i for i, r in enumerate(rows) if "k_dsyn" in r["Kernel_Name"] or "k_dgen" in r["Kernel_Name"]]
 idx = ends[-2] + 1 if len(ends) >= 2 else 0           # first kernel after the previous step's last decode kernel
 t0 = int(rows[idx]["Start_Timestamp"]); prev_end = t0
 for r in rows[idx:]:

@@ -22,6 +22,7 @@
 #include "ulcx_libm.h"
 
 #define WG 256
+#define FFT_PACKED                // packed binary32 butterflies (ulcx_fft.h): bit-identical, half the instructions
 #include "ulcx_fft.h"
 
 // ---------------------------------------------------------------------------
