@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
 """bench.py — whole-job throughput of the batched ulc-codec hot path on MI355X.
 
-Workload (BASELINE.json configs[1] + configs[2] shape): B independent 44.1 kHz stereo
-streams, BlockSize 2048, VBR quality 50.  One *step* = encode K consecutive blocks of
-every stream (ulcx_encode_dev) and decode the B*K blocks just produced
-(ulcx_decode_dev); inputs, outputs and codec state stay resident in HBM.
-value = channel-samples that went through encode+decode per second (Msamples/s).
+Workloads (BASELINE.json `configs`; --config picks one, the default is the headline):
+  vbr50         configs[1] + configs[2]: B independent 44.1 kHz stereo streams per GPU, BlockSize 2048, VBR quality 50;
+                the decode leg decodes the B*K blocks the encode leg produced.  Weak scaling (4096 streams per GPU).
+  cbr64_48k     configs[3]: CBR 64 kbps, 48 kHz M/S stereo, BlockSize 2048, 32768 streams in total, split over the GPUs
+                (fixed total: strong scaling).
+  wswitch_4096  configs[4]: window-switch stress, transient-heavy stereo (>= 5 bursts/s, onset strengths over three
+                decades), BlockSize 4096, VBR 50, 16384 streams in total, split over the GPUs (strong scaling).
+--mode both|encode|decode selects what a *step* is: encode K consecutive blocks of every stream (ulcx_encode_dev), decode
+them (ulcx_decode_dev), or both back to back.  Inputs, outputs and codec state stay resident in HBM; the same K input
+blocks are fed every step (the codec state advances, the data repeats - throughput does not depend on it).
+value = channel-samples that went through the step per second (Msamples/s; a sample counts once, whichever legs the step has),
+whole job over all ranks.
 
-Prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel,
-priced live from hipEvents on the launch stream) and, at N=1, `cpu_baseline` (the C
-oracle timed on the host cores on a bounded sample of the same workload).
+Prints ONE JSON line (contract in the task statement) with `roofline` (the dominant kernel priced live from hipEvents on
+its launch stream, plus the whole encode / decode legs against the same algorithmic bytes) and, at N=1, `cpu_baseline`
+(the C oracle timed on the host cores on a bounded sample of the same workload).
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -24,12 +30,20 @@ sys.path.insert(0, os.path.join(ROOT, "ulc-codec_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-BS, CH, RATE, QUALITY = 2048, 2, 44100, 50.0
+BS, CH, RATE, QUALITY = 2048, 2, 44100, 50.0          # the headline workload (tests import these and make_pcm)
+
+CONFIGS = {
+    #               BlockSize rate   mode  param  streams/GPU  total streams  bursts/s  decades  BASELINE.json
+    "vbr50":        dict(bs=2048, rate=44100, mode="vbr", p0=50.0, per_gpu=4096, total=None,  bursts=4.0, decades=2.0, ref="configs[1] encode, configs[2] decode"),
+    "cbr64_48k":    dict(bs=2048, rate=48000, mode="cbr", p0=64.0, per_gpu=None, total=32768, bursts=4.0, decades=2.0, ref="configs[3]"),
+    "wswitch_4096": dict(bs=4096, rate=44100, mode="vbr", p0=50.0, per_gpu=None, total=16384, bursts=6.0, decades=3.0, ref="configs[4]"),
+}
 
 
-def make_pcm(torch, B, n, device, seed):
+def make_pcm(torch, B, n, device, seed, bursts_per_s=4.0, decades=2.0):
     """Seeded synthetic PCM16-grid audio: 3 tones + noise + sparse decaying bursts; second
-    channel = delayed scaled copy + independent noise."""
+    channel = delayed scaled copy + independent noise.  bursts_per_s / decades: rate of the noise bursts
+    and the spread of their onset strengths (config 5: >= 5 per second over three decades)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     t = torch.arange(n, device=device, dtype=torch.float32)[None, :] / RATE
@@ -40,10 +54,10 @@ def make_pcm(torch, B, n, device, seed):
         ph = torch.empty(B, 1, device=device).uniform_(0, 6.2831853, generator=g)
         x += a * torch.sin(6.2831853 * f * t + ph)
     x += 0.02 * torch.randn(B, n, device=device, generator=g)
-    # bursts: ~4 per second at random positions, exponential decay tau = 300 samples
-    nb = max(1, int(4 * n / RATE))
+    # bursts at random positions, exponential decay tau = 300 samples
+    nb = max(1, int(bursts_per_s * n / RATE))
     pos = torch.randint(0, n, (B, nb), device=device, generator=g)
-    amp = 10 ** torch.empty(B, nb, device=device).uniform_(-2.5, -0.5, generator=g)
+    amp = 10 ** torch.empty(B, nb, device=device).uniform_(-0.5 - decades, -0.5, generator=g)
     idx = torch.arange(n, device=device)[None, :]
     for j in range(nb):
         d = (idx - pos[:, j:j + 1]).float()
@@ -55,32 +69,41 @@ def make_pcm(torch, B, n, device, seed):
     return pcm.contiguous()          # [B][n][2] f32
 
 
-def cpu_baseline(sample_pcm, n_blocks, target_seconds=4.0):
-    """Oracle (kind 'port') encode+decode on the host cores.  sample_pcm: numpy [S][n][C]."""
+def cpu_baseline(sample_pcm, n_blocks, cfg, legs, target_seconds=4.0):
+    """Oracle (kind 'port') on the host cores: the legs of the step on a bounded sample.  sample_pcm: numpy [S][n][C]."""
     import numpy as np
     from ulc_testlib import oracle, ptr, f32p, u8p, i32p
     lib = oracle()
     S = sample_pcm.shape[0]
-    slot = 2 * CH * BS + 16
+    bs, rate = cfg["bs"], cfg["rate"]
+    slot = 2 * CH * bs + 16
     cores = os.cpu_count() or 1
     threads = max(1, min(cores, 64))
+    enc_fn = lib.orc_encode_stream_vbr if cfg["mode"] == "vbr" else lib.orc_encode_stream_cbr
 
     def one(pcm, out, bits, dec):
-        lib.orc_encode_stream_vbr(RATE, CH, BS, ptr(pcm, f32p), n_blocks, QUALITY, ptr(out, u8p), slot, ptr(bits, i32p), None, None)
-        lib.orc_decode_stream(CH, BS, ptr(out, u8p), slot, n_blocks, ptr(dec, f32p), None)
+        if "encode" in legs or "decode" not in legs:
+            enc_fn(rate, CH, bs, ptr(pcm, f32p), n_blocks, cfg["p0"], ptr(out, u8p), slot, ptr(bits, i32p), None, None)
+        if "decode" in legs:
+            lib.orc_decode_stream(CH, bs, ptr(out, u8p), slot, n_blocks, ptr(dec, f32p), None)
 
     flat = [np.ascontiguousarray(sample_pcm[i].reshape(-1)) for i in range(S)]
-    # warm the oracle's lazily built tables single-threaded, and time one stream to size the sample
-    out0 = np.zeros((n_blocks, slot), np.uint8); b0 = np.zeros(n_blocks, np.int32); d0 = np.zeros(n_blocks * BS * CH, np.float32)
-    one(flat[0], out0, b0, d0)
-    t0 = time.perf_counter(); one(flat[0], out0, b0, d0); t1 = time.perf_counter() - t0
+    outs = []
+    for i in range(S):                                   # (decode-only legs need encoded input: made once, untimed)
+        o = np.zeros((n_blocks, slot), np.uint8); b = np.zeros(n_blocks, np.int32)
+        enc_fn(rate, CH, bs, ptr(flat[i], f32p), n_blocks, cfg["p0"], ptr(o, u8p), slot, ptr(b, i32p), None, None)
+        outs.append(o)
+    d0 = np.zeros(n_blocks * bs * CH, np.float32); b0 = np.zeros(n_blocks, np.int32)
+    t0 = time.perf_counter(); one(flat[0], outs[0].copy(), b0, d0); t1 = time.perf_counter() - t0
     reps = max(1, int(target_seconds / max(t1, 1e-4)))
     done = [0] * threads
 
     def worker(i):
-        out = np.zeros((n_blocks, slot), np.uint8); b = np.zeros(n_blocks, np.int32); d = np.zeros(n_blocks * BS * CH, np.float32)
+        b = np.zeros(n_blocks, np.int32); d = np.zeros(n_blocks * bs * CH, np.float32)
+        mine = [o.copy() for o in outs]
         for r in range(reps):
-            one(flat[(i + r) % S], out, b, d)
+            j = (i + r) % S
+            one(flat[j], mine[j], b, d)
             done[i] += 1
 
     ths = [threading.Thread(target=worker, args=(i,)) for i in range(threads)]
@@ -89,10 +112,13 @@ def cpu_baseline(sample_pcm, n_blocks, target_seconds=4.0):
     for th in ths: th.join()
     el = time.perf_counter() - t0
     streams = sum(done)
-    samples = streams * n_blocks * BS * CH
+    samples = streams * n_blocks * bs * CH
     return {"value": samples / el / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": f"{streams} stream-encodes+decodes of {n_blocks} blocks ({S} distinct seeded streams of the bench batch) in {el:.1f} s, "
-                      f"one oracle instance per thread, gcc -O2 scalar C"}
+            "sample": f"{streams} stream-{'+'.join(legs)}s of {n_blocks} blocks ({S} distinct seeded streams of the bench batch) in {el:.1f} s, "
+                      f"one oracle instance per thread; scalar C port of the reference built gcc -O2 -ffp-contract=off as the reference's "
+                      f"Makefile builds libulc - the reference's own SIMD lives in libfourier, which is absent from the tree, so no AVX2/FMA "
+                      f"reference path can be timed (an -mavx2 build of the port without contraction is bit-identical and within a few per "
+                      f"cent: DESIGN.md §8)"}
 
 
 def main():
@@ -100,9 +126,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=4096, help="independent streams per GPU (BASELINE configs[1]: 4096)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="vbr50")
+    ap.add_argument("--mode", choices=["both", "encode", "decode"], default="both")
+    ap.add_argument("--streams", type=int, default=0, help="independent streams per GPU (default: the config's; fixed-total configs split their total over the GPUs)")
     ap.add_argument("--blocks", type=int, default=16, help="consecutive blocks per stream per step")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pmc-summary", default="", help="tools/pmc_summary.py output of a rocprofv3 --pmc run of THIS command: fills roofline.traffic (else null)")
     ap.add_argument("--pcm16", action="store_true", help="separate configuration (SURVEY.md 8f rank 4): PCM16 ingest and PCM16 output "
                     "fused into the first/last kernel instead of the C API's f32; NOT the headline line")
     args = ap.parse_args()
@@ -110,6 +139,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    cfg = CONFIGS[args.config]
+    bs, rate = cfg["bs"], cfg["rate"]
+    global RATE
+    RATE = rate
 
     cpu = None
     import numpy as np
@@ -117,6 +150,8 @@ def main():
     import ulc_amd
     if not os.path.exists(ulc_amd.LIB_PATH):
         raise SystemExit("libulc_amd.so missing — run __graft_entry__.build(); there is no CPU fallback")
+    if torch.cuda.device_count() < (world if world > 1 else 1):
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} visible GPU(s): one process per GPU")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -124,21 +159,29 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
-    B, K = args.streams, args.blocks
-    n = K * BS
-    # independent streams shard across ranks by plain batch split (shard.py): rank r owns global streams
-    # [r*B, (r+1)*B) — per-GPU work fixed as N grows (weak scaling), no collective on the data path
     import shard
-    ids = shard.weak_scaling_ids(B, rank)
-    pcm = make_pcm(torch, B, n, dev, seed=1234 + ids[0])
-    enc = ulc_amd.BatchEncoder(B, CH, BS, RATE, K, device=dev.index)
-    dec = ulc_amd.BatchDecoder(B, CH, BS, K, device=dev.index)
+    # independent streams shard across ranks by plain batch split (shard.py), no collective on the data path.
+    # weak: every rank owns its own B streams; strong (fixed-total configs): rank r owns stream_range(total, r, world)
+    strong = cfg["total"] is not None and not args.streams
+    if strong:
+        lo, hi = shard.stream_range(cfg["total"], rank, world)
+        B, first_id = hi - lo, lo
+    else:
+        B = args.streams or cfg["per_gpu"] or 4096
+        first_id = shard.weak_scaling_ids(B, rank)[0]
+    K = args.blocks
+    n = K * bs
+    pcm = make_pcm(torch, B, n, dev, seed=1234 + first_id, bursts_per_s=cfg["bursts"], decades=cfg["decades"])
+    enc = ulc_amd.BatchEncoder(B, CH, bs, rate, K, device=dev.index)
+    dec = ulc_amd.BatchDecoder(B, CH, bs, K, device=dev.index)
     slot = enc.slot
     d_out = torch.zeros(B * K * slot, dtype=torch.uint8, device=dev)
     d_bits = torch.zeros(B * K, dtype=torch.int32, device=dev)
     d_dec = torch.zeros(B * n * CH, dtype=torch.float32, device=dev)
     d_dbits = torch.zeros(B * K, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
+    emode = ulc_amd.MODE_VBR if cfg["mode"] == "vbr" else ulc_amd.MODE_CBR
+    legs = ["encode", "decode"] if args.mode == "both" else [args.mode]
 
     if args.pcm16:
         pcm16 = torch.clamp(torch.round(pcm * 32767.0), -32768, 32767).to(torch.int16)
@@ -146,15 +189,21 @@ def main():
         del pcm
         pcm = pcm16.to(torch.float32) * (2.0 ** -15)            # what the CPU baseline leg would read
 
-    def step16():
-        enc.encode_dev_pcm16(pcm16.data_ptr(), K, d_out.data_ptr(), d_bits.data_ptr(), mode=ulc_amd.MODE_VBR, p0=QUALITY, stream=stream)
-        dec.decode_dev_pcm16(d_out.data_ptr(), slot, K, d_dec16.data_ptr(), d_dbits.data_ptr(), stream=stream)
+    def do_encode():
+        if args.pcm16:
+            enc.encode_dev_pcm16(pcm16.data_ptr(), K, d_out.data_ptr(), d_bits.data_ptr(), mode=emode, p0=cfg["p0"], stream=stream)
+        else:
+            enc.encode_dev(pcm.data_ptr(), K, d_out.data_ptr(), d_bits.data_ptr(), mode=emode, p0=cfg["p0"], stream=stream)
+
+    def do_decode():
+        if args.pcm16:
+            dec.decode_dev_pcm16(d_out.data_ptr(), slot, K, d_dec16.data_ptr(), d_dbits.data_ptr(), stream=stream)
+        else:
+            dec.decode_dev(d_out.data_ptr(), slot, K, d_dec.data_ptr(), d_dbits.data_ptr(), stream=stream)
 
     def step():
-        if args.pcm16:
-            return step16()
-        enc.encode_dev(pcm.data_ptr(), K, d_out.data_ptr(), d_bits.data_ptr(), mode=ulc_amd.MODE_VBR, p0=QUALITY, stream=stream)
-        dec.decode_dev(d_out.data_ptr(), slot, K, d_dec.data_ptr(), d_dbits.data_ptr(), stream=stream)
+        if "encode" in legs: do_encode()
+        if "decode" in legs: do_decode()
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -162,81 +211,102 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if args.mode == "decode":
+        do_encode()                                              # the blocks the decode leg reads: produced once, untimed
     for _ in range(args.warmup):
         step()
     barrier()
-    enc_ms, dec_ms = {}, {}
     t0 = time.perf_counter()
-    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
-    enc_t = dec_t = 0.0
     for i in range(args.steps):
         step()
     barrier()
-    el = time.perf_counter() - t0
-    # per-kernel device times of one more (untimed) step, from the library's own hipEvents on the launch stream
+    el_rank = time.perf_counter() - t0
+    # per-kernel device times of a few more (untimed) steps, from the library's own hipEvents on the launch stream
     acc_enc, acc_dec, nacc = {}, {}, 3
     for _ in range(nacc):
         step(); torch.cuda.synchronize(dev)
-        for k_, v in enc.stage_ms().items(): acc_enc[k_] = acc_enc.get(k_, 0.0) + v / nacc
-        for k_, v in dec.stage_ms().items(): acc_dec[k_] = acc_dec.get(k_, 0.0) + v / nacc
-    el = shard.max_over_ranks(el, dist, dev)
+        if "encode" in legs:
+            for k_, v in enc.stage_ms().items(): acc_enc[k_] = acc_enc.get(k_, 0.0) + v / nacc
+        if "decode" in legs:
+            for k_, v in dec.stage_ms().items(): acc_dec[k_] = acc_dec.get(k_, 0.0) + v / nacc
+    el = shard.max_over_ranks(el_rank, dist, dev)
+    per_rank_ms = [el_rank / args.steps * 1e3]
+    if dist is not None:
+        got = [None] * world
+        dist.all_gather_object(got, el_rank / args.steps * 1e3)
+        per_rank_ms = got
+    if args.mode == "encode":
+        do_decode(); torch.cuda.synchronize(dev)                 # the check below wants a decode of the last encode either way
     bits_host = d_bits.cpu().numpy()
     dbits_host = d_dbits.cpu().numpy()
     ok = bool((dbits_host > 0).all() and (dbits_host <= bits_host).all())
-    value = shard.whole_job_throughput(B * K * BS * CH * args.steps, world, el) / 1e6
+    assert ok, "decode of the encoded blocks failed: some block was rejected or consumed more bits than were written"
+    units = B * K * bs * CH                                      # channel-samples through the step (each goes through every leg of it), this rank
+    if strong:
+        total_units = cfg["total"] * K * bs * CH
+        value = total_units * args.steps / el / 1e6
+    else:
+        value = shard.whole_job_throughput(units * args.steps, world, el) / 1e6
 
-    # ---- roofline of the dominant kernel (algorithmic bytes: SURVEY.md §8d / BASELINE.md §4)
+    # ---- roofline (algorithmic bytes: SURVEY.md §8d / BASELINE.md §4)
     mean_bytes = float(bits_host.mean()) / 8.0
     smp_bytes = 2 if args.pcm16 else 4
-    alg_bytes_block = smp_bytes * CH * BS + mean_bytes + 8  # f32 (PCM16 with --pcm16) in (or out) + stream bytes + size/WindowCtrl metadata
+    alg_bytes_block = smp_bytes * CH * bs + mean_bytes + 8      # samples in (or out) + stream bytes + size/WindowCtrl metadata
     pseudo = ("cbr_probe_passes", "k_heapsel", "wc_pipeline_exposed")   # intervals, not kernels (join wait / side-stream launches)
     allk = {**{("enc", k_): v for k_, v in acc_enc.items() if k_ not in pseudo}, **{("dec", k_): v for k_, v in acc_dec.items()}}
     (side, kname), kms = max(allk.items(), key=lambda kv: kv[1])
     # kms is the kernel's time per step; a kernel launched n times per step (k_xf: one launch per chunk of blocks of
     # the window-control pipeline) has kms = sum of its n launches, each timed by its own hipEvent pair on its stream.
-    # Per launch: bytes/n over kms/n - the same ratio.  profiles/*_pmc_summary.json carries n and the measured traffic.
     launches = float(enc.xf_launches()) if kname == "k_xf" else 1.0      # from the library: chunks of the last call
-    traffic = None
-    pj = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if os.path.exists(pj):
+    traffic = None                                                       # HBM bytes per launch: only from a PMC pass of this very command
+    if args.pmc_summary and os.path.exists(args.pmc_summary):
         try:
-            ent = json.load(open(pj)).get(kname, {})
-            traffic = ent.get("hbm_bytes_per_launch")                   # (key name: it is the kernel's bytes per STEP of 65536 blocks)
+            ent = json.load(open(args.pmc_summary)).get(kname, {})
+            traffic = ent.get("hbm_bytes_per_launch")
             if traffic is not None:
-                traffic = traffic * (B * K / 65536.0) / launches
+                traffic = traffic / launches
         except Exception:
             traffic = None
     launch_bytes = alg_bytes_block * B * K / launches
     kms_launch = kms / launches
     achieved = launch_bytes / (kms_launch * 1e-3) / 1e9
     enc_total = sum(acc_enc.values()); dec_total = sum(acc_dec.values())
+    leg_bytes = alg_bytes_block * B * K
+    enc_gbs = leg_bytes / (enc_total * 1e-3) / 1e9 if enc_total else None
+    dec_gbs = leg_bytes / (dec_total * 1e-3) / 1e9 if dec_total else None
+    step_gbs = leg_bytes * len(legs) / (el_rank / args.steps) / 1e9         # (the step moves the algorithmic bytes once per leg)
 
     if rank == 0 and world == 1 and not args.no_cpu:
         S = 8
         sample = pcm[:S].cpu().numpy()
-        # release the GPU objects' host threads are idle; oracle runs on host cores only
-        cpu = cpu_baseline(sample, K)
+        cpu = cpu_baseline(sample, K, cfg, legs)
 
     if rank == 0:
+        what = {"both": "encode+decode", "encode": "encode", "decode": "decode"}[args.mode]
+        rc = "VBR -%g" % cfg["p0"] if cfg["mode"] == "vbr" else "CBR %g kbps" % cfg["p0"]
+        wl = (f"{args.config} ({cfg['ref']}): Batch={B} independent {rate / 1000:g} kHz stereo streams/GPU x {K} blocks, BlockSize={bs}, {rc}; "
+              f"step = {' then '.join(legs)}" + (f"; {cfg['total']} streams in total over {world} GPU(s)" if strong else "")
+              + (" -- PCM16 ingest/output variant (int16 samples in HBM, not the C API's f32)" if args.pcm16 else ""))
         line = {
-            "metric": "encode+decode Msamples/s at BlockSize=2048 stereo (channel-samples through VBR-50 encode then decode)",
+            "metric": f"{what} Msamples/s at BlockSize={bs} stereo (channel-samples through {what}, {rc})",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Batch={B} independent 44.1 kHz stereo streams/GPU x {K} blocks, BlockSize=2048, VBR -50 encode "
-                                   f"(BASELINE configs[1]) then decode of the {B*K} blocks produced (configs[2] shape)"
-                                   + (" -- PCM16 ingest/output variant (int16 samples in HBM, not the C API's f32)" if args.pcm16 else ""),
-                       "streams_per_gpu": B, "blocks_per_stream_per_step": K, "block_size": BS, "channels": CH, "rate_hz": RATE,
-                       "parallelism": f"batch split over {world} GPU(s), no collective on the data path"},
+            "config": {"workload": wl, "config": args.config, "mode": args.mode,
+                       "streams_per_gpu": B, "blocks_per_stream_per_step": K, "block_size": bs, "channels": CH, "rate_hz": rate,
+                       "parallelism": f"batch split over {world} GPU(s), no collective on the data path",
+                       "per_rank_ms_per_step": [round(float(x), 4) for x in per_rank_ms]},
             "roofline": {"bound": "hbm", "kernel": f"{kname} ({side})", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_block": alg_bytes_block, "blocks_per_launch": B * K / launches,
-                         "launches_per_step": launches, "kernel_ms": kms_launch},
+                         "launches_per_step": launches, "kernel_ms": kms_launch,
+                         # the pipeline, not only its largest kernel: every leg moves the same algorithmic bytes
+                         "encode_achieved": enc_gbs, "encode_frac": enc_gbs / HBM_PEAK_GBS if enc_gbs else None,
+                         "decode_achieved": dec_gbs, "decode_frac": dec_gbs / HBM_PEAK_GBS if dec_gbs else None,
+                         "step_achieved": step_gbs, "step_frac": step_gbs / HBM_PEAK_GBS},
             "whole_pipeline": {"encode_ms": enc_total, "decode_ms": dec_total,
-                               "encode_Msamples_s": B * K * BS * CH / (enc_total * 1e-3) / 1e6,
-                               "decode_Msamples_s": B * K * BS * CH / (dec_total * 1e-3) / 1e6,
-                               "encode_hbm_frac": alg_bytes_block * B * K / (enc_total * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "decode_hbm_frac": alg_bytes_block * B * K / (dec_total * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "encode_Msamples_s": B * K * bs * CH / (enc_total * 1e-3) / 1e6 if enc_total else None,
+                               "decode_Msamples_s": B * K * bs * CH / (dec_total * 1e-3) / 1e6 if dec_total else None,
                                "mean_block_bytes": mean_bytes, "decode_ok": ok},
             "kernels_ms": {**{f"enc.{k_}": round(v, 4) for k_, v in acc_enc.items()}, **{f"dec.{k_}": round(v, 4) for k_, v in acc_dec.items()}},
         }

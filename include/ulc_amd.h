@@ -118,10 +118,10 @@ int  ulcx_encoder_slot_bytes(const ulcx_encoder *enc);   /* bytes reserved per e
 
 /* Encode nBlocks consecutive blocks of every stream.  All pointers are DEVICE
  * pointers; work is enqueued on hipStream (a hipStream_t, NULL = default stream)
- * and is asynchronous with respect to the host (VBR).  CBR/ABR calls wait once, inside
- * the call, for the transform stage (a 4-byte read-back sizes the rate-control probe
- * loop); everything after it is enqueued asynchronously again.  Internally the call
- * also uses private side streams, all joined back into hipStream before it returns.
+ * and is asynchronous with respect to the host in every mode: nothing inside the call
+ * waits for the device (the CBR/ABR rate search enqueues its full number of probe passes;
+ * passes that find every block converged return at once on the device).  Internally the
+ * call also uses private side streams, all joined back into hipStream before it returns.
  *   d_pcm  [nStreams][nBlocks][BlockSize][nChan] f32 interleaved (the layout the
  *          reference's EncodeBlock reads: ulcEncoder_BlockTransform.c:96-98)
  *   d_out  [nStreams][nBlocks][slot_bytes] encoded blocks, byte aligned, each

@@ -153,7 +153,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.tailSum, NB * nChan * 4 * 8, true);
     if (const char *ev = getenv("ULCX_WAVE")) c.useWave = (ev[0] != '0');
     c.dbgSkip = 0; if (const char *ev = getenv("ULCX_DBG_SKIP")) c.dbgSkip = atoi(ev);   // timing experiments only (breaks results)
-    DA(c.cbrLo, NB, true); DA(c.cbrHi, NB, true); DA(c.cbrDone, NB, true); DA(c.cbrBudget, NB, true); DA(c.cbrMaxRange, 1, true);
+    DA(c.cbrLo, NB, true); DA(c.cbrHi, NB, true); DA(c.cbrDone, NB, true); DA(c.cbrBudget, NB, true); DA(c.cbrLive, 1, true);
     DA(c.keep, NB * cb / 32, true);
     DA(c.fbList, NB, true);
     DA(c.fbCount, 4, true);

@@ -781,7 +781,7 @@ __global__ __launch_bounds__(64) void k_cplx(UlcxEncCtx c) {
         }
         c.cbrLo[blk] = lo; c.cbrHi[blk] = hi;
         c.cbrDone[blk] = done;
-        if (!done) atomicMax(c.cbrMaxRange, hi - lo);      // the host sizes the probe loop from it
+        if (!done) atomicAdd(c.cbrLive, 1);                // rate searches still open: the probe passes leave at once when it reaches 0
         c.nout[blk] = nOut;
         c.cbrBudget[blk] = budget;
     }
@@ -1012,6 +1012,8 @@ void ulcx_enc_finalize_keys(const UlcxEncCtx &c, hipStream_t st) {
 //   probe passes skip blocks whose rate search has converged; fbMode 1 skips blocks that left the lock-step
 //   path because a threshold tie group straddled the cut (c.isFb, set once per call); fbMode 2 processes
 //   only those, restricted to the slots [fbLo, fbHi) of the fallback list whose ranks are resident.
+// lock-step probe pass with no open rate search left (the number of passes is fixed on the host; the blocks decide how many do work)
+__device__ __forceinline__ bool probes_over(const UlcxEncCtx &c, int finalPass) { return !finalPass && c.fbMode != 2 && *c.cbrLive <= 0; }
 __device__ __forceinline__ bool skip_block(const UlcxEncCtx &c, int blk, int finalPass) {
     if (!finalPass && c.cbrDone[blk]) return true;
     if (c.fbMode == 1) return c.isFb[blk] != 0;
@@ -1038,6 +1040,7 @@ __device__ __forceinline__ uint32_t key_ord(float f) {          // ascending ord
 }
 
 __global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
+    if (probes_over(c, finalPass)) return;
     __shared__ int hist[256];
     __shared__ uint32_t s_prefix;
     __shared__ int s_need;
@@ -1089,6 +1092,7 @@ __global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
         c.fbList[slot] = blk;
         c.ownSlot[blk] = slot;
         c.isFb[blk] = 1;
+        if (!finalPass) atomicSub(c.cbrLive, 1);              // (the exact path finishes its search on its own)
     }
 }
 
@@ -1096,6 +1100,7 @@ __global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
 // the 256-bin histogram of each radix pass lives in a private 1 KB LDS slice.
 template <int R>
 __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass) {
+    if (probes_over(c, finalPass)) return;
     int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int blk = blockIdx.x * 4 + wv;                        // 4 waves per workgroup, one block per wave
     if (blk >= c.B * c.K) return;
@@ -1162,6 +1167,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
         c.fbList[slot] = blk;
         c.ownSlot[blk] = slot;
         c.isFb[blk] = 1;
+        if (!finalPass) atomicSub(c.cbrLive, 1);              // (the exact path finishes its search on its own)
     }
 }
 
@@ -1395,6 +1401,7 @@ __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
     }
 }
 __global__ __launch_bounds__(WG) void k_gapsums(UlcxEncCtx c, int finalPass) {
+    if (probes_over(c, finalPass)) return;
     if (c.fbMode != 2) { gapsums_block(c, finalPass, blockIdx.x); return; }
     int n = fb_count(c);
     for (int v = blockIdx.x; v < n; v += gridDim.x) { gapsums_block(c, finalPass, c.fbList[c.fbLo + v]); __syncthreads(); }
@@ -1460,6 +1467,7 @@ __device__ void tailsums_lane(const UlcxEncCtx &c, int finalPass, int tid0, int 
     ts[chain] = acc;
 }
 __global__ __launch_bounds__(64) void k_tailsums(UlcxEncCtx c, int finalPass) {
+    if (probes_over(c, finalPass)) return;
     if (c.fbMode != 2) { tailsums_lane(c, finalPass, blockIdx.x * 64 + threadIdx.x, c.B * c.K); return; }
     int n = fb_count(c), total = n * c.C * 32;
     for (int t = blockIdx.x * 64; t < total; t += gridDim.x * 64) tailsums_lane(c, finalPass, t + threadIdx.x, n);
@@ -1704,6 +1712,7 @@ __device__ void encode_units_lane(const UlcxEncCtx &c, int finalPass, int gid, i
     c.unitNyb[gid] = w.n;
 }
 __global__ __launch_bounds__(64) void k_encode_units(UlcxEncCtx c, int finalPass) {
+    if (probes_over(c, finalPass)) return;
     if (c.fbMode != 2) { encode_units_lane(c, finalPass, blockIdx.x * 64 + threadIdx.x, c.B * c.K); return; }
     int n = fb_count(c), total = n * c.C * 4;
     for (int t = blockIdx.x * 64; t < total; t += gridDim.x * 64) encode_units_lane(c, finalPass, t + threadIdx.x, n);
@@ -2077,6 +2086,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
 // one wave per (block, channel), looping over that channel's subblocks.
 template <bool SMALL>
 __global__ __launch_bounds__(256) void k_encode_wave(UlcxEncCtx c, int finalPass, WaveCaps caps, int phase) {
+    if (probes_over(c, finalPass)) return;
     extern __shared__ float e2all[];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wv: wave-uniform, so is all unit geometry
     const WaveCaps capS = { WAVE_SK, WAVE_SZ, WAVE_SN };
@@ -2126,7 +2136,7 @@ __device__ void pack_block(const UlcxEncCtx &c, int finalPass, int blk) {
             if (bitsTot < budget) lo = nOut;
             else if (bitsTot > budget) hi = nOut - 1;
             else { lo = nOut; stop = true; }
-            if (stop || !(lo < hi - 1)) { c.cbrDone[blk] = 1; c.nout[blk] = lo; }   // final pass encodes at Lo (ulcEncoder.c:113-114)
+            if (stop || !(lo < hi - 1)) { c.cbrDone[blk] = 1; c.nout[blk] = lo; if (c.fbMode != 2) atomicSub(c.cbrLive, 1); }   // final pass encodes at Lo (ulcEncoder.c:113-114)
             else c.nout[blk] = (int)((unsigned)(lo + hi) / 2u);
             c.cbrLo[blk] = lo; c.cbrHi[blk] = hi;
         }
@@ -2158,6 +2168,7 @@ __device__ void pack_block(const UlcxEncCtx &c, int finalPass, int blk) {
     if (lane == 0) c.bits[blk] = bitsTot;
 }
 __global__ __launch_bounds__(64) void k_pack(UlcxEncCtx c, int finalPass) {
+    if (probes_over(c, finalPass)) return;
     if (c.fbMode != 2) { pack_block(c, finalPass, blockIdx.x); return; }
     int n = fb_count(c);
     for (int v = blockIdx.x; v < n; v += gridDim.x) pack_block(c, finalPass, c.fbList[c.fbLo + v]);
@@ -2239,7 +2250,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     hipEvent_t evFork = aux.evFork, evJoin = aux.evJoin, evFork2 = aux.evFork2, *evWC = aux.evWC;
     const int wcPipe = (side && side2 && side3) ? aux.wcPipe : 1;
     if (aux.nXf) *aux.nXf = 0;
-    if (c.mode != ULCX_MODE_VBR) CK(hipMemsetAsync(c.cbrMaxRange, 0, sizeof(int), st));
+    if (c.mode != ULCX_MODE_VBR) CK(hipMemsetAsync(c.cbrLive, 0, sizeof(int), st));
     int NB = c.B * c.K;
     int stage = 0;
 #define MARK() do { if (ev) CK(hipEventRecord(ev[stage++], st)); } while (0)
@@ -2389,14 +2400,8 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     int probes = 0;
     if (c.mode != ULCX_MODE_VBR) {
         probes = 2; int m = N; while (m > 1) { probes++; m >>= 1; }
-        // The search interval halves per probe, and k_cplx has already taken the probes that are over budget for
-        // certain: read back the widest interval left (one 4-byte copy behind k_cplx; the only host wait of the
-        // call, CBR/ABR only) and run just ceil(log2(range)) + 2 lock-step passes instead of log2(N) + 2.
-        hipStream_t cs = noiseAside ? side3 : st;
-        int range = -1;
-        CK(hipMemcpyAsync(&range, c.cbrMaxRange, sizeof(int), hipMemcpyDeviceToHost, cs));
-        CK(hipStreamSynchronize(cs));
-        if (range >= 0) { int need = 2; int r = range; while (r > 1) { need++; r = (r + 1) >> 1; } if (need < probes) probes = need; }
+        // No read-back: the host always enqueues the full count and a pass whose blocks have all converged (c.cbrLive,
+        // counted down on the device) returns at the top of every kernel - nothing inside the call waits for the device.
     }
     auto launch_select = [&](int fin) {
         int R = N / 64;

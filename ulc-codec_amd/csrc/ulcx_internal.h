@@ -76,7 +76,7 @@ struct UlcxEncCtx {
     uint8_t *unitBuf;                    // [NB][C][unitCap]
     int    *unitNyb;                     // [NB][C*4]
     int    *cbrBudget;                   // [NB] bit budget (ulcEncoder.c:96)
-    int    *cbrMaxRange;                 // [1] widest Hi-Lo left after k_cplx (sizes the host's probe loop)
+    int    *cbrLive;                     // [1] rate searches of the lock-step path still open (probe passes leave at once at 0)
     int    *slow;                        // [NB] wave-encoder give-up bits (1: small caps, 2: full caps -> k_encode_units); then 2 queue counters, 2 retry queues [NB]
     float2 *gapSum;                      // [NB][C*BS] {Sum, SumW} of the noise run in front of each kept coefficient (speculative)
     float  *tailSum;                     // [NB][C*4][8] five HF-extension sums + start index of the tail they assume
