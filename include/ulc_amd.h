@@ -89,6 +89,12 @@ int  ULC_DecoderState_Init(struct ULC_DecoderState_t *State);
 void ULC_DecoderState_Destroy(struct ULC_DecoderState_t *State);
 int  ULC_DecodeBlock(struct ULC_DecoderState_t *State, float *DstData, const void *SrcBuffer);
 
+/* Bytes of SrcBuffer that ULC_DecodeBlock (the reference's, ulcDecoder.c:82-216, and this library's) touches for the
+ * block that starts there: a host-side walk of the block syntax that only counts.  Reads nothing at or past maxBytes and
+ * returns at most maxBytes.  Host code, no GPU involved: ULC_DecodeBlock stages exactly this many bytes, and a
+ * container reader can use it to index a .ulc payload (blocks carry no length, tools/ulcDecodeTool.c:153-165). */
+int  ulcx_block_extent_bytes(const void *SrcBuffer, int nChan, int BlockSize, int maxBytes);
+
 /* ------------------------------------------------------------------------- */
 /* 2. Batched layer                                                           */
 /* ------------------------------------------------------------------------- */
@@ -164,7 +170,8 @@ void ulcx_decoder_destroy(ulcx_decoder *dec);
 int  ulcx_decoder_reset(ulcx_decoder *dec);
 
 /* Decode nBlocks consecutive blocks of every stream (device pointers).
- *   d_in   [nStreams][nBlocks][slotBytes] encoded blocks (each starts at its slot)
+ *   d_in   [nStreams][nBlocks][slotBytes] encoded blocks (each starts at its slot; slotBytes need not exceed the
+ *          largest block: nothing outside [d_in, d_in + nStreams*nBlocks*slotBytes) is read)
  *   d_pcm  [nStreams][nBlocks][BlockSize][nChan] f32 interleaved
  *          (ulcDecoder.c:291-297)
  *   d_bits [nStreams][nBlocks] int32 bits consumed per block; 0 = corrupt: that

@@ -133,3 +133,52 @@ def test_batched_front_end_is_built_and_prints_usage():
     assert r.returncode == 1 and b"ulcx-tool encode" in r.stderr
     und = subprocess.check_output(["nm", "-u", exe]).decode()
     assert "ulcx_encode_host" in und and "orc_" not in und
+
+
+def test_block_extent_walk_matches_the_decoder_and_never_overreads(lib):
+    """ulcx_block_extent_bytes (host code, what ULC_DecodeBlock stages): the byte count equals what the oracle decoder
+    consumed, on hand-assembled streams with every code of the syntax and on encoder output - with every block placed
+    flush against an unreadable page, so one byte too many is a fault, not a pass."""
+    import mmap
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ulc_testlib import synth_block_stream, synth_pcm, oracle_encode_stream, oracle_decode_stream
+    lib.ulcx_block_extent_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    libc = C.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    PAGE = mmap.PAGESIZE
+    npages = 6
+    m = mmap.mmap(-1, (npages + 1) * PAGE)
+    base = C.addressof(C.c_char.from_buffer(m))
+    assert base % PAGE == 0
+    assert libc.mprotect(base + npages * PAGE, PAGE, 0) == 0, "mprotect(PROT_NONE) failed"
+    end = base + npages * PAGE
+    checked = 0
+    cases = []
+    for bs, ch in ((512, 2), (2048, 2), (1024, 1), (256, 3)):
+        slot = 2 * ch * bs + 16
+        for s_ in range(3):
+            blocks, bits = synth_block_stream(777 + 13 * s_ + bs, 8, ch, bs, slot)
+            cases.append((blocks, bits, ch, bs, slot))
+    for bs, ch, rate in ((2048, 2, 44100), (2048, 1, 44100), (4096, 2, 48000)):
+        pcm = synth_pcm(3, 8 * bs, ch, rate, transient=True, seed=bs)
+        out, bits, wc, cplx = oracle_encode_stream(pcm, bs, rate, quality=60.0)
+        cases.append((out, bits, ch, bs, 2 * ch * bs + 16))
+    for blocks, bits, ch, bs, slot in cases:
+        rc, pcm_, rbits = oracle_decode_stream(np.ascontiguousarray(blocks), ch, bs)
+        assert rc == 0
+        for k in range(blocks.shape[0]):
+            nbytes = (int(rbits[k]) + 7) // 8                    # bits consumed are nybble granular: a half-used byte is read
+            assert nbytes <= npages * PAGE
+            dst = end - nbytes
+            C.memmove(dst, blocks[k].ctypes.data, nbytes)
+            got = lib.ulcx_block_extent_bytes(C.c_void_p(dst), ch, bs, slot)
+            assert got == nbytes, f"block {k} (bs {bs}, ch {ch}): walk says {got} bytes, the decoder consumed {nbytes}"
+            checked += 1
+    assert checked > 100
+    # a corrupt block (a zero run past the end of its subblock) ends where the reference's decoder gives up, and the bound holds
+    bad = np.array([0x00, 0x1F, 0xFF], np.uint8)               # header 0h (N/1), quantizer 0, then 1h,Fh,Fh = 288 zeros... at BlockSize 256
+    C.memmove(end - 3, bad.ctypes.data, 3)
+    assert lib.ulcx_block_extent_bytes(C.c_void_p(end - 3), 1, 256, 3) <= 3
+    libc.mprotect(base + npages * PAGE, PAGE, 3)
+    del m

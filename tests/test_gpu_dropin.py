@@ -149,3 +149,41 @@ def test_abr_workflow_analyse_then_encode_matches_the_reference_tools(tmp_path):
         _run([TOOL, "encode", str(sub), arg, str(p)])
         assert open(sub / (p.stem + ".ulc"), "rb").read() == open(refdir / (p.stem + ".ulc"), "rb").read(), \
             f"{p.name}: ABR file differs from ulcencodetool's"
+
+
+def test_decode_block_reads_exactly_the_block_and_matches_the_oracle():
+    """ULC_DecodeBlock through the drop-in ABI with every block flush against an unreadable page (the reference reads
+    SrcBuffer only as far as the block runs, ulcDecoder.h:54): one byte too many is a fault.  Output = oracle decode."""
+    import ctypes as C
+    import mmap
+    from ulc_testlib import oracle_encode_stream
+    lib = C.CDLL(os.path.join(ROOT, "ulc-codec_amd", "libulc_amd.so"))
+
+    class Dec(C.Structure):
+        _fields_ = [("nChan", C.c_int), ("BlockSize", C.c_int), ("LastSubBlockSize", C.c_int), ("BufferData", C.c_void_p),
+                    ("TransformBuffer", C.c_void_p), ("TransformTemp", C.c_void_p), ("TransformInvLap", C.c_void_p)]
+    lib.ULC_DecodeBlock.argtypes = [C.POINTER(Dec), C.POINTER(C.c_float), C.c_void_p]
+    libc = C.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    PAGE = mmap.PAGESIZE
+    m = mmap.mmap(-1, 5 * PAGE)
+    base = C.addressof(C.c_char.from_buffer(m))
+    assert libc.mprotect(base + 4 * PAGE, PAGE, 0) == 0
+    end = base + 4 * PAGE
+    bs, ch, rate, nblk = 2048, 2, 44100, 10
+    pcm = synth_pcm(9, nblk * bs, ch, rate, transient=True, seed=4)
+    out, bits, wc, cplx = oracle_encode_stream(pcm, bs, rate, quality=50.0)
+    rc, ref_pcm, ref_bits = oracle_decode_stream(out, ch, bs)
+    assert rc == 0
+    st = Dec(); st.nChan = ch; st.BlockSize = bs
+    assert lib.ULC_DecoderState_Init(C.byref(st)) == 1
+    got = np.zeros((nblk, bs * ch), np.float32)
+    for k in range(nblk):
+        nbytes = (int(ref_bits[k]) + 7) // 8
+        dst = end - nbytes
+        C.memmove(dst, out[k].ctypes.data, nbytes)
+        r = lib.ULC_DecodeBlock(C.byref(st), got[k].ctypes.data_as(C.POINTER(C.c_float)), C.c_void_p(dst))
+        assert r == ref_bits[k], f"block {k}: {r} bits consumed, oracle {ref_bits[k]}"
+    lib.ULC_DecoderState_Destroy(C.byref(st))
+    assert np.array_equal(got.reshape(nblk * bs, ch).view(np.uint32), ref_pcm.view(np.uint32))
+    libc.mprotect(base + 4 * PAGE, PAGE, 3)

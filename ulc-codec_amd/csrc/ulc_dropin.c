@@ -12,8 +12,14 @@
 #include <string.h>
 #include "../../include/ulc_amd.h"
 
-struct enc_priv { ulcx_encoder *enc; unsigned char *out; int slot; };
+struct enc_priv { ulcx_encoder *enc; unsigned char *out; int slot; int failed; };
 struct dec_priv { ulcx_decoder *dec; unsigned char *in; int slot; };
+
+/* HIP device the drop-in states live on: ULC_AMD_DEVICE (ordinal), default 0 */
+static int dropin_device(void) {
+    const char *v = getenv("ULC_AMD_DEVICE");
+    return (v && v[0]) ? atoi(v) : 0;
+}
 
 /* ulcEncoder.c:25-80: 1 on success, -1 on failure */
 int ULC_EncoderState_Init(struct ULC_EncoderState_t *State) {
@@ -23,7 +29,7 @@ int ULC_EncoderState_Init(struct ULC_EncoderState_t *State) {
     State->TransformIndex = NULL;
     State->TransientBuffer = NULL;
     ulcx_encoder *enc = NULL;
-    int rc = ulcx_encoder_create(&enc, 0, 1, State->nChan, State->BlockSize, State->RateHz, 1);
+    int rc = ulcx_encoder_create(&enc, dropin_device(), 1, State->nChan, State->BlockSize, State->RateHz, 1);
     if (rc != ULCX_OK) {
         if (rc != ULCX_ERR_ARG) fprintf(stderr, "libulc_amd: encoder init failed: %s\n", ulcx_last_error());
         return -1;
@@ -31,6 +37,7 @@ int ULC_EncoderState_Init(struct ULC_EncoderState_t *State) {
     struct enc_priv *p = (struct enc_priv *)malloc(sizeof(*p));
     if (!p) { ulcx_encoder_destroy(enc); return -1; }
     p->enc = enc;
+    p->failed = 0;
     p->slot = ulcx_encoder_slot_bytes(enc);
     p->out = (unsigned char *)malloc((size_t)p->slot);
     if (!p->out) { ulcx_encoder_destroy(enc); free(p); return -1; }
@@ -56,10 +63,14 @@ static const void *encode_one(struct ULC_EncoderState_t *State, const float *Src
     struct enc_priv *p = (struct enc_priv *)State->BufferData;
     int32_t bits = 0, wc = 0; float cplx = 0.0f;
     int rc = ulcx_encode_host(p->enc, mode, p0, p1, Src, 1, p->out, &bits, &wc, &cplx);
-    if (rc != ULCX_OK) {
-        /* the reference cannot fail here; a lost GPU is fatal for a drop-in */
-        fprintf(stderr, "libulc_amd: encode failed: %s\n", ulcx_last_error());
-        abort();
+    if (p->failed || rc != ULCX_OK) {
+        /* the reference cannot fail here and has no way to say so: the error is sticky (reported once, ulcx_last_error() keeps
+         * the cause), and this and every later call on the state return an empty block (Size 0) instead of taking the process down */
+        if (!p->failed) fprintf(stderr, "libulc_amd: encode failed: %s\n", ulcx_last_error());
+        p->failed = 1;
+        memset(p->out, 0, (size_t)p->slot);
+        if (Size) *Size = 0;
+        return p->out;
     }
     State->WindowCtrl = wc;
     State->BlockComplexity = cplx;
@@ -81,7 +92,7 @@ int ULC_DecoderState_Init(struct ULC_DecoderState_t *State) {
     State->BufferData = NULL;
     State->TransformBuffer = State->TransformTemp = State->TransformInvLap = NULL;
     ulcx_decoder *dec = NULL;
-    int rc = ulcx_decoder_create(&dec, 0, 1, State->nChan, State->BlockSize, 1);
+    int rc = ulcx_decoder_create(&dec, dropin_device(), 1, State->nChan, State->BlockSize, 1);
     if (rc != ULCX_OK) {
         if (rc != ULCX_ERR_ARG) fprintf(stderr, "libulc_amd: decoder init failed: %s\n", ulcx_last_error());
         return -1;
@@ -106,13 +117,56 @@ void ULC_DecoderState_Destroy(struct ULC_DecoderState_t *State) {
     free(p);
     State->BufferData = NULL;
 }
-/* ulcDecoder.c:198-302.  NOTE: the reference reads SrcBuffer only as far as the block
- * extends; the tool hands in a sliding window with at least MaxBlockSize bytes valid
- * (tools/ulcDecodeTool.c:123-166), which is what ULC_DecodeBlockN below relies on. */
+/* Bytes of SrcBuffer the reference's decoder would touch (ulcDecoder.c:82-88: a byte is read with its first nybble): a host
+ * walk of the block syntax (ulcDecoder.c:99-216, FormatSpecs.md:57-141) that only counts - header, then per channel and
+ * subblock the opening quantizer and codes until the subblock's coefficients are accounted for or a run overshoots (the
+ * reference returns there).  Never reads at or past maxBytes. */
+int ulcx_block_extent_bytes(const void *SrcBuffer, int nChan, int BS, int maxBytes) {
+    const unsigned char *src = (const unsigned char *)SrcBuffer;
+    static const unsigned short pattern[16] = { 0x0000, 0x0008, 0x0019, 0x0091, 0x012A, 0x01A2, 0x02A1, 0x0A21,
+                                                0x123B, 0x12B3, 0x13B2, 0x1B32, 0x23B1, 0x2B31, 0x3B21, 0xB321 };   /* ulcHelper.h:24-46 */
+    const long maxNyb = 2L * maxBytes;
+    long n = 0;                                              /* nybbles consumed */
+#define NYB() ((n < maxNyb) ? (unsigned)((src[n >> 1] >> ((n & 1) * 4)) & 0xF) : 0xFu); if (n >= maxNyb) return maxBytes; n++
+    unsigned wc, v;
+    wc = NYB();
+    if (wc & 8) { v = NYB(); wc |= v << 4; } else wc |= 1 << 4;
+    for (int ch = 0; ch < nChan; ch++) {
+        unsigned pat = pattern[(wc >> 4) & 15];
+        do {
+            int N = BS >> (pat & 7);
+            const int whole = (N == BS);
+            /* opening quantizer (ulcDecoder.c:89-107): Eh takes a second nybble; Eh,Fh = stop; a bare Fh leaves quantizer 0 */
+            v = NYB();
+            if (v == 0xE) { v = NYB(); if (v == 0xF) N = 0; }
+            while (N > 0) {
+                v = NYB();
+                if (v == 0x0) { v = NYB(); int r = (int)v + 1; if (r > N) goto done; N -= r; }
+                else if (v == 0x1) { unsigned y = NYB(); unsigned x = NYB(); int r = (int)((y << 4) | x) + 33; if (r > N) goto done; N -= r; }
+                else if (v == 0x8) { unsigned z = NYB(); unsigned y = NYB(); unsigned x = NYB(); int r = (int)((z << 5) | (y << 1) | (x & 1)) + 16; if (r > N) goto done; N -= r; }
+                else if (v == 0xF) {
+                    v = NYB();
+                    if (v == 0xF) { v = NYB(); v = NYB(); v = NYB(); N = 0; }        /* noise to the end */
+                    else if (v == 0xE) { v = NYB(); if (v == 0xF) N = 0; }            /* extended quantizer / stop */
+                }
+                else N -= 1;
+            }
+            if (whole) break;                                /* ulcDecoder.c:242-245 */
+        } while (pat >>= 4);
+    }
+done:
+#undef NYB
+    { long bytes = (n + 1) >> 1; return bytes < maxBytes ? (int)bytes : maxBytes; }
+}
+
+/* ulcDecoder.c:198-302.  The reference reads SrcBuffer only as far as the block extends (ulcDecoder.h:54), and so does this:
+ * the block's extent is found on the host first, exactly those bytes are staged (the rest of the staging slot is zero). */
 int ULC_DecodeBlock(struct ULC_DecoderState_t *State, float *DstData, const void *SrcBuffer) {
     struct dec_priv *p = (struct dec_priv *)State->BufferData;
     int32_t bits = 0;
-    memcpy(p->in, SrcBuffer, (size_t)p->slot);
+    const int ext = ulcx_block_extent_bytes(SrcBuffer, State->nChan, State->BlockSize, p->slot);
+    memcpy(p->in, SrcBuffer, (size_t)ext);
+    memset(p->in + ext, 0, (size_t)(p->slot - ext));
     int rc = ulcx_decode_host(p->dec, p->in, p->slot, 1, DstData, &bits);
     if (rc != ULCX_OK) { fprintf(stderr, "libulc_amd: decode failed: %s\n", ulcx_last_error()); return 0; }
     return bits;

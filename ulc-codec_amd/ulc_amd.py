@@ -20,7 +20,7 @@ EXPORTS = [
     "ulcx_encoder_slot_bytes", "ulcx_encode_dev", "ulcx_encode_dev_pcm16", "ulcx_encode_host", "ulcx_encoder_debug_fetch",
     "ulcx_decoder_create", "ulcx_decoder_destroy", "ulcx_decoder_reset", "ulcx_decode_dev", "ulcx_decode_dev_pcm16", "ulcx_decode_host",
     "ulcx_encoder_last_fallbacks", "ulcx_ulc_header_pack", "ulcx_ulc_header_parse", "ulcx_ulc_rate_kbps",
-    "ulcx_pack_streams_dev", "ulcx_decode_packed_dev", "ulcx_decode_packed_host", "ulcx_encoder_stage_ms", "ulcx_encoder_stage_name", "ulcx_encoder_last_xf_launches", "ulcx_decoder_stage_ms", "ulcx_decoder_stage_name",
+    "ulcx_pack_streams_dev", "ulcx_decode_packed_dev", "ulcx_decode_packed_host", "ulcx_encoder_stage_ms", "ulcx_encoder_stage_name", "ulcx_encoder_last_xf_launches", "ulcx_decoder_stage_ms", "ulcx_decoder_stage_name", "ulcx_block_extent_bytes",
 ]
 
 
@@ -67,6 +67,7 @@ def lib():
         l.ulcx_encoder_stage_ms.argtypes = [C.c_void_p, _f32p, C.c_int]
         l.ulcx_encoder_last_xf_launches.argtypes = [C.c_void_p]
         l.ulcx_decoder_stage_ms.argtypes = [C.c_void_p, _f32p, C.c_int]
+        l.ulcx_block_extent_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         l.ulcx_encoder_stage_name.restype = C.c_char_p
         l.ulcx_decoder_stage_name.restype = C.c_char_p
         _lib = l
