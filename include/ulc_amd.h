@@ -107,7 +107,8 @@ enum {
     ULCX_ERR_NO_DEVICE = -2,   /* HIP runtime / gfx950 device not usable */
     ULCX_ERR_HIP       = -3,   /* a HIP call failed (message in ulcx_last_error) */
     ULCX_ERR_NOMEM     = -4,
-    ULCX_ERR_UNSUPPORTED = -5  /* valid for the reference, not built for the device yet (BlockSize > 8192) */
+    ULCX_ERR_UNSUPPORTED = -5  /* valid for the reference, not built for the device (no geometry is refused on this ground any more:
+                                  BlockSize up to 32768 and up to 255 channels are accepted, as ulcEncoder.c:32-34 / ulcDecoder.c:33-35 do) */
 };
 
 enum { ULCX_MODE_VBR = 0, ULCX_MODE_CBR = 1, ULCX_MODE_ABR = 2 };

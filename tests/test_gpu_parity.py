@@ -250,7 +250,10 @@ def test_packed_stream_pack_and_decode():
 
 
 @pytest.mark.parametrize("bs,ch,rate,B,K,calls,q", [
-    (8192, 2, 48000, 2, 3, 1, 40.0),     # largest block size built for the device
+    (8192, 2, 48000, 2, 3, 1, 40.0),     # largest block size the fast transform kernel takes
+    (16384, 2, 48000, 1, 3, 1, 50.0),    # above it: one array at a time (k_xf_big), general decoder kernel
+    (32768, 1, 44100, 2, 3, 1, 50.0),    # the reference's largest BlockSize (ulcEncoder.c:32-34)
+    (8192, 6, 48000, 1, 2, 1, 50.0),     # three M/S pairs of large blocks
     (2048, 6, 48000, 2, 4, 1, 50.0),     # 5.1-style: three M/S pairs
     (1024, 5, 44100, 3, 4, 1, 70.0),     # odd channel count > 2
     (2048, 2, 44100, 1, 1, 6, 50.0),     # one stream, one block per call: the drop-in shim's shape

@@ -711,6 +711,125 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
 }
 
 // ---------------------------------------------------------------------------
+// The same transform for BlockSize > 8192 (ulcEncoder.c:32-34 accepts up to 32768): the four arrays of a channel pair do
+// not fit in LDS together, so ONE array at a time - per channel the MDCT (coefficients, non-zero count), then the MDST
+// (line energies; Re^2 re-formed from the stored coefficient) - folded sample by sample through ms_sample()/win_apply(),
+// transformed by the whole workgroup (fftn_dif: the same butterflies, a barrier per pass).  Every arithmetic step is the
+// one k_xf takes, in the same order; not tuned (such block sizes are not a throughput case).
+// ---------------------------------------------------------------------------
+template <typename IN>
+__global__ __launch_bounds__(WG) void k_xf_big(UlcxEncCtx c, int k0, int k1) {
+    extern __shared__ float lds[];
+    const int BS = c.BS, C = c.C;
+    const int kc = k1 - k0;
+    const int NBk = c.B * kc;
+    const int vb = blockIdx.x;
+    if (vb >= NBk) return;
+    const int s = vb / kc, k = k0 + vb % kc;
+    const int blk = s * c.K + k;
+    const int tid = threadIdx.x;
+    float2 *z = (float2 *)lds;                         // one array of up to BS/2 complex, unpadded
+    __shared__ int s_nnz;
+    if (tid == 0) s_nnz = 0;
+    const int *wrow = c.wcArr + (size_t)s * (c.maxK + 2) + k;
+    const int wcPrev = wrow[0], wc = wrow[1], wcNext = wrow[2];
+    const int nextOv = first_overlap(wcNext, BS);
+    int ovFirst;                                       // right overlap of the previous block's last subblock
+    {
+        unsigned pp = ulcx_pattern(wcPrev);
+        int lastS = BS;
+        do { lastS = BS >> (pp & 7); } while (pp >>= 4);
+        ovFirst = first_overlap(wc, BS);
+        if (ovFirst > lastS) ovFirst = lastS;
+    }
+    const size_t cb = (size_t)C * BS;
+    float *coefO = c.coef + (size_t)blk * cb;
+    float *nsumO = c.nsum + (size_t)blk * (cb / 2);
+    float *ampO = c.amp2 + (size_t)blk * (BS / 2);
+    int nnz = 0;
+    __syncthreads();
+    for (int ch = 0; ch < C; ch++) {
+        unsigned pat = ulcx_pattern(wc);
+        int off = 0, ovL = ovFirst;
+        do {
+            const int S = BS >> (pat & 7);
+            const int d = pat & 7;
+            pat >>= 4;
+            int ov;
+            if (pat) { ov = BS >> (pat & 7); if (pat & 8) ov >>= (wc & 7); }
+            else ov = nextOv;
+            if (ov > S) ov = S;
+            const int M = S >> 1;
+            const int t0 = (k - 1) * BS - BS / 2 + off - S / 2;   // the subblock's frame = [t0, t0 + 2S) (closed form of the lapping FIFO, as k_xf)
+            const int aL = (S - ovL) >> 1, aR = (S - ov) >> 1;
+            const float *rise = c.T.winRise + ovL, *fall = c.T.winFall + ov;
+            const float2 *pre = c.T.pre[d];
+            const int bits = 31 - __clz(M);
+            const float norm = 2.0f / S;
+            for (int kind = 0; kind < 2; kind++) {                // 0: MDCT, 1: MDST
+                // 1. TDAC fold + DCT-IV pre-twiddle
+                for (int jj = tid; jj < M / 2; jj += WG) {
+                    const int iA = 2 * jj, iB = S - 2 - 2 * jj, iC = S + 2 * jj, iD = 2 * S - 2 - 2 * jj;
+                    const int ipos[8] = { iA, iA + 1, iB, iB + 1, iC, iC + 1, iD, iD + 1 };
+                    float xs[8];
+#pragma unroll
+                    for (int r = 0; r < 8; r++) xs[r] = win_apply(ms_sample<IN>(c, s, t0 + ipos[r], ch), ipos[r], S, aL, ovL, aR, ov, rise, fall);
+#pragma unroll
+                    for (int hsel = 0; hsel < 2; hsel++) {
+                        const int n = hsel ? M / 2 + jj : M / 2 - 1 - jj;
+                        const float lb = hsel ? xs[0] : xs[1], la = hsel ? xs[3] : xs[2];
+                        const float ra = hsel ? xs[4] : xs[5], rb = hsel ? xs[7] : xs[6];
+                        const float vr = ra + rb, wr = ra - rb;
+                        const float vl = la - lb, wl = lb + la;
+                        const float v1 = hsel ? vl : vr, v2 = hsel ? vr : vl;
+                        const float w1 = hsel ? wl : wr, w2 = hsel ? wr : wl;
+                        z[n] = kind ? cmulc(make_float2(w2, w1), pre[n]) : cmulc(make_float2(v1, v2), pre[n]);
+                    }
+                }
+                __syncthreads();
+                // 2. M-point FFT by the workgroup
+                fftn_dif(z, 1, M, c.T.tw[d], tid);
+                // 3. post-twiddle + normalise (BlockTransform.c:243-281)
+                for (int kk = tid; kk < M / 2; kk += WG) {
+                    const int kA = kk, kB = M - 1 - kk;
+                    const int r1 = (int)(__brev((unsigned)kA) >> (32 - bits));
+                    const int r2 = (int)(__brev((unsigned)kB) >> (32 - bits));
+                    const float2 y1 = cmulc(z[r1], pre[kA]), y2 = cmulc(z[r2], pre[kB]);
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        const int j = p ? kB : kA;
+                        const size_t gi = (size_t)ch * BS + off + 2 * j;
+                        if (kind == 0) {
+                            const float m0 = p ? y2.x : y1.x, m1 = p ? -y1.y : -y2.y;
+                            const float re0 = m0 * norm, re1 = m1 * norm;
+                            nnz += (fabsf(re0) < 0.5f * ULCX_COEF_EPS) ? 0 : 1;
+                            nnz += (fabsf(re1) < 0.5f * ULCX_COEF_EPS) ? 0 : 1;
+                            *(float2 *)(coefO + gi) = make_float2(re0, re1);
+                        } else {
+                            const float m0 = p ? y2.x : y1.x, m1 = p ? y1.y : y2.y;
+                            const float im0 = m0 * norm, im1 = m1 * norm;
+                            const float2 re = *(const float2 *)(coefO + gi);
+                            const float re0s = re.x * re.x, im0s = im0 * im0, re1s = re.y * re.y, im1s = im1 * im1;
+                            const float a0 = re0s + im0s, a1 = re1s + im1s;
+                            nsumO[(size_t)ch * (BS / 2) + off / 2 + j] = a0 + a1;       // (0 + a0) + a1
+                            float am = (ch == 0) ? 0.0f : ampO[off / 2 + j];            // channel order preserved
+                            am += a0; am += a1;
+                            ampO[off / 2 + j] = am;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            off += S; ovL = ov;
+        } while (pat);
+    }
+    for (int o = 32; o > 0; o >>= 1) nnz += __shfl_down(nnz, o);
+    if ((tid & 63) == 0) atomicAdd(&s_nnz, nnz);
+    __syncthreads();
+    if (tid == 0) c.nnz[blk] = s_nnz;
+}
+
+// ---------------------------------------------------------------------------
 // Block complexity + nOutCoef (BlockTransform.c:279-325, ulcEncoder.c:93-158)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_cplx(UlcxEncCtx c) {
@@ -2204,6 +2323,7 @@ __global__ __launch_bounds__(WG) void k_state_update(UlcxEncCtx c) {
 // ---------------------------------------------------------------------------
 // 4 padded arrays of BS/2 complex + BS/4 twiddles + counter (+ BS/2 floats of line energies for C > 2)
 size_t ulcx_enc_xf_lds_bytes(int BS, int C) {
+    if (BS > 8192) return (size_t)BS * 4;                       // k_xf_big: one unpadded array of BS/2 complex
     int ps = ulcx_xf_pad_shift(BS, C);
     size_t z = (size_t)4 * (BS + (BS >> ps)) * 4;               // four padded arrays of BS/2 complex
     size_t full = z + (size_t)BS * 2 + 32 + (C > 2 ? (size_t)BS * 2 : 0);
@@ -2221,6 +2341,11 @@ static void launch_wc_ef(const UlcxEncCtx &c, hipStream_t st, int k0, int k1) {
     else hipLaunchKernelGGL((k_wc_ef<EF_NW, float>), dim3((c.B + EF_SPW - 1) / EF_SPW), dim3(EF_NW * 64), EF_LDS_BYTES, st, c, k0, k1);
 }
 static void launch_xf(const UlcxEncCtx &c, unsigned grid, size_t lds, hipStream_t st, int k0, int k1) {
+    if (c.BS > 8192) {                                      // one array at a time (k_xf_big)
+        if (c.pcm16) hipLaunchKernelGGL(k_xf_big<int16_t>, dim3(grid), dim3(WG), lds, st, c, k0, k1);
+        else hipLaunchKernelGGL(k_xf_big<float>, dim3(grid), dim3(WG), lds, st, c, k0, k1);
+        return;
+    }
     if (c.pcm16) {
         if (c.C == 2) hipLaunchKernelGGL((k_xf<true, int16_t>), dim3(grid), dim3(WG), lds, st, c, k0, k1);
         else hipLaunchKernelGGL((k_xf<false, int16_t>), dim3(grid), dim3(WG), lds, st, c, k0, k1);
@@ -2268,6 +2393,8 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             CK(hipFuncSetAttribute((const void *)k_xf<false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             CK(hipFuncSetAttribute((const void *)k_xf<true, int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             CK(hipFuncSetAttribute((const void *)k_xf<false, int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CK(hipFuncSetAttribute((const void *)k_xf_big<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CK(hipFuncSetAttribute((const void *)k_xf_big<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
         const bool wcFuse = c.C == 2 && [] { const char *v = getenv("ULCX_WC_FUSE"); return !(v && v[0] == '0'); }();   // stereo: k_wc_energy + k_wc_forward in one kernel (k_wc_ef)
         auto launch_wc = [&](hipStream_t s2, int k0, int k1, bool marks) -> int {

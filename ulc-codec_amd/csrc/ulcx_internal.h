@@ -7,7 +7,7 @@
 
 #define ULCX_NBARK 25
 #define ULCX_MAX_SUB 4
-#define ULCX_MAX_BS_DEVICE 8192        // LDS budget of the transform kernels
+#define ULCX_MAX_BS_DEVICE 32768       // the reference's own limit (ulcEncoder.c:32-34); above 8192 the transform takes one array at a time (k_xf_big)
 #define ULCX_COEF_EPS (0x1.0p-31f)     // include/ulcEncoder.h:36
 #define ULCX_HEAP_LDS_BYTES (128 * 1024)
 #define ULCX_HEAP_GRID 256
