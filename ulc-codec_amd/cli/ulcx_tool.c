@@ -195,6 +195,10 @@ static int do_decode(int argc, char **argv) {
         if (fread(buf, 1, (size_t)len, f) != (size_t)len) DIE("short read on '%s'", argv[a + s]);
         fclose(f);
         if (ulcx_ulc_header_parse(&h[s], buf, (size_t)len)) DIE("'%s' is not a ULC2 container", argv[a + s]);
+        /* the header is untrusted input: validate it before anything is sized or indexed from it */
+        if (h[s].StreamOffs < 24 || (long)h[s].StreamOffs > len) DIE("'%s': stream offset %u outside the file (%ld bytes)", argv[a + s], h[s].StreamOffs, len);
+        if (h[s].nChan < 1 || h[s].nChan > 255 || h[s].BlockSize < 256 || h[s].BlockSize > 32768 || (h[s].BlockSize & (h[s].BlockSize - 1)))
+            DIE("'%s': invalid geometry in the header (BlockSize %u, %u channels)", argv[a + s], h[s].BlockSize, h[s].nChan);
         if (h[s].BlockSize != h[0].BlockSize || h[s].nChan != h[0].nChan || h[s].RateHz != h[0].RateHz)
             DIE("'%s': all inputs of one call must share block size, channels and rate", argv[a + s]);
         pay[s] = buf; payBytes[s] = (int32_t)(len - (long)h[s].StreamOffs);
