@@ -1079,13 +1079,28 @@ __device__ __forceinline__ float key0_of(float re) {
     asm volatile("" : "+v"(k));
     return (fabsf(re) < 0.5f * ULCX_COEF_EPS) ? __uint_as_float(0xff800000u) : k;
 }
-// key of coefficient i of block blk, from the stored coefficient and c.mask (the masking level per line); once
+// Psyopt.c:140-150: masking level of line pair jp (0 <= jp < BS/2) of a block: interpolation between the Bark levels of
+// its subblock (bark4 = the block's [4][25] levels from k_pbark).  Evaluated where the keys are formed: no array of it in HBM.
+__device__ __forceinline__ float mask_level(const UlcxEncCtx &c, const float *bark4, int wc, int jp) {
+    unsigned pat = ulcx_pattern(wc);
+    int off = 0, d = 0, S = c.BS, j = 0;
+    for (;; j++) { d = pat & 7; S = c.BS >> d; if (2 * jp < off + S) break; off += S; pat >>= 4; }
+    const int line = jp - off / 2;
+    const float *bark = bark4 + j * ULCX_NBARK;
+    const int bi = c.T.bandIdx[d][line];
+    const float fr = c.T.bandFrac[d][line];
+    const float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
+    const float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
+    return L * (1.0f - fr) + R * fr;
+}
+// key of coefficient i of block blk, from the stored coefficient and the masking level of its line; once
 // k_keys_finalize has run for the call (c.keyFinal: the multi-pass selection kernel of unusual geometries, the parity
 // tap) c.key holds the same values
 __device__ __forceinline__ float load_final_key(const UlcxEncCtx &c, int blk, int i) {
     if (c.keyFinal) return c.key[(size_t)blk * (c.C * c.BS) + i];
     int ch = i >> c.lgBS, n = i & (c.BS - 1);
-    return final_key(key0_of(c.coef[(size_t)blk * (c.C * c.BS) + i]), c.mask[(size_t)blk * (c.BS / 2) + (n >> 1)], ch);
+    const int wcB = c.wcArr[(size_t)(blk / c.K) * (c.maxK + 2) + (blk % c.K) + 1];
+    return final_key(key0_of(c.coef[(size_t)blk * (c.C * c.BS) + i]), mask_level(c, c.barkP + (size_t)blk * 4 * ULCX_NBARK, wcB, n >> 1), ch);
 }
 
 // Psyopt.c:140-150: masking level per line
@@ -1235,7 +1250,18 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
     }
     uint32_t u[R];
     {
-        const float *msk = c.mask + (size_t)blk * (c.BS / 2);
+        // the block's masking level per line (Psyopt.c:140-150), formed by the wave into LDS (BS/2 <= 32 R values) instead of
+        // being read from an array another kernel wrote
+        extern __shared__ float sel_lds[];                    // per wave: BS/2 masking levels + the block's 4 x 25 Bark levels
+        float *msk = sel_lds + wv * (c.BS / 2 + 4 * ULCX_NBARK);
+        float *sbarkw = msk + c.BS / 2;
+        {
+            for (int i = lane; i < 4 * ULCX_NBARK; i += 64) sbarkw[i] = c.barkP[(size_t)blk * 4 * ULCX_NBARK + i];
+            const int wcB = c.wcArr[(size_t)(blk / c.K) * (c.maxK + 2) + (blk % c.K) + 1];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int jp = lane; jp < c.BS / 2; jp += 64) msk[jp] = mask_level(c, sbarkw, wcB, jp);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         // batches of 8: the loads of one batch are in flight together, but the compiler may not hoist all R of them
         // above the arithmetic (that doubled the register count and halved the occupancy)
 #pragma unroll
@@ -2506,7 +2532,9 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             int rcn = launch_noise(side2, false); if (rcn) return rcn;
             CK(hipEventRecord(evNoise, side2));
         }
-        hipLaunchKernelGGL(k_mask, dim3(NB), dim3(WG), 0, st, c);                                          MARK();
+        // ("k_mask": gone - the masking level per line is formed where the keys are, mask_level(); geometries on the generic
+        //  selection kernel evaluate it per key)
+        MARK();
     }
     if (noiseAside) CK(hipStreamWaitEvent(st, evCplx, 0));
     // --- selection + encode pass(es)
@@ -2530,14 +2558,15 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         // No read-back: the host always enqueues the full count and a pass whose blocks have all converged (c.cbrLive,
         // counted down on the device) returns at the top of every kernel - nothing inside the call waits for the device.
     }
+    const size_t selLds = (size_t)4 * (c.BS / 2 + 4 * ULCX_NBARK) * sizeof(float);
     auto launch_select = [&](int fin) {
         int R = N / 64;
         switch (R) {
-            case 64: hipLaunchKernelGGL(k_select_wave<64>, dim3((NB + 3) / 4), dim3(256), 0, st, c, fin); return true;
-            case 32: hipLaunchKernelGGL(k_select_wave<32>, dim3((NB + 3) / 4), dim3(256), 0, st, c, fin); return true;
-            case 16: hipLaunchKernelGGL(k_select_wave<16>, dim3((NB + 3) / 4), dim3(256), 0, st, c, fin); return true;
-            case 8:  hipLaunchKernelGGL(k_select_wave<8>, dim3((NB + 3) / 4), dim3(256), 0, st, c, fin); return true;
-            case 4:  hipLaunchKernelGGL(k_select_wave<4>, dim3((NB + 3) / 4), dim3(256), 0, st, c, fin); return true;
+            case 64: hipLaunchKernelGGL(k_select_wave<64>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;
+            case 32: hipLaunchKernelGGL(k_select_wave<32>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;
+            case 16: hipLaunchKernelGGL(k_select_wave<16>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;
+            case 8:  hipLaunchKernelGGL(k_select_wave<8>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;
+            case 4:  hipLaunchKernelGGL(k_select_wave<4>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;
             default: return false;
         }
     };
