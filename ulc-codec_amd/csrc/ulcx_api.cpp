@@ -139,7 +139,6 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.nsum, NB * cb / 2, false);
     DA(c.npair, NB * cb, false);
     DA(c.amp2, NB * BlockSize / 2, false);
-    DA(c.mask, NB * BlockSize / 2, false);
     DA(c.barkN, NB * nChan * 4 * ULCX_NBARK, true);
     DA(c.barkP, NB * 4 * ULCX_NBARK, true);
     DA(c.nnz, NB, true);

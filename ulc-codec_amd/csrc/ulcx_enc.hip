@@ -1103,31 +1103,6 @@ __device__ __forceinline__ float load_final_key(const UlcxEncCtx &c, int blk, in
     return final_key(key0_of(c.coef[(size_t)blk * (c.C * c.BS) + i]), mask_level(c, c.barkP + (size_t)blk * 4 * ULCX_NBARK, wcB, n >> 1), ch);
 }
 
-// Psyopt.c:140-150: masking level per line
-__global__ __launch_bounds__(WG) void k_mask(UlcxEncCtx c) {
-    // one workgroup per block: Bark levels in LDS, BS/512 lines per thread
-    __shared__ float sbark[4 * ULCX_NBARK];
-    int blk = blockIdx.x, tid = threadIdx.x;
-    int half = c.BS / 2;
-    int s = blk / c.K, k = blk % c.K;
-    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
-    if (tid < 4 * ULCX_NBARK) sbark[tid] = c.barkP[(size_t)blk * 4 * ULCX_NBARK + tid];
-    __syncthreads();
-    float *dst = c.mask + (size_t)blk * half;
-    for (int jp = tid; jp < half; jp += WG) {
-        unsigned pat = ulcx_pattern(wc);
-        int off = 0, d = 0, S = c.BS, j = 0;
-        for (;; j++) { d = pat & 7; S = c.BS >> d; if (2 * jp < off + S) break; off += S; pat >>= 4; }
-        int line = jp - off / 2;
-        const float *bark = sbark + j * ULCX_NBARK;
-        int bi = c.T.bandIdx[d][line];
-        float fr = c.T.bandFrac[d][line];
-        float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
-        float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
-        stnt(dst + jp, L * (1.0f - fr) + R * fr);
-    }
-}
-
 // debug/parity tap only: materialise the final keys in c.key (ulcx_encoder_debug_fetch)
 __global__ __launch_bounds__(WG) void k_keys_finalize(UlcxEncCtx c) {
     size_t gid = (size_t)blockIdx.x * WG + threadIdx.x;

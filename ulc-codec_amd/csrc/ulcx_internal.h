@@ -64,7 +64,6 @@ struct UlcxEncCtx {
     float  *nsum;                        // [NB][C*BS/2] per-line |X|^2 (noise input)
     float  *npair;                       // [NB][C*BS]   {w, w*log} pairs (TransformNoise)
     float  *amp2;                        // [NB][BS/2]
-    float  *mask;                        // [NB][BS/2]   masking level per line (MaskingNp)
     float  *barkN;                       // [NB][C*4][25]
     float  *barkP;                       // [NB][4][25]
     int    *nnz;                         // [NB]
