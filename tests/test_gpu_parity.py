@@ -139,6 +139,31 @@ def test_decode_bit_exact(bs, ch, rate, q):
     dec.close()
 
 
+@pytest.mark.parametrize("bs,ch,rate,q", [(2048, 2, 44100, 50.0), (512, 1, 48000, 70.0)])
+def test_decode_block_filling_its_slot_exactly(bs, ch, rate, q):
+    """slotBytes = the byte count of the call's largest block (what a caller sizing slots to the container's MaxBlockSize
+    passes): that block ends on the last byte of its slot and must decode like any other (no hidden headroom)."""
+    amd = _amd()
+    B, K = 7, 6
+    pcm = _streams(B, K, bs, ch, rate, True, seed=11)
+    wide = 2 * ch * bs + 16
+    refs = [oracle_encode_debug(pcm[s], bs, rate, 0, q, slot=wide) for s in range(B)]
+    nbytes = np.stack([(r["bits"] + 7) // 8 for r in refs])         # [B][K]
+    slot = int(nbytes.max())
+    tight = np.zeros((B, K, slot), np.uint8)
+    for s in range(B):
+        for k in range(K):
+            tight[s, k, :nbytes[s, k]] = refs[s]["out"][k, :nbytes[s, k]]
+    dec = amd.BatchDecoder(B, ch, bs, K)
+    got, gbits = dec.decode(tight)
+    for s in range(B):
+        rc, ref_pcm, ref_bits = oracle_decode_stream(refs[s]["out"], ch, bs)
+        assert rc == 0
+        assert np.array_equal(gbits[s], ref_bits), f"stream {s}: bits consumed differ with slot = {slot} bytes"
+        assert np.array_equal(got[s], ref_pcm), f"stream {s}: decoded PCM differs with slot = {slot} bytes"
+    dec.close()
+
+
 @pytest.mark.parametrize("bs,ch,B,K,calls", [(512, 2, 40, 6, 2), (2048, 2, 70, 5, 2), (1024, 1, 33, 7, 1), (256, 3, 20, 4, 2), (4096, 2, 9, 3, 1)])
 def test_decode_hand_assembled_streams(bs, ch, B, K, calls):
     """Every code of the block syntax, including those the encoder never emits: decimation codes
