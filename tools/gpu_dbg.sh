@@ -1,8 +1,7 @@
 #!/bin/bash
-# scratch: stand-alone kernel times (single stream) of two library builds
+# scratch: parity tests + the window-switching configuration
 cd "$(dirname "$0")/.."
-cp ulc-codec_amd/libulc_amd.so /tmp/lib_keep.so
-for f in ab/*.so; do cp $f ulc-codec_amd/libulc_amd.so; ULCX_ASYNC_FB=0 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu --mode encode 2>/dev/null | python -c "
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | tail -2
+timeout 600 python bench.py --config wswitch_4096 --steps 3 --warmup 1 --no-cpu 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); k=d['kernels_ms']; w=d['whole_pipeline']
-print('$(basename $f .so)', 'step %.3f |' % (d['ms_per_step']), ' '.join('%s %.2f' % (n.split('.')[1][2:], v) for n, v in k.items() if v > 0.03))"; done
-cp /tmp/lib_keep.so ulc-codec_amd/libulc_amd.so
+print('wswitch step %.3f enc %.3f dec %.3f |' % (d['ms_per_step'], w['encode_ms'], w['decode_ms']), ' '.join('%s %.2f' % (n.split('.')[1][2:], v) for n, v in k.items() if v > 0.05))"

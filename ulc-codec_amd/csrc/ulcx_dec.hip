@@ -560,9 +560,10 @@ __device__ __forceinline__ int dec_time_wave(const UlcxDecCtx &c, float2 *zc, fl
 #pragma unroll
             for (int t = 0; t < DEC_MAXT; t++) {
                 const int n = lane + 64 * t;
-                if (n < S) dv[t] = (n < avail) ? L[H2 - 1 - n] : tj[padf(n - avail)];
+                // (L may be global memory, tj is LDS: separate branches, never a select between the two pointers)
+                if (n < S) { if (n < avail) dv[t] = L[H2 - 1 - n]; else dv[t] = tj[padf(n - avail)]; }
                 if (n < avail) {
-                    if (S <= avail) qv[t] = (n < avail - S) ? L[H2 - 1 - (n + S)] : tj[padf(n - (avail - S))];
+                    if (S <= avail) { if (n < avail - S) qv[t] = L[H2 - 1 - (n + S)]; else qv[t] = tj[padf(n - (avail - S))]; }
                     else qv[t] = tj[padf(S - avail + n)];
                 }
             }
@@ -608,8 +609,8 @@ struct DsynLds { int zFloats, lapFloats, twFloats, listFloats; };
 __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int twInLds) {
     DsynLds l;
     l.zFloats = (fast ? 2 : 1) * 2 * FFT_PADDEDS(BS / 2, DPS);
-    l.lapFloats = fast ? 2 * (BS / 2) : 0;
-    l.twFloats = fast ? BS / 2 : 0;
+    l.lapFloats = (fast && BS <= 2048) ? 2 * (BS / 2) : 0;      // (above 2048 the stereo kernel keeps the lapping state in global memory: a third workgroup per CU)
+    l.twFloats = (fast && BS <= 2048) ? BS / 2 : 0;               // (likewise the FFT twiddles: read from the tables in global memory, L1/L2-hot, a fourth workgroup per CU)
     l.listFloats = 2 * (64 + DSYN_PWORDS(BS)) + 128;             // per wave: prefix counts, sign-parity stream; per workgroup: 128 block / channel RNG states
     (void)C; (void)twInLds;
     return l;
@@ -618,7 +619,7 @@ __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int 
 // ---------------------------------------------------------------------------
 // Stereo streams (BlockSize <= 4096): one workgroup = one stream, one wave per channel up to the end of the FFTs.
 // ---------------------------------------------------------------------------
-template <typename OUT, int DEC_MAXT>
+template <typename OUT, int DEC_MAXT, bool LAPG>
 __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
     extern __shared__ float lds[];
     const int BS = c.BS, H2 = BS / 2;
@@ -627,16 +628,20 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const DsynLds L = dsyn_lds(BS, C, 1, 1);
     float2 *z    = (float2 *)lds;
-    float  *lap  = lds + L.zFloats;
+    float *glap = c.lap + (size_t)s * C * H2;
+    // lapping state: in LDS for the stream's blocks of this call, or (LAPG: BlockSize 4096) used where it lives.  Every
+    // element is read and rewritten by the same thread in un-decimated blocks and by the same wave in decimated ones;
+    // the barriers between the two kinds of block order the rest.
+    float  *lap;
+    if constexpr (LAPG) lap = glap; else lap = lds + L.zFloats;
     float2 *twl  = (float2 *)(lds + L.zFloats + L.lapFloats);        // FFT twiddles: the full-size table, or the three of a decimated block's sizes
     SynWave sw;
     sw.pre  = (int *)(lds + L.zFloats + L.lapFloats + L.twFloats) + wv * (64 + DSYN_PWORDS(BS));
     sw.seedTab = (uint32_t *)(sw.pre + 64);
     uint32_t *bseed = (uint32_t *)(lds + L.zFloats + L.lapFloats + L.twFloats + 2 * (64 + DSYN_PWORDS(BS)));   // [0,64): RNG state at each block's start, [64,128): at its second channel
     sw.lane = lane;
-    float *glap = c.lap + (size_t)s * C * H2;
-    for (int i = tid; i < 2 * H2; i += WG) lap[i] = glap[i];
-    for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
+    if (!LAPG) for (int i = tid; i < 2 * H2; i += WG) lap[i] = glap[i];
+    if (!LAPG) for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
     bool twFull = true;
     int lastSub = c.lastSub[s];
     int dead = c.dead[s];
@@ -690,7 +695,7 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
         int nsub = 1;
         if (!whole) { nsub = 0; unsigned q = pat0; do nsub++; while (q >>= 4); }
         auto unit_draws = [&](int ch, int j) { return ((j + 1 < nsub) ? udraw[ch * 4 + j + 1] : (ch + 1 < C) ? udraw[(ch + 1) * 4] : c.draws[blk]) - udraw[ch * 4 + j]; };
-        if (whole != twFull) {
+        if (!LAPG && whole != twFull) {
             // twiddle tables for this block's transform sizes: the full-size one, or those of N/2, N/4, N/8 back to back
             if (whole) for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
             else for (int i = tid; i < 7 * BS / 32; i += WG) {
@@ -724,7 +729,8 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                     zj[pn2] = cmulc(make_float2(b.x, a.y), pre[n2]);
                 }
                 STAMP(11);
-                fft_wave_dif(zj, M, twl + (d <= 1 ? 0 : d == 2 ? BS / 8 : 3 * BS / 16), lane, DPS);
+                if constexpr (LAPG) fft_wave_dif(zj, M, c.T.tw[d], lane, DPS);
+                else fft_wave_dif(zj, M, twl + (d <= 1 ? 0 : d == 2 ? BS / 8 : 3 * BS / 16), lane, DPS);
                 }
                 STAMP(3);
                 off += S;
@@ -805,7 +811,7 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
 #ifdef ULCX_DSYN_STAMPS
     if (lane == 0) for (int i = 0; i < 12; i++) ((unsigned long long *)(c.scratch + (size_t)s * 4 * BS))[wv * 12 + i] = stq.t[i];
 #endif
-    for (int i = tid; i < 2 * H2; i += WG) glap[i] = lap[i];
+    if (!LAPG) for (int i = tid; i < 2 * H2; i += WG) glap[i] = lap[i];
     if (tid == 0) { c.lastSub[s] = lastSub; c.seed[s] = seed; c.dead[s] = dead; }
 }
 
@@ -979,13 +985,13 @@ int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev) {
     size_t lds = ulcx_dec_lds_bytes(c.BS, c.C, c.fastOK, c.twInLds);
     const bool small = c.BS <= 2048;                      // register slots of the decimated-block path (dec_time_wave)
     const void *fn = !c.fastOK ? (c.pcm16 ? (const void *)k_dgen<int16_t> : (const void *)k_dgen<float>)
-                   : c.pcm16 ? (small ? (const void *)k_dsyn<int16_t, 16> : (const void *)k_dsyn<int16_t, 32>)
-                             : (small ? (const void *)k_dsyn<float, 16> : (const void *)k_dsyn<float, 32>);
+                   : c.pcm16 ? (small ? (const void *)k_dsyn<int16_t, 16, false> : (const void *)k_dsyn<int16_t, 32, true>)
+                             : (small ? (const void *)k_dsyn<float, 16, false> : (const void *)k_dsyn<float, 32, true>);
     if (lds > 48 * 1024) CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (c.dbgSkip & 8) {}
     else if (!c.fastOK) { if (c.pcm16) hipLaunchKernelGGL(k_dgen<int16_t>, dim3(c.B), dim3(WG), lds, st, c); else hipLaunchKernelGGL(k_dgen<float>, dim3(c.B), dim3(WG), lds, st, c); }
-    else if (c.pcm16) { if (small) hipLaunchKernelGGL((k_dsyn<int16_t, 16>), dim3(c.B), dim3(WG), lds, st, c); else hipLaunchKernelGGL((k_dsyn<int16_t, 32>), dim3(c.B), dim3(WG), lds, st, c); }
-    else { if (small) hipLaunchKernelGGL((k_dsyn<float, 16>), dim3(c.B), dim3(WG), lds, st, c); else hipLaunchKernelGGL((k_dsyn<float, 32>), dim3(c.B), dim3(WG), lds, st, c); }
+    else if (c.pcm16) { if (small) hipLaunchKernelGGL((k_dsyn<int16_t, 16, false>), dim3(c.B), dim3(WG), lds, st, c); else hipLaunchKernelGGL((k_dsyn<int16_t, 32, true>), dim3(c.B), dim3(WG), lds, st, c); }
+    else { if (small) hipLaunchKernelGGL((k_dsyn<float, 16, false>), dim3(c.B), dim3(WG), lds, st, c); else hipLaunchKernelGGL((k_dsyn<float, 32, true>), dim3(c.B), dim3(WG), lds, st, c); }
     if (ev) CK(hipEventRecord(ev[stage++], st));
     CK(hipGetLastError());
     return ULCX_OK;

@@ -2517,7 +2517,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         // geometries the one-wave-per-block selection does not cover go through the multi-pass kernel, which reads every
         // key several times: form the final keys once for it (and for the exact path's heapsort)
         const int Nk = c.C * c.BS, R = Nk / 64;
-        const bool selWave = (Nk % 64 == 0) && (R == 4 || R == 8 || R == 16 || R == 32 || R == 64);
+        const bool selWave = (Nk % 64 == 0) && (R == 4 || R == 8 || R == 16 || R == 32 || R == 64 || R == 128);
         if (!selWave) { ulcx_enc_finalize_keys(c, st); c.keyFinal = 1; }
     }
     int N = c.C * c.BS;
@@ -2537,6 +2537,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     auto launch_select = [&](int fin) {
         int R = N / 64;
         switch (R) {
+            case 128: hipLaunchKernelGGL(k_select_wave<128>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;   // (BlockSize 4096 stereo: ~200 VGPRs, one wave per SIMD)
             case 64: hipLaunchKernelGGL(k_select_wave<64>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;
             case 32: hipLaunchKernelGGL(k_select_wave<32>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;
             case 16: hipLaunchKernelGGL(k_select_wave<16>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;
