@@ -224,6 +224,12 @@ int  ulcx_decode_packed_dev(ulcx_decoder *dec, const uint8_t *d_payload, long lo
 int  ulcx_decode_packed_host(ulcx_decoder *dec, const uint8_t *h_payload, long long payloadStride, const int32_t *h_payloadBytes,
                              int nBlocks, float *h_pcm, int32_t *h_bits);
 
+/* Whole files (what ulcx-tool does, tools/ulcDecodeTool.c:123-166 batched): upload every stream's payload ONCE - the
+ * read positions are rewound - then each ulcx_decode_resident_host call decodes the next nBlocks blocks of every stream
+ * from the device-resident copy.  (ulcx_decode_packed_host uploads all payloads on every call.) */
+int  ulcx_decoder_upload_payload(ulcx_decoder *dec, const uint8_t *h_payload, long long payloadStride, const int32_t *h_payloadBytes);
+int  ulcx_decode_resident_host(ulcx_decoder *dec, int nBlocks, float *h_pcm, int32_t *h_bits);
+
 /* Timing helper for bench.py: device time (ms, hipEvent) of the kernels the last
  * ulcx_*_dev call enqueued, per pipeline stage; returns number of stages written.
  * Only valid after the stream has been synchronised. */

@@ -264,6 +264,11 @@ def test_packed_stream_pack_and_decode():
     for s in range(B):
         rc2, ref_pcm, ref_bits = oracle_decode_stream(refs[s]["out"], ch, bs)
         assert np.array_equal(gb[s], ref_bits) and np.array_equal(got[s], ref_pcm), s
+    # the same from a payload uploaded once (what ulcx-tool does for whole files)
+    dec.upload_payload(host, nbytes)
+    p5, b5 = dec.decode_resident(K // 2)
+    p6, b6 = dec.decode_resident(K // 2)
+    assert np.array_equal(np.concatenate([p5, p6], axis=1), got) and np.array_equal(np.concatenate([b5, b6], axis=1), gb)
     # a truncated payload ends its stream there
     dec.reset()
     cut = nbytes.copy(); cut[2] = nbytes[2] // 2

@@ -1,21 +1,9 @@
 #!/bin/bash
-# scratch: per-launch kernel durations of one CBR encode call (65536 blocks)
+# scratch: parity + A/B of early k_nbark launches (environment switch, one box)
 cd "$(dirname "$0")/.."
-export TMPDIR=/tmp; rm -rf gpurun_out/cbr_tr
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/cbr_tr -- python3 bench.py --config cbr64_48k --streams 4096 --mode encode --steps 1 --warmup 1 --no-cpu > gpurun_out/cbr_tr.txt 2>&1
-f=$(find gpurun_out/cbr_tr -name "*kernel_trace.csv" | head -1)
-python3 - "$f" <<'PY'
-import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-rows = [r for r in rows if r['Kernel_Name'].replace('void ','').startswith('k_')]
-rows.sort(key=lambda r: int(r['Start_Timestamp']))
-# last call: find last k_cplx
-idx = max(i for i, r in enumerate(rows) if 'k_cplx' in r['Kernel_Name'])
-t0 = int(rows[idx]['Start_Timestamp'])
-out = []
-for r in rows[idx:]:
-    n = r['Kernel_Name'].replace('void ','').split('(')[0]
-    out.append((n, (int(r['Start_Timestamp'])-t0)/1e6, (int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6))
-for n, s, d in out:
-    if d > 0.02: print("%-28s start %8.3f dur %7.3f" % (n[:28], s, d))
-PY
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -2
+for r in 1 2 3; do for v in 0 1; do
+if [ $v = 1 ]; then export ULCX_NBARK_LATE=1; else unset ULCX_NBARK_LATE; fi
+timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); k=d['kernels_ms']; w=d['whole_pipeline']
+print('late=$v', 'step %.3f enc %.3f dec %.3f |' % (d['ms_per_step'], w['encode_ms'], w['decode_ms']), ' '.join('%s %.2f' % (n.split('.')[1][2:], v) for n, v in k.items() if v > 0.05))"; done; done

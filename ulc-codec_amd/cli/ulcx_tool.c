@@ -223,10 +223,11 @@ static int do_decode(int argc, char **argv) {
         if (!fo[s]) DIE("cannot create '%s'", path);
         wav_write_header(fo[s], (int)h[s].RateHz, C, isFloat, h[s].nBlocks * (uint32_t)bs);
     }
+    if (ulcx_decoder_upload_payload(dec, payload, stride, payBytes) != ULCX_OK) DIE("upload: %s", ulcx_last_error());   /* once, not per call */
     int rcAll = 0;
     for (uint32_t k0 = 0; k0 < maxBlk; k0 += KBLOCKS) {
         int K = (maxBlk - k0 < KBLOCKS) ? (int)(maxBlk - k0) : KBLOCKS;
-        if (ulcx_decode_packed_host(dec, payload, stride, payBytes, K, pcm, bits) != ULCX_OK) DIE("decode: %s", ulcx_last_error());
+        if (ulcx_decode_resident_host(dec, K, pcm, bits) != ULCX_OK) DIE("decode: %s", ulcx_last_error());
         for (int s = 0; s < B; s++)
             for (int k = 0; k < K && k0 + (uint32_t)k < h[s].nBlocks; k++) {
                 if (!bits[s * K + k]) { fprintf(stderr, "ulcx-tool: %s: corrupted stream at block %u\n", argv[a + s], k0 + (uint32_t)k); rcAll = 1; }

@@ -34,6 +34,7 @@ struct ulcx_decoder {
     hipEvent_t ev[ULCX_DEC_STAGES + 1];
     bool evOk, evRecorded;
     uint8_t *d_in; int d_in_bytes; float *d_pcm; int32_t *d_bits;
+    uint8_t *d_pay; int32_t *d_payBytes; long long payStride;     // resident packed payloads (ulcx_decoder_upload_payload)
 };
 
 extern "C" int ulcx_device_count(void) {
@@ -326,6 +327,8 @@ extern "C" int ulcx_encoder_last_xf_launches(ulcx_encoder *e) { return (e && e->
 static void cleanup(ulcx_decoder *e) {
     if (!e) return;
     for (void *p : e->allocs) hipFree(p);
+    if (e->d_pay) hipFree(e->d_pay);
+    if (e->d_payBytes) hipFree(e->d_payBytes);
     if (e->tables) hipFree(e->tables);
     if (e->evOk) for (auto &v : e->ev) hipEventDestroy(v);
     delete e;
@@ -377,7 +380,7 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     ulcx_decoder *e = new ulcx_decoder();
     e->device = device; e->B = nStreams; e->C = nChan; e->BS = BlockSize; e->maxK = maxBlocksPerCall;
     e->tables = nullptr; e->evOk = false; e->evRecorded = false;
-    e->d_in = nullptr; e->d_in_bytes = 0; e->d_pcm = nullptr; e->d_bits = nullptr;
+    e->d_in = nullptr; e->d_in_bytes = 0; e->d_pcm = nullptr; e->d_bits = nullptr; e->d_pay = nullptr; e->d_payBytes = nullptr; e->payStride = 0;
     UlcxDecCtx &c = e->ctx;
     memset(&c, 0, sizeof(c));
     c.B = nStreams; c.C = nChan; c.BS = BlockSize; c.lgBS = ilog2i(BlockSize); c.maxK = maxBlocksPerCall;
@@ -531,6 +534,39 @@ extern "C" int ulcx_decode_packed_host(ulcx_decoder *e, const uint8_t *h_payload
     }
     hipFree(dp); hipFree(dn); hipFree(dpcm); hipFree(dbits);
     return rc;
+}
+
+// Whole files: the payloads go to the device once, every later call decodes the next nBlocks of every stream from there
+// (ulcx_decode_packed_host re-uploads everything per call: fine for one call, quadratic over a long file).
+extern "C" int ulcx_decoder_upload_payload(ulcx_decoder *e, const uint8_t *h_payload, long long payloadStride, const int32_t *h_payloadBytes) {
+    if (!e || !h_payload || !h_payloadBytes || payloadStride < 1) return ULCX_ERR_ARG;
+    CKR(hipSetDevice(e->device));
+    if (e->d_pay) { hipFree(e->d_pay); e->d_pay = nullptr; }
+    if (e->d_payBytes) { hipFree(e->d_payBytes); e->d_payBytes = nullptr; }
+    size_t bytes = (size_t)e->B * (size_t)payloadStride;
+    CKR(hipMalloc((void **)&e->d_pay, bytes + 16)); CKR(hipMalloc((void **)&e->d_payBytes, sizeof(int32_t) * e->B));
+    CKR(hipMemset(e->d_pay, 0, bytes + 16));
+    CKR(hipMemcpy(e->d_pay, h_payload, bytes, hipMemcpyHostToDevice));
+    CKR(hipMemcpy(e->d_payBytes, h_payloadBytes, sizeof(int32_t) * e->B, hipMemcpyHostToDevice));
+    e->payStride = payloadStride;
+    return ulcx_decoder_reset(e);
+}
+extern "C" int ulcx_decode_resident_host(ulcx_decoder *e, int nBlocks, float *h_pcm, int32_t *h_bits) {
+    if (!e || !h_pcm || !h_bits || nBlocks < 1 || nBlocks > e->maxK) return ULCX_ERR_ARG;
+    if (!e->d_pay) { ulcx_set_error("ulcx_decode_resident_host: no payload uploaded"); return ULCX_ERR_ARG; }
+    CKR(hipSetDevice(e->device));
+    size_t cb = (size_t)e->C * e->BS, NB = (size_t)e->B * nBlocks;
+    if (!e->d_pcm) {
+        int rc0; size_t NBmax = (size_t)e->B * e->maxK;
+        if ((rc0 = dalloc(e->allocs, &e->d_pcm, NBmax * cb, false))) return rc0;
+        if ((rc0 = dalloc(e->allocs, &e->d_bits, NBmax, false))) return rc0;
+    }
+    int rc = ulcx_decode_packed_dev(e, e->d_pay, e->payStride, e->d_payBytes, nBlocks, e->d_pcm, e->d_bits, nullptr);
+    if (rc != ULCX_OK) return rc;
+    CKR(hipDeviceSynchronize());
+    CKR(hipMemcpy(h_pcm, e->d_pcm, sizeof(float) * NB * cb, hipMemcpyDeviceToHost));
+    CKR(hipMemcpy(h_bits, e->d_bits, sizeof(int32_t) * NB, hipMemcpyDeviceToHost));
+    return ULCX_OK;
 }
 
 // diagnostic: first nBytes of the general-path staging buffer (a -DULCX_DSYN_STAMPS build leaves per-phase cycle counts there)

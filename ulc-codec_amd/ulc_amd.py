@@ -20,7 +20,7 @@ EXPORTS = [
     "ulcx_encoder_slot_bytes", "ulcx_encode_dev", "ulcx_encode_dev_pcm16", "ulcx_encode_host", "ulcx_encoder_debug_fetch",
     "ulcx_decoder_create", "ulcx_decoder_destroy", "ulcx_decoder_reset", "ulcx_decode_dev", "ulcx_decode_dev_pcm16", "ulcx_decode_host",
     "ulcx_encoder_last_fallbacks", "ulcx_ulc_header_pack", "ulcx_ulc_header_parse", "ulcx_ulc_rate_kbps",
-    "ulcx_pack_streams_dev", "ulcx_decode_packed_dev", "ulcx_decode_packed_host", "ulcx_encoder_stage_ms", "ulcx_encoder_stage_name", "ulcx_encoder_last_xf_launches", "ulcx_decoder_stage_ms", "ulcx_decoder_stage_name", "ulcx_block_extent_bytes",
+    "ulcx_pack_streams_dev", "ulcx_decode_packed_dev", "ulcx_decode_packed_host", "ulcx_decoder_upload_payload", "ulcx_decode_resident_host", "ulcx_encoder_stage_ms", "ulcx_encoder_stage_name", "ulcx_encoder_last_xf_launches", "ulcx_decoder_stage_ms", "ulcx_decoder_stage_name", "ulcx_block_extent_bytes",
 ]
 
 
@@ -59,6 +59,8 @@ def lib():
         l.ulcx_encoder_last_fallbacks.argtypes = [C.c_void_p]
         l.ulcx_decode_packed_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         l.ulcx_decode_packed_host.argtypes = [C.c_void_p, _u8p, C.c_longlong, _i32p, C.c_int, _f32p, _i32p]
+        l.ulcx_decoder_upload_payload.argtypes = [C.c_void_p, _u8p, C.c_longlong, _i32p]
+        l.ulcx_decode_resident_host.argtypes = [C.c_void_p, C.c_int, _f32p, _i32p]
         l.ulcx_pack_streams_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
                                             C.c_void_p, C.c_void_p, C.c_void_p]
         l.ulcx_ulc_header_pack.argtypes = [_u8p, C.POINTER(FileHeader)]
@@ -203,6 +205,18 @@ class BatchDecoder:
         bits = np.zeros((B, n_blocks), np.int32)
         _check(lib().ulcx_decode_packed_host(self.h, _p(payload, _u8p), stride, _p(nbytes, _i32p), n_blocks, _p(pcm, _f32p), _p(bits, _i32p)),
                "ulcx_decode_packed_host")
+        return pcm, bits
+
+    def upload_payload(self, payload, payload_bytes):
+        """Packed payloads to the device once (rewinds the read positions); decode_resident() then walks them."""
+        payload = np.ascontiguousarray(payload, dtype=np.uint8)
+        nbytes = np.ascontiguousarray(payload_bytes, dtype=np.int32)
+        _check(lib().ulcx_decoder_upload_payload(self.h, _p(payload, _u8p), payload.shape[1], _p(nbytes, _i32p)), "ulcx_decoder_upload_payload")
+
+    def decode_resident(self, n_blocks):
+        pcm = np.zeros((self.B, n_blocks * self.BS, self.C), np.float32)
+        bits = np.zeros((self.B, n_blocks), np.int32)
+        _check(lib().ulcx_decode_resident_host(self.h, n_blocks, _p(pcm, _f32p), _p(bits, _i32p)), "ulcx_decode_resident_host")
         return pcm, bits
 
     def decode_dev(self, d_in, slot, n_blocks, d_pcm, d_bits, stream=0):
