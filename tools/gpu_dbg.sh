@@ -1,7 +1,7 @@
 #!/bin/bash
-# scratch: sequential vs overlapped steps
+# scratch: decoder without the FIFO shuffle: parity, fuzz, A/B
 cd "$(dirname "$0")/.."
-for r in 1 2; do for f in "" "--overlap"; do
-timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu $f 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); w=d['whole_pipeline']
-print('overlap=%s' % d['config']['overlap'], 'value %.0f step %.3f enc %.3f dec %.3f ok %s' % (d['value'], d['ms_per_step'], w['encode_ms'], w['decode_ms'], w['decode_ok']))"; done; done
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_dropin.py -m gpu -x -q 2>&1 | tail -2
+bash tools/ab_dec.sh
+timeout 600 python bench.py --config wswitch_4096 --steps 3 --warmup 1 --no-cpu --mode decode 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('wswitch decode ms', d['ms_per_step'])"

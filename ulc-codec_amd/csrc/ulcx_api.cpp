@@ -33,7 +33,7 @@ struct ulcx_decoder {
     std::vector<void *> allocs;
     hipEvent_t ev[ULCX_DEC_STAGES + 1];
     bool evOk, evRecorded;
-    uint8_t *d_in; int d_in_bytes; float *d_pcm; int32_t *d_bits;
+    uint8_t *d_in; size_t d_in_bytes; float *d_pcm; int32_t *d_bits;
     uint8_t *d_pay; int32_t *d_payBytes; long long payStride;     // resident packed payloads (ulcx_decoder_upload_payload)
 };
 
@@ -453,10 +453,10 @@ extern "C" int ulcx_decode_host(ulcx_decoder *e, const uint8_t *h_in, int slotBy
     CKR(hipSetDevice(e->device));
     size_t NBmax = (size_t)e->B * e->maxK, cb = (size_t)e->C * e->BS, NB = (size_t)e->B * nBlocks;
     size_t inBytes = NBmax * (size_t)slotBytes + 16;
-    if (!e->d_in || (size_t)e->d_in_bytes < inBytes) {
+    if (!e->d_in || e->d_in_bytes < inBytes) {
         int rc;
         if ((rc = dalloc(e->allocs, &e->d_in, inBytes, true))) return rc;
-        e->d_in_bytes = (int)inBytes;
+        e->d_in_bytes = inBytes;
     }
     if (!e->d_pcm) {
         int rc;

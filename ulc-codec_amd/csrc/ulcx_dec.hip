@@ -484,18 +484,26 @@ __device__ __forceinline__ void synth_unit(const UlcxDecCtx &c, const SynWave &s
 }
 
 // ---------------------------------------------------------------------------
-// Time domain of one channel of a DECIMATED block of a stereo stream, by one wave, entirely in LDS
-// (ulcDecoder.c:219-273).  The channel's array holds the spectra of its subblocks back to back (subblock offsets are
-// multiples of 32 floats, so the padding of the parts is the padding of the whole).  In order - each subblock
-// overlaps with what the previous one left in the lapping state - windowed overlap-add and the reversed-time
-// centring FIFO; the time samples of subblock j replace its own spectrum.  Every in-place move is "all lanes read
-// into registers, wave barrier, all lanes write".  Returns the size of the last subblock.
+// Time domain of one channel of a DECIMATED block of a stereo stream, by one wave (ulcDecoder.c:219-273).
+// The reference keeps BS/2 pending samples per channel in TransformInvLap, time-reversed: the tail of the last subblock
+// (to be overlapped with the next) in front, behind it a FIFO that delays decimated subblocks to the centre of the
+// block, and it moves the FIFO once per subblock.  Read in time order (P[n] = Lap[BS/2-1-n]) the two parts are ONE list,
+// and a subblock of size S at coefficient offset off only ever (i) replaces the M = S/2 pending samples in front of
+// time off by the first half of its windowed output, (ii) appends the second half and (iii) appends its own tail:
+//     T[off-M+p]     = c A - s B      A = T[off-M+p], B = z[M+p]          (pass-through below the ramp)
+//     T[off+M-1-p]   = s A + c B
+//     T[off+M+i]     = z[M-1-i]
+// on the timeline T = [pending (times -BS/2..-1) | this block's BS new samples]; the block's output is T[-BS/2 .. BS/2)
+// and T[BS/2 .. BS) is the new pending list.  Nothing is shifted.  T's non-negative times live in the channel's FFT
+// array (a subblock's spectrum sits at [off, off+S): everything it writes at times >= off lands in its own region, so
+// "all lanes read, wave barrier, all lanes write" is enough), negative times in the lapping state L (L[-1-t]).
+// Returns the size of the last subblock; the caller emits the output and stores the new pending list (dec_time_finish).
 // DEC_MAXT = (BlockSize/2)/64 register slots per lane: a template parameter of the kernel (16: BlockSize <= 2048, 32: <= 4096)
 // ---------------------------------------------------------------------------
 template <int DEC_MAXT>
 __device__ __forceinline__ int dec_time_wave(const UlcxDecCtx &c, float2 *zc, float *L, int wc, unsigned pat0, int nsub, int lastSub, int lane) {
-    const int BS = c.BS, H2 = BS / 2;
-    // ---- time domain, subblock by subblock
+    const int BS = c.BS;
+    float *arr = (float *)zc;                                    // times >= 0, padded
     int last = lastSub;
     unsigned pat = pat0; int off = 0;
     for (int j = 0; j < nsub; j++, pat >>= 4) {
@@ -504,78 +512,56 @@ __device__ __forceinline__ int dec_time_wave(const UlcxDecCtx &c, float2 *zc, fl
         if (pat & 8) ov >>= (wc & 7);
         if (ov > last) ov = last;
         last = S;
-        float2 *zj = zc + FFT_PADS(off >> 1, DPS);
-        float *tj = (float *)zj;                                 // the subblock's time samples, natural order, padded
+        const float2 *zj = zc + FFT_PADS(off >> 1, DPS);
         const float2 *pre = c.T.pre[d];
         const int a = (S - ov) >> 1;
         const float *fall = c.T.winFall + ov, *rise = c.T.winRise + ov;
         const int bits = 31 - __clz(M);
-        // post-twiddle fused with the windowed overlap (oracle/orc_fourier.c orc_imdct): pair p: A = lap[M-1-p], B = zz[M+p]
-        {
-            float o[DEC_MAXT / 4][4], nl[DEC_MAXT / 4][2];
+        const int tA = off - M;                                  // time of A(0)
+        // post-twiddle fused with the windowed overlap (oracle/orc_fourier.c orc_imdct): pair p: A = T[tA+p], B = z[M+p]
+        float o[DEC_MAXT / 4][4], nl[DEC_MAXT / 4][2];
 #pragma unroll
-            for (int t = 0; t < DEC_MAXT / 4; t++) {
-                const int kk = lane + 64 * t;
-                if (kk < M / 2) {
-                    const int k1 = kk, k2 = M - 1 - kk;
-                    const int r1 = FFT_PADS((int)(__brev((unsigned)k1) >> (32 - bits)), DPS);
-                    const int r2 = FFT_PADS((int)(__brev((unsigned)k2) >> (32 - bits)), DPS);
-                    const float2 y1 = cmulc(zj[r1], pre[k1]), y2 = cmulc(zj[r2], pre[k2]);
-                    const float Av[2] = { L[2 * k1], L[2 * k1 + 1] };
-                    const float Bv[2] = { -y1.y, y2.x };
-                    const int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
+        for (int t = 0; t < DEC_MAXT / 4; t++) {
+            const int kk = lane + 64 * t;
+            if (kk < M / 2) {
+                const int k1 = kk, k2 = M - 1 - kk;
+                const int r1 = FFT_PADS((int)(__brev((unsigned)k1) >> (32 - bits)), DPS);
+                const int r2 = FFT_PADS((int)(__brev((unsigned)k2) >> (32 - bits)), DPS);
+                const float2 y1 = cmulc(zj[r1], pre[k1]), y2 = cmulc(zj[r2], pre[k2]);
+                const int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
+                float Av[2];
+                // (L may be global memory, arr is LDS: separate branches, never a select between the two pointers)
+                if (tA + pv[1] < 0) { Av[0] = L[-1 - (tA + pv[0])]; Av[1] = L[-1 - (tA + pv[1])]; }      // (pv[1] = pv[0]-1, even time: both on the same side of 0)
+                else { Av[0] = arr[padf(tA + pv[0])]; Av[1] = arr[padf(tA + pv[1])]; }
+                const float Bv[2] = { -y1.y, y2.x };
 #pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const int p = pv[q];
-                        const float A = Av[q], B = Bv[q];
-                        if (p < a) { o[t][2 * q] = A; o[t][2 * q + 1] = B; }
-                        else {
-                            const float cw = fall[p - a], sn = rise[p - a];
-                            const float m0 = cw * A, m1 = sn * B, m2 = sn * A, m3 = cw * B;
-                            o[t][2 * q] = m0 - m1;
-                            o[t][2 * q + 1] = m2 + m3;
-                        }
+                for (int q = 0; q < 2; q++) {
+                    const int p = pv[q];
+                    const float A = Av[q], B = Bv[q];
+                    if (p < a) { o[t][2 * q] = A; o[t][2 * q + 1] = B; }
+                    else {
+                        const float cw = fall[p - a], sn = rise[p - a];
+                        const float m0 = cw * A, m1 = sn * B, m2 = sn * A, m3 = cw * B;
+                        o[t][2 * q] = m0 - m1;
+                        o[t][2 * q + 1] = m2 + m3;
                     }
-                    nl[t][0] = y1.x; nl[t][1] = -y2.y;
                 }
+                nl[t][0] = y1.x; nl[t][1] = -y2.y;              // z[2 k1], z[2 k1 + 1]: the tail at times off+M+pv[0], off+M+pv[1]
             }
-            WAVE_SYNC();
-#pragma unroll
-            for (int t = 0; t < DEC_MAXT / 4; t++) {
-                const int kk = lane + 64 * t;
-                if (kk < M / 2) {
-                    const int k1 = kk;
-                    const int p0 = M - 1 - 2 * k1, p1 = M - 2 - 2 * k1;
-                    tj[padf(p0)] = o[t][0]; tj[padf(S - 1 - p0)] = o[t][1];
-                    tj[padf(p1)] = o[t][2]; tj[padf(S - 1 - p1)] = o[t][3];
-                    L[2 * k1] = nl[t][0]; L[2 * k1 + 1] = nl[t][1];
-                }
-            }
-            WAVE_SYNC();
         }
-        // reversed-time centring FIFO in lap[M .. BS/2) (ulcDecoder.c:253-272): queue[q] = lap[BS/2-1-q], q = 0 the oldest
-        {
-            const int avail = (BS - S) >> 1;
-            float dv[DEC_MAXT], qv[DEC_MAXT];
+        WAVE_SYNC();
 #pragma unroll
-            for (int t = 0; t < DEC_MAXT; t++) {
-                const int n = lane + 64 * t;
-                // (L may be global memory, tj is LDS: separate branches, never a select between the two pointers)
-                if (n < S) { if (n < avail) dv[t] = L[H2 - 1 - n]; else dv[t] = tj[padf(n - avail)]; }
-                if (n < avail) {
-                    if (S <= avail) { if (n < avail - S) qv[t] = L[H2 - 1 - (n + S)]; else qv[t] = tj[padf(n - (avail - S))]; }
-                    else qv[t] = tj[padf(S - avail + n)];
-                }
+        for (int t = 0; t < DEC_MAXT / 4; t++) {
+            const int kk = lane + 64 * t;
+            if (kk < M / 2) {
+                const int p0 = M - 1 - 2 * kk, p1 = p0 - 1;
+                if (tA + p1 < 0) { L[-1 - (tA + p0)] = o[t][0]; L[-1 - (tA + p1)] = o[t][2]; }
+                else { arr[padf(tA + p0)] = o[t][0]; arr[padf(tA + p1)] = o[t][2]; }
+                arr[padf(off + M - 1 - p0)] = o[t][1]; arr[padf(off + M - 1 - p1)] = o[t][3];
+                arr[padf(off + M + p0)] = nl[t][0]; arr[padf(off + M + p1)] = nl[t][1];
             }
-            WAVE_SYNC();
-#pragma unroll
-            for (int t = 0; t < DEC_MAXT; t++) {
-                const int n = lane + 64 * t;
-                if (n < S) tj[padf(n)] = dv[t];
-                if (n < avail) L[H2 - 1 - n] = qv[t];
-            }
-            WAVE_SYNC();
         }
+        WAVE_SYNC();
         off += S;
     }
     return last;
@@ -798,10 +784,22 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
             WAVE_SYNC();
             const int newLast = dec_time_wave<DEC_MAXT>(c, zc, lap + wv * H2, wc, pat0, nsub, lastSub, lane);
             __syncthreads();
+            // output = times [-BS/2, BS/2) of both channels: the old pending lists (time -1-i at lap[i]), then the arrays
             const float *t0 = (const float *)z, *t1 = (const float *)(z + Mp0);
-            for (int n = 2 * tid; n < BS; n += 2 * WG) {
+            const float *L0 = lap, *L1 = lap + H2;
+            for (int n = 2 * tid; n < H2; n += 2 * WG) {
+                const float mx = L0[H2 - 1 - n], my = L0[H2 - 2 - n], sx = L1[H2 - 1 - n], sy = L1[H2 - 2 - n];
+                st4(outp + 2 * n, mx + sx, mx - sx, my + sy, my - sy);
+            }
+            for (int n = 2 * tid; n < H2; n += 2 * WG) {
                 const float2 m = *(const float2 *)(t0 + padf(n)), sd = *(const float2 *)(t1 + padf(n));
-                st4(outp + 2 * n, m.x + sd.x, m.x - sd.x, m.y + sd.y, m.y - sd.y);
+                st4(outp + 2 * (H2 + n), m.x + sd.x, m.x - sd.x, m.y + sd.y, m.y - sd.y);
+            }
+            __syncthreads();
+            // new pending lists: times [BS/2, BS) of the arrays
+            for (int i = tid; i < 2 * H2; i += WG) {
+                const int ch = i >= H2 ? 1 : 0, m = i - ch * H2;
+                lap[ch * H2 + H2 - 1 - m] = ((const float *)(z + ch * Mp0))[padf(H2 + m)];
             }
             __syncthreads();
             lastSub = newLast;
