@@ -370,6 +370,7 @@ __device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &
                                             float tailRR, const float *tailMag) {
     const int lane = sw.lane;
     uint32_t *P = sw.seedTab;                                 // the unit's whole stream: max(64, BS/32) words + a zero word
+    const uint2 ent0 = (lane < nE) ? list[lane] : make_uint2(0u, 0u);     // round 0 of the run list: in flight behind the draws
     // ---- 1. sign-parity stream, 2048 draws per pass (one pass unless the unit has more than 2048 noise coefficients)
     uint32_t passPar = 0;                                     // parity of the top bits of all earlier passes
     for (int dbase = 0; dbase < unitDraws; dbase += 2048) {
@@ -395,7 +396,7 @@ __device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &
         for (int e0 = 0; e0 < nE; e0 += 64) {
             const int e = e0 + lane;
             const bool have = e < nE;
-            const uint2 ent = have ? list[e] : make_uint2(0u, 0u);
+            const uint2 ent = (e0 == 0) ? ent0 : (have ? list[e] : make_uint2(0u, 0u));
             const int pos = ent.x & 0xFFFF, isTail = (int)(ent.x >> 31);
             const int np = (int)((ent.x >> 16) & 0x7FFF) + isTail;
             const int nseg = have ? ((pos + np - 1) >> 5) - (pos >> 5) + 1 : 0;
@@ -450,16 +451,22 @@ __device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &
 // plain-run record (up to seven coefficients each, ulcDecoder.c:69-73), then the noise runs (synth_noise).
 // ur = {first plain-run record, their count, first noise record, their count} of the unit.
 __device__ __forceinline__ void synth_unit(const UlcxDecCtx &c, const SynWave &sw, int S, const uint2 *__restrict__ prec, const uint2 *__restrict__ nrec,
-                                           int4 ur, uint32_t unitSeed, int unitDraws, float tailRR, const float *tailMag) {
+                                           int4 ur, uint32_t unitSeed, int unitDraws, float tailRR, const float *tailMag, int zeroFloat2 = 0) {
     const int lane = sw.lane;
     // seedTab[l] = RNG state after 32*l draws of the unit = unitSeed through T^(32 l): two table-driven steps per lane
     // (hex digits 1 and 2 of 32*l), their loads in flight behind the coefficient scatter
     uint32_t sj = rng_jump_digit(c.jumpT, unitSeed, 1, (uint32_t)(lane & 7) << 1);
     const uint2 *pr = prec + ur.x;
+    const uint2 recFirst = (lane < ur.y) ? pr[lane] : make_uint2(0u, 0u);   // round 0 of the plain-run records: in flight behind the zero fill
+    if (zeroFloat2) {                                            // (the caller's array: cleared here, behind the loads above)
+        float2 *Az = (float2 *)sw.A;
+        for (int i = lane; i < zeroFloat2; i += 64) Az[i] = make_float2(0.0f, 0.0f);
+        WAVE_SYNC();
+    }
     for (int r0 = 0; r0 < ur.y; r0 += 64) {
         const int r = r0 + lane;
         if (r < ur.y) {
-            const uint2 rec = pr[r];
+            const uint2 rec = (r0 == 0) ? recFirst : pr[r];
             const int pos = rec.x & 0x7FFF, qi = (rec.x >> 15) & 31, m = (rec.x >> 20) & 7;
             const float quant = expand_quantizer(qi);
             float *dst = sw.A + padf(pos);
@@ -698,11 +705,11 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
             for (int j = 0; j < nsub; j++, pat >>= 4) {
                 const int d = pat & 7, S = BS >> d, M = S >> 1, Mp = FFT_PADDEDS(M, DPS);
                 float2 *zj = zc + FFT_PADS(off >> 1, DPS);
-                for (int i = lane; i < Mp; i += 64) zj[i] = make_float2(0.0f, 0.0f);
                 sw.A = (float *)zj;
                 const uint32_t unitSeed = (j == 0) ? bseed[wv * 64 + (k & 63)] : rng_jump(c.jumpT, bseed[k & 63], (uint32_t)udraw[wv * 4 + j]);
                 STAMP(1);
-                if (!(c.dbgSkip & 1)) synth_unit(c, sw, S, prec, nrec, urec[wv * 4 + j], unitSeed, unit_draws(wv, j), utail[wv * 4 + j].y, tmag + (size_t)(wv * 4 + j) * c.tailStride);
+                if (!(c.dbgSkip & 1)) synth_unit(c, sw, S, prec, nrec, urec[wv * 4 + j], unitSeed, unit_draws(wv, j), utail[wv * 4 + j].y, tmag + (size_t)(wv * 4 + j) * c.tailStride, Mp);
+                else for (int i = lane; i < Mp; i += 64) zj[i] = make_float2(0.0f, 0.0f);
                 STAMP(2);
                 // DCT-IV pre-twiddle in place: n and M-1-n together read and write the same two complex slots
                 const float2 *pre = c.T.pre[d];
