@@ -234,6 +234,10 @@ int  ulcx_decode_resident_host(ulcx_decoder *dec, int nBlocks, float *h_pcm, int
  * ulcx_*_dev call enqueued, per pipeline stage; returns number of stages written.
  * Only valid after the stream has been synchronised. */
 int  ulcx_encoder_stage_ms(ulcx_encoder *enc, float *ms, int maxStages);
+/* The events behind the two calls above are recorded around every kernel of every ulcx_*_dev call (default on);
+ * a caller that never reads them can switch them off. */
+int  ulcx_encoder_set_timing(ulcx_encoder *enc, int on);
+int  ulcx_decoder_set_timing(ulcx_decoder *dec, int on);
 const char *ulcx_encoder_stage_name(int stage);
 /* Launches of the transform kernel (k_xf) in the last call: the stage time above is their sum (1 when the
  * window-control pipeline is off). */

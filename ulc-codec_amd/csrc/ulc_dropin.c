@@ -37,6 +37,7 @@ int ULC_EncoderState_Init(struct ULC_EncoderState_t *State) {
     struct enc_priv *p = (struct enc_priv *)malloc(sizeof(*p));
     if (!p) { ulcx_encoder_destroy(enc); return -1; }
     p->enc = enc;
+    ulcx_encoder_set_timing(enc, 0);                          /* nobody reads per-kernel events through this ABI */
     p->failed = 0;
     p->slot = ulcx_encoder_slot_bytes(enc);
     p->out = (unsigned char *)malloc((size_t)p->slot);
@@ -100,6 +101,7 @@ int ULC_DecoderState_Init(struct ULC_DecoderState_t *State) {
     struct dec_priv *p = (struct dec_priv *)malloc(sizeof(*p));
     if (!p) { ulcx_decoder_destroy(dec); return -1; }
     p->dec = dec;
+    ulcx_decoder_set_timing(dec, 0);
     /* a block is at most 4 nybbles per coefficient + header; the caller's buffer is read
      * only up to the end of the block, so copy that bound (ulcDecoder.h:54) */
     p->slot = 2 * State->nChan * State->BlockSize + 16;

@@ -20,7 +20,7 @@ struct ulcx_encoder {
     hipEvent_t ev[ULCX_ENC_STAGES + 1];
     bool evOk, evRecorded;
     int lastK;
-    hipStream_t side; hipEvent_t evFork, evJoin, evFork2; bool sideOk;
+    hipStream_t side; hipEvent_t evFork, evJoin, evFork2; bool sideOk; bool timing;
     hipEvent_t evWC[7 + 3 * ULCX_WC_MAXCH]; int wcPipe; hipStream_t side2, side3, side4; hipEvent_t evE[ULCX_WC_MAXCH]; hipEvent_t evXf[2 * ULCX_XF_MAXCH]; int nXf;      // window-control / transform chunk pipeline (ULCX_WC_PIPE chunks, default 4)
     bool keysFinal;
     // staging for the host-pointer API
@@ -32,7 +32,7 @@ struct ulcx_decoder {
     void *tables;
     std::vector<void *> allocs;
     hipEvent_t ev[ULCX_DEC_STAGES + 1];
-    bool evOk, evRecorded;
+    bool evOk, evRecorded, timing;
     uint8_t *d_in; size_t d_in_bytes; float *d_pcm; int32_t *d_bits;
     uint8_t *d_pay; int32_t *d_payBytes; long long payStride;     // resident packed payloads (ulcx_decoder_upload_payload)
 };
@@ -112,7 +112,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     if (rc) return rc;
     ulcx_encoder *e = new ulcx_encoder();
     e->device = device; e->B = nStreams; e->C = nChan; e->BS = BlockSize; e->rate = RateHz; e->maxK = maxBlocksPerCall;
-    e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->lastK = 0; e->sideOk = false; e->side = nullptr; e->keysFinal = false;
+    e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->timing = true; e->lastK = 0; e->sideOk = false; e->side = nullptr; e->keysFinal = false;
     e->d_pcm = nullptr; e->d_out = nullptr; e->d_bits = nullptr; e->d_wc = nullptr; e->d_cplx = nullptr;
     UlcxEncCtx &c = e->ctx;
     memset(&c, 0, sizeof(c));
@@ -218,8 +218,8 @@ static int encode_dev_any(ulcx_encoder *e, int mode, float p0, float p1, const f
     aux.evFork = e->evFork; aux.evJoin = e->evJoin; aux.evFork2 = e->evFork2; aux.evWC = e->evWC; aux.evXf = e->evXf;
     aux.wcPipe = (nBlocks >= 2 * e->wcPipe) ? e->wcPipe : (nBlocks >= 6 && e->wcPipe > 1 ? 3 : 1); aux.nXf = &e->nXf;
     aux.wcSteps = -1; if (const char *sv = getenv("ULCX_WC_STEPS")) aux.wcSteps = atoi(sv);   // -1: default; 0: the transform's chunks
-    int rc = ulcx_enc_launch(c, (hipStream_t)hipStream, e->ev, aux);
-    e->evRecorded = (rc == ULCX_OK);
+    int rc = ulcx_enc_launch(c, (hipStream_t)hipStream, e->timing ? e->ev : nullptr, aux);
+    e->evRecorded = (rc == ULCX_OK) && e->timing;
     e->lastK = nBlocks;
     e->keysFinal = false;
     return rc;
@@ -379,7 +379,7 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     if (rc) return rc;
     ulcx_decoder *e = new ulcx_decoder();
     e->device = device; e->B = nStreams; e->C = nChan; e->BS = BlockSize; e->maxK = maxBlocksPerCall;
-    e->tables = nullptr; e->evOk = false; e->evRecorded = false;
+    e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->timing = true;
     e->d_in = nullptr; e->d_in_bytes = 0; e->d_pcm = nullptr; e->d_bits = nullptr; e->d_pay = nullptr; e->d_payBytes = nullptr; e->payStride = 0;
     UlcxDecCtx &c = e->ctx;
     memset(&c, 0, sizeof(c));
@@ -436,8 +436,8 @@ static int decode_dev_any(ulcx_decoder *e, const uint8_t *d_in, int slotBytes, i
     UlcxDecCtx c = e->ctx;
     c.K = nBlocks; c.slot = slotBytes; c.in = d_in; c.pcm = d_pcm; c.pcm16 = d_pcm16; c.bits = d_bits;
     c.inBytes = (long long)e->B * nBlocks * slotBytes;
-    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->ev);
-    e->evRecorded = (rc == ULCX_OK);
+    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->timing ? e->ev : nullptr);
+    e->evRecorded = (rc == ULCX_OK) && e->timing;
     return rc;
 }
 extern "C" int ulcx_decode_dev(ulcx_decoder *e, const uint8_t *d_in, int slotBytes, int nBlocks, float *d_pcm, int32_t *d_bits, void *hipStream) {
@@ -510,8 +510,8 @@ extern "C" int ulcx_decode_packed_dev(ulcx_decoder *e, const uint8_t *d_payload,
     c.K = nBlocks; c.slot = 0; c.in = d_payload; c.pcm = d_pcm; c.pcm16 = nullptr; c.bits = d_bits;
     c.packed = 1; c.payStride = payloadStride; c.payBytes = d_payloadBytes;
     c.inBytes = (long long)e->B * payloadStride;
-    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->ev);
-    e->evRecorded = (rc == ULCX_OK);
+    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->timing ? e->ev : nullptr);
+    e->evRecorded = (rc == ULCX_OK) && e->timing;
     return rc;
 }
 extern "C" int ulcx_decode_packed_host(ulcx_decoder *e, const uint8_t *h_payload, long long payloadStride, const int32_t *h_payloadBytes,
@@ -578,6 +578,10 @@ extern "C" int ulcx_decoder_debug_scratch(ulcx_decoder *e, void *h_out, size_t s
         CKR(hipMemcpy((char *)h_out + (size_t)s * nBytes, (const char *)e->ctx.scratch + (size_t)s * strideBytes, nBytes, hipMemcpyDeviceToHost));
     return ULCX_OK;
 }
+// per-stage hipEvents around every kernel (ulcx_*_stage_ms): on by default; a caller that does not read them can switch
+// them off - each record is a marker packet in the stream between two kernels
+extern "C" int ulcx_encoder_set_timing(ulcx_encoder *e, int on) { if (!e) return ULCX_ERR_ARG; e->timing = on != 0; if (!on) e->evRecorded = false; return ULCX_OK; }
+extern "C" int ulcx_decoder_set_timing(ulcx_decoder *e, int on) { if (!e) return ULCX_ERR_ARG; e->timing = on != 0; if (!on) e->evRecorded = false; return ULCX_OK; }
 static const char *kDecStage[ULCX_DEC_STAGES] = { "k_dscan", "k_dsyn" };
 extern "C" const char *ulcx_decoder_stage_name(int i) { return (i >= 0 && i < ULCX_DEC_STAGES) ? kDecStage[i] : ""; }
 extern "C" int ulcx_decoder_stage_ms(ulcx_decoder *e, float *ms, int maxStages) {

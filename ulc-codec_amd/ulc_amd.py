@@ -20,7 +20,7 @@ EXPORTS = [
     "ulcx_encoder_slot_bytes", "ulcx_encode_dev", "ulcx_encode_dev_pcm16", "ulcx_encode_host", "ulcx_encoder_debug_fetch",
     "ulcx_decoder_create", "ulcx_decoder_destroy", "ulcx_decoder_reset", "ulcx_decode_dev", "ulcx_decode_dev_pcm16", "ulcx_decode_host",
     "ulcx_encoder_last_fallbacks", "ulcx_ulc_header_pack", "ulcx_ulc_header_parse", "ulcx_ulc_rate_kbps",
-    "ulcx_pack_streams_dev", "ulcx_decode_packed_dev", "ulcx_decode_packed_host", "ulcx_decoder_upload_payload", "ulcx_decode_resident_host", "ulcx_encoder_stage_ms", "ulcx_encoder_stage_name", "ulcx_encoder_last_xf_launches", "ulcx_decoder_stage_ms", "ulcx_decoder_stage_name", "ulcx_block_extent_bytes",
+    "ulcx_pack_streams_dev", "ulcx_decode_packed_dev", "ulcx_decode_packed_host", "ulcx_decoder_upload_payload", "ulcx_decode_resident_host", "ulcx_encoder_stage_ms", "ulcx_encoder_stage_name", "ulcx_encoder_last_xf_launches", "ulcx_decoder_stage_ms", "ulcx_decoder_stage_name", "ulcx_block_extent_bytes", "ulcx_encoder_set_timing", "ulcx_decoder_set_timing",
 ]
 
 
@@ -59,6 +59,8 @@ def lib():
         l.ulcx_encoder_last_fallbacks.argtypes = [C.c_void_p]
         l.ulcx_decode_packed_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         l.ulcx_decode_packed_host.argtypes = [C.c_void_p, _u8p, C.c_longlong, _i32p, C.c_int, _f32p, _i32p]
+        l.ulcx_encoder_set_timing.argtypes = [C.c_void_p, C.c_int]
+        l.ulcx_decoder_set_timing.argtypes = [C.c_void_p, C.c_int]
         l.ulcx_decoder_upload_payload.argtypes = [C.c_void_p, _u8p, C.c_longlong, _i32p]
         l.ulcx_decode_resident_host.argtypes = [C.c_void_p, C.c_int, _f32p, _i32p]
         l.ulcx_pack_streams_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
@@ -158,6 +160,9 @@ class BatchEncoder:
     def xf_launches(self):
         return int(lib().ulcx_encoder_last_xf_launches(self.h))
 
+    def set_timing(self, on):
+        _check(lib().ulcx_encoder_set_timing(self.h, int(bool(on))), "ulcx_encoder_set_timing")
+
     def stage_ms(self):
         ms = np.zeros(32, np.float32)
         n = lib().ulcx_encoder_stage_ms(self.h, _p(ms, _f32p), 32)
@@ -225,6 +230,9 @@ class BatchDecoder:
     def decode_dev_pcm16(self, d_in, slot, n_blocks, d_pcm16, d_bits, stream=0):
         """PCM16 output: d_pcm16 is a device pointer to int16 [B][K][BS][C]; converted on store as tools/WavIO_Helper.c:56-63."""
         _check(lib().ulcx_decode_dev_pcm16(self.h, d_in, slot, n_blocks, d_pcm16, d_bits, stream or None), "ulcx_decode_dev_pcm16")
+
+    def set_timing(self, on):
+        _check(lib().ulcx_decoder_set_timing(self.h, int(bool(on))), "ulcx_decoder_set_timing")
 
     def stage_ms(self):
         ms = np.zeros(8, np.float32)
