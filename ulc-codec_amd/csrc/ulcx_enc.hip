@@ -904,6 +904,11 @@ __global__ __launch_bounds__(64) void k_cplx(UlcxEncCtx c) {
         c.nout[blk] = nOut;
         c.cbrBudget[blk] = budget;
     }
+    // per-call flags of the block, cleared here instead of by three fill launches in front of the selection (which waits
+    // for this kernel): exact-path membership, the wave writer's retry state, and once per call the two queue counters
+    c.isFb[blk] = 0;
+    if (c.useWave) c.slow[blk] = 0;
+    if (blk == 0) { *c.fbCount = 0; if (c.useWave) { c.slow[c.B * c.K] = 0; c.slow[c.B * c.K + 1] = 0; } }
     int s = blk / c.K, k = blk % c.K;
     if (c.wcOut)   c.wcOut[blk]   = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     if (c.cplxOut) c.cplxOut[blk] = cx;
@@ -2620,8 +2625,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         }
         return ULCX_OK;
     };
-    CK(hipMemsetAsync(c.fbCount, 0, sizeof(int), st));
-    CK(hipMemsetAsync(c.isFb, 0, sizeof(int) * (size_t)NB, st));
+    // (c.fbCount, c.isFb and the first pass's c.slow are cleared by k_cplx)
     // VBR (one pass): the exact path runs on a side stream next to the encode pass of all other blocks.
     // CBR/ABR: it runs after the lock-step passes (a block joins it at whatever pass it first straddles).
     // The exact path forks at the FINAL pass (a block can first straddle there) and runs beside the main path's
@@ -2631,7 +2635,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         int fin = (p == probes) ? 1 : 0;
         bool ev0 = (p == 0);
         const bool async_fb = canFork && fin;
-        if (c.useWave) CK(hipMemsetAsync(c.slow, 0, sizeof(int) * ((size_t)NB + 2), st));
+        if (c.useWave && p > 0) CK(hipMemsetAsync(c.slow, 0, sizeof(int) * ((size_t)NB + 2), st));
         if (!launch_select(fin)) {
             hipLaunchKernelGGL(k_select, dim3(NB), dim3(WG), 0, st, c, fin);
         }
