@@ -132,6 +132,16 @@ struct NybWin {
         const uint32_t hi = di == 0 ? cur.y : di == 1 ? cur.z : di == 2 ? cur.w : nxt.x;
         return __builtin_amdgcn_alignbit(hi, lo, sh);
     }
+    // the same, 64 bits wide: a trip's run of plain nybbles (<= 28 bits) and the code behind it (<= 20 bits) from one look
+    __device__ __forceinline__ uint64_t at64(int pos) {
+        const int q = (pos >> 2) + 2 * a;
+        if ((q >> 5) > chunk) { cur = nxt; chunk++; nxt = load_chunk(chunk + 1); }
+        const int di = (q >> 3) & 3, sh = (q & 7) * 4;
+        const uint32_t d0 = di == 0 ? cur.x : di == 1 ? cur.y : di == 2 ? cur.z : cur.w;
+        const uint32_t d1 = di == 0 ? cur.y : di == 1 ? cur.z : di == 2 ? cur.w : nxt.x;
+        const uint32_t d2 = di == 0 ? cur.z : di == 1 ? cur.w : di == 2 ? nxt.x : nxt.y;
+        return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+    }
 };
 
 // Syntax walk of one block starting at p (limit = bits that may be consumed, readBytes = bytes that may be
@@ -190,7 +200,8 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
     // One trip = a run of plain coefficient nybbles (possibly empty), then ONE other code: every lane does both parts every
     // trip, so lanes that alternate between the two kinds (the usual stream) do not wait for each other's other half.
     while (!fin) {
-        uint32_t w = win.at(pos);
+        const uint64_t w64 = win.at64(pos);
+        uint32_t w = (uint32_t)w64;
         // 1. plain coefficients (+-2..+-7), up to the seven the window holds.  Never across the unit end or the block's bits;
         //    not at a unit's opening code.
         int m = first ? 0 : plain_prefix(w);
@@ -201,7 +212,7 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
             nP++;
             pos += 4 * m; N -= m;
             if (N == 0) next_unit();
-            w = win.at(pos);
+            w = (uint32_t)(w64 >> (4 * m));
         }
         if (fin) break;
         // 2. one code
