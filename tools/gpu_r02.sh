@@ -2,7 +2,7 @@
 # round-2 artefacts: smoke, bench lines (headline, per mode, per config), rocprof kernel stats of the headline command,
 # PMC traffic passes of the same command, kernel timeline.  Everything lands in gpurun_out/r02/.
 cd "$(dirname "$0")/.."
-O=gpurun_out/r02b; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
+O=gpurun_out/r02c; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?" >> $O/smoke.txt
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --mode encode > $O/bench_encode.json 2>> $O/bench.err
@@ -22,3 +22,4 @@ rocprofv3 --kernel-trace --output-format csv -d $O/tl -- python3 bench.py --step
 python tools/timeline.py $(find $O/tl -name "*kernel_trace.csv" | head -1) > $O/timeline.txt
 rm -rf $O/prof $O/pmc_rd $O/pmc_wr $O/tl
 ls -la $O; head -c 400 $O/bench.json; echo; cat $O/smoke.txt | tail -2; head -12 $O/pmc_summary.txt
+python tools/dropin_rate.py > $O/dropin_rate.txt 2>&1
