@@ -1024,19 +1024,27 @@ __global__ __launch_bounds__(WG) void k_nline(UlcxEncCtx c) {
     if (tid < 4 * ULCX_NBARK) sbark[tid] = c.barkN[(size_t)(blk * c.C + ch) * 4 * ULCX_NBARK + tid];
     __syncthreads();
     float2 *dst = (float2 *)(c.npair + (size_t)blk * (c.C * c.BS) + (size_t)ch * c.BS);
-    for (int jp = tid; jp < half; jp += WG) {
+    // two neighbouring line pairs per thread: one 16-byte store (subblocks are multiples of 32 lines: both are in the same one)
+    for (int jp = 2 * tid; jp < half; jp += 2 * WG) {
         unsigned pat = ulcx_pattern(wc);
         int off = 0, d = 0, S = c.BS, j = 0;
         for (;; j++) { d = pat & 7; S = c.BS >> d; if (2 * jp < off + S) break; off += S; pat >>= 4; }
         int line = jp - off / 2;
         const float *bark = sbark + j * ULCX_NBARK;
-        int bi = c.T.bandIdx[d][line];
-        float fr = c.T.bandFrac[d][line];
-        float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
-        float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
-        float noise = L * (1.0f - fr) + R * fr;
-        float w = ulcx_expf(0.5f * noise);
-        stnt(dst + jp, make_float2(w, w * (noise + 0x1.62E430p-1f)));
+        const int2 bi2 = *(const int2 *)(c.T.bandIdx[d] + line);
+        const float2 fr2 = *(const float2 *)(c.T.bandFrac[d] + line);
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            int bi = q ? bi2.y : bi2.x;
+            float fr = q ? fr2.y : fr2.x;
+            float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
+            float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
+            float noise = L * (1.0f - fr) + R * fr;
+            float w = ulcx_expf(0.5f * noise);
+            o[2 * q] = w; o[2 * q + 1] = w * (noise + 0x1.62E430p-1f);
+        }
+        stnt((float4 *)(dst + jp), make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
