@@ -94,52 +94,54 @@ struct NybWin {
     int a;                       // bytes between p16 and the block's first byte
     int readBytes;               // block bytes that may be used (later ones read as 0)
     const uint8_t *bufBeg, *bufEnd;   // the caller's whole input: nothing outside it is touched
-    uint4 cur, nxt; int chunk;
+    uint32_t c0, c1, c2, c3, n0, n1, n2, n3; int chunk;       // current and next 16-byte chunk (scalars: a struct member picked
+                                                              // by a run-time index makes the compiler move the window to LDS)
 
-    __device__ __forceinline__ uint4 load_chunk(int ci) const {
+    __device__ __forceinline__ void load_chunk(int ci, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) const {
         const uint8_t *q = p16 + (ptrdiff_t)ci * 16;
         const int rel = ci * 16 - a;                       // block-relative offset of the chunk's first byte
-        uint32_t d[4];
-        if (q >= bufBeg && q + 16 <= bufEnd) { uint4 v = *(const uint4 *)q; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+        uint32_t d0, d1, d2, d3;
+        if (q >= bufBeg && q + 16 <= bufEnd) { const uint4 v = *(const uint4 *)q; d0 = v.x; d1 = v.y; d2 = v.z; d3 = v.w; }
         else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                uint32_t w = 0;
-                for (int t = 0; t < 4; t++) { const uint8_t *b = q + 4 * j + t; if (b >= bufBeg && b < bufEnd) w |= (uint32_t)*b << (8 * t); }
-                d[j] = w;
-            }
+            auto word = [&](int j) { uint32_t w = 0; for (int t = 0; t < 4; t++) { const uint8_t *b = q + 4 * j + t; if (b >= bufBeg && b < bufEnd) w |= (uint32_t)*b << (8 * t); } return w; };
+            d0 = word(0); d1 = word(1); d2 = word(2); d3 = word(3);
         }
         if (rel + 16 > readBytes) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int keep = readBytes - (rel + 4 * j);
-                uint32_t m = keep >= 4 ? 0xFFFFFFFFu : keep <= 0 ? 0u : ((1u << (8 * keep)) - 1u);
-                d[j] &= m;
-            }
+            auto mask = [&](int j) { const int keep = readBytes - (rel + 4 * j); return keep >= 4 ? 0xFFFFFFFFu : keep <= 0 ? 0u : ((1u << (8 * keep)) - 1u); };
+            d0 &= mask(0); d1 &= mask(1); d2 &= mask(2); d3 &= mask(3);
         }
-        return make_uint4(d[0], d[1], d[2], d[3]);
+        o0 = d0; o1 = d1; o2 = d2; o3 = d3;
     }
     __device__ __forceinline__ void init(const uint8_t *p, int rb, const uint8_t *b0, const uint8_t *b1) {
         a = (int)((uintptr_t)p & 15); p16 = p - a; readBytes = rb; bufBeg = b0; bufEnd = b1;
-        chunk = 0; cur = load_chunk(0); nxt = load_chunk(1);
+        chunk = 0; load_chunk(0, c0, c1, c2, c3); load_chunk(1, n0, n1, n2, n3);
     }
-    // window at bit position pos of the block (positions only ever advance, by at most 7 nybbles per call)
+    __device__ __forceinline__ void advance(int q) {
+        if ((q >> 5) > chunk) { c0 = n0; c1 = n1; c2 = n2; c3 = n3; chunk++; load_chunk(chunk + 1, n0, n1, n2, n3); }
+    }
+    // window at bit position pos of the block (positions only ever advance, by at most 12 nybbles per call)
     __device__ __forceinline__ uint32_t at(int pos) {
         const int q = (pos >> 2) + 2 * a;
-        if ((q >> 5) > chunk) { cur = nxt; chunk++; nxt = load_chunk(chunk + 1); }
+        advance(q);
         const int di = (q >> 3) & 3, sh = (q & 7) * 4;
-        const uint32_t lo = di == 0 ? cur.x : di == 1 ? cur.y : di == 2 ? cur.z : cur.w;
-        const uint32_t hi = di == 0 ? cur.y : di == 1 ? cur.z : di == 2 ? cur.w : nxt.x;
+        uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3, x4 = n0;
+        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4));
+        const uint32_t lo = di == 0 ? x0 : di == 1 ? x1 : di == 2 ? x2 : x3;
+        const uint32_t hi = di == 0 ? x1 : di == 1 ? x2 : di == 2 ? x3 : x4;
         return __builtin_amdgcn_alignbit(hi, lo, sh);
     }
     // the same, 64 bits wide: a trip's run of plain nybbles (<= 28 bits) and the code behind it (<= 20 bits) from one look
     __device__ __forceinline__ uint64_t at64(int pos) {
         const int q = (pos >> 2) + 2 * a;
-        if ((q >> 5) > chunk) { cur = nxt; chunk++; nxt = load_chunk(chunk + 1); }
+        advance(q);
         const int di = (q >> 3) & 3, sh = (q & 7) * 4;
-        const uint32_t d0 = di == 0 ? cur.x : di == 1 ? cur.y : di == 2 ? cur.z : cur.w;
-        const uint32_t d1 = di == 0 ? cur.y : di == 1 ? cur.z : di == 2 ? cur.w : nxt.x;
-        const uint32_t d2 = di == 0 ? cur.z : di == 1 ? cur.w : di == 2 ? nxt.x : nxt.y;
+        // (values first, opaque to the optimiser, then selects: a select between loads of struct members becomes a load from
+        //  a selected address, and a window that is indexed at run time is moved to LDS - one LDS round trip per trip)
+        uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3, x4 = n0, x5 = n1;
+        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5));
+        const uint32_t d0 = di == 0 ? x0 : di == 1 ? x1 : di == 2 ? x2 : x3;
+        const uint32_t d1 = di == 0 ? x1 : di == 1 ? x2 : di == 2 ? x3 : x4;
+        const uint32_t d2 = di == 0 ? x2 : di == 1 ? x3 : di == 2 ? x4 : x5;
         return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
     }
 };
