@@ -50,32 +50,40 @@ struct Code {
     int np;             // noise coefficients of a run (tail: the caller uses N)
     int l, dn, sv;      // noise level / tail decay / signed square of a plain coefficient
     int qnew;           // new quantizer index or -1
-    bool plain, zrun, n8, tail, stop;
+    int plain, zrun, n8, tail, stop;     // 0 / 1
 };
+// Classification by bit tests on constants indexed with the nybble, and arithmetic on the 0/1 results: written with
+// comparisons (v0 == 0, == 1, == 8, == Fh ...) the compiler recognises a switch and lowers it to a tree of branches with
+// EXEC-mask bookkeeping - in a kernel whose every instruction costs a wave ~9 cycles.
 __device__ __forceinline__ Code decode_code(uint32_t w, bool first) {
     Code k;
-    const bool q15 = first & ((w & 0xF) == 0xF);
+    const int f = first ? 1 : 0;
+    const int q15 = f & (int)(((w & 0xF) + 1) >> 4);
     w = first ? ((w << 4) | 0xF) : w;
     const int v0 = w & 0xF, v1 = (w >> 4) & 0xF, v2 = (w >> 8) & 0xF, v3 = (w >> 12) & 0xF, v4 = (w >> 16) & 0xF;
-    k.plain = (v0 != 0x0) & (v0 != 0x1) & (v0 != 0x8) & (v0 != 0xF);
-    const bool z0 = (v0 == 0x0), z1 = (v0 == 0x1), esc = (v0 == 0xF);
-    k.n8 = (v0 == 0x8);
-    k.zrun = z0 | z1;
-    k.tail = esc & (v1 == 0xF) & !q15;
-    const bool qext = esc & (v1 == 0xE);
-    k.stop = qext & (v2 == 0xF);
-    const bool q1 = esc & !k.tail & !qext;
-    int sv = (v0 ^ 0x8) - 0x8;
-    k.sv = (sv < 0) ? (-sv * sv) : (+sv * sv);
-    int len = k.plain ? 1 : z0 ? 2 : z1 ? 3 : k.n8 ? 4 : k.tail ? 5 : qext ? 3 : 2;
-    k.len = len - (first ? 1 : 0);
-    k.n = k.plain ? 1 : z0 ? v1 + 1 : z1 ? ((v1 << 4) | v2) + 33 : 0;
-    k.np = k.n8 ? ((((v1 << 4) | v2) << 1) | (v3 & 1)) + 16 : 0;
-    k.l = k.n8 ? (v3 >> 1) + 1 : v2 + 1;
+    const int z0 = (0x0001 >> v0) & 1, z1 = (0x0002 >> v0) & 1, esc = (0x8000 >> v0) & 1;
+    k.n8 = (0x0100 >> v0) & 1;
+    k.plain = (0x7EFC >> v0) & 1;
+    k.zrun = (0x0003 >> v0) & 1;
+    k.tail = esc & ((v1 + 1) >> 4) & (q15 ^ 1);
+    const int qext = esc & ((0x4000 >> v1) & 1);
+    k.stop = qext & ((v2 + 1) >> 4);
+    const int q1 = esc & (k.tail ^ 1) & (qext ^ 1);
+    const int sgn = (v0 ^ 0x8) - 0x8;
+    const int sq = sgn * sgn;
+    k.sv = (sgn < 0) ? -sq : sq;
+    // nybbles: 1 plain, 2 short zero run, 3 long zero run, 4 noise run; Fh: 2, +1 quantizer extension / stop, +3 tail
+    const int len0 = (int)((0x2111111411111132ull >> (4 * v0)) & 0xF);
+    k.len = len0 + 3 * k.tail + qext - f;
+    const int v12 = (v1 << 4) | v2;
+    k.n = k.plain + z0 * (v1 + 1) + z1 * (v12 + 33);
+    k.np = k.n8 * (((v12 << 1) | (v3 & 1)) + 16);
+    k.l = (v2 + 1) + k.n8 * ((v3 >> 1) - v2);
     k.dn = (v3 << 4) | v4;
     // (opening Fh: the reference expands quantizer -2, ulcDecoder.c:89-98,107 - a shift by -2, i.e. by 30 on x86-64:
     //  the unit's quantizer is exactly 0 until a change code; index 30 expands to the same 0)
-    k.qnew = q15 ? 30 : q1 ? v1 : (qext & !k.stop) ? 0xE + v2 : -1;
+    const int qn = -1 + q1 * (v1 + 1) + (qext & (k.stop ^ 1)) * (0xE + v2 + 1);
+    k.qnew = q15 ? 30 : qn;
     return k;
 }
 // number of leading nybbles of w (low first, at most 7) that are plain coefficients, i.e. none of 0h 1h 8h Fh
@@ -178,7 +186,7 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
     uint2 *prec = c.prec + (size_t)blk * c.precStride;
     uint2 *nrec = c.nrec + (size_t)blk * c.nrecStride;
     int nP = 0, nN = 0, uP0 = 0, uN0 = 0;                           // records written so far in the block / at the current unit's start
-    int u = 0, draws = 0, uslot = 0, uDraw0 = 0;
+    int u = 0, draws = 0, uslot = 0, uDraw0 = 0, uj = 0, uch4 = 0;
     udraw[0] = 0;
     utail[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     int S = c.BS >> (pat & 7), N = S;
@@ -189,8 +197,10 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
         u++;
         fin = bad | (u >= total);
         if (!fin) {
-            int ch = u / nsub, j = u - ch * nsub;
-            uslot = ch * 4 + j;
+            uj++;                                                  // (subblock within the channel, channel * 4: counters, not a division by nsub)
+            if (uj == nsub) { uj = 0; uch4 += 4; }
+            const int j = uj;
+            uslot = uch4 + j;
             udraw[uslot] = draws; uDraw0 = draws;
             utail[uslot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             uP0 = nP; uN0 = nN;
