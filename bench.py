@@ -263,6 +263,13 @@ def main():
     pseudo = ("cbr_probe_passes", "k_heapsel", "wc_pipeline_exposed")   # intervals, not kernels (join wait / side-stream launches)
     allk = {**{("enc", k_): v for k_, v in acc_enc.items() if k_ not in pseudo}, **{("dec", k_): v for k_, v in acc_dec.items()}}
     (side, kname), kms = max(allk.items(), key=lambda kv: kv[1])
+    # A stage interval of the main stream also holds what the side streams run beside it (k_select's holds the noise
+    # chain's kernels: 1.3 ms in-stream, 0.74 ms alone), so the largest interval is not always the largest kernel.  For the
+    # one-pass (VBR) configurations the roofline kernel is fixed: the transform for encode / both (largest kernel by its
+    # own time and by HBM traffic, each launch timed by its own event pair), the synthesis kernel for decode.
+    if cfg["mode"] == "vbr":
+        want = ("dec", "k_dsyn") if args.mode == "decode" else ("enc", "k_xf")
+        if want in allk: (side, kname), kms = want, allk[want]
     # kms is the kernel's time per step; a kernel launched n times per step (k_xf: one launch per chunk of blocks of
     # the window-control pipeline) has kms = sum of its n launches, each timed by its own hipEvent pair on its stream.
     launches = float(enc.xf_launches()) if kname == "k_xf" else 1.0      # from the library: chunks of the last call

@@ -1,13 +1,8 @@
 #!/bin/bash
-# scratch: window-control step / transform chunk sweeps (environment switches)
 cd "$(dirname "$0")/.."
-run() { timeout 300 python bench.py --no-cpu --mode encode --steps 20 --warmup 3 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); k=d['kernels_ms']; print('$1', 'ms_per_step %.3f' % d['ms_per_step'], 'xf %.2f exposed %.2f' % (k['enc.05_k_xf'] if 'enc.05_k_xf' in k else -1, [v for n,v in k.items() if 'exposed' in n][0]))"; }
-for r in 1 2; do
-unset ULCX_WC_STEPS ULCX_WC_PIPE; run "default(steps4,pipe4)"
-ULCX_WC_STEPS=0 run "steps=chunks pipe4"
-ULCX_WC_STEPS=0 ULCX_WC_PIPE=5 run "steps=chunks pipe5"
-ULCX_WC_STEPS=0 ULCX_WC_PIPE=6 run "steps=chunks pipe6"
-ULCX_WC_STEPS=8 ULCX_WC_PIPE=5 run "steps8 pipe5"
-ULCX_WC_STEPS=5 ULCX_WC_PIPE=6 run "steps5 pipe6"
-done
+O=gpurun_out/r02d2; rm -rf $O; mkdir -p $O
+python bench.py > $O/bench.json 2> $O/bench.err
+python bench.py --mode encode > $O/bench_encode.json 2>> $O/bench.err
+python bench.py --no-cpu --pmc-summary profiles/r02_d_pmc_summary.json > $O/bench_with_traffic.json 2>> $O/bench.err
+python bench.py --config wswitch_4096 --steps 3 --warmup 1 > $O/bench_wswitch_4096.json 2>> $O/bench.err
+head -c 300 $O/bench.json; tail -2 $O/bench.err
