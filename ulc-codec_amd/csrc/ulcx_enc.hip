@@ -1890,11 +1890,15 @@ __device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const flo
                                           unsigned long long &lo, unsigned long long &hi, int &cnt, bool dbgNoSum = false) {
     // a trip's nybbles (at most four) are gathered in a 16-bit word and appended once: one 64-bit shift per trip
     // (nybbles past the 32nd are dropped but counted: the caller treats cnt > 32 as an overflow)
+    // (selects between VALUES, both words updated every time: written as if / else on lo and hi the compiler indexes
+    //  the pair at run time and keeps it in scratch memory - a load, an OR and a store per code)
     auto append = [&](unsigned code, int len) {
-        if (cnt < 16) {
-            lo |= (unsigned long long)code << (4 * cnt);
-            if (cnt + len > 16) hi |= (unsigned long long)code >> (4 * (16 - cnt));
-        } else if (cnt < 32) hi |= (unsigned long long)code << (4 * (cnt - 16));
+        const int sh = 4 * cnt;
+        const unsigned long long c64 = code;
+        const unsigned long long toLo = (cnt < 16) ? (c64 << (sh & 63)) : 0ull;
+        const unsigned long long spill = (cnt > 0 && cnt < 16) ? (c64 >> ((64 - sh) & 63)) : 0ull;      // the part of a code that crosses nybble 16
+        const unsigned long long toHi = (cnt >= 16 && cnt < 32) ? (c64 << ((sh - 64) & 63)) : spill;
+        lo |= toLo; hi |= toHi;
         cnt += len;
     };
     while (zr) {
