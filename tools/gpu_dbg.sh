@@ -1,8 +1,6 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-O=gpurun_out/r02d2; rm -rf $O; mkdir -p $O
-python bench.py > $O/bench.json 2> $O/bench.err
-python bench.py --mode encode > $O/bench_encode.json 2>> $O/bench.err
-python bench.py --no-cpu --pmc-summary profiles/r02_d_pmc_summary.json > $O/bench_with_traffic.json 2>> $O/bench.err
-python bench.py --config wswitch_4096 --steps 3 --warmup 1 > $O/bench_wswitch_4096.json 2>> $O/bench.err
-head -c 300 $O/bench.json; tail -2 $O/bench.err
+for r in 1 2 3; do for v in 0 1; do
+if [ $v = 1 ]; then export ULCX_NOISE_LOWPRI=1; else unset ULCX_NOISE_LOWPRI; fi
+ULCX_BENCH_TIMING=1 timeout 300 python bench.py --no-cpu --steps 20 --warmup 3 --mode encode 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); k=d['kernels_ms']; print('lowpri=$v ms_per_step %.3f |' % d['ms_per_step'], ' '.join('%s %.2f' % (n.split('.')[1][2:], v) for n, v in k.items() if v > 0.05))"; done; done
