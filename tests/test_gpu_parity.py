@@ -417,3 +417,23 @@ def test_runtime_switches_keep_parity(env):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_timing_events_can_be_switched_off():
+    """ulcx_encoder_set_timing / ulcx_decoder_set_timing: without the per-kernel events the results are the same and
+    the stage tables are empty; switched on again they are filled."""
+    amd = _amd()
+    bs, ch, rate, B, K = 1024, 2, 44100, 3, 4
+    pcm = _streams(B, K, bs, ch, rate, True, seed=31)
+    refs = [oracle_encode_debug(pcm[s], bs, rate, 0, 55.0, slot=2 * ch * bs + 16) for s in range(B)]
+    for timing in (False, True):
+        enc = amd.BatchEncoder(B, ch, bs, rate, K); dec = amd.BatchDecoder(B, ch, bs, K)
+        enc.set_timing(timing); dec.set_timing(timing)
+        res = enc.encode(pcm, amd.MODE_VBR, 55.0)
+        for s in range(B):
+            _compare_encode(res, refs[s], s, 0, K, None, f"timing={timing}")
+        got, gbits = dec.decode(res[0])
+        rc, ref_pcm, ref_bits = oracle_decode_stream(refs[0]["out"], ch, bs)
+        assert rc == 0 and np.array_equal(got[0], ref_pcm) and np.array_equal(gbits[0], ref_bits)
+        assert bool(enc.stage_ms()) == timing and bool(dec.stage_ms()) == timing
+        enc.close(); dec.close()
