@@ -673,8 +673,11 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
                     if (q >= nch) break;
                     int ch = ch0 + q;
                     float2 *zc = q ? zc1 : zc0, *zs = q ? zs1 : zs0;
-                    float2 yc1 = cmulc(zc[FFT_PADS(r1, ps)], P1), yc2 = cmulc(zc[FFT_PADS(r2, ps)], P2);
-                    float2 ys1 = cmulc(zs[FFT_PADS(r1, ps)], P1), ys2 = cmulc(zs[FFT_PADS(r2, ps)], P2);
+                    // (packed-f32 complex multiplies: lane-wise IEEE, the same four products and two sums as cmulc)
+                    const fft_v2f Pv1 = { P1.x, P1.y }, Pv2 = { P2.x, P2.y };
+                    auto cm = [](float2 d, fft_v2f w) { const fft_v2f dv = { d.x, d.y }; const fft_v2f r = fft_cmulc_pk(dv, w); return make_float2(r.x, r.y); };
+                    float2 yc1 = cm(zc[FFT_PADS(r1, ps)], Pv1), yc2 = cm(zc[FFT_PADS(r2, ps)], Pv2);
+                    float2 ys1 = cm(zs[FFT_PADS(r1, ps)], Pv1), ys2 = cm(zs[FFT_PADS(r2, ps)], Pv2);
                     // pair j = k1: coefficients 2k1, 2k1+1 ; pair j = k2: coefficients 2k2, 2k2+1
                     float mdct[4] = { yc1.x, -yc2.y, yc2.x, -yc1.y };
                     float mdst[4] = { ys1.x,  ys2.y, ys2.x,  ys1.y };
