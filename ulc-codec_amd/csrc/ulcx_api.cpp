@@ -129,6 +129,27 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     c.cplxScale = 0x1.62E430p-1f * (31 - __builtin_clz((unsigned)BlockSize));   // BlockTransform.c:320
     rc = ulcx_tables_build(&c.T, &e->tables, BlockSize, RateHz, true);
     if (rc) { cleanup(e); return rc; }
+    {   // k_bark_uniform keeps one snapshot of the running sums per Bark band that is open (lower edge passed, upper edge
+        // not yet): the most the full-size band tables ever have open at once sizes its ring
+        int most = 0;
+        const int N = BlockSize / 2;
+        for (int t = 0; t < 2; t++) {
+            const short *beg = t ? c.T.pBeg[0] : c.T.nBeg[0], *end = t ? c.T.pEnd[0] : c.T.nEnd[0];
+            for (int b = 0; b < ULCX_NBARK; b++) {
+                if (beg[b] > end[b] || end[b] > N) most = 1 << 20;
+                if (b && (beg[b] < beg[b - 1] || end[b] < end[b - 1])) most = 1 << 20;
+            }
+            for (int pos = 0; pos <= N; pos++) {
+                int open = 0;
+                for (int b = 0; b < ULCX_NBARK; b++) open += (beg[b] <= pos && pos <= end[b]) ? 1 : 0;
+                if (open > most) most = open;
+            }
+        }
+        int ring = 4;
+        while (ring < most) ring *= 2;
+        const char *bu = getenv("ULCX_BARK_UNIFORM");                    // =0: k_nbark for every block (the round-1 path)
+        c.barkRing = (ring <= 8 && N % 32 == 0 && !(bu && bu[0] == '0')) ? ring : 0;
+    }
     size_t B = nStreams, K = maxBlocksPerCall, NB = B * K, cb = (size_t)nChan * BlockSize;
     DA(c.hist, B * 2 * BlockSize * nChan, true);
     DA(c.wcs, B, true);
@@ -142,6 +163,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.amp2, NB * BlockSize / 2, false);
     DA(c.barkN, NB * nChan * 4 * ULCX_NBARK, true);
     DA(c.barkP, NB * 4 * ULCX_NBARK, true);
+    if (c.barkRing) { DA(c.barkRawN, NB * nChan * ULCX_NBARK * 3, false); DA(c.barkRawP, NB * ULCX_NBARK * 3, false); DA(c.decList, NB, false); DA(c.decCount, 1, true); }
     DA(c.nnz, NB, true);
     DA(c.cplx, NB, true);
     DA(c.nout, NB, true);

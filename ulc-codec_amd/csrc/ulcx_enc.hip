@@ -525,6 +525,7 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
 
     const int *wrow = c.wcArr + (size_t)s * (c.maxK + 2) + k;
     int wcPrev = wrow[0], wc = wrow[1], wcNext = wrow[2];
+    if (c.barkRing && tid == 0 && (ulcx_pattern(wc) & ~8u) != 0) c.decList[atomicAdd(c.decCount, 1)] = blk;     // (its Bark sums take the lane-per-subblock kernels)
     int nextOv = first_overlap(wcNext, BS);
     int ovFirst;                                       // right overlap of the previous block's last subblock
     {
@@ -736,6 +737,7 @@ __global__ __launch_bounds__(WG) void k_xf_big(UlcxEncCtx c, int k0, int k1) {
     if (tid == 0) s_nnz = 0;
     const int *wrow = c.wcArr + (size_t)s * (c.maxK + 2) + k;
     const int wcPrev = wrow[0], wc = wrow[1], wcNext = wrow[2];
+    if (c.barkRing && threadIdx.x == 0 && (ulcx_pattern(wc) & ~8u) != 0) c.decList[atomicAdd(c.decCount, 1)] = blk;
     const int nextOv = first_overlap(wcNext, BS);
     int ovFirst;                                       // right overlap of the previous block's last subblock
     {
@@ -977,12 +979,15 @@ __device__ __forceinline__ bool unit_geom(int wc, int j, int BS, int &d, int &of
 }
 
 // Psyopt.c:185-225
-__global__ __launch_bounds__(64) void k_nbark(UlcxEncCtx c) {
+__global__ __launch_bounds__(64) void k_nbark(UlcxEncCtx c, int useList) {
     int tid0 = blockIdx.x * 64 + threadIdx.x;
-    int nBC = c.B * c.K * c.C;
+    // (with k_bark_uniform taking the un-decimated blocks: only the blocks k_xf listed as decimated)
+    const int nBlk = useList ? *c.decCount : c.B * c.K;
+    int nBC = nBlk * c.C;
     if (tid0 >= nBC * 4) return;
     // subblock index slowest: waves of j >= 1 are empty for un-decimated blocks and exit at once
     int j = tid0 / nBC, rem = tid0 - j * nBC, blk = rem / c.C, ch = rem - blk * c.C;
+    if (useList) blk = c.decList[blk];
     int gid = (blk * c.C + ch) * 4 + j;
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
@@ -1052,11 +1057,12 @@ __global__ __launch_bounds__(WG) void k_nline(UlcxEncCtx c) {
 }
 
 // Psyopt.c:86-137 on the channel-summed energies
-__global__ __launch_bounds__(64) void k_pbark(UlcxEncCtx c) {
+__global__ __launch_bounds__(64) void k_pbark(UlcxEncCtx c, int useList) {
     int tid0 = blockIdx.x * 64 + threadIdx.x;
-    int NBk = c.B * c.K;
+    int NBk = useList ? *c.decCount : c.B * c.K;
     if (tid0 >= NBk * 4) return;
     int j = tid0 / NBk, blk = tid0 - j * NBk;
+    if (useList) blk = c.decList[blk];
     int gid = blk * 4 + j;
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
@@ -1080,6 +1086,115 @@ __global__ __launch_bounds__(64) void k_pbark(UlcxEncCtx c) {
         }
         bark[b] = unmask;
     }
+}
+
+// k_nbark / k_pbark for the UN-DECIMATED blocks (about nine in ten; UlcxEncCtx::barkRing != 0): same sums in the same order,
+// but every lane of a wave has the same subblock geometry, so the band edges are scalar control flow and the lines come
+// through LDS.  A wave takes 64 consecutive rows (a row = the BS/2 lines of one block[,channel]) in tiles of 32 lines: a load
+// instruction covers 128-byte pieces of eight rows (one lane per row reading global memory touches 64 cache lines per
+// instruction), the tile goes to LDS row-padded, every lane then walks its own row.  Both cursors of the reference
+// (Psyopt.c:23-51) are prefixes of one running sum from line 0: the lane keeps a single prefix and a snapshot of it at the
+// lower edge of each band still open (ring in LDS); a band's three sums are prefix(upper edge) - snapshot, the very
+// subtraction the reference makes.  Lanes whose block is decimated run along and store nothing (their blocks are on k_xf's
+// list for the lane-per-subblock kernels).  The per-band arithmetic (binary64 log, divisions) is k_bark_levels, one lane
+// per band.
+template <bool NOISE>
+__global__ __launch_bounds__(64) void k_bark_uniform(UlcxEncCtx c) {
+    extern __shared__ double bk_lds[];
+    const int lane = threadIdx.x, RM = c.barkRing - 1;
+    double *ring = bk_lds + lane;                                // [barkRing][3][64]
+    float *tile = (float *)(bk_lds + c.barkRing * 3 * 64);       // [64][36]
+    const int half = c.BS / 2;
+    const int nRows = NOISE ? c.B * c.K * c.C : c.B * c.K;
+    const int row0 = blockIdx.x * 64;
+    const int row = min(row0 + lane, nRows - 1);                 // (lanes past the end repeat the last row and store nothing)
+    const int blk = NOISE ? row / c.C : row;
+    const bool mine = (row0 + lane < nRows) && (ulcx_pattern(c.wcArr[(size_t)(blk / c.K) * (c.maxK + 2) + (blk % c.K) + 1]) & ~8u) == 0;
+    if (!__ballot(mine)) return;
+    const float *src = NOISE ? c.nsum : c.amp2;
+    double *raw = (NOISE ? c.barkRawN : c.barkRawP) + (size_t)row * ULCX_NBARK * 3;
+    const uint32_t *sched = c.T.barkSched + (NOISE ? 0 : ULCX_MAX_SUB * ULCX_BARK_EVENTS);      // the full-size subblock's edges
+    // tile loads: lane (r8, q) fetches 16 bytes q of rows r8, r8+8, ... of the wave
+    // (named registers, not arrays: an array here ends up in scratch, whose traffic queues behind the prefetch)
+    const int r8 = lane >> 3, q4 = (lane & 7) * 4;
+#define BK_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define BK_DECL(i) const float *ld##i = src + (size_t)min(row0 + r8 + 8 * i, nRows - 1) * half + q4; float4 nx##i = *(const float4 *)ld##i;
+    BK_ROWS(BK_DECL)
+    double fl = 0.0, pk = 0.0, pw = 0.0;
+    const float *mineRow = tile + lane * 36;
+    int pos = 0, tileOf = -1;
+    const uint32_t evLane = sched[lane < ULCX_BARK_EVENTS ? lane : ULCX_BARK_EVENTS - 1];      // edge e of the list sits in lane e
+    for (int e = 0; e < ULCX_BARK_EVENTS; e++) {
+        const uint32_t ev = (uint32_t)__builtin_amdgcn_readlane((int)evLane, e);
+        const int epos = ev & 0xffff, kind = (ev >> 16) & 3, b = ev >> 24;
+        if (kind == 3) break;
+        // the lines up to the edge (uniform count)
+        while (pos < epos) {
+            if ((pos >> 5) != tileOf) {                          // next tile: registers -> LDS, prefetch the one after
+                tileOf = pos >> 5;
+                __syncthreads();                                 // (one wave: orders the LDS traffic, costs nothing)
+#define BK_PUT(i) *(float4 *)(tile + (r8 + 8 * i) * 36 + q4) = nx##i;
+                BK_ROWS(BK_PUT)
+                __syncthreads();
+                if (tileOf + 1 < half / 32) {
+#define BK_GET(i) nx##i = *(const float4 *)(ld##i + 32 * (tileOf + 1));
+                    BK_ROWS(BK_GET)
+                }
+            }
+            if ((pos & 3) == 0 && pos + 4 <= epos) {             // four lines from one 16-byte LDS read (a tile is 32 lines)
+                const float4 v = *(const float4 *)(mineRow + (pos & 31));
+                linesum_add(v.x, fl, pk, pw); linesum_add(v.y, fl, pk, pw); linesum_add(v.z, fl, pk, pw); linesum_add(v.w, fl, pk, pw);
+                pos += 4;
+            } else { linesum_add(mineRow[pos & 31], fl, pk, pw); pos++; }
+        }
+        double *r = ring + ((b & RM) * 3) * 64;
+        if (kind == 0) { r[0] = fl; r[64] = pk; r[128] = pw; }               // lower edge: snapshot
+        else if (kind == 1) {                                                // upper edge: the band's three sums
+            if (mine) { raw[b * 3] = fl - r[0]; raw[b * 3 + 1] = pk - r[64]; raw[b * 3 + 2] = pw - r[128]; }
+        } else break;                                                        // end of the subblock
+    }
+}
+
+// The Bark levels of the un-decimated blocks from the band sums of k_bark_uniform: one lane per (row, band), 32 lanes per
+// row.  A band without energy takes the level of the last band below it that had some (Psyopt.c:118-129, :207-218: the
+// level variable is simply not reassigned).
+template <bool NOISE>
+__global__ __launch_bounds__(WG) void k_bark_levels(UlcxEncCtx c) {
+    const int nRows = NOISE ? c.B * c.K * c.C : c.B * c.K;
+    const long long gid = (long long)blockIdx.x * WG + threadIdx.x;
+    int row = (int)(gid >> 5);
+    const int b = (int)(gid & 31), lane = threadIdx.x & 63;
+    bool alive = row < nRows;
+    if (!alive) row = 0;
+    const int blk = NOISE ? row / c.C : row;
+    alive = alive && (ulcx_pattern(c.wcArr[(size_t)(blk / c.K) * (c.maxK + 2) + (blk % c.K) + 1]) & ~8u) == 0;
+    if (!__ballot(alive)) return;
+    float level = 0.0f;
+    bool has = false;
+    if (alive && b < ULCX_NBARK) {
+        const double *raw = (NOISE ? c.barkRawN : c.barkRawP) + ((size_t)row * ULCX_NBARK + b) * 3;
+        double sf = raw[0], sp = raw[1], sw = raw[2];
+        const int l0 = NOISE ? c.T.nBeg[0][b] : c.T.pBeg[0][b], l1 = NOISE ? c.T.nEnd[0][b] : c.T.pEnd[0][b];
+        if (sw > 0.0) {
+            has = true;
+            if (NOISE) {                                         // Psyopt.c:207-216
+                double scale = 1.0 / (double)(l1 - l0);
+                sp = sp / sw;
+                sf = sf * scale;
+                level = 0.5f * (float)(ulcx_log(sw * scale) + sf - sp);
+            } else {                                             // Psyopt.c:118-127
+                sp = sp / sw;
+                sf = sf / (double)(l1 - l0);
+                level = (float)(sp - sf - ulcx_log(sw));
+            }
+        }
+    }
+    const unsigned hm = (unsigned)(__ballot(has) >> (lane & 32));              // this row's bands with energy
+    const unsigned below = hm & (unsigned)((2ull << b) - 1);
+    const int srcBand = below ? 31 - __clz(below) : b;
+    const float taken = __shfl(level, (lane & 32) + srcBand);
+    if (alive && b < ULCX_NBARK)
+        (NOISE ? c.barkN : c.barkP)[(size_t)row * 4 * ULCX_NBARK + b] = below ? taken : (NOISE ? -100.0f : 0.0f);
 }
 
 // BlockTransform.c:337-345: key = 2*key0 + MaskingNp[n/2] + Log[0.5^2]*(Chan&1), formed where the
@@ -2397,6 +2512,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     const int wcPipe = (side && side2 && side3) ? aux.wcPipe : 1;
     if (aux.nXf) *aux.nXf = 0;
     if (c.mode != ULCX_MODE_VBR) CK(hipMemsetAsync(c.cbrLive, 0, sizeof(int), st));
+    if (c.barkRing) CK(hipMemsetAsync(c.decCount, 0, sizeof(int), st));           // k_xf lists this call's decimated blocks
     int NB = c.B * c.K;
     int stage = 0;
 #define MARK() do { if (ev) CK(hipEventRecord(ev[stage++], st)); } while (0)
@@ -2496,8 +2612,13 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     int nUnits = NB * c.C * 4;
     // (the noise log-spectrum does not feed the keys: it is launched after the selection so that the
     //  main stream has work to run beside the side-stream heapsort of tie-straddle blocks)
+    const size_t barkLds = (size_t)c.barkRing * 3 * 64 * 8 + 64 * 36 * 4;
     auto launch_noise = [&](hipStream_t s2, bool ev0) -> int {
-        hipLaunchKernelGGL(k_nbark, dim3((nUnits + 63) / 64), dim3(64), 0, s2, c);                         if (ev0) MARK();
+        if (c.barkRing) {
+            hipLaunchKernelGGL(k_bark_uniform<true>, dim3((NB * c.C + 63) / 64), dim3(64), barkLds, s2, c);
+            hipLaunchKernelGGL(k_bark_levels<true>, dim3((unsigned)(((size_t)NB * c.C * 32 + WG - 1) / WG)), dim3(WG), 0, s2, c);
+        }
+        hipLaunchKernelGGL(k_nbark, dim3((nUnits + 63) / 64), dim3(64), 0, s2, c, c.barkRing ? 1 : 0);    if (ev0) MARK();
         hipLaunchKernelGGL(k_nline, dim3(NB * c.C), dim3(WG), 0, s2, c);                                   if (ev0) MARK();
         return ULCX_OK;
     };
@@ -2520,7 +2641,12 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         CK(hipEventRecord(evState, side3));
     } else { hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c);                         MARK(); }
     {
-        hipLaunchKernelGGL(k_pbark, dim3((NB * 4 + 63) / 64), dim3(64), 0, st, c);                         MARK();
+        const bool uniP = c.barkRing && getenv("ULCX_BARK_UNIFORM_P");       // (psycho sums: one wave per SIMD either way, no gain measured)
+        if (uniP) {
+            hipLaunchKernelGGL(k_bark_uniform<false>, dim3((NB + 63) / 64), dim3(64), barkLds, st, c);
+            hipLaunchKernelGGL(k_bark_levels<false>, dim3((unsigned)(((size_t)NB * 32 + WG - 1) / WG)), dim3(WG), 0, st, c);
+        }
+        hipLaunchKernelGGL(k_pbark, dim3((NB * 4 + 63) / 64), dim3(64), 0, st, c, uniP ? 1 : 0);          MARK();
         if (noiseAside) {
             CK(hipEventRecord(evTail0, st));                       // (reused: behind k_pbark)
             CK(hipStreamWaitEvent(side2, evTail0, 0));

@@ -7,6 +7,7 @@
 
 #define ULCX_NBARK 25
 #define ULCX_MAX_SUB 4
+#define ULCX_BARK_EVENTS 52              // 25 lower edges + 25 upper edges + end of subblock (+ pad)
 #define ULCX_MAX_BS_DEVICE 32768       // the reference's own limit (ulcEncoder.c:32-34); above 8192 the transform takes one array at a time (k_xf_big)
 #define ULCX_COEF_EPS (0x1.0p-31f)     // include/ulcEncoder.h:36
 #define ULCX_HEAP_LDS_BYTES (128 * 1024)
@@ -23,6 +24,7 @@ struct UlcxTables {
     const float  *winRise;
     const int    *bandIdx[ULCX_MAX_SUB]; // per line < S/2: (int)Bark(line)         Psyopt.c:141-143,237-239
     const float  *bandFrac[ULCX_MAX_SUB];//               Bark(line) - (int)Bark(line)
+    const uint32_t *barkSched;           // [2][ULCX_MAX_SUB][ULCX_BARK_EVENTS] band edges in line order (k_bark_uniform)
     // Bark band edges per subblock size (lines of the S/2-line pseudo-DFT)
     short nBeg[ULCX_MAX_SUB][ULCX_NBARK], nEnd[ULCX_MAX_SUB][ULCX_NBARK];   // noise:  [b, b+2)        Psyopt.c:198-205
     short pBeg[ULCX_MAX_SUB][ULCX_NBARK], pEnd[ULCX_MAX_SUB][ULCX_NBARK];   // psycho: [b-.75, b+.25)  Psyopt.c:109-116
@@ -38,6 +40,8 @@ struct UlcxWcState {                     // per stream, persistent (ulcEncoder.h
 struct UlcxEncCtx {
     // geometry
     int B, K, C, BS, lgBS;               // streams, blocks this call, channels, block size
+    int barkRing;                        // k_bark_uniform: snapshots a lane keeps of open Bark bands (power of two; 0 = k_nbark / k_pbark for every block)
+    int *decList, *decCount;             // blocks of this call with a decimated window (k_bark_classify): they take k_nbark / k_pbark
     int maxK;                            // allocation stride for per-call arrays
     int slot;                            // bytes per output slot
     int unitCap;                         // bytes per (chan,subblock) nybble staging row = 2*BS+32 per channel
@@ -66,6 +70,7 @@ struct UlcxEncCtx {
     float  *amp2;                        // [NB][BS/2]
     float  *barkN;                       // [NB][C*4][25]
     float  *barkP;                       // [NB][4][25]
+    double *barkRawN, *barkRawP;         // [rows][25][3] ordered sums of each band of un-decimated blocks (k_bark_uniform -> k_bark_levels)
     int    *nnz;                         // [NB]
     float  *cplx;                        // [NB]
     int    *nout;                        // [NB]   nOutCoef of the current pass

@@ -93,6 +93,30 @@ int ulcx_tables_build(UlcxTables *T, void **devBlob, int BS, int rateHz, bool fo
                 rise[ov + i] = (float)sin(th);
             }
     }
+    // k_bark_uniform: the band edges of a subblock size as one list in line order, [noise|psycho][d][ULCX_BARK_EVENTS] words
+    // line | kind << 16 | band << 24 (kind 0: lower edge, 1: upper edge, 2: end of the subblock); at equal lines lower
+    // edges come first (a band of no lines opens, then closes)
+    size_t offSched = reserve(sizeof(uint32_t) * 2 * ULCX_MAX_SUB * ULCX_BARK_EVENTS);
+    if (forEncoder) {
+        uint32_t *sch = (uint32_t *)(blob.data() + offSched);
+        for (int t = 0; t < 2; t++) for (int d = 0; d < ULCX_MAX_SUB; d++) {
+            const short *beg = t ? T->pBeg[d] : T->nBeg[d], *end = t ? T->pEnd[d] : T->nEnd[d];
+            uint32_t *o = sch + (size_t)(t * ULCX_MAX_SUB + d) * ULCX_BARK_EVENTS;
+            int n = 0, bo = 0, bc = 0, N = (BS >> d) / 2;
+            bool ordered = true;
+            for (int b = 0; b < ULCX_NBARK; b++) {
+                if (beg[b] > end[b] || end[b] > N) ordered = false;
+                if (b && (beg[b] < beg[b - 1] || end[b] < end[b - 1])) ordered = false;
+            }
+            if (ordered) while (bc < ULCX_NBARK) {
+                int pos = (bo < ULCX_NBARK && beg[bo] <= end[bc]) ? beg[bo] : end[bc];
+                while (bo < ULCX_NBARK && beg[bo] == pos) { o[n++] = (uint32_t)pos | (0u << 16) | ((uint32_t)bo << 24); bo++; }
+                while (bc < bo && end[bc] == pos) { o[n++] = (uint32_t)pos | (1u << 16) | ((uint32_t)bc << 24); bc++; }
+            }
+            o[n++] = (uint32_t)N | (2u << 16);
+            while (n < ULCX_BARK_EVENTS) o[n++] = 0xffffu | (3u << 16);
+        }
+    }
     void *dev = nullptr;
     hipError_t e = hipMalloc(&dev, blob.size());
     if (e != hipSuccess) { ulcx_set_error("hipMalloc(tables): %s", hipGetErrorString(e)); return ULCX_ERR_NOMEM; }
@@ -107,6 +131,7 @@ int ulcx_tables_build(UlcxTables *T, void **devBlob, int BS, int rateHz, bool fo
             T->bandFrac[d] = (const float *)(base + offFrac[d]);
         }
     }
+    T->barkSched = (const uint32_t *)(base + offSched);
     T->winFall = (const float *)(base + offFall);
     T->winRise = (const float *)(base + offRise);
     *devBlob = dev;
