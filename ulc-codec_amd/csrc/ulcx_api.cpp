@@ -149,6 +149,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
         while (ring < most) ring *= 2;
         const char *bu = getenv("ULCX_BARK_UNIFORM");                    // =0: k_nbark for every block (the round-1 path)
         c.barkRing = (ring <= 8 && N % 32 == 0 && !(bu && bu[0] == '0')) ? ring : 0;
+        if ((size_t)nStreams * maxBlocksPerCall < 256 && !(bu && bu[0] == '1')) c.barkRing = 0;   // (a few blocks per call - the drop-in's one: three launches for nothing; =1 forces it, as the tests do)
     }
     size_t B = nStreams, K = maxBlocksPerCall, NB = B * K, cb = (size_t)nChan * BlockSize;
     DA(c.hist, B * 2 * BlockSize * nChan, true);
