@@ -25,9 +25,25 @@
 __device__ __forceinline__ float expand_quantizer(int q) {        // ulcDecoder.c:96-98
     return 0x1.0p-31f * (float)((1u << (31 - 5)) >> q);
 }
-__device__ __forceinline__ uint32_t xorshift32(uint32_t s) {      // ulcDecoder.c:75-81
+__host__ __device__ constexpr uint32_t xorshift32(uint32_t s) {    // ulcDecoder.c:75-81
     s ^= s << 13; s ^= s >> 17; s ^= s << 5;
     return s;
+}
+// The decoder only looks at the top bit of a draw, and xorshift32 is linear over GF(2): the top bit of the i-th draw from
+// state s is the parity of s & m[i-1], with m fixed (row 31 of T^i).  Computed at compile time.
+struct XsTopMasks { uint32_t m[32]; };
+constexpr XsTopMasks xs_top_masks() {
+    XsTopMasks k = {};
+    for (int i = 0; i < 32; i++) {
+        uint32_t m = 0;
+        for (int b = 0; b < 32; b++) {
+            uint32_t t = 1u << b;
+            for (int d = 0; d <= i; d++) t = xorshift32(t);
+            if (t >> 31) m |= 1u << b;
+        }
+        k.m[i] = m;
+    }
+    return k;
 }
 
 // ---------------------------------------------------------------------------
@@ -397,9 +413,10 @@ __device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &
     // ---- 1. sign-parity stream, 2048 draws per pass (one pass unless the unit has more than 2048 noise coefficients)
     uint32_t passPar = 0;                                     // parity of the top bits of all earlier passes
     for (int dbase = 0; dbase < unitDraws; dbase += 2048) {
-        uint32_t seed = sj, W = 0;
+        constexpr XsTopMasks K = xs_top_masks();
+        uint32_t W = 0;
 #pragma unroll
-        for (int i = 0; i < 32; i++) { seed = xorshift32(seed); W = (W >> 1) | (seed & 0x80000000u); }   // bit i = top bit of draw dbase+32*lane+i+1
+        for (int i = 0; i < 32; i++) W |= (uint32_t)(__popc(sj & K.m[i]) & 1) << i;                     // bit i = top bit of draw dbase+32*lane+i+1
         uint32_t x = W;
         x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16;                                 // bit i = parity of bits 0..i
         const unsigned long long odd = __ballot((__popc(W) & 1) != 0);
@@ -408,6 +425,9 @@ __device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &
         passPar ^= (uint32_t)__popcll(odd) & 1u;
         if (dbase + 2048 < unitDraws) {
             // next pass: lane l needs the state 2048 + 32 l draws on = T^(32 l) of lane 63's end state
+            uint32_t seed = sj;
+#pragma unroll
+            for (int i = 0; i < 32; i++) seed = xorshift32(seed);
             const uint32_t endState = (uint32_t)__builtin_amdgcn_readlane((int)seed, 63);
             sj = rng_jump(c.jumpT, endState, (uint32_t)lane << 5);
         }
