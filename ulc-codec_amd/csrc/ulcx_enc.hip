@@ -1541,6 +1541,18 @@ __global__ __launch_bounds__(64) void k_heapsel_pipe(UlcxEncCtx c, int fullRanki
         while (__ballot(pos != IDLE)) HEAP_SIFT_STEP();
 #undef HEAP_SIFT_STEP
         __syncthreads();
+        if (!fullRanking) {
+            // one-pass call: the kept set straight from here (what k_keep_ranks would do in a launch of its own behind this
+            // kernel - the end of the call waits for this chain)
+            __threadfence_block();
+            uint32_t *keep = c.keep + (size_t)blk * (N / 32);
+            if (lane == 0) c.slow[blk] = 0;
+            for (int i = lane; i < N; i += 64) {
+                unsigned long long m = __ballot(rank[i] < kSel);
+                if (lane == 0)  keep[i >> 5] = (uint32_t)m;
+                if (lane == 32) keep[i >> 5] = (uint32_t)(m >> 32);
+            }
+        }
     }
 }
 
@@ -2760,8 +2772,10 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         UlcxEncCtx cf = c; cf.fbMode = 2; cf.fbLo = lo; cf.fbHi = lo + c.rankSlots;
         for (int p = 0; p <= probes; p++) {
             int fin = (p == probes) ? 1 : 0;
-            hipLaunchKernelGGL(k_keep_ranks, dim3(fbGrid), dim3(WG), 0, s2, cf, fin);
-            if (cf.useWave) CK(hipMemsetAsync(cf.slow + NB + 1, 0, sizeof(int), s2));      // its own retry-queue counter
+            // (one-pass calls: k_heapsel_pipe has written the kept set, and for the first group of rank slots k_cplx cleared the counter)
+            const bool fromSort = (probes == 0 && ldsEntries);
+            if (!fromSort) hipLaunchKernelGGL(k_keep_ranks, dim3(fbGrid), dim3(WG), 0, s2, cf, fin);
+            if (cf.useWave && !(fromSort && lo == 0)) CK(hipMemsetAsync(cf.slow + NB + 1, 0, sizeof(int), s2));      // its own retry-queue counter
             int rc = launch_encode(cf, s2, fin, false, false); if (rc) return rc;
         }
         return ULCX_OK;
