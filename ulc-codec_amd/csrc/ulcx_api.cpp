@@ -21,7 +21,7 @@ struct ulcx_encoder {
     bool evOk, evRecorded;
     int lastK;
     hipStream_t side; hipEvent_t evFork, evJoin, evFork2; bool sideOk; bool timing;
-    hipEvent_t evWC[7 + 3 * ULCX_WC_MAXCH]; int wcPipe; hipStream_t side2, side3, side4; hipEvent_t evE[ULCX_WC_MAXCH]; hipEvent_t evXf[2 * ULCX_XF_MAXCH]; int nXf;      // window-control / transform chunk pipeline (ULCX_WC_PIPE chunks, default 4)
+    hipEvent_t evWC[7 + 3 * ULCX_WC_MAXCH + ULCX_XF_MAXCH + 1]; int wcPipe; hipStream_t side2, side3, side4; hipEvent_t evE[ULCX_WC_MAXCH]; hipEvent_t evXf[2 * ULCX_XF_MAXCH]; int nXf;      // window-control / transform chunk pipeline (ULCX_WC_PIPE chunks, default 4)
     bool keysFinal;
     // staging for the host-pointer API
     float *d_pcm; uint8_t *d_out; int32_t *d_bits, *d_wc; float *d_cplx;

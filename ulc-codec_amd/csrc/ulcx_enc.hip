@@ -837,9 +837,10 @@ __global__ __launch_bounds__(WG) void k_xf_big(UlcxEncCtx c, int k0, int k1) {
 // ---------------------------------------------------------------------------
 // Block complexity + nOutCoef (BlockTransform.c:279-325, ulcEncoder.c:93-158)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_cplx(UlcxEncCtx c) {
-    int blk = blockIdx.x * 64 + threadIdx.x;
-    if (blk >= c.B * c.K) return;
+__global__ __launch_bounds__(64) void k_cplx(UlcxEncCtx c, int k0, int k1) {
+    const int gidc = blockIdx.x * 64 + threadIdx.x, kcc = k1 - k0;     // blocks [k0, k1) of every stream
+    if (gidc >= c.B * kcc) return;
+    const int blk = (gidc / kcc) * c.K + k0 + gidc % kcc;
     int n = c.C * c.BS;
     const float4 *p = (const float4 *)(c.coef + (size_t)blk * n);
     float cx = 0.0f, cw = 0.0f;
@@ -2530,6 +2531,8 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
 #define MARK() do { if (ev) CK(hipEventRecord(ev[stage++], st)); } while (0)
     MARK();
     // --- window control
+    hipEvent_t *evX = evWC + 7 + 3 * ULCX_WC_MAXCH;            // [ULCX_XF_MAXCH] transform chunk done, [ULCX_XF_MAXCH]: all early k_cplx launches done
+    const bool cplxEarly = wcPipe > 1 && side && side2 && side3 && [] { const char *v = getenv("ULCX_CPLX_EARLY"); return !(v && v[0] == '0'); }();
     {
         int SG = (c.B + 63) / 64;
         // Chunks of blocks: the window-control kernels of chunk j+1.. (two stream-long serial recurrences, a few
@@ -2614,11 +2617,23 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                     if (ev) CK(hipEventRecord(aux.evXf[2 * jx], st));
                     launch_xf(c, ((nbk + 7) / 8) * 8, lds, st, x0, x1);
                     if (ev) CK(hipEventRecord(aux.evXf[2 * jx + 1], st));
+                    if (cplxEarly) CK(hipEventRecord(evX[jx], st));
                     jx++;
                 }
             }
             if (aux.nXf) *aux.nXf = nCh;
             MARK();
+            // The ordered complexity sums (k_cplx: lane-serial, HBM-bound) per transform chunk, on the envelope kernels' stream (all
+            // of those are enqueued by now): only the last chunk's are left beside k_pbark (0.40 -> 0.28 ms there, +0.06..0.1 in
+            // the transform: 0.04 ms per encode; ULCX_CPLX_EARLY=0 launches them once behind the transform)
+            if (cplxEarly) {
+                for (int j = 0; j < nCh; j++) {
+                    CK(hipStreamWaitEvent(side, evX[j], 0));
+                    const int kc2 = cut[j + 1] - cut[j];
+                    hipLaunchKernelGGL(k_cplx, dim3((c.B * kc2 + 63) / 64), dim3(64), 0, side, c, cut[j], cut[j + 1]);
+                }
+                CK(hipEventRecord(evX[ULCX_XF_MAXCH], side));
+            }
         }
     }
     int nUnits = NB * c.C * 4;
@@ -2645,13 +2660,14 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     if (noiseAside) {
         CK(hipEventRecord(evN0, st));
         CK(hipStreamWaitEvent(side3, evN0, 0));
-        hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, side3, c);
+        if (cplxEarly) CK(hipStreamWaitEvent(side3, evX[ULCX_XF_MAXCH], 0));          // (launched per transform chunk: below)
+        else hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, side3, c, 0, c.K);
         CK(hipEventRecord(evCplx, side3));
         MARK();
         // the state for the next call only needs the transform to be done with the history: off the main stream
         launch_state_update(c, side3);
         CK(hipEventRecord(evState, side3));
-    } else { hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c);                         MARK(); }
+    } else { hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c, 0, c.K);                 MARK(); }
     {
         const bool uniP = c.barkRing && getenv("ULCX_BARK_UNIFORM_P");       // (psycho sums: one wave per SIMD either way, no gain measured)
         if (uniP) {
