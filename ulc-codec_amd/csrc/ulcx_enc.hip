@@ -2532,7 +2532,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     MARK();
     // --- window control
     hipEvent_t *evX = evWC + 7 + 3 * ULCX_WC_MAXCH;            // [ULCX_XF_MAXCH] transform chunk done, [ULCX_XF_MAXCH]: all early k_cplx launches done
-    const bool cplxEarly = wcPipe > 1 && side && side2 && side3 && [] { const char *v = getenv("ULCX_CPLX_EARLY"); return !(v && v[0] == '0'); }();
+    const bool cplxEarly = wcPipe > 1 && side && side2 && side3 && [] { const char *v = getenv("ULCX_CPLX_EARLY"); return v && v[0] == '1'; }();
     {
         int SG = (c.B + 63) / 64;
         // Chunks of blocks: the window-control kernels of chunk j+1.. (two stream-long serial recurrences, a few
@@ -2623,9 +2623,9 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             }
             if (aux.nXf) *aux.nXf = nCh;
             MARK();
-            // The ordered complexity sums (k_cplx: lane-serial, HBM-bound) per transform chunk, on the envelope kernels' stream (all
-            // of those are enqueued by now): only the last chunk's are left beside k_pbark (0.40 -> 0.28 ms there, +0.06..0.1 in
-            // the transform: 0.04 ms per encode; ULCX_CPLX_EARLY=0 launches them once behind the transform)
+            // ULCX_CPLX_EARLY=1: the ordered complexity sums (k_cplx: lane-serial, HBM-bound) per transform chunk, on the envelope
+            // kernels' stream (all of those are enqueued by now): only the last chunk's are left beside k_pbark (0.40 -> 0.28 ms
+            // there) - but the transform's launches get 0.06..0.1 ms longer; 0.04 ms per encode at best, within the noise: off
             if (cplxEarly) {
                 for (int j = 0; j < nCh; j++) {
                     CK(hipStreamWaitEvent(side, evX[j], 0));
