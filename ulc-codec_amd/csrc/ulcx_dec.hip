@@ -8,10 +8,11 @@
 //             and the decaying-noise level chain of each unit's tail.
 //   k_dsyn    stereo streams: one workgroup (2 waves) per stream, blocks in order, one wave per channel:
 //             the records are scattered STRAIGHT INTO the FFT's LDS arrays, noise runs are synthesised
-//             32 coefficients per lane from a jumped-ahead xorshift state, then IMDCT (one DCT-IV =
-//             complex FFT per channel, one wave per array, no barrier between the passes), sine-window
-//             overlap-add, reversed-time centring FIFO, inverse M/S, interleave
-//             (libulc/ulcDecoder.c:198-302; IMDCT per FormatSpecs.md:150-157).
+//             32 coefficients per lane from a jumped-ahead xorshift state (top bits by parity masks), then
+//             IMDCT (one DCT-IV = complex FFT per channel, one wave per array, no barrier between the
+//             passes), sine-window overlap-add, the centring of decimated subblocks on one timeline
+//             (the reference's reversed-time FIFO without the shifting: dec_time_wave), inverse M/S,
+//             interleave (libulc/ulcDecoder.c:198-302; IMDCT per FormatSpecs.md:150-157).
 //   k_dgen    every other geometry (mono, multichannel, BlockSize > 4096): same pieces, one array.
 // Compiled with -ffp-contract=off (see ulcx_enc.hip).
 #include "ulcx_internal.h"

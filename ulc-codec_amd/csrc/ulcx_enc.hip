@@ -9,10 +9,12 @@
 //        DCT-IV = complex FFTs staged entirely in LDS, normalise, keys, per-line
 //        energies                                      (BlockTransform.c:229-281)
 //   cplx        ordered f32 sums -> BlockComplexity, nOutCoef (BlockTransform.c:279-325, ulcEncoder.c:140-158)
-//   nbark/nline noise log-spectrum                     (ulcEncoder_Psyopt.c:168-250)
-//   pbark/keys  masking levels + final importance keys (ulcEncoder_Psyopt.c:60-155, BlockTransform.c:337-345)
-//   select      top-nOutCoef set by LDS radix select; exact heapsort emulation only
-//               for tie groups straddling the cut      (BlockTransform.c:20-77)
+//   bark_uniform/bark_levels/nbark/nline  noise log-spectrum (un-decimated blocks on the geometry-uniform
+//               kernel, the rest lane per subblock)    (ulcEncoder_Psyopt.c:168-250)
+//   pbark       masking Bark levels                    (ulcEncoder_Psyopt.c:60-155)
+//   select      one wave per block: keys (coefficient + masking level, BlockTransform.c:337-345) in registers,
+//               the nOutCoef-th largest by bisection; exact heapsort emulation only for tie groups
+//               straddling the cut                     (BlockTransform.c:20-77)
 //   encode/pack nybble stream                          (ulcEncoder_Encode.c:23-360, ulcEncoder_NoiseFill.c)
 // All float arithmetic is written in the reference's operation order and this file is
 // compiled with -ffp-contract=off: no fused multiply-add is formed anywhere except the
