@@ -8,12 +8,12 @@ sys.path.insert(0, os.path.join(ROOT, "ulc-codec_amd")); sys.path.insert(0, os.p
 import ulc_amd
 from ulc_testlib import synth_pcm, oracle_encode_debug, oracle_decode_stream
 
-def run(budget=120.0, seed=1, max_bs=8192):
+def run(budget=120.0, seed=1, max_bs=8192, sizes=None, chans=None):
   rng = np.random.default_rng(seed)
   t0 = time.time(); n = 0; nblk = 0
   while time.time() - t0 < budget:
-      bs = int(rng.choice([b for b in [256, 512, 1024, 2048, 2048, 4096, 8192] if b <= max_bs]))
-      ch = int(rng.choice([1, 2, 2, 2, 3]))
+      bs = int(rng.choice(sizes if sizes else [b for b in [256, 512, 1024, 2048, 2048, 4096, 8192] if b <= max_bs]))
+      ch = int(rng.choice(chans if chans else [1, 2, 2, 2, 3]))
       rate = int(rng.choice([22050, 32000, 44100, 48000, 96000]))
       B = int(rng.integers(1, 9)); K = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 9, 10, 12, 16, 21])); calls = int(rng.integers(1, 4))
       if K > 8: B = min(B, 3)                                         # (long calls exercise the chunked window-control pipeline)
