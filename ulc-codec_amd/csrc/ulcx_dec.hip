@@ -767,6 +767,7 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                 }
                 STAMP(11);
                 if constexpr (LAPG) fft_wave_dif(zj, M, c.T.tw[d], lane, DPS);
+                else if (M == 1024) fft_wave_dif_ct<1024, DPS>(zj, twl, lane);     // (BlockSize 2048, un-decimated: index arithmetic folded at compile time)
                 else fft_wave_dif(zj, M, twl + (d <= 1 ? 0 : d == 2 ? BS / 8 : 3 * BS / 16), lane, DPS);
                 }
                 STAMP(3);

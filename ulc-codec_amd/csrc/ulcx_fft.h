@@ -226,6 +226,56 @@ __device__ __forceinline__ void fft_wave_pass(float2 *z, int M, int h, const flo
 #endif
 }
 
+// The same pass with the transform size, the stage and the padding as compile-time constants: the padded indices of a
+// lane's points, the twiddle indices and the trip count fold to constants and immediate offsets (a third of the generic
+// pass's vector instructions is index arithmetic).  Same butterflies, same twiddles, same order.
+template <int R, int M, int H, int PS>
+__device__ __forceinline__ void fft_wave_pass_ct(float2 *z, const float2 *__restrict__ tw, int lane) {
+    constexpr int NP = 1 << R;
+    constexpr int q = H >> (R - 1);
+    constexpr int stepA = M / (2 * H);
+    fft_v2f *zv = (fft_v2f *)z; const fft_v2f *twv = (const fft_v2f *)tw;
+#pragma unroll
+    for (int g0 = 0; g0 < (M >> R); g0 += 64) {
+        const int gg = g0 + lane;
+        if ((M >> R) < 64 && gg >= (M >> R)) break;
+        const int j = gg & (q - 1);
+        const int p0 = ((gg - j) << R) + j;
+        fft_v2f x[NP];
+#pragma unroll
+        for (int m = 0; m < NP; m++) x[m] = zv[FFT_PADS(p0 + m * q, PS)];
+#pragma unroll
+        for (int s = 0; s < R; s++) {
+            const int half = NP >> (s + 1);
+#pragma unroll
+            for (int m = 0; m < NP; m++) {
+                if (m & half) continue;
+                const int t = m & (half - 1);
+                const fft_v2f w = twv[(j + t * q) * (stepA << s)];
+                const fft_v2f a = x[m], b = x[m + half];
+                x[m] = a + b;
+                x[m + half] = fft_cmulc_pk(a - b, w);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NP; m++) zv[FFT_PADS(p0 + m * q, PS)] = x[m];
+    }
+}
+template <int M, int PS, int REM, int H> struct FftWaveCt {
+    static __device__ __forceinline__ void run(float2 *z, const float2 *__restrict__ tw, int lane) {
+        constexpr int passes = (REM + 3) >> 2;
+        constexpr int r = (REM + passes - 1) / passes;
+        fft_wave_pass_ct<r, M, H, PS>(z, tw, lane);
+        FftWaveCt<M, PS, REM - r, (H >> r)>::run(z, tw, lane);
+    }
+};
+template <int M, int PS, int H> struct FftWaveCt<M, PS, 0, H> { static __device__ __forceinline__ void run(float2 *, const float2 *, int) {} };
+template <int M, int PS> __device__ __forceinline__ void fft_wave_dif_ct(float2 *z, const float2 *__restrict__ tw, int lane) {
+    constexpr int lg = M == 4096 ? 12 : M == 2048 ? 11 : M == 1024 ? 10 : M == 512 ? 9 : M == 256 ? 8 : M == 128 ? 7 : 6;
+    static_assert((1 << lg) == M, "power of two between 64 and 4096");
+    FftWaveCt<M, PS, lg, (M >> 1)>::run(z, tw, lane);
+}
+
 // whole M-point transform of one padded array by one wave (M = 16 .. 4096)
 __device__ __forceinline__ void fft_wave_dif(float2 *z, int M, const float2 *__restrict__ tw, int lane, int ps) {
     int rem = 31 - __clz(M);
