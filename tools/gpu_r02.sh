@@ -2,7 +2,7 @@
 # round-2 artefacts: smoke, bench lines (headline, per mode, per config), rocprof kernel stats of the headline command,
 # PMC traffic passes of the same command, kernel timeline.  Everything lands in gpurun_out/r02/.
 cd "$(dirname "$0")/.."
-O=gpurun_out/r02h; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
+O=gpurun_out/r02i; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?" >> $O/smoke.txt
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --mode encode > $O/bench_encode.json 2>> $O/bench.err
