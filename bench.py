@@ -124,6 +124,46 @@ def cpu_baseline(sample_pcm, n_blocks, cfg, legs, target_seconds=4.0):
                       f"cent: DESIGN.md §8)"}
 
 
+def self_launch(n):
+    """Start n ranks of this script (one per GPU) and wait for them.  The launcher process initialises no GPU runtime (a
+    process that has must not be replaced or forked); rank r gets LOCAL_RANK = r and talks to the others over 127.0.0.1."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=(None if r == 0 else subprocess.DEVNULL)))
+    worst = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            rc = p.poll()
+            if rc is None:
+                continue
+            procs.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                if deadline is None:                      # one rank failed: the others would wait for it in a collective
+                    deadline = time.time() + 20.0
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                p.kill()                                  # (exact children of this process, by handle)
+            for p in procs:
+                p.wait()
+            procs = []
+        time.sleep(0.05)
+    if worst:
+        sys.stderr.write(f"bench.py: a rank of the {n}-GPU run failed (exit code {worst}); no result line\n")
+    return worst if worst > 0 else (1 if worst else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,9 +179,18 @@ def main():
                     "fused into the first/last kernel instead of the C API's f32; NOT the headline line")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: this process becomes the launcher.  It starts N
+    # ranks of itself (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), never touches
+    # the GPU, forwards rank 0's JSON line and exits with the worst exit code.  Under torch.distributed.run the
+    # environment already carries WORLD_SIZE and this is skipped.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: they must agree "
+                         f"(python bench.py --gpus N starts its own N ranks)")
     cfg = CONFIGS[args.config]
     bs, rate = cfg["bs"], cfg["rate"]
     global RATE
@@ -153,14 +202,20 @@ def main():
     import ulc_amd
     if not os.path.exists(ulc_amd.LIB_PATH):
         raise SystemExit("libulc_amd.so missing — run __graft_entry__.build(); there is no CPU fallback")
-    if torch.cuda.device_count() < (world if world > 1 else 1):
-        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} visible GPU(s): one process per GPU")
+    # ULCX_BENCH_SHARE_GPU=1 (tests only, never a result): the ranks share the visible device(s) and talk over gloo, so the
+    # N > 1 code path of this file can run on a 1-GPU box; the line it prints says so in `data`.
+    share = world > 1 and os.environ.get("ULCX_BENCH_SHARE_GPU") == "1"
+    ndev = torch.cuda.device_count()
+    if ndev < (1 if share else world):
+        raise SystemExit(f"bench.py: {world} ranks but only {ndev} visible GPU(s): one process per GPU")
     dist = None
+    dev_index = (local_rank % ndev) if share else (local_rank if world > 1 else 0)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        torch.cuda.set_device(dev_index)
+        if share: dist.init_process_group("gloo")
+        else: dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     import shard
     # independent streams shard across ranks by plain batch split (shard.py), no collective on the data path.
@@ -237,7 +292,7 @@ def main():
             for k_, v in enc.stage_ms().items(): acc_enc[k_] = acc_enc.get(k_, 0.0) + v / nacc
         if "decode" in legs:
             for k_, v in dec.stage_ms().items(): acc_dec[k_] = acc_dec.get(k_, 0.0) + v / nacc
-    el = shard.max_over_ranks(el_rank, dist, dev)
+    el = shard.max_over_ranks(el_rank, dist, None if share else dev)
     per_rank_ms = [el_rank / args.steps * 1e3]
     if dist is not None:
         got = [None] * world
@@ -248,7 +303,7 @@ def main():
     bits_host = d_bits.cpu().numpy()
     dbits_host = d_dbits.cpu().numpy()
     ok = bool((dbits_host > 0).all() and (dbits_host <= bits_host).all())
-    assert ok or os.environ.get("ULCX_DBG_SKIP"), "decode of the encoded blocks failed: some block was rejected or consumed more bits than were written"
+    assert ok, "decode of the encoded blocks failed: some block was rejected or consumed more bits than were written"
     units = B * K * bs * CH                                      # channel-samples through the step (each goes through every leg of it), this rank
     if strong:
         total_units = cfg["total"] * K * bs * CH
@@ -306,7 +361,7 @@ def main():
             "metric": f"{what} Msamples/s at BlockSize={bs} stereo (channel-samples through {what}, {rc})",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" + (" (TEST RUN: ranks share one GPU, gloo control plane - not a result)" if share else ""),
             "config": {"workload": wl, "config": args.config, "mode": args.mode,
                        "streams_per_gpu": B, "blocks_per_stream_per_step": K, "block_size": bs, "channels": CH, "rate_hz": rate,
                        "parallelism": f"batch split over {world} GPU(s), no collective on the data path",

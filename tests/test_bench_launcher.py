@@ -1,0 +1,55 @@
+"""bench.py --gpus N starts its own N ranks (one process per GPU) when no launcher is around it.
+
+CPU: on a box without GPUs `--gpus 2` must start two ranks, both must stop at the device check, the launcher must exit
+non-zero and print no result line (never a silent `n_gpus: 1`).
+GPU: on the 1-GPU box the two ranks share the device over a gloo control plane (ULCX_BENCH_SHARE_GPU=1: the N > 1 code
+path of bench.py - sharding, barrier, MAX over ranks, gather of the per-rank times - with everything but RCCL's transport)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpus_2_without_devices_spawns_two_ranks_and_fails_cleanly():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the run would succeed")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu"])
+    assert r.returncode != 0
+    assert r.stderr.count("2 ranks but only") == 2, r.stderr          # both ranks started and both refused
+    assert "no result line" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]   # nothing that could be read as a result
+
+
+def test_launcher_and_world_size_must_agree():
+    r = _run(["--gpus", "4"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "must agree" in r.stderr
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_the_gpu_box():
+    r = _run(["--gpus", "2", "--streams", "64", "--blocks", "4", "--steps", "2", "--warmup", "1", "--no-cpu"],
+             env={"ULCX_BENCH_SHARE_GPU": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["config"]["per_rank_ms_per_step"]) == 2
+    assert d["whole_pipeline"]["decode_ok"] is True
+    assert "TEST RUN" in d["data"]
+    # weak scaling: the whole job is both ranks' streams
+    assert d["config"]["streams_per_gpu"] == 64
+    assert abs(d["value"] - 2 * 64 * 4 * 2048 * 2 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e6) < 1e-6 * d["value"]

@@ -3,6 +3,7 @@
 # available on the GPU pool: this is the CPU half).  Restores the normal build afterwards.
 cd "$(dirname "$0")/.."
 cp oracle/liboracle.so /tmp/liboracle_keep.so
+trap 'cp /tmp/liboracle_keep.so oracle/liboracle.so' EXIT      # the normal build comes back whatever happens
 SRC="orc_fourier.c orc_encoder.c orc_decoder.c"
 (cd oracle && gcc -O1 -g -fPIC -ffp-contract=off -fsanitize=undefined -shared -o liboracle.so $SRC -lm -lubsan)
 python -m pytest tests -q -m "not gpu" -p no:cacheprovider > /tmp/ubsan.txt 2>&1; echo "UBSan: exit $?, reports: $(grep -c 'runtime error' /tmp/ubsan.txt); $(tail -1 /tmp/ubsan.txt)"

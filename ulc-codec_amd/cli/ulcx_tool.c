@@ -201,6 +201,12 @@ static int do_decode(int argc, char **argv) {
             DIE("'%s': invalid geometry in the header (BlockSize %u, %u channels)", argv[a + s], h[s].BlockSize, h[s].nChan);
         if (h[s].BlockSize != h[0].BlockSize || h[s].nChan != h[0].nChan || h[s].RateHz != h[0].RateHz)
             DIE("'%s': all inputs of one call must share block size, channels and rate", argv[a + s]);
+        /* block count and payload size too: a block is at least two bytes (window nybble + one code per channel), so a
+         * header that counts more blocks than the payload can hold is corrupt, and so is a payload the 32-bit read
+         * positions of the library cannot address; the WAV header's sample count is checked in 64 bits */
+        if (len - (long)h[s].StreamOffs > 0x7fffffffL) DIE("'%s': payload of %ld bytes is more than this tool takes (2 GiB)", argv[a + s], len - (long)h[s].StreamOffs);
+        if ((uint64_t)h[s].nBlocks > (uint64_t)(len - (long)h[s].StreamOffs) / 2) DIE("'%s': header counts %u blocks, the payload has %ld bytes", argv[a + s], h[s].nBlocks, len - (long)h[s].StreamOffs);
+        if ((uint64_t)h[s].nBlocks * h[s].BlockSize * h[s].nChan * 4 > 0xfffff000ull) DIE("'%s': %u blocks decode to more than a WAV file holds", argv[a + s], h[s].nBlocks);
         pay[s] = buf; payBytes[s] = (int32_t)(len - (long)h[s].StreamOffs);
         if (payBytes[s] + 8 > stride) stride = payBytes[s] + 8;
         if (h[s].nBlocks > maxBlk) maxBlk = h[s].nBlocks;

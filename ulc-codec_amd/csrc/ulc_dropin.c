@@ -12,7 +12,7 @@
 #include <string.h>
 #include "../../include/ulc_amd.h"
 
-struct enc_priv { ulcx_encoder *enc; unsigned char *out; int slot; int failed; };
+struct enc_priv { ulcx_encoder *enc; unsigned char *out; int slot; };
 struct dec_priv { ulcx_decoder *dec; unsigned char *in; int slot; };
 
 /* HIP device the drop-in states live on: ULC_AMD_DEVICE (ordinal), default 0 */
@@ -38,7 +38,6 @@ int ULC_EncoderState_Init(struct ULC_EncoderState_t *State) {
     if (!p) { ulcx_encoder_destroy(enc); return -1; }
     p->enc = enc;
     ulcx_encoder_set_timing(enc, 0);                          /* nobody reads per-kernel events through this ABI */
-    p->failed = 0;
     p->slot = ulcx_encoder_slot_bytes(enc);
     p->out = (unsigned char *)malloc((size_t)p->slot);
     if (!p->out) { ulcx_encoder_destroy(enc); free(p); return -1; }
@@ -64,14 +63,13 @@ static const void *encode_one(struct ULC_EncoderState_t *State, const float *Src
     struct enc_priv *p = (struct enc_priv *)State->BufferData;
     int32_t bits = 0, wc = 0; float cplx = 0.0f;
     int rc = ulcx_encode_host(p->enc, mode, p0, p1, Src, 1, p->out, &bits, &wc, &cplx);
-    if (p->failed || rc != ULCX_OK) {
-        /* the reference cannot fail here and has no way to say so: the error is sticky (reported once, ulcx_last_error() keeps
-         * the cause), and this and every later call on the state return an empty block (Size 0) instead of taking the process down */
-        if (!p->failed) fprintf(stderr, "libulc_amd: encode failed: %s\n", ulcx_last_error());
-        p->failed = 1;
-        memset(p->out, 0, (size_t)p->slot);
-        if (Size) *Size = 0;
-        return p->out;
+    if (rc != ULCX_OK) {
+        /* The reference cannot fail here and its ABI has no way to say so; its tools never look at *Size
+         * (tools/ulcEncodeTool.c:157-168 write (Size+7)/8 bytes and carry on), so any "empty block" convention would leave a
+         * .ulc whose header counts blocks the payload lacks, with exit code 0.  A lost device mid-file is therefore fatal,
+         * loudly: message, then abort(). */
+        fprintf(stderr, "libulc_amd: encode failed (%s): the ULC_EncodeBlock_* ABI cannot report an error - aborting\n", ulcx_last_error());
+        abort();
     }
     State->WindowCtrl = wc;
     State->BlockComplexity = cplx;

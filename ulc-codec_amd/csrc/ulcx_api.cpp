@@ -23,6 +23,8 @@ struct ulcx_encoder {
     hipStream_t side; hipEvent_t evFork, evJoin, evFork2; bool sideOk; bool timing;
     hipEvent_t evWC[7 + 3 * ULCX_WC_MAXCH + ULCX_XF_MAXCH + 1]; int wcPipe; hipStream_t side2, side3, side4; hipEvent_t evE[ULCX_WC_MAXCH]; hipEvent_t evXf[2 * ULCX_XF_MAXCH]; int nXf;      // window-control / transform chunk pipeline (ULCX_WC_PIPE chunks, default 4)
     bool keysFinal;
+    int wcSteps, cplxEarly, wcFuse, barkUniP; bool wcEStream;      // environment switches, read once at create
+    int nWcLad, nXfLad, wcLad[ULCX_WC_MAXCH], xfLad[ULCX_XF_MAXCH];   // ULCX_WC_LADDER / ULCX_XF_LADDER: step sizes in blocks
     // staging for the host-pointer API
     float *d_pcm; uint8_t *d_out; int32_t *d_bits, *d_wc; float *d_cplx;
 };
@@ -175,7 +177,10 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.gapSum, NB * cb, false);
     DA(c.tailSum, NB * nChan * 4 * 8, true);
     if (const char *ev = getenv("ULCX_WAVE")) c.useWave = (ev[0] != '0');
-    c.dbgSkip = 0; if (const char *ev = getenv("ULCX_DBG_SKIP")) c.dbgSkip = atoi(ev);   // timing experiments only (breaks results)
+    c.dbgSkip = 0;
+#ifdef ULCX_ABLATE
+    if (const char *ev = getenv("ULCX_DBG_SKIP")) c.dbgSkip = atoi(ev);   // timing experiments only (breaks results)
+#endif
     DA(c.cbrLo, NB, true); DA(c.cbrHi, NB, true); DA(c.cbrDone, NB, true); DA(c.cbrBudget, NB, true); DA(c.cbrLive, 1, true);
     DA(c.keep, NB * cb / 32, true);
     DA(c.fbList, NB, true);
@@ -206,6 +211,14 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
         }
         e->wcPipe = e->sideOk ? 4 : 1;                         // transform chunks per call: 1 block, then thirds (4 vs 5 chunks: 9.50 vs 9.56 ms per bench step)
         if (const char *pv = getenv("ULCX_WC_PIPE")) { int n = atoi(pv); if (n >= 1 && n <= ULCX_XF_MAXCH && n != 2 && (n == 1 || e->sideOk)) e->wcPipe = n; }
+        e->wcSteps = -1; if (const char *sv = getenv("ULCX_WC_STEPS")) e->wcSteps = atoi(sv);      // -1: default; 0: the transform's chunks
+        e->wcEStream = getenv("ULCX_WC_ESTREAM") != nullptr;
+        { const char *v = getenv("ULCX_CPLX_EARLY"); e->cplxEarly = (v && v[0] == '1') ? 1 : 0; }
+        { const char *v = getenv("ULCX_WC_FUSE"); e->wcFuse = (v && v[0] == '0') ? 0 : 1; }
+        e->barkUniP = getenv("ULCX_BARK_UNIFORM_P") ? 1 : 0;
+        auto parse_ladder = [](const char *v, int *dst, int cap) { int n = 0; while (v && *v && n < cap) { int x = atoi(v); if (x < 1) return 0; dst[n++] = x; while (*v && *v != ',') v++; if (*v == ',') v++; } return n; };
+        e->nWcLad = parse_ladder(getenv("ULCX_WC_LADDER"), e->wcLad, ULCX_WC_MAXCH);
+        e->nXfLad = parse_ladder(getenv("ULCX_XF_LADDER"), e->xfLad, ULCX_XF_MAXCH);
     }
     DA(c.isFb, NB, true);
     DA(c.ownSlot, NB, true);
@@ -237,10 +250,20 @@ static int encode_dev_any(ulcx_encoder *e, int mode, float p0, float p1, const f
     c.vbrTarget = (mode == ULCX_MODE_VBR) ? 0x1.E4EFB7p3f * logf(100.0f / p0) : 0.0f;     // ulcEncoder.c:144 (host libm, data independent)
     c.pcm = d_pcm; c.pcm16 = d_pcm16; c.out = d_out; c.bits = d_bits; c.wcOut = d_wc; c.cplxOut = d_cplx;
     UlcxEncAux aux;
-    aux.side = e->sideOk ? e->side : nullptr; aux.side2 = e->sideOk ? e->side2 : nullptr; aux.side3 = e->sideOk ? e->side3 : nullptr; aux.side4 = (e->sideOk && getenv("ULCX_WC_ESTREAM")) ? e->side4 : nullptr; aux.evE = e->evE;
+    aux.side = e->sideOk ? e->side : nullptr; aux.side2 = e->sideOk ? e->side2 : nullptr; aux.side3 = e->sideOk ? e->side3 : nullptr; aux.side4 = (e->sideOk && e->wcEStream) ? e->side4 : nullptr; aux.evE = e->evE;
     aux.evFork = e->evFork; aux.evJoin = e->evJoin; aux.evFork2 = e->evFork2; aux.evWC = e->evWC; aux.evXf = e->evXf;
     aux.wcPipe = (nBlocks >= 2 * e->wcPipe) ? e->wcPipe : (nBlocks >= 6 && e->wcPipe > 1 ? 3 : 1); aux.nXf = &e->nXf;
-    aux.wcSteps = -1; if (const char *sv = getenv("ULCX_WC_STEPS")) aux.wcSteps = atoi(sv);   // -1: default; 0: the transform's chunks
+    aux.wcSteps = e->wcSteps; aux.cplxEarly = e->cplxEarly; aux.wcFuse = e->wcFuse; aux.barkUniP = e->barkUniP;
+    aux.nWcCut = aux.nXfCut = 0;
+    if (aux.wcPipe > 1) {
+        // schedules as cumulative block counts; a ladder applies when it sums to this call's block count and every transform
+        // chunk ends where a window-control step ends
+        auto cum = [&](const int *lad, int n, int *dst) { int t = 0; dst[0] = 0; for (int i = 0; i < n; i++) { t += lad[i]; dst[i + 1] = t; } return (n > 0 && t == nBlocks) ? n : 0; };
+        aux.nWcCut = cum(e->wcLad, e->nWcLad, aux.wcCut);
+        aux.nXfCut = e->nXfLad ? cum(e->xfLad, e->nXfLad, aux.xfCut) : (aux.nWcCut <= ULCX_XF_MAXCH ? cum(e->wcLad, e->nWcLad, aux.xfCut) : 0);
+        for (int j = 1; j <= aux.nXfCut && aux.nWcCut; j++) { bool hit = false; for (int w = 1; w <= aux.nWcCut; w++) hit = hit || aux.wcCut[w] == aux.xfCut[j]; if (!hit) aux.nWcCut = 0; }
+        if (!aux.nWcCut || !aux.nXfCut) aux.nWcCut = aux.nXfCut = 0;
+    }
     int rc = ulcx_enc_launch(c, (hipStream_t)hipStream, e->timing ? e->ev : nullptr, aux);
     e->evRecorded = (rc == ULCX_OK) && e->timing;
     e->lastK = nBlocks;
@@ -407,7 +430,9 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     UlcxDecCtx &c = e->ctx;
     memset(&c, 0, sizeof(c));
     c.B = nStreams; c.C = nChan; c.BS = BlockSize; c.lgBS = ilog2i(BlockSize); c.maxK = maxBlocksPerCall;
+#ifdef ULCX_ABLATE
     if (const char *ev = getenv("ULCX_DBG_SKIP")) c.dbgSkip = atoi(ev);
+#endif
     // stereo streams up to BlockSize 4096 keep their lapping state, both channels' FFT arrays and the twiddles in LDS, one wave
     // per channel (k_dsyn); everything else takes the general kernel (k_dgen: one array, state in HBM)
     c.fastOK = (nChan == 2 && BlockSize <= 4096) ? 1 : 0;
@@ -592,7 +617,10 @@ extern "C" int ulcx_decode_resident_host(ulcx_decoder *e, int nBlocks, float *h_
     return ULCX_OK;
 }
 
-// diagnostic: first nBytes of the general-path staging buffer (a -DULCX_DSYN_STAMPS build leaves per-phase cycle counts there)
+// diagnostic, only in a `make EXTRA=-DULCX_DSYN_STAMPS` build (tools/dsyn_stamps.py): first nBytes of the general-path staging
+// buffer, where that build leaves per-phase cycle counts
+#ifdef ULCX_DSYN_STAMPS
+extern "C" int ulcx_decoder_debug_scratch(ulcx_decoder *e, void *h_out, size_t strideBytes, size_t nBytes, int nStreams);
 extern "C" int ulcx_decoder_debug_scratch(ulcx_decoder *e, void *h_out, size_t strideBytes, size_t nBytes, int nStreams) {
     if (!e || !h_out) return ULCX_ERR_ARG;
     CKR(hipSetDevice(e->device));
@@ -601,6 +629,7 @@ extern "C" int ulcx_decoder_debug_scratch(ulcx_decoder *e, void *h_out, size_t s
         CKR(hipMemcpy((char *)h_out + (size_t)s * nBytes, (const char *)e->ctx.scratch + (size_t)s * strideBytes, nBytes, hipMemcpyDeviceToHost));
     return ULCX_OK;
 }
+#endif
 // per-stage hipEvents around every kernel (ulcx_*_stage_ms): on by default; a caller that does not read them can switch
 // them off - each record is a marker packet in the stream between two kernels
 extern "C" int ulcx_encoder_set_timing(ulcx_encoder *e, int on) { if (!e) return ULCX_ERR_ARG; e->timing = on != 0; if (!on) e->evRecorded = false; return ULCX_OK; }

@@ -752,12 +752,12 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                 sw.A = (float *)zj;
                 const uint32_t unitSeed = (j == 0) ? bseed[wv * 64 + (k & 63)] : rng_jump(c.jumpT, bseed[k & 63], (uint32_t)udraw[wv * 4 + j]);
                 STAMP(1);
-                if (!(c.dbgSkip & 1)) synth_unit(c, sw, S, prec, nrec, urec[wv * 4 + j], unitSeed, unit_draws(wv, j), utail[wv * 4 + j].y, tmag + (size_t)(wv * 4 + j) * c.tailStride, Mp);
+                if (!(ULCX_DBG(c) & 1)) synth_unit(c, sw, S, prec, nrec, urec[wv * 4 + j], unitSeed, unit_draws(wv, j), utail[wv * 4 + j].y, tmag + (size_t)(wv * 4 + j) * c.tailStride, Mp);
                 else for (int i = lane; i < Mp; i += 64) zj[i] = make_float2(0.0f, 0.0f);
                 STAMP(2);
                 // DCT-IV pre-twiddle in place: n and M-1-n together read and write the same two complex slots
                 const float2 *pre = c.T.pre[d];
-                if (!(c.dbgSkip & 2)) {
+                if (!(ULCX_DBG(c) & 2)) {
                 for (int n = lane; n < M / 2; n += 64) {
                     const int n2 = M - 1 - n;
                     const int pn = FFT_PADS(n, DPS), pn2 = FFT_PADS(n2, DPS);
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
             int ov = BS;                                             // ulcDecoder.c:234-239
             if (pat0 & 8) ov >>= (wc & 7);
             if (ov > lastSub) ov = lastSub;
-            if (!(c.dbgSkip & 4)) {
+            if (!(ULCX_DBG(c) & 4)) {
                 const int S = BS, M = M0;
                 const float2 *pre = c.T.pre[0];
                 const float2 *z0 = z, *z1 = z + Mp0;
@@ -1038,7 +1038,7 @@ int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev) {
                    : c.pcm16 ? (small ? (const void *)k_dsyn<int16_t, 16, false> : (const void *)k_dsyn<int16_t, 32, true>)
                              : (small ? (const void *)k_dsyn<float, 16, false> : (const void *)k_dsyn<float, 32, true>);
     if (lds > 48 * 1024) CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (c.dbgSkip & 8) {}
+    if (ULCX_DBG(c) & 8) {}
     else if (!c.fastOK) { if (c.pcm16) hipLaunchKernelGGL(k_dgen<int16_t>, dim3(c.B), dim3(WG), lds, st, c); else hipLaunchKernelGGL(k_dgen<float>, dim3(c.B), dim3(WG), lds, st, c); }
     else if (c.pcm16) { if (small) hipLaunchKernelGGL((k_dsyn<int16_t, 16, false>), dim3(c.B), dim3(WG), lds, st, c); else hipLaunchKernelGGL((k_dsyn<int16_t, 32, true>), dim3(c.B), dim3(WG), lds, st, c); }
     else { if (small) hipLaunchKernelGGL((k_dsyn<float, 16, false>), dim3(c.B), dim3(WG), lds, st, c); else hipLaunchKernelGGL((k_dsyn<float, 32, true>), dim3(c.B), dim3(WG), lds, st, c); }

@@ -646,7 +646,7 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
                     }
                 }
             };
-            if (!(c.dbgSkip & 2)) {
+            if (!(ULCX_DBG(c) & 2)) {
                 const bool inPcm = (t0 >= 0), fullOv = (ovL == S) && (ov == S);
                 if (inPcm && fullOv) fold(std::true_type{}, std::true_type{});
                 else if (inPcm) fold(std::true_type{}, std::false_type{});
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
             __syncthreads();
 
             // 2. 2*nch M-point FFTs in LDS, one wave per array, no barriers in between
-            if (!(c.dbgSkip & 1)) for (int a = __builtin_amdgcn_readfirstlane(tid >> 6); a < 2 * nch; a += WG / 64) {
+            if (!(ULCX_DBG(c) & 1)) for (int a = __builtin_amdgcn_readfirstlane(tid >> 6); a < 2 * nch; a += WG / 64) {
                 if (twInLds) fft_wave_dif(z + a * Mp, M, twl, tid & 63, ps);
                 else fft_wave_dif(z + a * Mp, M, c.T.tw[d], tid & 63, ps);
             }
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
             // 3. post-twiddle + normalise + keys + per-line energies (BlockTransform.c:243-281)
             int bits = 31 - __clz(M);
             float norm = 2.0f / S;
-            if (!(c.dbgSkip & 4)) for (int kk = tid; kk < M / 2; kk += WG) {
+            if (!(ULCX_DBG(c) & 4)) for (int kk = tid; kk < M / 2; kk += WG) {
                 int k1 = kk, k2 = M - 1 - kk;
                 int r1 = (int)(__brev((unsigned)k1) >> (32 - bits));
                 int r2 = (int)(__brev((unsigned)k2) >> (32 - bits));
@@ -2122,7 +2122,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
     }
     bool overflow = nK > E2_KCAP;
     WAVE_SYNC();
-    if ((c.dbgSkip >> 8) == 1) return;
+    if ((ULCX_DBG(c) >> 8) == 1) return;
 
     // C. zone segmentation: the greedy scan of Encode.c:218-269 (a zone breaks at the first coefficient whose level puts
     //    max > 4*min over the zone so far), without walking the coefficients one by one:
@@ -2180,7 +2180,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
         if (nZ > E2_ZCAP) overflow = true;
     }
     WAVE_SYNC();
-    if ((c.dbgSkip >> 8) == 2) return;
+    if ((ULCX_DBG(c) >> 8) == 2) return;
 
     // D. quantizer per zone + nybbles of its change code (Encode.c:240-244, 32-45)
     if (!overflow) {
@@ -2201,7 +2201,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
         }
     }
     WAVE_SYNC();
-    if ((c.dbgSkip >> 8) == 3) return;
+    if ((ULCX_DBG(c) >> 8) == 3) return;
 
     // E. quantise kept items, drop the ones that collapse (Encode.c:114), compact in place.
     //    Bit 15 of the compacted index records "the kept item right before me was coded too",
@@ -2230,7 +2230,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
         }
     }
     WAVE_SYNC();
-    if ((c.dbgSkip >> 8) == 4) return;
+    if ((ULCX_DBG(c) >> 8) == 4) return;
 
     // F+H. gaps -> run codes; positions by prefix sum; emission
     int total = 0;
@@ -2248,7 +2248,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
                 int zr = idx - start;
                 float amp0 = -2.0f;
                 if (zr >= 16 && (raw & 0x8000) && c.useGapSums) amp0 = gapU[idx].x;
-                gap_codes(start, zr, (float)(1u << zqi[z]), coefU, pairU, amp0, lo, hi, cnt, (c.dbgSkip & 0x40) != 0);
+                gap_codes(start, zr, (float)(1u << zqi[z]), coefU, pairU, amp0, lo, hi, cnt, (ULCX_DBG(c) & 0x40) != 0);
             }
             int mine = (m < nC) ? pre + cnt + 1 : 0;
             int tot, ex = wave_excl_scan(mine, lane, tot);
@@ -2270,7 +2270,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
         }
         overflow = __any(overflow);
     }
-    if ((c.dbgSkip >> 8) == 5) return;
+    if ((ULCX_DBG(c) >> 8) == 5) return;
 
     // G. tail (Encode.c:271-312)
     if (!overflow) {
@@ -2534,7 +2534,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     MARK();
     // --- window control
     hipEvent_t *evX = evWC + 7 + 3 * ULCX_WC_MAXCH;            // [ULCX_XF_MAXCH] transform chunk done, [ULCX_XF_MAXCH]: all early k_cplx launches done
-    const bool cplxEarly = wcPipe > 1 && side && side2 && side3 && [] { const char *v = getenv("ULCX_CPLX_EARLY"); return v && v[0] == '1'; }();
+    const bool cplxEarly = wcPipe > 1 && side && side2 && side3 && aux.cplxEarly;
     {
         int SG = (c.B + 63) / 64;
         // Chunks of blocks: the window-control kernels of chunk j+1.. (two stream-long serial recurrences, a few
@@ -2550,7 +2550,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             CK(hipFuncSetAttribute((const void *)k_xf_big<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             CK(hipFuncSetAttribute((const void *)k_xf_big<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
-        const bool wcFuse = c.C == 2 && [] { const char *v = getenv("ULCX_WC_FUSE"); return !(v && v[0] == '0'); }();   // stereo: k_wc_energy + k_wc_forward in one kernel (k_wc_ef)
+        const bool wcFuse = c.C == 2 && aux.wcFuse;   // stereo: k_wc_energy + k_wc_forward in one kernel (k_wc_ef)
         auto launch_wc = [&](hipStream_t s2, int k0, int k1, bool marks) -> int {
             int kc = k1 - k0;
             if (wcFuse) { if (marks) MARK(); launch_wc_ef(c, s2, k0, k1);                                             if (marks) MARK(); }
@@ -2582,17 +2582,27 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             if (nW < 0) nW = (c.K >= 8) ? 4 : 0;                               // default: 4 uniform steps (of >= 2 blocks)
             if (nW > ULCX_WC_MAXCH) nW = ULCX_WC_MAXCH;
             if (nW > c.K) nW = c.K;
-            const bool sameCuts = nW < 1;
+            bool sameCuts = nW < 1;
             if (sameCuts) nW = nCh;
             int cut[ULCX_XF_MAXCH + 1];
             cut[0] = 0; cut[1] = 1;
             for (int j = 2; j <= nCh; j++) cut[j] = 1 + (c.K - 1) * (j - 1) / (nCh - 1);
+            // explicit schedules (the encoder's ladder for this K, or ULCX_WC_LADDER / ULCX_XF_LADDER): window-control steps
+            // wcs[] and transform chunks cut[] as cumulative block counts
+            int wcs[ULCX_WC_MAXCH + 1];
+            const bool ladder = aux.nWcCut > 0 && aux.nXfCut > 0 && aux.wcCut[aux.nWcCut] == c.K && aux.xfCut[aux.nXfCut] == c.K;
+            if (ladder) {
+                nW = aux.nWcCut; for (int j = 0; j <= nW; j++) wcs[j] = aux.wcCut[j];
+                for (int j = 0; j <= aux.nXfCut; j++) cut[j] = aux.xfCut[j];
+                sameCuts = false;
+            } else for (int w = 0; w <= nW; w++) wcs[w] = sameCuts ? cut[w] : (int)((long long)c.K * w / nW);
+            const int nChX = ladder ? aux.nXfCut : nCh;
             CK(hipEventRecord(ev0, st));
             CK(hipStreamWaitEvent(side, ev0, 0));
             if (side4) CK(hipStreamWaitEvent(side4, ev0, 0));
             int jx = 0;                                        // next transform chunk to enqueue
             for (int w = 0; w < nW; w++) {
-                int k0 = sameCuts ? cut[w] : (int)((long long)c.K * w / nW), k1 = sameCuts ? cut[w + 1] : (int)((long long)c.K * (w + 1) / nW), kc = k1 - k0;
+                const int k0 = wcs[w], k1 = wcs[w + 1], kc = k1 - k0;
                 // (optionally the envelope kernel gets its own stream, ULCX_WC_ESTREAM=1; measured slower: beside it the
                 //  chain kernels slow down by more than the time it takes between two links of the chain)
                 hipStream_t es = side4 ? side4 : side;
@@ -2612,7 +2622,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                 hipLaunchKernelGGL(k_wc_decide, dim3((c.B * kc + 63) / 64), dim3(64), 0, side3, c, k0, k1);
                 CK(hipEventRecord(evD[w], side3));
                 // transform chunks whose last block is now decided
-                while (jx < nCh && cut[jx + 1] <= k1) {
+                while (jx < nChX && cut[jx + 1] <= k1) {
                     int x0 = cut[jx], x1 = cut[jx + 1];
                     int nbk = c.B * (x1 - x0);
                     CK(hipStreamWaitEvent(st, evD[w], 0));
@@ -2623,13 +2633,13 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                     jx++;
                 }
             }
-            if (aux.nXf) *aux.nXf = nCh;
+            if (aux.nXf) *aux.nXf = nChX;
             MARK();
             // ULCX_CPLX_EARLY=1: the ordered complexity sums (k_cplx: lane-serial, HBM-bound) per transform chunk, on the envelope
             // kernels' stream (all of those are enqueued by now): only the last chunk's are left beside k_pbark (0.40 -> 0.28 ms
             // there) - but the transform's launches get 0.06..0.1 ms longer; 0.04 ms per encode at best, within the noise: off
             if (cplxEarly) {
-                for (int j = 0; j < nCh; j++) {
+                for (int j = 0; j < nChX; j++) {
                     CK(hipStreamWaitEvent(side, evX[j], 0));
                     const int kc2 = cut[j + 1] - cut[j];
                     hipLaunchKernelGGL(k_cplx, dim3((c.B * kc2 + 63) / 64), dim3(64), 0, side, c, cut[j], cut[j + 1]);
@@ -2671,7 +2681,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         CK(hipEventRecord(evState, side3));
     } else { hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c, 0, c.K);                 MARK(); }
     {
-        const bool uniP = c.barkRing && getenv("ULCX_BARK_UNIFORM_P");       // (psycho sums: one wave per SIMD either way, no gain measured)
+        const bool uniP = c.barkRing && aux.barkUniP;       // (psycho sums: one wave per SIMD either way, no gain measured)
         if (uniP) {
             hipLaunchKernelGGL(k_bark_uniform<false>, dim3((NB + 63) / 64), dim3(64), barkLds, st, c);
             hipLaunchKernelGGL(k_bark_levels<false>, dim3((unsigned)(((size_t)NB * 32 + WG - 1) / WG)), dim3(WG), 0, st, c);
@@ -2710,6 +2720,10 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         // counted down on the device) returns at the top of every kernel - nothing inside the call waits for the device.
     }
     const size_t selLds = (size_t)4 * (c.BS / 2 + 4 * ULCX_NBARK) * sizeof(float);
+    if (selLds > 48 * 1024) {                                  // (mono BlockSize 8192, stereo 4096: 67 KB)
+        CK(hipFuncSetAttribute((const void *)k_select_wave<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)selLds));
+        CK(hipFuncSetAttribute((const void *)k_select_wave<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)selLds));
+    }
     auto launch_select = [&](int fin) {
         int R = N / 64;
         switch (R) {

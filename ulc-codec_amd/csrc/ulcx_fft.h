@@ -152,6 +152,10 @@ __device__ void fftn_dif(float2 *z0, int nArr, int M, const float2 *__restrict__
 // distinct slots per 16-lane group; ps = 4 leaves the middle pass 2-way conflicted but is what ships - the
 // transforms are not LDS-bandwidth-bound and the smaller arrays keep one more workgroup per CU.
 // ---------------------------------------------------------------------------
+// Between two passes of one wave: pass n+1 reads LDS elements that OTHER lanes of the wave stored in pass n.  The hardware
+// runs a wave's LDS operations in order; this fence + wave barrier (no instruction is emitted) keeps the compiler from
+// moving a load of pass n+1 above a store of pass n to an address it can prove different for the same lane.
+#define FFT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define FFT_PADS(p, ps) ((p) + ((p) >> (ps)))
 #define FFT_PADDEDS(M, ps) ((M) + ((M) >> (ps)))
 
@@ -266,6 +270,7 @@ template <int M, int PS, int REM, int H> struct FftWaveCt {
         constexpr int passes = (REM + 3) >> 2;
         constexpr int r = (REM + passes - 1) / passes;
         fft_wave_pass_ct<r, M, H, PS>(z, tw, lane);
+        FFT_WAVE_SYNC();
         FftWaveCt<M, PS, REM - r, (H >> r)>::run(z, tw, lane);
     }
 };
@@ -290,5 +295,6 @@ __device__ __forceinline__ void fft_wave_dif(float2 *z, int M, const float2 *__r
             default: fft_wave_pass<1>(z, M, h, tw, lane, ps); break;
         }
         h >>= r; rem -= r;
+        FFT_WAVE_SYNC();
     }
 }

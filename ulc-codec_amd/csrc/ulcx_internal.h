@@ -12,6 +12,13 @@
 #define ULCX_COEF_EPS (0x1.0p-31f)     // include/ulcEncoder.h:36
 #define ULCX_HEAP_LDS_BYTES (128 * 1024)
 #define ULCX_HEAP_GRID 256
+// Ablation switches for timing experiments (they break the results): compiled in only with `make EXTRA=-DULCX_ABLATE`,
+// then set by ULCX_DBG_SKIP=bits at create time.  The shipped library has no such branches.
+#ifdef ULCX_ABLATE
+#define ULCX_DBG(c) ((c).dbgSkip)
+#else
+#define ULCX_DBG(c) 0
+#endif
 
 // Host-precomputed, data-independent tables: everything
 // the reference evaluates with sinhf/asinhf/cos/sin or expf on arguments that depend
@@ -162,6 +169,9 @@ struct UlcxEncAux {
     hipEvent_t *evXf;                    // [2*ULCX_XF_MAXCH] timing pairs around each transform chunk (used when ev != NULL)
     int wcPipe;                          // chunks of blocks pipelined between window control and transform; 1 = off
     int wcSteps;                         // fine steps of the window-control kernels per call (ULCX_WC_STEPS)
+    int cplxEarly, wcFuse, barkUniP;     // ULCX_CPLX_EARLY / ULCX_WC_FUSE / ULCX_BARK_UNIFORM_P, read once when the encoder is created
+    int nWcCut, nXfCut;                  // explicit schedules (0 = derive from wcSteps / wcPipe): cumulative block counts, last = K
+    int wcCut[ULCX_WC_MAXCH + 1], xfCut[ULCX_XF_MAXCH + 1];
     int *nXf;                            // out: transform chunk launches this call
 };
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, const UlcxEncAux &aux);

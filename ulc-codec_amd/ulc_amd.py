@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libulc_amd.so")
+# ULC_AMD_LIB: another build of the same library (A/B timing runs, tools/ab_all.sh); the default is the in-tree one
+LIB_PATH = os.environ.get("ULC_AMD_LIB") or os.path.join(_HERE, "libulc_amd.so")
 
 MODE_VBR, MODE_CBR, MODE_ABR = 0, 1, 2
 _f32p = C.POINTER(C.c_float)
