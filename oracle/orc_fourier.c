@@ -15,24 +15,35 @@
  * *published contract* of the two functions:
  *   - IMDCT formula and sine window: /root/reference/FormatSpecs.md:150-157
  *   - argument meaning / buffer roles: the call sites above
- * and the float operation order is *defined by this project* ("fourier spec v1",
+ * and the float operation order is *defined by this project* ("fourier spec v2",
  * DESIGN.md §3).  The HIP kernels implement the same operation order; the
  * double-precision O(N^2) evaluators at the bottom of this file are the referee
  * for the 1e-5 accuracy bound.
  *
- * fourier spec v1
+ * fourier spec v2  (round 3; v1 was the same structure with 4 products + 2 sums per
+ * complex multiply, no fused operations and every twiddle multiplied)
  * ---------------
  *   DCT-IV of length N (unnormalised)   X[k] = sum_n u[n] cos(pi/N (n+1/2)(k+1/2))
  *   computed through one complex FFT of M = N/2 points:
  *     t[n]  = (u[2n] + i u[N-1-2n]) * conj(P[n]),  P[n] = exp(i pi (8n+1)/(8N))
  *     T     = FFT_M(t)    radix-2 decimation-in-frequency, in place, natural-order
  *                         input, bit-reversed output, twiddle W[j] = exp(-2 pi i j/M)
- *     y[k]  = T[k] * conj(P[k]);   X[2k] = Re y[k];   X[N-1-2k] = -Im y[k]
- *   complex multiply by conj(c + i s):  (re*c + im*s,  im*c - re*s), every product
- *   and sum individually rounded to binary32 (no fused multiply-add), always
- *   performed (also for the trivial twiddle).
+ *     y[k]  = T[k] * conj(P[k]);   X[2k] = Re y[k] = fma(T.im, s, T.re*c);
+ *                                  X[N-1-2k] = -Im y[k] = fma(T.re, s, -(T.im*c))   (formed directly)
+ *   complex multiply of d by conj(c + i s), two products and two fused multiply-adds
+ *   (the real libfourier is an FMA build too, Makefile:125-145 of the reference):
+ *       re = fma(d.im, s, d.re*c)         im = fma(-d.re, s, d.im*c)
+ *   (on the device: v_pk_mul_f32 + v_pk_fma_f32).
+ *   Butterflies of the last three stages (half-size h <= 4) whose twiddle is exactly
+ *   1 (index 0) or -i (index M/4) are not multiplied: the difference passes through
+ *   as it is, or as (d.im, -d.re).  Every other butterfly multiplies, also by a
+ *   twiddle that happens to be trivial (stages h >= 8: one lane of a wave would
+ *   otherwise take another path than the other 63).
+ *   The inverse transform's overlap rotation is fused the same way:
+ *       Out[p] = fma(c, A, -(s*B))        Out[N-1-p] = fma(s, A, c*B)
  *   All tables are evaluated in binary64 with the host libm and rounded once to
- *   binary32.
+ *   binary32.  Built with -mfma: fmaf() is one instruction (and correctly rounded
+ *   either way).
  */
 #include <math.h>
 #include <stdint.h>
@@ -123,7 +134,10 @@ static float *scratch(int nfloats) {
     return g_scratch;
 }
 
-/* ---- spec v1 DCT-IV ------------------------------------------------------- */
+/* ---- spec v2 DCT-IV ------------------------------------------------------- */
+/* d * conj(c + i s): two products, two fused multiply-adds */
+#define CMULC_FMA(OR, OI, DR, DI, C, S) do { float m0_ = (DR) * (C), m2_ = (DI) * (C); \
+                                             (OR) = fmaf((DI), (S), m0_); (OI) = fmaf(-(DR), (S), m2_); } while (0)
 /* x[] (re,im interleaved, M complex points) is transformed in place; output
  * index k lives at position brev[k]. */
 static void fft_dif_inplace(float *x, int M, const dct4_tab_t *t) {
@@ -134,13 +148,13 @@ static void fft_dif_inplace(float *x, int M, const dct4_tab_t *t) {
                 int p = base + j, q = p + h;
                 float ar = x[2*p], ai = x[2*p+1];
                 float br = x[2*q], bi = x[2*q+1];
-                float c = t->tw_c[j * step], s = t->tw_s[j * step];
                 float dr = ar - br, di = ai - bi;
                 x[2*p]   = ar + br;
                 x[2*p+1] = ai + bi;
-                float m0 = dr * c, m1 = di * s, m2 = di * c, m3 = dr * s;
-                x[2*q]   = m0 + m1;
-                x[2*q+1] = m2 - m3;
+                int idx = j * step;
+                if (h <= 4 && idx == 0)          { x[2*q] = dr; x[2*q+1] = di; }            /* W = 1  */
+                else if (h <= 4 && idx == M / 4) { x[2*q] = di; x[2*q+1] = -dr; }           /* W = -i */
+                else CMULC_FMA(x[2*q], x[2*q+1], dr, di, t->tw_c[idx], t->tw_s[idx]);
             }
         }
     }
@@ -152,20 +166,19 @@ void orc_dct4(float *X, const float *u, float *work, int N) {
     int M = N / 2;
     for (int n = 0; n < M; n++) {
         float a = u[2*n], b = u[N-1-2*n];
-        float c = t->pre_c[n], s = t->pre_s[n];
-        float m0 = a * c, m1 = b * s, m2 = b * c, m3 = a * s;
-        work[2*n]   = m0 + m1;
-        work[2*n+1] = m2 - m3;
+        CMULC_FMA(work[2*n], work[2*n+1], a, b, t->pre_c[n], t->pre_s[n]);
     }
     fft_dif_inplace(work, M, t);
     for (int k = 0; k < M; k++) {
         int p = t->brev[k];
         float r = work[2*p], i = work[2*p+1];
+        /* y = T conj(P):  X[2k] = Re y = fma(i, s, r c);  X[N-1-2k] = -Im y = fma(r, s, -(i c)), formed directly (the
+         * negative of fma(-r, s, i c) differs from it in the sign of an exact zero, and compilers fold the one into the
+         * other: the spec is the direct form) */
         float c = t->pre_c[k], s = t->pre_s[k];
-        float m0 = r * c, m1 = i * s, m2 = i * c, m3 = r * s;
-        float yr = m0 + m1, yi = m2 - m3;
-        X[2*k]     = yr;
-        X[N-1-2*k] = -yi;
+        float m0 = r * c, m2 = i * c;
+        X[2*k]     = fmaf(i, s, m0);
+        X[N-1-2*k] = fmaf(r, s, -m2);
     }
 }
 
@@ -222,7 +235,7 @@ void orc_mdct_mdst(float *MDCT, float *MDST, const float *New, float *Lap, float
  * (/root/reference/libulc/ulcDecoder.c:253-272).  For pair p < N/2:
  *   A = Lap[N/2-1-p], B = z[N/2+p];
  *   p <  a :  Out[p] = A,           Out[N-1-p] = B
- *   p >= a :  Out[p] = c*A - s*B,   Out[N-1-p] = s*A + c*B,  (c,s) = (fall,rise)[p-a]
+ *   p >= a :  Out[p] = fma(c,A,-(s*B)),  Out[N-1-p] = fma(s,A,c*B),  (c,s) = (fall,rise)[p-a]
  * then Lap[i] <- z[i], i < N/2.
  */
 void orc_imdct(float *Out, const float *In, float *Lap, float *Tmp, int N, int Overlap) {
@@ -240,9 +253,9 @@ void orc_imdct(float *Out, const float *In, float *Lap, float *Tmp, int N, int O
             Out[N-1-p] = B;
         } else {
             float c = wt->fall[p-a], s = wt->rise[p-a];
-            float m0 = c * A, m1 = s * B, m2 = s * A, m3 = c * B;
-            Out[p]     = m0 - m1;
-            Out[N-1-p] = m2 + m3;
+            float m1 = s * B, m3 = c * B;
+            Out[p]     = fmaf(c, A, -m1);
+            Out[N-1-p] = fmaf(s, A, m3);
         }
     }
     for (int i = 0; i < H; i++) Lap[i] = z[i];

@@ -37,6 +37,7 @@ struct ulcx_decoder {
     bool evOk, evRecorded, timing;
     uint8_t *d_in; size_t d_in_bytes; float *d_pcm; int32_t *d_bits;
     uint8_t *d_pay; int32_t *d_payBytes; long long payStride;     // resident packed payloads (ulcx_decoder_upload_payload)
+    hipStream_t side; hipEvent_t evFork, evScan[ULCX_DEC_MAXCH]; bool sideOk; int nChunks;   // walk / synthesis pipeline (ULCX_DEC_PIPE chunks)
 };
 
 extern "C" int ulcx_device_count(void) {
@@ -377,6 +378,7 @@ static void cleanup(ulcx_decoder *e) {
     if (e->d_payBytes) hipFree(e->d_payBytes);
     if (e->tables) hipFree(e->tables);
     if (e->evOk) for (auto &v : e->ev) hipEventDestroy(v);
+    if (e->sideOk) { hipStreamDestroy(e->side); hipEventDestroy(e->evFork); for (auto &v : e->evScan) hipEventDestroy(v); }
     delete e;
 }
 static int dec_reset_state(ulcx_decoder *e) {
@@ -417,6 +419,11 @@ static void build_rng_tables(std::vector<uint32_t> &jumpT) {
     }
 }
 
+static UlcxDecAux dec_aux(ulcx_decoder *e) {
+    UlcxDecAux a; a.side = e->sideOk ? e->side : nullptr; a.evFork = e->evFork; a.evScan = e->evScan; a.nChunks = e->nChunks;
+    return a;
+}
+
 extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams, int nChan, int BlockSize, int maxBlocksPerCall) {
     if (!out) return ULCX_ERR_ARG;
     *out = nullptr;
@@ -427,6 +434,7 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     e->device = device; e->B = nStreams; e->C = nChan; e->BS = BlockSize; e->maxK = maxBlocksPerCall;
     e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->timing = true;
     e->d_in = nullptr; e->d_in_bytes = 0; e->d_pcm = nullptr; e->d_bits = nullptr; e->d_pay = nullptr; e->d_payBytes = nullptr; e->payStride = 0;
+    e->sideOk = false; e->side = nullptr; e->nChunks = 1;
     UlcxDecCtx &c = e->ctx;
     memset(&c, 0, sizeof(c));
     c.B = nStreams; c.C = nChan; c.BS = BlockSize; c.lgBS = ilog2i(BlockSize); c.maxK = maxBlocksPerCall;
@@ -468,6 +476,22 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
         if (hipMemcpy(dj, jt.data(), sizeof(uint32_t) * jt.size(), hipMemcpyHostToDevice) != hipSuccess) { ulcx_set_error("hipMemcpy(rng tables)"); cleanup(e); return ULCX_ERR_HIP; }
         c.jumpT = dj;
     }
+    {   // side stream of the walk / synthesis pipeline; ULCX_DEC_PIPE=n chunks (1 = off; default 4), ULCX_ASYNC_FB=0: no side streams at all
+        const char *fb = getenv("ULCX_ASYNC_FB");
+        const char *pv = getenv("ULCX_DEC_PIPE");
+        int n = pv ? atoi(pv) : 4;
+        if (n < 1) n = 1;
+        if (n > ULCX_DEC_MAXCH) n = ULCX_DEC_MAXCH;
+        if (!(fb && fb[0] == '0') && n > 1) {
+            bool ok = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess;
+            if (ok) {
+                ok = hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming) == hipSuccess;
+                for (auto &v : e->evScan) ok = ok && hipEventCreateWithFlags(&v, hipEventDisableTiming) == hipSuccess;
+                e->sideOk = ok;
+                if (ok) e->nChunks = n;
+            }
+        }
+    }
     for (auto &v : e->ev) { if (hipEventCreate(&v) != hipSuccess) { ulcx_set_error("hipEventCreate failed"); cleanup(e); return ULCX_ERR_HIP; } }
     e->evOk = true;
     rc = dec_reset_state(e);
@@ -484,7 +508,7 @@ static int decode_dev_any(ulcx_decoder *e, const uint8_t *d_in, int slotBytes, i
     UlcxDecCtx c = e->ctx;
     c.K = nBlocks; c.slot = slotBytes; c.in = d_in; c.pcm = d_pcm; c.pcm16 = d_pcm16; c.bits = d_bits;
     c.inBytes = (long long)e->B * nBlocks * slotBytes;
-    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->timing ? e->ev : nullptr);
+    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->timing ? e->ev : nullptr, dec_aux(e));
     e->evRecorded = (rc == ULCX_OK) && e->timing;
     return rc;
 }
@@ -558,7 +582,7 @@ extern "C" int ulcx_decode_packed_dev(ulcx_decoder *e, const uint8_t *d_payload,
     c.K = nBlocks; c.slot = 0; c.in = d_payload; c.pcm = d_pcm; c.pcm16 = nullptr; c.bits = d_bits;
     c.packed = 1; c.payStride = payloadStride; c.payBytes = d_payloadBytes;
     c.inBytes = (long long)e->B * payloadStride;
-    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->timing ? e->ev : nullptr);
+    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->timing ? e->ev : nullptr, dec_aux(e));
     e->evRecorded = (rc == ULCX_OK) && e->timing;
     return rc;
 }

@@ -304,16 +304,16 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
 
 // Pass 1 - one lane per block.
 __global__ __launch_bounds__(64) void k_dscan(UlcxDecCtx c) {
-    int blk = blockIdx.x * 64 + threadIdx.x;
-    if (blk >= c.B * c.K) return;
+    int blk = c.s0 * c.K + blockIdx.x * 64 + threadIdx.x;          // streams [s0, s1) of the batch (ulcx_dec_launch pipelines chunks)
+    if (blk >= c.s1 * c.K) return;
     scan_block(c, blk, c.in + (size_t)blk * c.slot, c.slot * 8, c.slot, c.in, c.in + c.inBytes);
 }
 
 // Pass 1, packed payloads - one lane per stream: a block's start is only known once the previous
 // block has been parsed (the container stores no block lengths, tools/ulcDecodeTool.c:153-165).
 __global__ __launch_bounds__(64) void k_dscan_packed(UlcxDecCtx c) {
-    int s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= c.B) return;
+    int s = c.s0 + blockIdx.x * 64 + threadIdx.x;
+    if (s >= c.s1) return;
     int off = c.packOff[s];
     int avail = c.payBytes[s];
     const uint8_t *base = c.in + (size_t)s * c.payStride;
@@ -578,13 +578,13 @@ __device__ __forceinline__ int dec_time_wave(const UlcxDecCtx &c, float2 *zc, fl
                 const int k1 = kk, k2 = M - 1 - kk;
                 const int r1 = FFT_PADS((int)(__brev((unsigned)k1) >> (32 - bits)), DPS);
                 const int r2 = FFT_PADS((int)(__brev((unsigned)k2) >> (32 - bits)), DPS);
-                const float2 y1 = cmulc(zj[r1], pre[k1]), y2 = cmulc(zj[r2], pre[k2]);
+                const float2 y1 = cmulc_post(zj[r1], pre[k1]), y2 = cmulc_post(zj[r2], pre[k2]);     // (Re y, -Im y)
                 const int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
                 float Av[2];
                 // (L may be global memory, arr is LDS: separate branches, never a select between the two pointers)
                 if (tA + pv[1] < 0) { Av[0] = L[-1 - (tA + pv[0])]; Av[1] = L[-1 - (tA + pv[1])]; }      // (pv[1] = pv[0]-1, even time: both on the same side of 0)
                 else { Av[0] = arr[padf(tA + pv[0])]; Av[1] = arr[padf(tA + pv[1])]; }
-                const float Bv[2] = { -y1.y, y2.x };
+                const float Bv[2] = { y1.y, y2.x };
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const int p = pv[q];
@@ -592,12 +592,12 @@ __device__ __forceinline__ int dec_time_wave(const UlcxDecCtx &c, float2 *zc, fl
                     if (p < a) { o[t][2 * q] = A; o[t][2 * q + 1] = B; }
                     else {
                         const float cw = fall[p - a], sn = rise[p - a];
-                        const float m0 = cw * A, m1 = sn * B, m2 = sn * A, m3 = cw * B;
-                        o[t][2 * q] = m0 - m1;
-                        o[t][2 * q + 1] = m2 + m3;
+                        const float m1 = sn * B, m3 = cw * B;               // spec v2: fused (orc_imdct)
+                        o[t][2 * q] = __builtin_fmaf(cw, A, -m1);
+                        o[t][2 * q + 1] = __builtin_fmaf(sn, A, m3);
                     }
                 }
-                nl[t][0] = y1.x; nl[t][1] = -y2.y;              // z[2 k1], z[2 k1 + 1]: the tail at times off+M+pv[0], off+M+pv[1]
+                nl[t][0] = y1.x; nl[t][1] = y2.y;               // z[2 k1], z[2 k1 + 1]: the tail at times off+M+pv[0], off+M+pv[1]
             }
         }
         WAVE_SYNC();
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
     extern __shared__ float lds[];
     const int BS = c.BS, H2 = BS / 2;
     constexpr int C = 2;
-    const int s = blockIdx.x, tid = threadIdx.x;
+    const int s = c.s0 + blockIdx.x, tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const DsynLds L = dsyn_lds(BS, C, 1, 1);
     float2 *z    = (float2 *)lds;
@@ -796,10 +796,10 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                     int r2 = (int)(__brev((unsigned)k2) >> (32 - bits));
                     r1 = FFT_PADS(r1, DPS); r2 = FFT_PADS(r2, DPS);
                     const float2 P1 = pre[k1], P2 = pre[k2];
-                    const float2 ya1 = cmulc(z0[r1], P1), ya2 = cmulc(z0[r2], P2);     // channel 0 (M)
-                    const float2 yb1 = cmulc(z1[r1], P1), yb2 = cmulc(z1[r2], P2);     // channel 1 (S)
+                    const float2 ya1 = cmulc_post(z0[r1], P1), ya2 = cmulc_post(z0[r2], P2);     // channel 0 (M): (Re y, -Im y)
+                    const float2 yb1 = cmulc_post(z1[r1], P1), yb2 = cmulc_post(z1[r2], P2);     // channel 1 (S)
                     const float A0m = L0[2 * k1], A1m = L0[2 * k1 + 1], A0s = L1[2 * k1], A1s = L1[2 * k1 + 1];
-                    const float Bm[2] = { -ya1.y, ya2.x }, Bs[2] = { -yb1.y, yb2.x };
+                    const float Bm[2] = { ya1.y, ya2.x }, Bs[2] = { yb1.y, yb2.x };
                     const float Am[2] = { A0m, A1m }, As[2] = { A0s, A1s };
                     const int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
                     float2 lo2[2], hi2[2];                                             // interleaved L/R at positions p and S-1-p
@@ -810,10 +810,11 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                         if (p < a) { mLo = Am[q]; mHi = Bm[q]; sLo = As[q]; sHi = Bs[q]; }
                         else {
                             const float cw = fall[p - a], sn = rise[p - a];
-                            const float m0 = cw * Am[q], m1 = sn * Bm[q], m2 = sn * Am[q], m3 = cw * Bm[q];
-                            mLo = m0 - m1; mHi = m2 + m3;
-                            const float s0 = cw * As[q], s1 = sn * Bs[q], s2 = sn * As[q], s3 = cw * Bs[q];
-                            sLo = s0 - s1; sHi = s2 + s3;
+                            // spec v2 (orc_imdct): Out[p] = fma(c, A, -(s B)), Out[S-1-p] = fma(s, A, c B)
+                            const float m1 = sn * Bm[q], m3 = cw * Bm[q];
+                            mLo = __builtin_fmaf(cw, Am[q], -m1); mHi = __builtin_fmaf(sn, Am[q], m3);
+                            const float s1 = sn * Bs[q], s3 = cw * Bs[q];
+                            sLo = __builtin_fmaf(cw, As[q], -s1); sHi = __builtin_fmaf(sn, As[q], s3);
                         }
                         // inverse M/S (ulcDecoder.c:281-289) + interleave (:292-297)
                         lo2[q] = make_float2(mLo + sLo, mLo - sLo);
@@ -822,8 +823,8 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                     // positions pv[1] = pv[0]-1 and S-1-pv[0], S-pv[0] are neighbours: two aligned 16-byte stores
                     st4(outp + 2 * pv[1], lo2[1].x, lo2[1].y, lo2[0].x, lo2[0].y);
                     st4(outp + 2 * (S - 1 - pv[0]), hi2[0].x, hi2[0].y, hi2[1].x, hi2[1].y);
-                    L0[2 * k1] = ya1.x; L0[2 * k1 + 1] = -ya2.y;
-                    L1[2 * k1] = yb1.x; L1[2 * k1 + 1] = -yb2.y;
+                    L0[2 * k1] = ya1.x; L0[2 * k1 + 1] = ya2.y;
+                    L1[2 * k1] = yb1.x; L1[2 * k1 + 1] = yb2.y;
                 }
             }
             STAMP(5);
@@ -874,7 +875,7 @@ template <typename OUT>
 __global__ __launch_bounds__(WG) void k_dgen(UlcxDecCtx c) {
     extern __shared__ float lds[];
     const int BS = c.BS, C = c.C, H2 = BS / 2;
-    const int s = blockIdx.x, tid = threadIdx.x;
+    const int s = c.s0 + blockIdx.x, tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const DsynLds L = dsyn_lds(BS, C, 0, 0);
     float2 *z = (float2 *)lds;
@@ -954,10 +955,10 @@ __global__ __launch_bounds__(WG) void k_dgen(UlcxDecCtx c) {
                         const int k1 = kk, k2 = M - 1 - kk;
                         const int r1 = FFT_PADS((int)(__brev((unsigned)k1) >> (32 - bits)), DPS);
                         const int r2 = FFT_PADS((int)(__brev((unsigned)k2) >> (32 - bits)), DPS);
-                        const float2 y1 = cmulc(z[r1], pre[k1]), y2 = cmulc(z[r2], pre[k2]);
-                        // zz[2k1] = y1.x, zz[2k1+1] = -y2.y (new lap);  zz[S-1-2k1] = -y1.y, zz[S-2-2k1] = y2.x (B values)
+                        const float2 y1 = cmulc_post(z[r1], pre[k1]), y2 = cmulc_post(z[r2], pre[k2]);      // (Re y, -Im y)
+                        // zz[2k1] = Re y1, zz[2k1+1] = -Im y2 (new lap);  zz[S-1-2k1] = -Im y1, zz[S-2-2k1] = Re y2 (B values)
                         const float A0 = Lp[2 * k1], A1 = Lp[2 * k1 + 1];
-                        const float Bv[2] = { -y1.y, y2.x };
+                        const float Bv[2] = { y1.y, y2.x };
                         const float Av[2] = { A0, A1 };
                         const int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
 #pragma unroll
@@ -967,13 +968,13 @@ __global__ __launch_bounds__(WG) void k_dgen(UlcxDecCtx c) {
                             if (p < a) { out[p] = A; out[S - 1 - p] = B; }
                             else {
                                 const float cw = fall[p - a], sn = rise[p - a];
-                                const float m0 = cw * A, m1 = sn * B, m2 = sn * A, m3 = cw * B;
-                                out[p] = m0 - m1;
-                                out[S - 1 - p] = m2 + m3;
+                                const float m1 = sn * B, m3 = cw * B;       // spec v2: fused (orc_imdct)
+                                out[p] = __builtin_fmaf(cw, A, -m1);
+                                out[S - 1 - p] = __builtin_fmaf(sn, A, m3);
                             }
                         }
                         Lp[2 * k1] = y1.x;
-                        Lp[2 * k1 + 1] = -y2.y;
+                        Lp[2 * k1 + 1] = y2.y;
                     }
                     __syncthreads();
                     if (S == BS) break;                              // ulcDecoder.c:242-245
@@ -1025,24 +1026,57 @@ size_t ulcx_dec_lds_bytes(int BS, int C, int fast, int twInLds) {
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)
 
-int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev) {
+// The syntax walk (k_dscan: one wave per 64 blocks, a chain of dependent instructions - it leaves most of the machine idle)
+// and the synthesis (k_dsyn: instruction-issue bound) are pipelined over chunks of streams: the walk of chunk i+1 runs on a
+// side stream beside the synthesis of chunk i.  aux.side == NULL (or a small batch): one chunk, everything on the caller's stream.
+int ulcx_dec_launch(const UlcxDecCtx &cIn, hipStream_t st, hipEvent_t *ev, const UlcxDecAux &aux) {
     int stage = 0;
     if (ev) CK(hipEventRecord(ev[stage++], st));
-    int NB = c.B * c.K;
-    if (c.packed) hipLaunchKernelGGL(k_dscan_packed, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
-    else hipLaunchKernelGGL(k_dscan, dim3((NB + 63) / 64), dim3(64), 0, st, c);
-    if (ev) CK(hipEventRecord(ev[stage++], st));
+    UlcxDecCtx c = cIn;
     size_t lds = ulcx_dec_lds_bytes(c.BS, c.C, c.fastOK, c.twInLds);
     const bool small = c.BS <= 2048;                      // register slots of the decimated-block path (dec_time_wave)
     const void *fn = !c.fastOK ? (c.pcm16 ? (const void *)k_dgen<int16_t> : (const void *)k_dgen<float>)
                    : c.pcm16 ? (small ? (const void *)k_dsyn<int16_t, 16, false> : (const void *)k_dsyn<int16_t, 32, true>)
                              : (small ? (const void *)k_dsyn<float, 16, false> : (const void *)k_dsyn<float, 32, true>);
     if (lds > 48 * 1024) CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (ULCX_DBG(c) & 8) {}
-    else if (!c.fastOK) { if (c.pcm16) hipLaunchKernelGGL(k_dgen<int16_t>, dim3(c.B), dim3(WG), lds, st, c); else hipLaunchKernelGGL(k_dgen<float>, dim3(c.B), dim3(WG), lds, st, c); }
-    else if (c.pcm16) { if (small) hipLaunchKernelGGL((k_dsyn<int16_t, 16, false>), dim3(c.B), dim3(WG), lds, st, c); else hipLaunchKernelGGL((k_dsyn<int16_t, 32, true>), dim3(c.B), dim3(WG), lds, st, c); }
-    else { if (small) hipLaunchKernelGGL((k_dsyn<float, 16, false>), dim3(c.B), dim3(WG), lds, st, c); else hipLaunchKernelGGL((k_dsyn<float, 32, true>), dim3(c.B), dim3(WG), lds, st, c); }
-    if (ev) CK(hipEventRecord(ev[stage++], st));
+    auto scan = [&](hipStream_t s2, int s0, int s1) {
+        UlcxDecCtx cc = c; cc.s0 = s0; cc.s1 = s1;
+        if (c.packed) hipLaunchKernelGGL(k_dscan_packed, dim3((s1 - s0 + 63) / 64), dim3(64), 0, s2, cc);
+        else hipLaunchKernelGGL(k_dscan, dim3(((s1 - s0) * c.K + 63) / 64), dim3(64), 0, s2, cc);
+    };
+    auto syn = [&](hipStream_t s2, int s0, int s1) {
+        UlcxDecCtx cc = c; cc.s0 = s0; cc.s1 = s1;
+        const unsigned g = (unsigned)(s1 - s0);
+        if (ULCX_DBG(c) & 8) {}
+        else if (!c.fastOK) { if (c.pcm16) hipLaunchKernelGGL(k_dgen<int16_t>, dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL(k_dgen<float>, dim3(g), dim3(WG), lds, s2, cc); }
+        else if (c.pcm16) { if (small) hipLaunchKernelGGL((k_dsyn<int16_t, 16, false>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<int16_t, 32, true>), dim3(g), dim3(WG), lds, s2, cc); }
+        else { if (small) hipLaunchKernelGGL((k_dsyn<float, 16, false>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<float, 32, true>), dim3(g), dim3(WG), lds, s2, cc); }
+    };
+    int nCh = (aux.side && aux.nChunks > 1) ? aux.nChunks : 1;
+    if (nCh > ULCX_DEC_MAXCH) nCh = ULCX_DEC_MAXCH;
+    if (c.B < 64 * nCh) nCh = 1;                          // (a chunk is at least a wave of the walk)
+    if (nCh == 1) {
+        scan(st, 0, c.B);
+        if (ev) CK(hipEventRecord(ev[stage++], st));
+        syn(st, 0, c.B);
+        if (ev) CK(hipEventRecord(ev[stage++], st));
+    } else {
+        // chunk boundaries on multiples of 64 streams.  Timing (ev): the "k_dscan" interval is the first chunk's walk (the
+        // exposed one), the "k_dsyn" interval everything behind it.
+        int cut[ULCX_DEC_MAXCH + 1];
+        for (int i = 0; i <= nCh; i++) cut[i] = (int)(((long long)c.B * i / nCh + 63) / 64 * 64);
+        cut[nCh] = c.B;
+        scan(st, cut[0], cut[1]);
+        if (ev) CK(hipEventRecord(ev[stage++], st));
+        CK(hipEventRecord(aux.evFork, st));
+        CK(hipStreamWaitEvent(aux.side, aux.evFork, 0));
+        for (int i = 1; i < nCh; i++) { scan(aux.side, cut[i], cut[i + 1]); CK(hipEventRecord(aux.evScan[i], aux.side)); }
+        for (int i = 0; i < nCh; i++) {
+            if (i > 0) CK(hipStreamWaitEvent(st, aux.evScan[i], 0));
+            syn(st, cut[i], cut[i + 1]);
+        }
+        if (ev) CK(hipEventRecord(ev[stage++], st));
+    }
     CK(hipGetLastError());
     return ULCX_OK;
 }

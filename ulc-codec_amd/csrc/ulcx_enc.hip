@@ -215,7 +215,9 @@ __global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c, int k0, int k1)
 // 32 streams per workgroup with 3 producer waves: 1.16 ms (the producers are the bottleneck), 32/15: 1.06, 16/15: 0.78,
 // 4/4: 0.95.
 #define EF_TS 68                                          // floats per (stream, filter) row of a tile: 64 steps + pad (rows stay 16-byte aligned, b128 reads conflict-free)
+#ifndef EF_RT
 #define EF_RT 4                                           // tiles in the ring
+#endif
 #define EF_SPW 8                                          // streams per workgroup
 #define EF_NW 9                                           // waves per workgroup: the chain + one producer per stream
 #define EF_TILE_FLOATS (EF_SPW * 2 * EF_TS)
@@ -251,7 +253,10 @@ __global__ __launch_bounds__(NW * 64) void k_wc_ef(UlcxEncCtx c, int k0, int k1)
         }
         // THREE tiles of loads in flight per producer wave (a tile period is shorter than the latency of a load when the
         // transform runs beside this kernel): register sets A0/A1/A2 rotate by unrolling the tile loop three times
-        float2 A0[NS][3], A1[NS][3], A2[NS][3];
+#ifndef EF_AHEAD
+#define EF_AHEAD 3
+#endif
+        float2 A[EF_AHEAD][NS][3];
         auto issue = [&](float2 (&A)[NS][3], int j) {     // the three samples of this lane's time step of tile j, every stream of this wave
             const int t = (k0 * c.BS + j * 64 + lane) - c.BS / 2;                                               // centre sample
 #pragma unroll
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(NW * 64) void k_wc_ef(UlcxEncCtx c, int k0, int k1)
             float2 v[NS];
 #pragma unroll
             for (int i = 0; i < NS; i++) v[i] = wc_energy_stereo(A[i][0], A[i][1], A[i][2]);
-            if (j + 3 < nT) issue(A, j + 3);
+            if (j + EF_AHEAD < nT) issue(A, j + EF_AHEAD);
             while (j >= __atomic_load_n(&flags[NP], __ATOMIC_ACQUIRE) + EF_RT) __builtin_amdgcn_s_sleep(4);     // ring full
             float *tile = ring + (j % EF_RT) * EF_TILE_FLOATS;
 #pragma unroll
@@ -281,13 +286,11 @@ __global__ __launch_bounds__(NW * 64) void k_wc_ef(UlcxEncCtx c, int k0, int k1)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __atomic_store_n(&flags[p], j + 1, __ATOMIC_RELEASE);
         };
-        issue(A0, 0);
-        if (nT > 1) issue(A1, 1);
-        if (nT > 2) issue(A2, 2);
-        for (int j = 0; j < nT; j += 3) {
-            step(A0, j);
-            if (j + 1 < nT) step(A1, j + 1);
-            if (j + 2 < nT) step(A2, j + 2);
+#pragma unroll
+        for (int a = 0; a < EF_AHEAD; a++) if (a < nT) issue(A[a], a);
+        for (int j = 0; j < nT; j += EF_AHEAD) {
+#pragma unroll
+            for (int a = 0; a < EF_AHEAD; a++) if (j + a < nT) step(A[a], j + a);
         }
         return;
     }
@@ -339,7 +342,10 @@ __global__ __launch_bounds__(64) void k_wc_backward(UlcxEncCtx c, int k0, int k1
     // Walk the block backwards in groups of U quads; a group's quads are addressed from one pointer with
     // immediate offsets, and the loads run D-1 groups ahead of the arithmetic: the chain is bound by instructions
     // per step, so address arithmetic is kept out of it.  The result overwrites the HP plane.
-    constexpr int U = 2, D = 4;                          // BS/4 is a multiple of U*D
+#ifndef WC_BACK_D
+#define WC_BACK_D 4
+#endif
+    constexpr int U = 2, D = WC_BACK_D;                  // BS/4 is a multiple of U*D
     const float4 *rp = (const float4 *)(e + (size_t)(nq - 1) * 512);   // quad being loaded (group head)
     float4 *wp = (float4 *)(e + (size_t)(nq - 1) * 512);               // quad being computed (group head)
     float4 xh[D][U], xb[D][U];
@@ -387,7 +393,10 @@ __global__ __launch_bounds__(64) void k_wc_integrate(UlcxEncCtx c, int k0, int k
     const int bin = c.BS / 8;             // >= 32, a multiple of 4*U
     const int nq = (k1 - k0) * c.BS / 4;
     // same structure as k_wc_forward: groups of U quads off one pointer, loads D-1 groups ahead
-    constexpr int U = 2, D = 8;
+#ifndef WC_INT_D
+#define WC_INT_D 8
+#endif
+    constexpr int U = 2, D = WC_INT_D;
     constexpr int QS = 512 / 4;
     const float4 *rp = v;
     float4 x[D][U];
@@ -676,14 +685,16 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
                     if (q >= nch) break;
                     int ch = ch0 + q;
                     float2 *zc = q ? zc1 : zc0, *zs = q ? zs1 : zs0;
-                    // (packed-f32 complex multiplies: lane-wise IEEE, the same four products and two sums as cmulc)
+                    // (packed-f32 complex multiplies: lane-wise IEEE, the same two products and two fused multiply-adds as cmulc)
                     const fft_v2f Pv1 = { P1.x, P1.y }, Pv2 = { P2.x, P2.y };
-                    auto cm = [](float2 d, fft_v2f w) { const fft_v2f dv = { d.x, d.y }; const fft_v2f r = fft_cmulc_pk(dv, w); return make_float2(r.x, r.y); };
+                    // (Re y, -Im y) of the DCT-IV post-twiddle, as cmulc_post; the MDST's sign (it alternates, (-1)^k) only ever
+                    //  meets a square
+                    auto cm = [](float2 d, fft_v2f w) { const fft_v2f dv = { d.x, d.y }; const fft_v2f r = fft_cmulc_post_pk(dv, w); return make_float2(r.x, r.y); };
                     float2 yc1 = cm(zc[FFT_PADS(r1, ps)], Pv1), yc2 = cm(zc[FFT_PADS(r2, ps)], Pv2);
                     float2 ys1 = cm(zs[FFT_PADS(r1, ps)], Pv1), ys2 = cm(zs[FFT_PADS(r2, ps)], Pv2);
                     // pair j = k1: coefficients 2k1, 2k1+1 ; pair j = k2: coefficients 2k2, 2k2+1
-                    float mdct[4] = { yc1.x, -yc2.y, yc2.x, -yc1.y };
-                    float mdst[4] = { ys1.x,  ys2.y, ys2.x,  ys1.y };
+                    float mdct[4] = { yc1.x, yc2.y, yc2.x, yc1.y };
+                    float mdst[4] = { ys1.x, ys2.y, ys2.x, ys1.y };
 #pragma unroll
                     for (int p = 0; p < 2; p++) {
                         float re0 = mdct[2*p] * norm,   im0 = mdst[2*p] * norm;
@@ -801,13 +812,13 @@ __global__ __launch_bounds__(WG) void k_xf_big(UlcxEncCtx c, int k0, int k1) {
                     const int kA = kk, kB = M - 1 - kk;
                     const int r1 = (int)(__brev((unsigned)kA) >> (32 - bits));
                     const int r2 = (int)(__brev((unsigned)kB) >> (32 - bits));
-                    const float2 y1 = cmulc(z[r1], pre[kA]), y2 = cmulc(z[r2], pre[kB]);
+                    const float2 y1 = cmulc_post(z[r1], pre[kA]), y2 = cmulc_post(z[r2], pre[kB]);      // (Re y, -Im y)
 #pragma unroll
                     for (int p = 0; p < 2; p++) {
                         const int j = p ? kB : kA;
                         const size_t gi = (size_t)ch * BS + off + 2 * j;
                         if (kind == 0) {
-                            const float m0 = p ? y2.x : y1.x, m1 = p ? -y1.y : -y2.y;
+                            const float m0 = p ? y2.x : y1.x, m1 = p ? y1.y : y2.y;
                             const float re0 = m0 * norm, re1 = m1 * norm;
                             nnz += (fabsf(re0) < 0.5f * ULCX_COEF_EPS) ? 0 : 1;
                             nnz += (fabsf(re1) < 0.5f * ULCX_COEF_EPS) ? 0 : 1;
@@ -1276,6 +1287,28 @@ __device__ __forceinline__ int fb_count(const UlcxEncCtx &c) {
 // set is {key > T} plus the tie group {key == T} when it fits entirely.  Only when the
 // tie group straddles the cut is the exact heapsort pop order needed (k_heapsel).
 // ---------------------------------------------------------------------------
+// Wave-wide reductions on the VALU's data-parallel primitives (row shifts inside rows of 16 lanes, then the two row
+// broadcasts of gfx9): six instructions and one v_readlane, no LDS round trips.  Every lane gets the result.
+#define ULCX_DPP_STEPS(OP) \
+    OP(0x111, 0xf) OP(0x112, 0xf) OP(0x114, 0xf) OP(0x118, 0xf) OP(0x142, 0xa) OP(0x143, 0xc)
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#define STEP(ctl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctl, rmask, 0xf, false);
+    ULCX_DPP_STEPS(STEP)
+#undef STEP
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#define STEP(ctl, rmask) { uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, ctl, rmask, 0xf, false); v = o < v ? o : v; }
+    ULCX_DPP_STEPS(STEP)
+#undef STEP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define STEP(ctl, rmask) { uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctl, rmask, 0xf, false); v = o > v ? o : v; }
+    ULCX_DPP_STEPS(STEP)
+#undef STEP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ uint32_t key_ord(float f) {          // ascending order-preserving map
     uint32_t u = __float_as_uint(f);
     if ((u << 1) == 0) u = 0;                                   // -0 and +0 compare equal in the reference
@@ -1357,12 +1390,13 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
         for (int i = lane; i < N / 32; i += 64) keep[i] = 0;
         return;
     }
+    extern __shared__ float sel_lds[];                        // per wave: BS/2 masking levels + the block's 4 x 25 Bark levels; later the candidate lists
+    const int selStride = ulcx_sel_lds_words(c.BS);
     uint32_t u[R];
     {
         // the block's masking level per line (Psyopt.c:140-150), formed by the wave into LDS (BS/2 <= 32 R values) instead of
         // being read from an array another kernel wrote
-        extern __shared__ float sel_lds[];                    // per wave: BS/2 masking levels + the block's 4 x 25 Bark levels
-        float *msk = sel_lds + wv * (c.BS / 2 + 4 * ULCX_NBARK);
+        float *msk = sel_lds + wv * selStride;
         float *sbarkw = msk + c.BS / 2;
         {
             for (int i = lane; i < 4 * ULCX_NBARK; i += 64) sbarkw[i] = c.barkP[(size_t)blk * 4 * ULCX_NBARK + i];
@@ -1383,26 +1417,81 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // T = kSel-th largest ordered key = the largest t with count(u >= t) >= kSel; found bit by bit
-    // (a histogram radix select serialises on LDS atomics here: log-domain keys share their top byte)
+    // T = kSel-th largest ordered key = the largest t with count(u >= t) >= kSel, found bit by bit - but not every bit on
+    // all R keys per lane (a histogram radix select serialises on LDS atomics here: log-domain keys share their top byte):
+    //  1. wave minimum and maximum: T shares their common leading bits, the probes start at the first bit that differs
+    //     (log-domain keys share 6-9 leading bits: that many full probes less);
+    //  2. full probes (R compares per lane) only until the window [T, T + 2^(bit+1)) that still holds T has few keys in it
+    //     (count above T minus count above the window's top, both known from the probes);
+    //  3. those candidates go to a few registers per lane through LDS (a lane's own list; a lane with more than SEL_CAP of
+    //     them, or a window that never gets small - ties, silence -, keeps the full probes) and the remaining bits are
+    //     resolved on SEL_CAP compares per lane.
+    // A probe that separates exactly kSel keys ends the search at once (the answer is the smallest key above it).
+    constexpr int SEL_CAP = ULCX_SEL_CAP, SEL_CAND = ULCX_SEL_CAND;
+    constexpr bool SEL_COMPACT = R > 2 * SEL_CAP;         // (few keys per lane: the full probes are as cheap)
     uint32_t T = 0;
-    for (int bit = 31; bit >= 0; bit--) {
-        uint32_t t = T | (1u << bit);
-        int cnt = 0;
+    {
+        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
 #pragma unroll
-        for (int r = 0; r < R; r++) cnt += (u[r] >= t) ? 1 : 0;
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-        if (cnt == kSel) {
-            // t falls between the kSel-th and the next key: the answer is the smallest key >= t, no need to
-            // resolve the remaining bits (typically half of them)
-            uint32_t mn = 0xFFFFFFFFu;
+        for (int r = 0; r < R; r++) { mn = u[r] < mn ? u[r] : mn; mx = u[r] > mx ? u[r] : mx; }
+        mn = wave_min_u32(mn); mx = wave_max_u32(mx);
+        const uint32_t dif = mn ^ mx;
+        if (ULCX_DBG(c) & 0x1000) T = mn;                  // (ablation build only: no search, everything is kept)
+        else if (dif == 0) T = mn;
+        else {
+            int bit = 31 - __clz(dif);
+            T = mx & ~((2u << bit) - 1u);                 // the common prefix (count(u >= T) = N >= kSel)
+            int cntLo = N, cntHi = 0;                     // keys >= T, keys >= T + 2^(bit+1)
+            bool compacted = false, tried = false;
+            uint32_t cd[SEL_CAP];
+            for (; bit >= 0; bit--) {
+                const uint32_t t = T | (1u << bit);
+                int cnt = 0;
+                if (!compacted) {
 #pragma unroll
-            for (int r = 0; r < R; r++) { uint32_t v = (u[r] >= t) ? u[r] : 0xFFFFFFFFu; mn = v < mn ? v : mn; }
-            for (int o = 32; o > 0; o >>= 1) { uint32_t w = (uint32_t)__shfl_xor((int)mn, o); mn = w < mn ? w : mn; }
-            T = mn;
-            break;
+                    for (int r = 0; r < R; r++) cnt += (u[r] >= t) ? 1 : 0;
+                    cnt = wave_sum_i32(cnt);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < SEL_CAP; j++) cnt += (cd[j] >= t) ? 1 : 0;
+                    cnt = cntHi + wave_sum_i32(cnt);
+                }
+                if (cnt == kSel) {
+                    // t falls between the kSel-th and the next key: the answer is the smallest key >= t, no need to
+                    // resolve the remaining bits (typically half of them)
+                    uint32_t m2 = 0xFFFFFFFFu;
+                    if (!compacted) {
+#pragma unroll
+                        for (int r = 0; r < R; r++) { uint32_t v = (u[r] >= t) ? u[r] : 0xFFFFFFFFu; m2 = v < m2 ? v : m2; }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < SEL_CAP; j++) { uint32_t v = (cd[j] >= t) ? cd[j] : 0xFFFFFFFFu; m2 = v < m2 ? v : m2; }
+                    }
+                    T = wave_min_u32(m2);
+                    break;
+                }
+                if (cnt > kSel) { T = t; cntLo = cnt; } else if (!compacted) cntHi = cnt;
+                if (SEL_COMPACT && !compacted && !tried && bit > 0 && cntLo - cntHi <= SEL_CAND) {
+                    // candidates: T <= u < T + 2^bit (the window the next probe halves)
+                    tried = true;
+                    uint32_t *cl = (uint32_t *)(sel_lds + wv * selStride);        // (the masking levels are used up)
+                    const uint32_t W = 1u << bit;
+                    int nL = 0;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const bool act = (u[r] - T) < W;
+                        if (act && nL < SEL_CAP) cl[nL * 64 + lane] = u[r];
+                        nL += act ? 1 : 0;
+                    }
+                    if (!__any(nL > SEL_CAP)) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                        for (int j = 0; j < SEL_CAP; j++) cd[j] = (j < nL) ? cl[j * 64 + lane] : 0u;       // (0 is below every probe)
+                        compacted = true;
+                    }
+                }
+            }
         }
-        if (cnt > kSel) T = t;
     }
     int g = 0, e = 0;
 #pragma unroll
@@ -2719,8 +2808,8 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         // No read-back: the host always enqueues the full count and a pass whose blocks have all converged (c.cbrLive,
         // counted down on the device) returns at the top of every kernel - nothing inside the call waits for the device.
     }
-    const size_t selLds = (size_t)4 * (c.BS / 2 + 4 * ULCX_NBARK) * sizeof(float);
-    if (selLds > 48 * 1024) {                                  // (mono BlockSize 8192, stereo 4096: 67 KB)
+    const size_t selLds = (size_t)4 * ulcx_sel_lds_words(c.BS) * sizeof(float);
+    if (selLds > 48 * 1024 && selLds <= ULCX_LDS_LIMIT && (N / 64 == 128 || N / 64 == 64)) {   // (mono BlockSize 8192: 67 KB)
         CK(hipFuncSetAttribute((const void *)k_select_wave<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)selLds));
         CK(hipFuncSetAttribute((const void *)k_select_wave<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)selLds));
     }

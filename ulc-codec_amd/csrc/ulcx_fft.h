@@ -1,19 +1,36 @@
 // ulcx_fft.h — LDS-resident complex FFT used by the forward and inverse transforms.
-// "fourier spec v1" (oracle/orc_fourier.c): radix-2 decimation in
+// "fourier spec v2" (oracle/orc_fourier.c): radix-2 decimation in
 // frequency, in place, natural-order input, bit-reversed output, twiddle table
-// W[j] = (cos, sin)(2 pi j / M); every complex multiply is 4 binary32 products and 2
-// sums, each individually rounded (file compiled with -ffp-contract=off).
+// W[j] = (cos, sin)(2 pi j / M).  A complex multiply d * conj(w) is two products and two
+// fused multiply-adds:  re = fma(d.y, w.y, d.x*w.x),  im = fma(-d.x, w.y, d.y*w.x)
+// (explicit: the file is compiled with -ffp-contract=off, the compiler fuses nothing by
+// itself).  In the last three stages (half-size <= 4) a butterfly whose twiddle is
+// exactly 1 (index 0) or -i (index M/4) is not multiplied: the difference passes as it
+// is, or as (d.y, -d.x).
 // Requires WG (workgroup size) to be defined by the includer.
 #pragma once
 #include <hip/hip_runtime.h>
 
-__device__ __forceinline__ float2 cmulc(float2 d, float2 w) {    // d * conj(w), 4 mul + 2 add, unfused
-    float m0 = d.x * w.x, m1 = d.y * w.y, m2 = d.y * w.x, m3 = d.x * w.y;
-    return make_float2(m0 + m1, m2 - m3);
+__device__ __forceinline__ float2 cmulc(float2 d, float2 w) {    // d * conj(w): 2 products + 2 fused multiply-adds (spec v2)
+    const float m0 = d.x * w.x, m2 = d.y * w.x;
+    return make_float2(__builtin_fmaf(d.y, w.y, m0), __builtin_fmaf(-d.x, w.y, m2));
+}
+// post-twiddle of the DCT-IV (orc_dct4): (Re y, -Im y) of y = d * conj(w), the second formed directly as fma(d.x, w.y, -(d.y*w.x))
+__device__ __forceinline__ float2 cmulc_post(float2 d, float2 w) {
+    const float m0 = d.x * w.x, m2 = d.y * w.x;
+    return make_float2(__builtin_fmaf(d.y, w.y, m0), __builtin_fmaf(d.x, w.y, -m2));
+}
+// the butterfly's lower output for a stage of half-size hs (in points) and twiddle index idx of an M-point transform:
+// exact rotations for the trivial twiddles of the last three stages, the multiply everywhere else (per-thread selects:
+// the workgroup-wide transforms are not the throughput paths)
+__device__ __forceinline__ float2 fft_twid(float2 d, int idx, int hs, int M, const float2 *__restrict__ tw) {
+    const float2 r = cmulc(d, tw[idx]);
+    if (hs > 4) return r;
+    return idx == 0 ? d : (idx * 4 == M ? make_float2(d.y, -d.x) : r);
 }
 
 
-// In-place radix-2 DIF FFT of two M-point arrays held in LDS ("fourier spec v1",
+// In-place radix-2 DIF FFT of two M-point arrays held in LDS ("fourier spec v2",
 // oracle/orc_fourier.c), executed as merged radix-2^2 passes: each thread carries four
 // points through two consecutive radix-2 stages in registers, which is arithmetically
 // identical to the two separate stages.
@@ -30,28 +47,26 @@ __device__ void fft2_dif(float2 *za, float2 *zb, int M, const float2 *__restrict
             int p0 = (gg - j) * 4 + j;            // (gg / q) * 2h + j, 2h = 4q
             int p1 = p0 + q, p2 = p0 + h, p3 = p2 + q;
             float2 x0 = z[p0], x1 = z[p1], x2 = z[p2], x3 = z[p3];
-            float2 wA0 = tw[j * stepA], wA1 = tw[(j + q) * stepA], wB = tw[j * stepB];
             float2 y0 = make_float2(x0.x + x2.x, x0.y + x2.y);
-            float2 y2 = cmulc(make_float2(x0.x - x2.x, x0.y - x2.y), wA0);
+            float2 y2 = fft_twid(make_float2(x0.x - x2.x, x0.y - x2.y), j * stepA, h, M, tw);
             float2 y1 = make_float2(x1.x + x3.x, x1.y + x3.y);
-            float2 y3 = cmulc(make_float2(x1.x - x3.x, x1.y - x3.y), wA1);
+            float2 y3 = fft_twid(make_float2(x1.x - x3.x, x1.y - x3.y), (j + q) * stepA, h, M, tw);
             z[p0] = make_float2(y0.x + y1.x, y0.y + y1.y);
-            z[p1] = cmulc(make_float2(y0.x - y1.x, y0.y - y1.y), wB);
+            z[p1] = fft_twid(make_float2(y0.x - y1.x, y0.y - y1.y), j * stepB, q, M, tw);
             z[p2] = make_float2(y2.x + y3.x, y2.y + y3.y);
-            z[p3] = cmulc(make_float2(y2.x - y3.x, y2.y - y3.y), wB);
+            z[p3] = fft_twid(make_float2(y2.x - y3.x, y2.y - y3.y), j * stepB, q, M, tw);
         }
         __syncthreads();
         h >>= 2;
     }
     if (h == 1) {
-        float2 w0 = tw[0];
         int half = M >> 1;
         for (int g = tid; g < 2 * half; g += WG) {
             float2 *z = (g < half) ? za : zb;
             int p = 2 * ((g < half) ? g : g - half);
             float2 a = z[p], b = z[p + 1];
             z[p] = make_float2(a.x + b.x, a.y + b.y);
-            z[p + 1] = cmulc(make_float2(a.x - b.x, a.y - b.y), w0);
+            z[p + 1] = make_float2(a.x - b.x, a.y - b.y);                   // (twiddle 1: spec v2 does not multiply)
         }
         __syncthreads();
     }
@@ -70,27 +85,25 @@ __device__ void fft1_dif(float2 *z, int M, const float2 *__restrict__ tw, int ti
             int p0 = (gg - j) * 4 + j;
             int p1 = p0 + q, p2 = p0 + h, p3 = p2 + q;
             float2 x0 = z[p0], x1 = z[p1], x2 = z[p2], x3 = z[p3];
-            float2 wA0 = tw[j * stepA], wA1 = tw[(j + q) * stepA], wB = tw[j * stepB];
             float2 y0 = make_float2(x0.x + x2.x, x0.y + x2.y);
-            float2 y2 = cmulc(make_float2(x0.x - x2.x, x0.y - x2.y), wA0);
+            float2 y2 = fft_twid(make_float2(x0.x - x2.x, x0.y - x2.y), j * stepA, h, M, tw);
             float2 y1 = make_float2(x1.x + x3.x, x1.y + x3.y);
-            float2 y3 = cmulc(make_float2(x1.x - x3.x, x1.y - x3.y), wA1);
+            float2 y3 = fft_twid(make_float2(x1.x - x3.x, x1.y - x3.y), (j + q) * stepA, h, M, tw);
             z[p0] = make_float2(y0.x + y1.x, y0.y + y1.y);
-            z[p1] = cmulc(make_float2(y0.x - y1.x, y0.y - y1.y), wB);
+            z[p1] = fft_twid(make_float2(y0.x - y1.x, y0.y - y1.y), j * stepB, q, M, tw);
             z[p2] = make_float2(y2.x + y3.x, y2.y + y3.y);
-            z[p3] = cmulc(make_float2(y2.x - y3.x, y2.y - y3.y), wB);
+            z[p3] = fft_twid(make_float2(y2.x - y3.x, y2.y - y3.y), j * stepB, q, M, tw);
         }
         __syncthreads();
         h >>= 2;
     }
     if (h == 1) {
-        float2 w0 = tw[0];
         int half = M >> 1;
         for (int g = tid; g < half; g += WG) {
             int p = 2 * g;
             float2 a = z[p], b = z[p + 1];
             z[p] = make_float2(a.x + b.x, a.y + b.y);
-            z[p + 1] = cmulc(make_float2(a.x - b.x, a.y - b.y), w0);
+            z[p + 1] = make_float2(a.x - b.x, a.y - b.y);                   // (twiddle 1: spec v2 does not multiply)
         }
         __syncthreads();
     }
@@ -112,21 +125,19 @@ __device__ void fftn_dif(float2 *z0, int nArr, int M, const float2 *__restrict__
             int p0 = (gg - j) * 4 + j;
             int p1 = p0 + q, p2 = p0 + h, p3 = p2 + q;
             float2 x0 = z[p0], x1 = z[p1], x2 = z[p2], x3 = z[p3];
-            float2 wA0 = tw[j * stepA], wA1 = tw[(j + q) * stepA], wB = tw[j * stepB];
             float2 y0 = make_float2(x0.x + x2.x, x0.y + x2.y);
-            float2 y2 = cmulc(make_float2(x0.x - x2.x, x0.y - x2.y), wA0);
+            float2 y2 = fft_twid(make_float2(x0.x - x2.x, x0.y - x2.y), j * stepA, h, M, tw);
             float2 y1 = make_float2(x1.x + x3.x, x1.y + x3.y);
-            float2 y3 = cmulc(make_float2(x1.x - x3.x, x1.y - x3.y), wA1);
+            float2 y3 = fft_twid(make_float2(x1.x - x3.x, x1.y - x3.y), (j + q) * stepA, h, M, tw);
             z[p0] = make_float2(y0.x + y1.x, y0.y + y1.y);
-            z[p1] = cmulc(make_float2(y0.x - y1.x, y0.y - y1.y), wB);
+            z[p1] = fft_twid(make_float2(y0.x - y1.x, y0.y - y1.y), j * stepB, q, M, tw);
             z[p2] = make_float2(y2.x + y3.x, y2.y + y3.y);
-            z[p3] = cmulc(make_float2(y2.x - y3.x, y2.y - y3.y), wB);
+            z[p3] = fft_twid(make_float2(y2.x - y3.x, y2.y - y3.y), j * stepB, q, M, tw);
         }
         __syncthreads();
         h >>= 2;
     }
     if (h == 1) {
-        float2 w0 = tw[0];
         int half = M >> 1;
         int hshift = 31 - __clz(half);
         for (int g = tid; g < nArr * half; g += WG) {
@@ -135,7 +146,7 @@ __device__ void fftn_dif(float2 *z0, int nArr, int M, const float2 *__restrict__
             float2 *z = z0 + a * M;
             float2 x = z[p], y = z[p + 1];
             z[p] = make_float2(x.x + y.x, x.y + y.y);
-            z[p + 1] = cmulc(make_float2(x.x - y.x, x.y - y.y), w0);
+            z[p + 1] = make_float2(x.x - y.x, x.y - y.y);                   // (twiddle 1: spec v2 does not multiply)
         }
         __syncthreads();
     }
@@ -159,25 +170,33 @@ __device__ void fftn_dif(float2 *z0, int nArr, int M, const float2 *__restrict__
 #define FFT_PADS(p, ps) ((p) + ((p) >> (ps)))
 #define FFT_PADDEDS(M, ps) ((M) + ((M) >> (ps)))
 
-// Packed binary32 arithmetic (v_pk_add_f32 / v_pk_mul_f32: both components of a complex number per instruction, each
-// component rounded exactly as the scalar instruction rounds it - no fusion, so the spec's operation order and results are
-// unchanged).  A radix-2 butterfly is 5 instructions instead of 10: sum, difference, two products (d * w.xx, d.yx * w.yy)
-// and one add whose high half is negated (m0 + m1, m2 - m3).
+// Packed binary32 arithmetic (both components of a complex number per instruction, each component rounded exactly as
+// the scalar instruction rounds it).  A general radix-2 butterfly is 4 instructions: sum, difference, v_pk_mul_f32
+// (d * w.xx) and v_pk_fma_f32 ((d.y, d.x) * (w.y, -w.y) + that): the spec's two products and two fused multiply-adds.
 typedef float fft_v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ fft_v2f fft_cmulc_pk(fft_v2f d, fft_v2f w) {      // d * conj(w), as cmulc
-    const fft_v2f p = d * __builtin_shufflevector(w, w, 0, 0);                                 // (d.x w.x, d.y w.x)
-    const fft_v2f q = __builtin_shufflevector(d, d, 1, 0) * __builtin_shufflevector(w, w, 1, 1);   // (d.y w.y, d.x w.y)
-    fft_v2f r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(p), "v"(q));                     // (p.x + q.x, p.y - q.y)
+    fft_v2f p, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(p) : "v"(d), "v"(w));                          // (d.x w.x, d.y w.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(d), "v"(w), "v"(p));   // (d.y w.y + p.x, d.x (-w.y) + p.y)
     return r;
 }
+__device__ __forceinline__ fft_v2f fft_cmulc_post_pk(fft_v2f d, fft_v2f w) {      // as cmulc_post: (Re, -Im) of d * conj(w)
+    fft_v2f p, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(p) : "v"(d), "v"(w));                          // (d.x w.x, d.y w.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(d), "v"(w), "v"(p));   // (d.y w.y + p.x, d.x w.y - p.y)
+    return r;
+}
+__device__ __forceinline__ fft_v2f fft_rot_mi(fft_v2f d) { const fft_v2f r = { d.y, -d.x }; return r; }      // d * (-i), exact
 
-template <int R>
+// LAST: the pass that ends at half-size 1 (a lane's points are adjacent, q = 1, j = 0): which of its butterflies have a
+// trivial twiddle is known at compile time.  In any other pass a stage of half-size <= 4 only occurs for 32-point
+// transforms (64-sample subblocks): lane selects there.
+template <int R, bool LAST, bool SEL = false>       // SEL: a pass that is not the last but reaches half-size <= 4
 __device__ __forceinline__ void fft_wave_pass(float2 *z, int M, int h, const float2 *__restrict__ tw, int lane, int ps) {
     constexpr int NP = 1 << R;
-#ifdef FFT_PACKED
     const int q = h >> (R - 1);                    // spacing of one lane's points
     const int stepA = M / (2 * h);
+#ifdef FFT_PACKED
     fft_v2f *zv = (fft_v2f *)z; const fft_v2f *twv = (const fft_v2f *)tw;
     for (int gg = lane; gg < (M >> R); gg += 64) {
         int j = gg & (q - 1);
@@ -192,18 +211,25 @@ __device__ __forceinline__ void fft_wave_pass(float2 *z, int M, int h, const flo
             for (int m = 0; m < NP; m++) {
                 if (m & half) continue;
                 int t = m & (half - 1);
-                const fft_v2f w = twv[(j + t * q) * (stepA << s)];
                 const fft_v2f a = x[m], b = x[m + half];
                 x[m] = a + b;
-                x[m + half] = fft_cmulc_pk(a - b, w);
+                const fft_v2f d = a - b;
+                if (LAST) {                            // half-size of the stage = half, twiddle index = t * M / (2 half)
+                    if (half <= 4 && t == 0) x[m + half] = d;
+                    else if (half <= 4 && 2 * t == half) x[m + half] = fft_rot_mi(d);
+                    else x[m + half] = fft_cmulc_pk(d, twv[t * (stepA << s)]);
+                } else {
+                    const int idx = (j + t * q) * (stepA << s);
+                    fft_v2f r = fft_cmulc_pk(d, twv[idx]);
+                    if (SEL) { if ((h >> s) <= 4) r = idx == 0 ? d : (idx * 4 == M ? fft_rot_mi(d) : r); }
+                    x[m + half] = r;
+                }
             }
         }
 #pragma unroll
         for (int m = 0; m < NP; m++) zv[FFT_PADS(p0 + m * q, ps)] = x[m];
     }
 #else
-    const int q = h >> (R - 1);                    // spacing of one lane's points
-    const int stepA = M / (2 * h);
     for (int gg = lane; gg < (M >> R); gg += 64) {
         int j = gg & (q - 1);
         int p0 = ((gg - j) << R) + j;
@@ -212,16 +238,14 @@ __device__ __forceinline__ void fft_wave_pass(float2 *z, int M, int h, const flo
         for (int m = 0; m < NP; m++) x[m] = z[FFT_PADS(p0 + m * q, ps)];
 #pragma unroll
         for (int s = 0; s < R; s++) {
-            constexpr int dummy = 0; (void)dummy;
             const int half = NP >> (s + 1);
 #pragma unroll
             for (int m = 0; m < NP; m++) {
                 if (m & half) continue;
                 int t = m & (half - 1);
-                float2 w = tw[(j + t * q) * (stepA << s)];
                 float2 a = x[m], b = x[m + half];
                 x[m] = make_float2(a.x + b.x, a.y + b.y);
-                x[m + half] = cmulc(make_float2(a.x - b.x, a.y - b.y), w);
+                x[m + half] = fft_twid(make_float2(a.x - b.x, a.y - b.y), (j + t * q) * (stepA << s), h >> s, M, tw);
             }
         }
 #pragma unroll
@@ -255,10 +279,18 @@ __device__ __forceinline__ void fft_wave_pass_ct(float2 *z, const float2 *__rest
             for (int m = 0; m < NP; m++) {
                 if (m & half) continue;
                 const int t = m & (half - 1);
-                const fft_v2f w = twv[(j + t * q) * (stepA << s)];
                 const fft_v2f a = x[m], b = x[m + half];
                 x[m] = a + b;
-                x[m + half] = fft_cmulc_pk(a - b, w);
+                const fft_v2f d = a - b;
+                constexpr int hs = H >> 0;                         // (half-size of the pass's first stage; stage s: hs >> s)
+                if (q == 1 && half <= 4 && t == 0) x[m + half] = d;                 // last pass: j = 0, half-size = half
+                else if (q == 1 && half <= 4 && 2 * t == half) x[m + half] = fft_rot_mi(d);
+                else {
+                    const int idx = (j + t * q) * (stepA << s);
+                    fft_v2f r = fft_cmulc_pk(d, twv[idx]);
+                    if (q != 1 && (hs >> s) <= 4) r = idx == 0 ? d : (idx * 4 == M ? fft_rot_mi(d) : r);
+                    x[m + half] = r;
+                }
             }
         }
 #pragma unroll
@@ -288,11 +320,27 @@ __device__ __forceinline__ void fft_wave_dif(float2 *z, int M, const float2 *__r
     while (rem > 0) {
         int passes = (rem + 3) >> 2;
         int r = (rem + passes - 1) / passes;       // 10 -> 4,3,3   9 -> 3,3,3   8 -> 4,4   5 -> 3,2
-        switch (r) {
-            case 4: fft_wave_pass<4>(z, M, h, tw, lane, ps); break;
-            case 3: fft_wave_pass<3>(z, M, h, tw, lane, ps); break;
-            case 2: fft_wave_pass<2>(z, M, h, tw, lane, ps); break;
-            default: fft_wave_pass<1>(z, M, h, tw, lane, ps); break;
+        if (rem == r) {                            // the last pass
+            switch (r) {
+                case 4: fft_wave_pass<4, true>(z, M, h, tw, lane, ps); break;
+                case 3: fft_wave_pass<3, true>(z, M, h, tw, lane, ps); break;
+                case 2: fft_wave_pass<2, true>(z, M, h, tw, lane, ps); break;
+                default: fft_wave_pass<1, true>(z, M, h, tw, lane, ps); break;
+            }
+        } else if ((h >> (r - 1)) <= 4) {          // (32-point transforms only: 3 + 2 stages)
+            switch (r) {
+                case 4: fft_wave_pass<4, false, true>(z, M, h, tw, lane, ps); break;
+                case 3: fft_wave_pass<3, false, true>(z, M, h, tw, lane, ps); break;
+                case 2: fft_wave_pass<2, false, true>(z, M, h, tw, lane, ps); break;
+                default: fft_wave_pass<1, false, true>(z, M, h, tw, lane, ps); break;
+            }
+        } else {
+            switch (r) {
+                case 4: fft_wave_pass<4, false>(z, M, h, tw, lane, ps); break;
+                case 3: fft_wave_pass<3, false>(z, M, h, tw, lane, ps); break;
+                case 2: fft_wave_pass<2, false>(z, M, h, tw, lane, ps); break;
+                default: fft_wave_pass<1, false>(z, M, h, tw, lane, ps); break;
+            }
         }
         h >>= r; rem -= r;
         FFT_WAVE_SYNC();

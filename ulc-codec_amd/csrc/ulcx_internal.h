@@ -104,6 +104,7 @@ struct UlcxEncCtx {
 
 struct UlcxDecCtx {
     int B, K, C, BS, lgBS, maxK;
+    int s0, s1;                          // streams [s0, s1) this launch works on (ulcx_dec_launch pipelines chunks of the batch)
     int slot;
     int dbgSkip;                         // timing experiments only (ULCX_DBG_SKIP)
     UlcxTables T;
@@ -175,7 +176,13 @@ struct UlcxEncAux {
     int *nXf;                            // out: transform chunk launches this call
 };
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, const UlcxEncAux &aux);
-int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev);
+#define ULCX_DEC_MAXCH 8
+struct UlcxDecAux {
+    hipStream_t side;                    // NULL: no pipelining
+    hipEvent_t evFork, *evScan;          // [ULCX_DEC_MAXCH]
+    int nChunks;
+};
+int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev, const UlcxDecAux &aux);
 size_t ulcx_dec_lds_bytes(int BS, int C, int fast, int twInLds);
 int ulcx_pack_launch(int nStreams, int nBlocks, int slotBytes, const uint8_t *d_slots, const int32_t *d_bits, uint8_t *d_payload,
                      long long stride, int32_t *d_payloadBytes, int32_t *d_maxBlock, hipStream_t st);
@@ -183,4 +190,11 @@ size_t ulcx_enc_xf_lds_bytes(int BS, int C);
 // FFT array padding of k_xf (ulcx_fft.h).  One complex per 8 makes every pass conflict-free but costs 2 KB of LDS at
 // BlockSize 2048 and with it the 4th workgroup per CU: measured 2.13 ms vs 1.88 ms with one per 16.
 __host__ __device__ static inline int ulcx_xf_pad_shift(int BS, int C) { (void)BS; (void)C; return 4; }
+// k_select_wave: candidate keys a lane keeps once the search window is small, and the LDS words of one wave's region
+// (masking levels + Bark levels first, the lanes' candidate lists later)
+#define ULCX_SEL_CAP 8
+#ifndef ULCX_SEL_CAND
+#define ULCX_SEL_CAND 128
+#endif
+__host__ __device__ static inline int ulcx_sel_lds_words(int BS) { int a = BS / 2 + 4 * ULCX_NBARK, b = ULCX_SEL_CAP * 64; return a > b ? a : b; }
 void ulcx_enc_finalize_keys(const UlcxEncCtx &c, hipStream_t st);

@@ -4,7 +4,7 @@
 // arguments:
 //   Bark band edges / per-line Bark position : libulc/ulcEncoder_Psyopt.c:109-116,141-143,198-205,237-239
 //                                              via libulc/ulcHelper.h:96-120
-//   DCT-IV / FFT twiddles, sine-window ramps : "fourier spec v1" (FormatSpecs.md:155)
+//   DCT-IV / FFT twiddles, sine-window ramps : "fourier spec v2" (FormatSpecs.md:155)
 // so that the device never needs sinhf/asinhf/cos/sin.
 #include <math.h>
 #include <stdarg.h>
