@@ -182,6 +182,18 @@ int  ulcx_decode_dev(ulcx_decoder *dec, const uint8_t *d_in, int slotBytes, int 
                      float *d_pcm, int32_t *d_bits, void *hipStream);
 int  ulcx_decode_host(ulcx_decoder *dec, const uint8_t *h_in, int slotBytes, int nBlocks,
                       float *h_pcm, int32_t *h_bits);
+/* One block of ONE stream per call, host pointers: what the drop-in ABI of section 1 does per ULC_EncodeBlock_* /
+ * ULC_DecodeBlock call (encoder / decoder created with nStreams = 1, maxBlocksPerCall = 1).  The call's whole launch
+ * sequence is captured into a HIP graph the first time (again when mode / parameters change) and replayed from pinned
+ * staging buffers with one synchronisation; when capture is not possible the same sequence is enqueued directly.
+ *   h_out     slot bytes (ulcx_encoder_slot_bytes)          stateOut  {WindowCtrl, NextWindowCtrl} and TransientFilter[3]
+ *                                                                     as the reference leaves them in its state struct
+ *                                                                     (ulcEncoder.h:57-64; BlockTransform.c:116-125)
+ *   lastSubBlockSize  ulcDecoder.h:24 / ulcDecoder.c:300 */
+int  ulcx_encode_block1(ulcx_encoder *enc, int mode, float param0, float param1, const float *h_pcm,
+                        uint8_t *h_out, int32_t *bits, float *cplx, int32_t stateOut[2], float transientFilter[3]);
+int  ulcx_decode_block1(ulcx_decoder *dec, const uint8_t *h_in, int nBytes, float *h_pcm, int32_t *bits, int32_t *lastSubBlockSize);
+
 /* PCM16 output: as ulcx_decode_dev, writing d_pcm16 [nStreams][nBlocks][BlockSize][nChan]
  * int16, converted on store exactly as the reference's WAV writer does with ULC_DecodeBlock's output
  * (tools/WavIO_Helper.c:9-13,56-63: lrintf(clamp(x * 2^15, -32768, 32767))). */

@@ -187,3 +187,60 @@ def test_decode_block_reads_exactly_the_block_and_matches_the_oracle():
     lib.ULC_DecoderState_Destroy(C.byref(st))
     assert np.array_equal(got.reshape(nblk * bs, ch).view(np.uint32), ref_pcm.view(np.uint32))
     libc.mprotect(base + 4 * PAGE, PAGE, 3)
+
+
+def test_state_fields_the_reference_updates_are_mirrored_back():
+    """The reference leaves WindowCtrl / NextWindowCtrl / TransientFilter (ulcEncoder_BlockTransform.c:116-125,
+    ulcEncoder_WindowControl.c:88-89,131) and LastSubBlockSize (ulcDecoder.c:300) in the caller's struct after every call;
+    so does the drop-in (the values are the device-resident state's, fetched with the block)."""
+    import ctypes as C
+    from ulc_testlib import _PATTERNS
+    lib = C.CDLL(os.path.join(ROOT, "ulc-codec_amd", "libulc_amd.so"))
+
+    class Enc(C.Structure):
+        _fields_ = [("RateHz", C.c_int), ("nChan", C.c_int), ("BlockSize", C.c_int), ("WindowCtrl", C.c_int), ("NextWindowCtrl", C.c_int),
+                    ("BlockComplexity", C.c_float), ("TransientFilter", C.c_float * 3), ("BufferData", C.c_void_p), ("SampleBuffer", C.c_void_p),
+                    ("TransformBuffer", C.c_void_p), ("TransformNoise", C.c_void_p), ("TransformFwdLap", C.c_void_p), ("TransformTemp", C.c_void_p),
+                    ("TransformIndex", C.c_void_p), ("TransientBuffer", C.c_void_p)]
+
+    class Dec(C.Structure):
+        _fields_ = [("nChan", C.c_int), ("BlockSize", C.c_int), ("LastSubBlockSize", C.c_int), ("BufferData", C.c_void_p),
+                    ("TransformBuffer", C.c_void_p), ("TransformTemp", C.c_void_p), ("TransformInvLap", C.c_void_p)]
+    f32p = C.POINTER(C.c_float)
+    lib.ULC_EncodeBlock_VBR.restype = C.c_void_p
+    lib.ULC_EncodeBlock_VBR.argtypes = [C.POINTER(Enc), f32p, C.POINTER(C.c_int), C.c_float]
+    lib.ULC_DecodeBlock.argtypes = [C.POINTER(Dec), f32p, C.c_void_p]
+    for ch, bs in ((2, 2048), (1, 1024)):
+        rate, nblk = 44100, 14
+        pcm = synth_pcm(7, nblk * bs, ch, rate, transient=True, seed=2)
+        ref = oracle_encode_debug(pcm, bs, rate, 0, 50.0)
+        e = Enc(); e.RateHz = rate; e.nChan = ch; e.BlockSize = bs
+        assert lib.ULC_EncoderState_Init(C.byref(e)) == 1
+        d = Dec(); d.nChan = ch; d.BlockSize = bs
+        assert lib.ULC_DecoderState_Init(C.byref(d)) == 1
+        size = C.c_int()
+        out = np.zeros(bs * ch, np.float32)
+        tf_prev = None
+        for k in range(nblk):
+            src = np.ascontiguousarray(pcm[k * bs:(k + 1) * bs].reshape(-1))
+            p = lib.ULC_EncodeBlock_VBR(C.byref(e), src.ctypes.data_as(f32p), C.byref(size), 50.0)
+            assert size.value == ref["bits"][k]
+            assert C.string_at(p, size.value // 8) == ref["out"][k, :size.value // 8].tobytes()
+            assert e.WindowCtrl == ref["wc"][k], f"call {k}: WindowCtrl {e.WindowCtrl:#x}, oracle {ref['wc'][k]:#x}"
+            if k + 1 < nblk:
+                assert e.NextWindowCtrl == ref["wc"][k + 1], f"call {k}: NextWindowCtrl {e.NextWindowCtrl:#x}, oracle's next block {ref['wc'][k + 1]:#x}"
+            assert e.BlockComplexity == ref["cplx"][k]
+            tf = tuple(e.TransientFilter)
+            assert all(np.isfinite(tf)) and (k == 0 or tf != tf_prev), "TransientFilter is the running filter state: it moves with the signal"
+            tf_prev = tf
+            blk = C.string_at(p, size.value // 8) + bytes(16)
+            assert lib.ULC_DecodeBlock(C.byref(d), out.ctypes.data_as(f32p), blk) == size.value
+            pat = _PATTERNS[(e.WindowCtrl >> 4) & 15]
+            last = bs
+            while True:
+                last = bs >> (pat & 7)
+                if last == bs: break                        # ulcDecoder.c:242-245
+                pat >>= 4
+                if not pat: break
+            assert d.LastSubBlockSize == last, f"call {k}: LastSubBlockSize {d.LastSubBlockSize}, expected {last} for WindowCtrl {e.WindowCtrl:#x}"
+        lib.ULC_EncoderState_Destroy(C.byref(e)); lib.ULC_DecoderState_Destroy(C.byref(d))

@@ -13,7 +13,7 @@
 #include "../../include/ulc_amd.h"
 
 struct enc_priv { ulcx_encoder *enc; unsigned char *out; int slot; };
-struct dec_priv { ulcx_decoder *dec; unsigned char *in; int slot; };
+struct dec_priv { ulcx_decoder *dec; int slot; };
 
 /* HIP device the drop-in states live on: ULC_AMD_DEVICE (ordinal), default 0 */
 static int dropin_device(void) {
@@ -61,8 +61,8 @@ void ULC_EncoderState_Destroy(struct ULC_EncoderState_t *State) {
 
 static const void *encode_one(struct ULC_EncoderState_t *State, const float *Src, int *Size, int mode, float p0, float p1) {
     struct enc_priv *p = (struct enc_priv *)State->BufferData;
-    int32_t bits = 0, wc = 0; float cplx = 0.0f;
-    int rc = ulcx_encode_host(p->enc, mode, p0, p1, Src, 1, p->out, &bits, &wc, &cplx);
+    int32_t bits = 0, st[2] = { 0, 0x10 }; float cplx = 0.0f, tf[3] = { 0.0f, 0.0f, 0.0f };
+    int rc = ulcx_encode_block1(p->enc, mode, p0, p1, Src, p->out, &bits, &cplx, st, tf);
     if (rc != ULCX_OK) {
         /* The reference cannot fail here and its ABI has no way to say so; its tools never look at *Size
          * (tools/ulcEncodeTool.c:157-168 write (Size+7)/8 bytes and carry on), so any "empty block" convention would leave a
@@ -71,7 +71,10 @@ static const void *encode_one(struct ULC_EncoderState_t *State, const float *Src
         fprintf(stderr, "libulc_amd: encode failed (%s): the ULC_EncodeBlock_* ABI cannot report an error - aborting\n", ulcx_last_error());
         abort();
     }
-    State->WindowCtrl = wc;
+    /* the fields the reference leaves behind in the caller's struct (ulcEncoder_BlockTransform.c:116-125, ulcEncoder_WindowControl.c:88-89,131) */
+    State->WindowCtrl = st[0];
+    State->NextWindowCtrl = st[1];
+    State->TransientFilter[0] = tf[0]; State->TransientFilter[1] = tf[1]; State->TransientFilter[2] = tf[2];
     State->BlockComplexity = cplx;
     if (Size) *Size = bits;
     return p->out;
@@ -103,8 +106,6 @@ int ULC_DecoderState_Init(struct ULC_DecoderState_t *State) {
     /* a block is at most 4 nybbles per coefficient + header; the caller's buffer is read
      * only up to the end of the block, so copy that bound (ulcDecoder.h:54) */
     p->slot = 2 * State->nChan * State->BlockSize + 16;
-    p->in = (unsigned char *)malloc((size_t)p->slot);
-    if (!p->in) { ulcx_decoder_destroy(dec); free(p); return -1; }
     State->BufferData = p;
     State->LastSubBlockSize = 0;
     return 1;
@@ -113,7 +114,6 @@ void ULC_DecoderState_Destroy(struct ULC_DecoderState_t *State) {
     struct dec_priv *p = (struct dec_priv *)State->BufferData;
     if (!p) return;
     ulcx_decoder_destroy(p->dec);
-    free(p->in);
     free(p);
     State->BufferData = NULL;
 }
@@ -163,11 +163,10 @@ done:
  * the block's extent is found on the host first, exactly those bytes are staged (the rest of the staging slot is zero). */
 int ULC_DecodeBlock(struct ULC_DecoderState_t *State, float *DstData, const void *SrcBuffer) {
     struct dec_priv *p = (struct dec_priv *)State->BufferData;
-    int32_t bits = 0;
+    int32_t bits = 0, lastSub = State->LastSubBlockSize;
     const int ext = ulcx_block_extent_bytes(SrcBuffer, State->nChan, State->BlockSize, p->slot);
-    memcpy(p->in, SrcBuffer, (size_t)ext);
-    memset(p->in + ext, 0, (size_t)(p->slot - ext));
-    int rc = ulcx_decode_host(p->dec, p->in, p->slot, 1, DstData, &bits);
+    int rc = ulcx_decode_block1(p->dec, (const unsigned char *)SrcBuffer, ext, DstData, &bits, &lastSub);
     if (rc != ULCX_OK) { fprintf(stderr, "libulc_amd: decode failed: %s\n", ulcx_last_error()); return 0; }
+    State->LastSubBlockSize = lastSub;                       /* ulcDecoder.c:300 */
     return bits;
 }

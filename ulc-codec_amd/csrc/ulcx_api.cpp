@@ -27,6 +27,11 @@ struct ulcx_encoder {
     int nWcLad, nXfLad, wcLad[ULCX_WC_MAXCH], xfLad[ULCX_XF_MAXCH];   // ULCX_WC_LADDER / ULCX_XF_LADDER: step sizes in blocks
     // staging for the host-pointer API
     float *d_pcm; uint8_t *d_out; int32_t *d_bits, *d_wc; float *d_cplx;
+    // single-block path (ulcx_encode_block1): own stream, pinned staging, the captured launch sequence
+    struct Block1Meta { int32_t bits, wc; float cplx; int32_t pad; UlcxWcState wcs; };
+    hipStream_t b1Stream; hipGraph_t b1Graph; hipGraphExec_t b1Exec; bool b1Init, b1Graphed, b1NoGraph;
+    int b1Mode; float b1P0, b1P1;
+    float *pinIn; uint8_t *pinOut; Block1Meta *pinMeta;
 };
 struct ulcx_decoder {
     int device, B, C, BS, maxK;
@@ -38,6 +43,9 @@ struct ulcx_decoder {
     uint8_t *d_in; size_t d_in_bytes; float *d_pcm; int32_t *d_bits;
     uint8_t *d_pay; int32_t *d_payBytes; long long payStride;     // resident packed payloads (ulcx_decoder_upload_payload)
     hipStream_t side; hipEvent_t evFork, evScan[ULCX_DEC_MAXCH]; bool sideOk; int nChunks;   // walk / synthesis pipeline (ULCX_DEC_PIPE chunks)
+    // single-block path (ulcx_decode_block1)
+    hipStream_t b1Stream; hipGraph_t b1Graph; hipGraphExec_t b1Exec; bool b1Init, b1Graphed, b1NoGraph; int b1Slot;
+    uint8_t *pinIn; float *pinPcm; int32_t *pinMeta;
 };
 
 extern "C" int ulcx_device_count(void) {
@@ -86,6 +94,13 @@ static void cleanup(ulcx_encoder *e) {
     for (void *p : e->allocs) hipFree(p);
     if (e->tables) hipFree(e->tables);
     if (e->evOk) for (auto &v : e->ev) hipEventDestroy(v);
+    if (e->b1Init) {
+        if (e->b1Graphed) { hipGraphExecDestroy(e->b1Exec); hipGraphDestroy(e->b1Graph); }
+        hipStreamDestroy(e->b1Stream);
+        if (e->pinIn) hipHostFree(e->pinIn);
+        if (e->pinOut) hipHostFree(e->pinOut);
+        if (e->pinMeta) hipHostFree(e->pinMeta);
+    }
     if (e->sideOk) { hipStreamDestroy(e->side); hipEventDestroy(e->evFork); hipEventDestroy(e->evJoin); hipEventDestroy(e->evFork2); for (auto &v : e->evWC) hipEventDestroy(v); for (auto &v : e->evXf) hipEventDestroy(v); hipStreamDestroy(e->side2); hipStreamDestroy(e->side3); hipStreamDestroy(e->side4); for (auto &v : e->evE) hipEventDestroy(v); }
     delete e;
 }
@@ -117,6 +132,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     e->device = device; e->B = nStreams; e->C = nChan; e->BS = BlockSize; e->rate = RateHz; e->maxK = maxBlocksPerCall;
     e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->timing = true; e->lastK = 0; e->sideOk = false; e->side = nullptr; e->keysFinal = false;
     e->d_pcm = nullptr; e->d_out = nullptr; e->d_bits = nullptr; e->d_wc = nullptr; e->d_cplx = nullptr;
+    e->b1Init = e->b1Graphed = e->b1NoGraph = false; e->pinIn = nullptr; e->pinOut = nullptr; e->pinMeta = nullptr;
     UlcxEncCtx &c = e->ctx;
     memset(&c, 0, sizeof(c));
     c.B = nStreams; c.C = nChan; c.BS = BlockSize; c.lgBS = ilog2i(BlockSize); c.maxK = maxBlocksPerCall; c.K = 0;
@@ -309,6 +325,70 @@ extern "C" int ulcx_encode_host(ulcx_encoder *e, int mode, float p0, float p1, c
     return ULCX_OK;
 }
 
+// One block of one stream per call (the drop-in ABI): include/ulc_amd.h.  The launch sequence of ulcx_encode_dev - side
+// streams and their event fork/joins included - is captured once into a graph together with the copies between the pinned
+// staging buffers and the device; a call is then memcpy, one graph launch, one synchronisation, memcpy.
+extern "C" int ulcx_encode_block1(ulcx_encoder *e, int mode, float p0, float p1, const float *h_pcm,
+                                  uint8_t *h_out, int32_t *bits, float *cplx, int32_t stateOut[2], float transientFilter[3]) {
+    if (!e || !h_pcm || !h_out || e->B != 1 || e->maxK != 1) { ulcx_set_error("ulcx_encode_block1: needs an encoder of one stream, one block per call"); return ULCX_ERR_ARG; }
+    CKR(hipSetDevice(e->device));
+    const size_t cb = (size_t)e->C * e->BS, slot = (size_t)e->ctx.slot;
+    if (!e->b1Init) {
+        int rc;
+        if (!e->d_pcm) {
+            if ((rc = dalloc(e->allocs, &e->d_pcm, cb, false))) return rc;
+            if ((rc = dalloc(e->allocs, &e->d_out, slot, false))) return rc;
+            if ((rc = dalloc(e->allocs, &e->d_bits, 1, false))) return rc;
+            if ((rc = dalloc(e->allocs, &e->d_wc, 1, false))) return rc;
+            if ((rc = dalloc(e->allocs, &e->d_cplx, 1, false))) return rc;
+        }
+        CKR(hipStreamCreateWithFlags(&e->b1Stream, hipStreamNonBlocking));
+        e->b1Init = true;
+        CKR(hipHostMalloc((void **)&e->pinIn, sizeof(float) * cb, hipHostMallocDefault));
+        CKR(hipHostMalloc((void **)&e->pinOut, slot, hipHostMallocDefault));
+        CKR(hipHostMalloc((void **)&e->pinMeta, sizeof(*e->pinMeta), hipHostMallocDefault));
+        e->timing = false;                                 // (per-kernel events cannot be captured, and nobody reads them here)
+    }
+    auto enqueue = [&]() -> int {
+        CKR(hipMemcpyAsync(e->d_pcm, e->pinIn, sizeof(float) * cb, hipMemcpyHostToDevice, e->b1Stream));
+        int rc = ulcx_encode_dev(e, mode, p0, p1, e->d_pcm, 1, e->d_out, e->d_bits, e->d_wc, e->d_cplx, e->b1Stream);
+        if (rc) return rc;
+        CKR(hipMemcpyAsync(e->pinOut, e->d_out, slot, hipMemcpyDeviceToHost, e->b1Stream));
+        CKR(hipMemcpyAsync(&e->pinMeta->bits, e->d_bits, sizeof(int32_t), hipMemcpyDeviceToHost, e->b1Stream));
+        CKR(hipMemcpyAsync(&e->pinMeta->wc, e->d_wc, sizeof(int32_t), hipMemcpyDeviceToHost, e->b1Stream));
+        CKR(hipMemcpyAsync(&e->pinMeta->cplx, e->d_cplx, sizeof(float), hipMemcpyDeviceToHost, e->b1Stream));
+        CKR(hipMemcpyAsync(&e->pinMeta->wcs, e->ctx.wcs, sizeof(UlcxWcState), hipMemcpyDeviceToHost, e->b1Stream));
+        return ULCX_OK;
+    };
+    memcpy(e->pinIn, h_pcm, sizeof(float) * cb);
+    if (e->b1Graphed && (e->b1Mode != mode || e->b1P0 != p0 || e->b1P1 != p1)) {          // the parameters are part of the captured kernels' arguments
+        hipGraphExecDestroy(e->b1Exec); hipGraphDestroy(e->b1Graph); e->b1Graphed = false;
+    }
+    if (!e->b1Graphed && !e->b1NoGraph) {
+        bool ok = hipStreamBeginCapture(e->b1Stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            const int rc = enqueue();
+            hipGraph_t g = nullptr;
+            const hipError_t ee = hipStreamEndCapture(e->b1Stream, &g);
+            ok = (rc == ULCX_OK) && ee == hipSuccess && g != nullptr;
+            if (ok) ok = hipGraphInstantiate(&e->b1Exec, g, nullptr, nullptr, 0) == hipSuccess;
+            if (ok) { e->b1Graph = g; e->b1Graphed = true; e->b1Mode = mode; e->b1P0 = p0; e->b1P1 = p1; }
+            else if (g) hipGraphDestroy(g);
+        }
+        if (!ok) { (void)hipGetLastError(); e->b1NoGraph = true; }                         // direct launches from here on
+    }
+    if (e->b1Graphed) CKR(hipGraphLaunch(e->b1Exec, e->b1Stream));
+    else { int rc = enqueue(); if (rc) return rc; }
+    CKR(hipStreamSynchronize(e->b1Stream));
+    const int32_t nb = e->pinMeta->bits;
+    memcpy(h_out, e->pinOut, (nb > 0 && (size_t)(nb + 7) / 8 <= slot) ? (size_t)(nb + 7) / 8 : slot);
+    if (bits) *bits = nb;
+    if (cplx) *cplx = e->pinMeta->cplx;
+    if (stateOut) { stateOut[0] = e->pinMeta->wcs.wcPrev; stateOut[1] = e->pinMeta->wcs.wcCur; }     // WindowCtrl of this block, NextWindowCtrl
+    if (transientFilter) for (int i = 0; i < 3; i++) transientFilter[i] = e->pinMeta->wcs.tf[i];
+    return ULCX_OK;
+}
+
 extern "C" int ulcx_encoder_debug_fetch(ulcx_encoder *e, int nBlocks, float *h_coef, float *h_noise, float *h_keys, uint8_t *h_keep, int32_t *h_nout) {
     if (!e || nBlocks < 1 || nBlocks > e->maxK) return ULCX_ERR_ARG;
     CKR(hipSetDevice(e->device));
@@ -379,6 +459,13 @@ static void cleanup(ulcx_decoder *e) {
     if (e->tables) hipFree(e->tables);
     if (e->evOk) for (auto &v : e->ev) hipEventDestroy(v);
     if (e->sideOk) { hipStreamDestroy(e->side); hipEventDestroy(e->evFork); for (auto &v : e->evScan) hipEventDestroy(v); }
+    if (e->b1Init) {
+        if (e->b1Graphed) { hipGraphExecDestroy(e->b1Exec); hipGraphDestroy(e->b1Graph); }
+        hipStreamDestroy(e->b1Stream);
+        if (e->pinIn) hipHostFree(e->pinIn);
+        if (e->pinPcm) hipHostFree(e->pinPcm);
+        if (e->pinMeta) hipHostFree(e->pinMeta);
+    }
     delete e;
 }
 static int dec_reset_state(ulcx_decoder *e) {
@@ -435,6 +522,7 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->timing = true;
     e->d_in = nullptr; e->d_in_bytes = 0; e->d_pcm = nullptr; e->d_bits = nullptr; e->d_pay = nullptr; e->d_payBytes = nullptr; e->payStride = 0;
     e->sideOk = false; e->side = nullptr; e->nChunks = 1;
+    e->b1Init = e->b1Graphed = e->b1NoGraph = false; e->pinIn = nullptr; e->pinPcm = nullptr; e->pinMeta = nullptr; e->b1Slot = 0;
     UlcxDecCtx &c = e->ctx;
     memset(&c, 0, sizeof(c));
     c.B = nStreams; c.C = nChan; c.BS = BlockSize; c.lgBS = ilog2i(BlockSize); c.maxK = maxBlocksPerCall;
@@ -476,10 +564,10 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
         if (hipMemcpy(dj, jt.data(), sizeof(uint32_t) * jt.size(), hipMemcpyHostToDevice) != hipSuccess) { ulcx_set_error("hipMemcpy(rng tables)"); cleanup(e); return ULCX_ERR_HIP; }
         c.jumpT = dj;
     }
-    {   // side stream of the walk / synthesis pipeline; ULCX_DEC_PIPE=n chunks (1 = off; default 4), ULCX_ASYNC_FB=0: no side streams at all
+    {   // side stream of the walk / synthesis pipeline; ULCX_DEC_PIPE=n chunks (default 1 = off), ULCX_ASYNC_FB=0: no side streams at all
         const char *fb = getenv("ULCX_ASYNC_FB");
         const char *pv = getenv("ULCX_DEC_PIPE");
-        int n = pv ? atoi(pv) : 4;
+        int n = pv ? atoi(pv) : 1;                             // default off: measured 1.31 / 1.45 / 1.54 / 2.6 ms per decode for 1 / 2 / 4 / 8 chunks
         if (n < 1) n = 1;
         if (n > ULCX_DEC_MAXCH) n = ULCX_DEC_MAXCH;
         if (!(fb && fb[0] == '0') && n > 1) {
@@ -543,6 +631,56 @@ extern "C" int ulcx_decode_host(ulcx_decoder *e, const uint8_t *h_in, int slotBy
     CKR(hipMemcpy(h_bits, e->d_bits, sizeof(int32_t) * NB, hipMemcpyDeviceToHost));
     return ULCX_OK;
 }
+extern "C" int ulcx_decode_block1(ulcx_decoder *e, const uint8_t *h_in, int nBytes, float *h_pcm, int32_t *bits, int32_t *lastSubBlockSize) {
+    if (!e || !h_in || !h_pcm || nBytes < 1 || e->B != 1 || e->maxK != 1) { ulcx_set_error("ulcx_decode_block1: needs a decoder of one stream, one block per call"); return ULCX_ERR_ARG; }
+    CKR(hipSetDevice(e->device));
+    const size_t cb = (size_t)e->C * e->BS;
+    const int slot = 2 * e->C * e->BS + 16;                       // the largest block
+    if (nBytes > slot) nBytes = slot;
+    if (!e->b1Init) {
+        int rc;
+        if (!e->d_in || e->d_in_bytes < (size_t)slot + 16) { if ((rc = dalloc(e->allocs, &e->d_in, (size_t)slot + 16, true))) return rc; e->d_in_bytes = (size_t)slot + 16; }
+        if (!e->d_pcm) { if ((rc = dalloc(e->allocs, &e->d_pcm, cb, false))) return rc; if ((rc = dalloc(e->allocs, &e->d_bits, 1, false))) return rc; }
+        CKR(hipStreamCreateWithFlags(&e->b1Stream, hipStreamNonBlocking));
+        e->b1Init = true; e->b1Slot = slot;
+        CKR(hipHostMalloc((void **)&e->pinIn, (size_t)slot, hipHostMallocDefault));
+        CKR(hipHostMalloc((void **)&e->pinPcm, sizeof(float) * cb, hipHostMallocDefault));
+        CKR(hipHostMalloc((void **)&e->pinMeta, 2 * sizeof(int32_t), hipHostMallocDefault));
+        e->timing = false;
+    }
+    auto enqueue = [&]() -> int {
+        CKR(hipMemcpyAsync(e->d_in, e->pinIn, (size_t)slot, hipMemcpyHostToDevice, e->b1Stream));
+        int rc = ulcx_decode_dev(e, e->d_in, slot, 1, e->d_pcm, e->d_bits, e->b1Stream);
+        if (rc) return rc;
+        CKR(hipMemcpyAsync(e->pinPcm, e->d_pcm, sizeof(float) * cb, hipMemcpyDeviceToHost, e->b1Stream));
+        CKR(hipMemcpyAsync(&e->pinMeta[0], e->d_bits, sizeof(int32_t), hipMemcpyDeviceToHost, e->b1Stream));
+        CKR(hipMemcpyAsync(&e->pinMeta[1], e->ctx.lastSub, sizeof(int32_t), hipMemcpyDeviceToHost, e->b1Stream));
+        return ULCX_OK;
+    };
+    memcpy(e->pinIn, h_in, (size_t)nBytes);
+    memset(e->pinIn + nBytes, 0, (size_t)(slot - nBytes));         // (only the block's own bytes are the caller's: the rest of the slot reads as zero)
+    if (!e->b1Graphed && !e->b1NoGraph) {
+        bool ok = hipStreamBeginCapture(e->b1Stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            const int rc = enqueue();
+            hipGraph_t g = nullptr;
+            const hipError_t ee = hipStreamEndCapture(e->b1Stream, &g);
+            ok = (rc == ULCX_OK) && ee == hipSuccess && g != nullptr;
+            if (ok) ok = hipGraphInstantiate(&e->b1Exec, g, nullptr, nullptr, 0) == hipSuccess;
+            if (ok) { e->b1Graph = g; e->b1Graphed = true; }
+            else if (g) hipGraphDestroy(g);
+        }
+        if (!ok) { (void)hipGetLastError(); e->b1NoGraph = true; }
+    }
+    if (e->b1Graphed) CKR(hipGraphLaunch(e->b1Exec, e->b1Stream));
+    else { int rc = enqueue(); if (rc) return rc; }
+    CKR(hipStreamSynchronize(e->b1Stream));
+    memcpy(h_pcm, e->pinPcm, sizeof(float) * cb);
+    if (bits) *bits = e->pinMeta[0];
+    if (lastSubBlockSize) *lastSubBlockSize = e->pinMeta[1];
+    return ULCX_OK;
+}
+
 // ---------------------------------------------------------------------------
 // .ulc container + packed streams (tools/ulc_Helper.h:10-20, ulcEncodeTool.c:92-100,160-195, ulcDecodeTool.c:73-80,123-166)
 // ---------------------------------------------------------------------------

@@ -507,6 +507,105 @@ __device__ __forceinline__ float win_apply(float x, int i, int S, int aL, int ov
     return (n < aR) ? x : (n < aR + ov) ? x * fall[n - aR] : 0.0f;
 }
 
+// The steady state of the headline geometry, every size a compile-time constant: stereo, BlockSize 2048, an un-decimated
+// block between two full-overlap neighbours (PCM16 ingest: from the call's third block on).  Same arithmetic, same
+// order as the general body of k_xf below (which documents it) - only the index arithmetic, the loop bounds and the window
+// selects fold away, and the four 1024-point transforms run the compile-time passes (fft_wave_dif_ct).
+template <typename IN>
+__device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int s, int k, int blk, int tid) {
+    constexpr int BS = 2048, S = 2048, M = 1024, PS = 4, Mp = FFT_PADDEDS(M, PS);
+    static_assert(WG == 256, "two fold / epilogue trips per thread");
+    float2 *z = (float2 *)lds;
+    float2 *twl = (float2 *)(lds + 4 * FFT_PADDEDS(BS, PS));
+    float2 *zc0 = z, *zs0 = z + Mp, *zc1 = z + 2 * Mp, *zs1 = z + 3 * Mp;
+    const float2 *pre = c.T.pre[0];
+    const float *rise = c.T.winRise + S, *fall = c.T.winFall + S;
+    // frame = [(k-2) BS, k BS): its first half (positions < S) is block k-2, its second half block k-1 of the stream's
+    // timeline; blocks -2 and -1 are the two the encoder keeps from the previous call (c.hist, always float)
+    const IN *pcmS = pcm_base<IN>(c) + (size_t)s * c.K * BS * 2;
+    const IN *frameLo = pcmS + (ptrdiff_t)(k - 2) * BS * 2, *frameHi = frameLo;       // (indexed with the frame position)
+    if constexpr (std::is_same<IN, float>::value) {
+        const float *histS = c.hist + (size_t)s * 2 * BS * 2;
+        if (k < 2) frameLo = histS + (size_t)k * BS * 2;                      // block k-2 = history block k
+        if (k < 1) frameHi = histS;                                            // block k-1 = history block 1: (hist + BS*2) - S*2
+    }
+#pragma unroll
+    for (int i = tid; i < M / 2; i += WG) twl[i] = c.T.tw[0][i];
+#pragma unroll
+    for (int jj0 = 0; jj0 < M / 2; jj0 += WG) {
+        const int jj = jj0 + tid;
+        const int iA = 2 * jj, iB = S - 2 - 2 * jj, iC = S + 2 * jj, iD = 2 * S - 2 - 2 * jj;
+        const int ip[4] = { iA, iB, iC, iD };
+        float2 xs[8];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float4 v = ld4((r < 2 ? frameLo : frameHi) + (size_t)ip[r] * 2);
+            const float2 fw = (r < 2) ? *(const float2 *)(rise + ip[r]) : *(const float2 *)(fall + ip[r] - S);     // (even positions: 8-byte aligned)
+            xs[2 * r]     = make_float2(((v.x + v.y) * 0.5f) * fw.x, ((v.x - v.y) * 0.5f) * fw.x);
+            xs[2 * r + 1] = make_float2(((v.z + v.w) * 0.5f) * fw.y, ((v.z - v.w) * 0.5f) * fw.y);
+        }
+#pragma unroll
+        for (int hsel = 0; hsel < 2; hsel++) {
+            const int n = hsel ? M / 2 + jj : M / 2 - 1 - jj;
+            const float2 lbv = hsel ? xs[0] : xs[1], lav = hsel ? xs[3] : xs[2];
+            const float2 rav = hsel ? xs[4] : xs[5], rbv = hsel ? xs[7] : xs[6];
+            const float2 P = pre[n];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const float ra = q ? rav.y : rav.x, rb = q ? rbv.y : rbv.x, la = q ? lav.y : lav.x, lb = q ? lbv.y : lbv.x;
+                const float vr = ra + rb, wr = ra - rb;
+                const float vl = la - lb, wl = lb + la;
+                const float v1 = hsel ? vl : vr, v2 = hsel ? vr : vl;
+                const float w1 = hsel ? wl : wr, w2 = hsel ? wr : wl;
+                float2 *zc = q ? zc1 : zc0, *zs = q ? zs1 : zs0;
+                zc[FFT_PADS(n, PS)] = cmulc(make_float2(v1, v2), P);
+                zs[FFT_PADS(n, PS)] = cmulc(make_float2(w2, w1), P);
+            }
+        }
+    }
+    __syncthreads();
+    fft_wave_dif_ct<M, PS>(z + __builtin_amdgcn_readfirstlane(tid >> 6) * Mp, twl, tid & 63);
+    __syncthreads();
+    float *coefO = c.coef + (size_t)blk * (2 * BS);
+    float *nsumO = c.nsum + (size_t)blk * BS;
+    float *ampO = c.amp2 + (size_t)blk * (BS / 2);
+    constexpr float norm = 2.0f / S;
+    int nnz = 0;
+#pragma unroll
+    for (int kk0 = 0; kk0 < M / 2; kk0 += WG) {
+        const int kk = kk0 + tid;
+        const int k1 = kk, k2 = M - 1 - kk;
+        const int r1 = (int)(__brev((unsigned)k1) >> 22), r2 = (int)(__brev((unsigned)k2) >> 22);
+        const float2 P1 = pre[k1], P2 = pre[k2];
+        const fft_v2f Pv1 = { P1.x, P1.y }, Pv2 = { P2.x, P2.y };
+        float am1 = 0.0f, am2 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const float2 *zc = q ? zc1 : zc0, *zs = q ? zs1 : zs0;
+            auto cm = [](float2 d, fft_v2f w) { const fft_v2f dv = { d.x, d.y }; const fft_v2f r = fft_cmulc_post_pk(dv, w); return make_float2(r.x, r.y); };
+            const float2 yc1 = cm(zc[FFT_PADS(r1, PS)], Pv1), yc2 = cm(zc[FFT_PADS(r2, PS)], Pv2);
+            const float2 ys1 = cm(zs[FFT_PADS(r1, PS)], Pv1), ys2 = cm(zs[FFT_PADS(r2, PS)], Pv2);
+            const float mdct[4] = { yc1.x, yc2.y, yc2.x, yc1.y };
+            const float mdst[4] = { ys1.x, ys2.y, ys2.x, ys1.y };
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const float re0 = mdct[2*p] * norm,   im0 = mdst[2*p] * norm;
+                const float re1 = mdct[2*p+1] * norm, im1 = mdst[2*p+1] * norm;
+                const float re0s = re0 * re0, im0s = im0 * im0, re1s = re1 * re1, im1s = im1 * im1;
+                const float a0 = re0s + im0s, a1 = re1s + im1s;
+                nnz += (fabsf(re0) < 0.5f * ULCX_COEF_EPS) ? 0 : 1;
+                nnz += (fabsf(re1) < 0.5f * ULCX_COEF_EPS) ? 0 : 1;
+                const int j = p ? k2 : k1;
+                stnt((float2 *)(coefO + q * BS + 2 * j), make_float2(re0, re1));
+                stnt(nsumO + q * (BS / 2) + j, a0 + a1);
+                if (p) { am2 += a0; am2 += a1; } else { am1 += a0; am1 += a1; }
+            }
+        }
+        ampO[k1] = am1; ampO[k2] = am2;
+    }
+    return nnz;
+}
+
 // ST: stereo instantiation (C = 2 as a compile-time constant: one channel pair, no per-pair branches)
 template <bool ST, typename IN>
 __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
@@ -552,6 +651,14 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
     int nnz = 0;
     __syncthreads();
 
+    // the steady state of the headline geometry takes the all-constants path (xf_fast_2048)
+    const bool fastBlk = ST && BS == 2048 && (k >= 2 || std::is_same<IN, float>::value) && (ulcx_pattern(wc) >> 4) == 0 && ovFirst == BS && nextOv >= BS
+#ifdef XF_NO_FAST
+                         && false
+#endif
+                         ;
+    if (fastBlk) nnz = xf_fast_2048<IN>(c, lds, s, k, blk, tid);
+    else
     for (int ch0 = 0; ch0 < C; ch0 += 2) {             // one M/S pair (or a trailing single channel) at a time
         const int nch = ST ? 2 : ((ch0 + 1 < C) ? 2 : 1);
         unsigned pat = ulcx_pattern(wc);
