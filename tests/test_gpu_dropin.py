@@ -234,7 +234,8 @@ def test_state_fields_the_reference_updates_are_mirrored_back():
             assert all(np.isfinite(tf)) and (k == 0 or tf != tf_prev), "TransientFilter is the running filter state: it moves with the signal"
             tf_prev = tf
             blk = C.string_at(p, size.value // 8) + bytes(16)
-            assert lib.ULC_DecodeBlock(C.byref(d), out.ctypes.data_as(f32p), blk) == size.value
+            used = lib.ULC_DecodeBlock(C.byref(d), out.ctypes.data_as(f32p), blk)        # bits consumed: nybble-granular (ulcDecodeTool.c:153 rounds up)
+            assert 0 < used <= size.value and (used + 7) // 8 * 8 == size.value
             pat = _PATTERNS[(e.WindowCtrl >> 4) & 15]
             last = bs
             while True:

@@ -168,7 +168,8 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
         while (ring < most) ring *= 2;
         const char *bu = getenv("ULCX_BARK_UNIFORM");                    // =0: k_nbark for every block (the round-1 path)
         c.barkRing = (ring <= 8 && N % 32 == 0 && !(bu && bu[0] == '0')) ? ring : 0;
-        if ((size_t)nStreams * maxBlocksPerCall < 256 && !(bu && bu[0] == '1')) c.barkRing = 0;   // (a few blocks per call - the drop-in's one: three launches for nothing; =1 forces it, as the tests do)
+        // (round 3: also for a few blocks per call - the drop-in's one: the four-wave kernel walks a row's 1024 lines in a
+        //  quarter of the time the lane-per-subblock kernels take, which is what a single stream waits for)
     }
     size_t B = nStreams, K = maxBlocksPerCall, NB = B * K, cb = (size_t)nChan * BlockSize;
     DA(c.hist, B * 2 * BlockSize * nChan, true);
@@ -232,7 +233,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
         e->wcEStream = getenv("ULCX_WC_ESTREAM") != nullptr;
         { const char *v = getenv("ULCX_CPLX_EARLY"); e->cplxEarly = (v && v[0] == '1') ? 1 : 0; }
         { const char *v = getenv("ULCX_WC_FUSE"); e->wcFuse = (v && v[0] == '0') ? 0 : 1; }
-        e->barkUniP = getenv("ULCX_BARK_UNIFORM_P") ? 1 : 0;
+        { const char *v = getenv("ULCX_BARK_UNIFORM_P"); e->barkUniP = (v && v[0] == '0') ? 0 : 1; }     // masking sums of un-decimated blocks on the uniform kernel too (round 3; =0: k_pbark for every block)
         auto parse_ladder = [](const char *v, int *dst, int cap) { int n = 0; while (v && *v && n < cap) { int x = atoi(v); if (x < 1) return 0; dst[n++] = x; while (*v && *v != ',') v++; if (*v == ',') v++; } return n; };
         e->nWcLad = parse_ladder(getenv("ULCX_WC_LADDER"), e->wcLad, ULCX_WC_MAXCH);
         e->nXfLad = parse_ladder(getenv("ULCX_XF_LADDER"), e->xfLad, ULCX_XF_MAXCH);

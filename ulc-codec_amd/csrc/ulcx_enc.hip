@@ -1219,61 +1219,123 @@ __global__ __launch_bounds__(64) void k_pbark(UlcxEncCtx c, int useList) {
 // subtraction the reference makes.  Lanes whose block is decimated run along and store nothing (their blocks are on k_xf's
 // list for the lane-per-subblock kernels).  The per-band arithmetic (binary64 log, divisions) is k_bark_levels, one lane
 // per band.
+// Round 3: the kernel is a workgroup of four waves per 64 rows.  A lane's 1024-line walk was bound by the instructions it
+// issues per line (the FastLog polynomial, two conversions, a product, three sums: about 30), not by the three dependent
+// sums - and a wave is one instruction stream.  So the work that does not depend on the running sums moves to the other
+// three waves: they fetch a tile of 32 lines x 64 rows (a load instruction covers 128-byte pieces of eight rows), form
+// FastLog of every value and leave {v, log v} pairs in LDS; wave 0 only walks its rows through the finished tile - two
+// conversions, the product and the three ordered sums per line (7 instructions) - while the others prepare the next tile
+// in the second buffer.  One barrier per tile.  Same sums, same order.
+#define BK_TL 32                                           // lines per tile
+#ifndef BK_AHEAD
+#define BK_AHEAD 4                                         // tiles of loads the producer waves keep in flight
+#endif
+#define BK_RS (2 * BK_TL + 4)                              // floats per row of a tile: {v, log v} pairs + pad (16-byte reads of 64 lanes conflict-free)
+#define BK_TILE_FLOATS (64 * BK_RS)
 template <bool NOISE>
-__global__ __launch_bounds__(64) void k_bark_uniform(UlcxEncCtx c) {
+__global__ __launch_bounds__(256) void k_bark_uniform(UlcxEncCtx c) {
     extern __shared__ double bk_lds[];
-    const int lane = threadIdx.x, RM = c.barkRing - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), RM = c.barkRing - 1;
     double *ring = bk_lds + lane;                                // [barkRing][3][64]
-    float *tile = (float *)(bk_lds + c.barkRing * 3 * 64);       // [64][36]
+    float *tiles = (float *)(bk_lds + c.barkRing * 3 * 64);      // [2][64][BK_RS]
     const int half = c.BS / 2;
     const int nRows = NOISE ? c.B * c.K * c.C : c.B * c.K;
     const int row0 = blockIdx.x * 64;
     const int row = min(row0 + lane, nRows - 1);                 // (lanes past the end repeat the last row and store nothing)
     const int blk = NOISE ? row / c.C : row;
     const bool mine = (row0 + lane < nRows) && (ulcx_pattern(c.wcArr[(size_t)(blk / c.K) * (c.maxK + 2) + (blk % c.K) + 1]) & ~8u) == 0;
-    if (!__ballot(mine)) return;
+    if (!__ballot(mine)) return;                                 // (every wave of the workgroup sees the same 64 rows)
     const float *src = NOISE ? c.nsum : c.amp2;
-    double *raw = (NOISE ? c.barkRawN : c.barkRawP) + (size_t)row * ULCX_NBARK * 3;
-    const uint32_t *sched = c.T.barkSched + (NOISE ? 0 : ULCX_MAX_SUB * ULCX_BARK_EVENTS);      // the full-size subblock's edges
-    // tile loads: lane (r8, q) fetches 16 bytes q of rows r8, r8+8, ... of the wave
-    // (named registers, not arrays: an array here ends up in scratch, whose traffic queues behind the prefetch)
-    const int r8 = lane >> 3, q4 = (lane & 7) * 4;
-#define BK_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-#define BK_DECL(i) const float *ld##i = src + (size_t)min(row0 + r8 + 8 * i, nRows - 1) * half + q4; float4 nx##i = *(const float4 *)ld##i;
-    BK_ROWS(BK_DECL)
-    double fl = 0.0, pk = 0.0, pw = 0.0;
-    const float *mineRow = tile + lane * 36;
-    int pos = 0, tileOf = -1;
-    const uint32_t evLane = sched[lane < ULCX_BARK_EVENTS ? lane : ULCX_BARK_EVENTS - 1];      // edge e of the list sits in lane e
-    for (int e = 0; e < ULCX_BARK_EVENTS; e++) {
-        const uint32_t ev = (uint32_t)__builtin_amdgcn_readlane((int)evLane, e);
-        const int epos = ev & 0xffff, kind = (ev >> 16) & 3, b = ev >> 24;
-        if (kind == 3) break;
-        // the lines up to the edge (uniform count)
-        while (pos < epos) {
-            if ((pos >> 5) != tileOf) {                          // next tile: registers -> LDS, prefetch the one after
-                tileOf = pos >> 5;
-                __syncthreads();                                 // (one wave: orders the LDS traffic, costs nothing)
-#define BK_PUT(i) *(float4 *)(tile + (r8 + 8 * i) * 36 + q4) = nx##i;
-                BK_ROWS(BK_PUT)
-                __syncthreads();
-                if (tileOf + 1 < half / 32) {
-#define BK_GET(i) nx##i = *(const float4 *)(ld##i + 32 * (tileOf + 1));
-                    BK_ROWS(BK_GET)
+    const int nT = half / BK_TL;
+    if (wv > 0) {
+        // producers: 192 lanes, a tile is 512 pieces of four lines (row = piece / 8, lines 4 (piece % 8) ..)
+        const int p0 = (wv - 1) * 64 + lane;
+        // BK_AHEAD tiles of loads in flight (a tile is consumed in well under a microsecond, a load from HBM takes two or
+        // three beside the other kernels of the step): register sets rotate by unrolling the tile loop BK_AHEAD times
+        constexpr int AH = BK_AHEAD;
+        float4 nx[AH][3];
+        auto fetch = [&](float4 (&r)[3], int t) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const int pc = p0 + 192 * i;
+                if (pc < 512) r[i] = *(const float4 *)(src + (size_t)min(row0 + (pc >> 3), nRows - 1) * half + t * BK_TL + (pc & 7) * 4);
+            }
+        };
+        auto put = [&](const float4 (&r)[3], int t) {
+            float *tile = tiles + (t & 1) * BK_TILE_FLOATS;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const int pc = p0 + 192 * i;
+                if (pc < 512) {
+                    const float4 v = r[i];
+                    float4 *o = (float4 *)(tile + (pc >> 3) * BK_RS + (pc & 7) * 8);
+                    o[0] = make_float4(v.x, fastlog(0x1.0p-126f + v.x), v.y, fastlog(0x1.0p-126f + v.y));
+                    o[1] = make_float4(v.z, fastlog(0x1.0p-126f + v.z), v.w, fastlog(0x1.0p-126f + v.w));
                 }
             }
-            if ((pos & 3) == 0 && pos + 4 <= epos) {             // four lines from one 16-byte LDS read (a tile is 32 lines)
-                const float4 v = *(const float4 *)(mineRow + (pos & 31));
-                linesum_add(v.x, fl, pk, pw); linesum_add(v.y, fl, pk, pw); linesum_add(v.z, fl, pk, pw); linesum_add(v.w, fl, pk, pw);
-                pos += 4;
-            } else { linesum_add(mineRow[pos & 31], fl, pk, pw); pos++; }
+        };
+        // tile u travels in register set u % AH: fetched AH tiles before it is put
+#pragma unroll
+        for (int a = 0; a < AH; a++) if (a < nT) fetch(nx[a], a);
+        put(nx[0], 0);
+        if (AH < nT) fetch(nx[0], AH);
+        __syncthreads();
+        for (int t0 = 0; t0 < nT; t0 += AH) {
+#pragma unroll
+            for (int a = 0; a < AH; a++) {
+                const int t = t0 + a;                            // wave 0 walks tile t now; tile t+1 goes to the other buffer
+                if (t < nT) {
+                    if (t + 1 < nT) { put(nx[(a + 1) % AH], t + 1); if (t + 1 + AH < nT) fetch(nx[(a + 1) % AH], t + 1 + AH); }
+                    __syncthreads();
+                }
+            }
         }
-        double *r = ring + ((b & RM) * 3) * 64;
-        if (kind == 0) { r[0] = fl; r[64] = pk; r[128] = pw; }               // lower edge: snapshot
-        else if (kind == 1) {                                                // upper edge: the band's three sums
-            if (mine) { raw[b * 3] = fl - r[0]; raw[b * 3 + 1] = pk - r[64]; raw[b * 3 + 2] = pw - r[128]; }
-        } else break;                                                        // end of the subblock
+        return;
     }
+    // wave 0: the rows' running sums
+    double *raw = (NOISE ? c.barkRawN : c.barkRawP) + (size_t)row * ULCX_NBARK * 3;
+    const uint32_t *sched = c.T.barkSched + (NOISE ? 0 : ULCX_MAX_SUB * ULCX_BARK_EVENTS);      // the full-size subblock's edges
+    const uint32_t evLane = sched[lane < ULCX_BARK_EVENTS ? lane : ULCX_BARK_EVENTS - 1];      // edge e of the list sits in lane e
+    double fl = 0.0, pk = 0.0, pw = 0.0;
+    auto add_line = [&](float vf, float lf) {                    // Psyopt.c:23-51: Floor += log, Peak += log * v, PeakW += v
+        const double v = (double)vf, vl = (double)lf;
+        fl += vl; pk += vl * v; pw += v;
+    };
+    // A tile's 32 lines are straight-line code: the row's sixteen 16-byte LDS reads are issued together, then per line two
+    // conversions, the product and the three ordered sums; the band edges (wave-uniform: every row has the full-size
+    // geometry) are looked at in front of every line - a scalar compare when there is none.  (As a loop over "lines up to
+    // the next edge" every pair of lines paid an LDS round trip and the loop's branches: 4500 cycles per tile instead of 900.)
+    int e = 0;
+    bool done = false;
+    uint32_t ev = (uint32_t)__builtin_amdgcn_readlane((int)evLane, 0);
+    auto edges_at = [&](int pos) {                               // every edge that sits in front of line `pos`
+        while (!done && (int)(ev & 0xffff) == pos) {
+            const int kind = (ev >> 16) & 3, b = ev >> 24;
+            double *r = ring + ((b & RM) * 3) * 64;
+            if (kind == 0) { r[0] = fl; r[64] = pk; r[128] = pw; }               // lower edge: snapshot
+            else if (kind == 1) {                                                // upper edge: the band's three sums
+                if (mine) { raw[b * 3] = fl - r[0]; raw[b * 3 + 1] = pk - r[64]; raw[b * 3 + 2] = pw - r[128]; }
+            } else { done = true; break; }                                       // end of the subblock / of the list
+            e++;
+            if (e >= ULCX_BARK_EVENTS) { done = true; break; }
+            ev = (uint32_t)__builtin_amdgcn_readlane((int)evLane, e);
+        }
+    };
+    __syncthreads();                                             // tile 0 is in place
+    for (int t = 0; t < nT; t++) {
+        const float4 *mineRow = (const float4 *)(tiles + (t & 1) * BK_TILE_FLOATS + lane * BK_RS);
+        float4 q[BK_TL / 2];
+#pragma unroll
+        for (int j = 0; j < BK_TL / 2; j++) q[j] = mineRow[j];
+#pragma unroll
+        for (int i = 0; i < BK_TL; i++) {
+            edges_at(t * BK_TL + i);
+            const float4 qq = q[i >> 1];
+            add_line((i & 1) ? qq.z : qq.x, (i & 1) ? qq.w : qq.y);
+        }
+        __syncthreads();
+    }
+    edges_at(half);                                              // the edges behind the last line
 }
 
 // The Bark levels of the un-decimated blocks from the band sums of k_bark_uniform: one lane per (row, band), 32 lanes per
@@ -2847,10 +2909,14 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     int nUnits = NB * c.C * 4;
     // (the noise log-spectrum does not feed the keys: it is launched after the selection so that the
     //  main stream has work to run beside the side-stream heapsort of tie-straddle blocks)
-    const size_t barkLds = (size_t)c.barkRing * 3 * 64 * 8 + 64 * 36 * 4;
+    const size_t barkLds = (size_t)c.barkRing * 3 * 64 * 8 + (size_t)2 * BK_TILE_FLOATS * 4;
+    if (c.barkRing && barkLds > 48 * 1024) {
+        CK(hipFuncSetAttribute((const void *)k_bark_uniform<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)barkLds));
+        CK(hipFuncSetAttribute((const void *)k_bark_uniform<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)barkLds));
+    }
     auto launch_noise = [&](hipStream_t s2, bool ev0) -> int {
         if (c.barkRing) {
-            hipLaunchKernelGGL(k_bark_uniform<true>, dim3((NB * c.C + 63) / 64), dim3(64), barkLds, s2, c);
+            hipLaunchKernelGGL(k_bark_uniform<true>, dim3((NB * c.C + 63) / 64), dim3(256), barkLds, s2, c);
             hipLaunchKernelGGL(k_bark_levels<true>, dim3((unsigned)(((size_t)NB * c.C * 32 + WG - 1) / WG)), dim3(WG), 0, s2, c);
         }
         hipLaunchKernelGGL(k_nbark, dim3((nUnits + 63) / 64), dim3(64), 0, s2, c, c.barkRing ? 1 : 0);    if (ev0) MARK();
@@ -2879,7 +2945,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     {
         const bool uniP = c.barkRing && aux.barkUniP;       // (psycho sums: one wave per SIMD either way, no gain measured)
         if (uniP) {
-            hipLaunchKernelGGL(k_bark_uniform<false>, dim3((NB + 63) / 64), dim3(64), barkLds, st, c);
+            hipLaunchKernelGGL(k_bark_uniform<false>, dim3((NB + 63) / 64), dim3(256), barkLds, st, c);
             hipLaunchKernelGGL(k_bark_levels<false>, dim3((unsigned)(((size_t)NB * 32 + WG - 1) / WG)), dim3(WG), 0, st, c);
         }
         hipLaunchKernelGGL(k_pbark, dim3((NB * 4 + 63) / 64), dim3(64), 0, st, c, uniP ? 1 : 0);          MARK();
