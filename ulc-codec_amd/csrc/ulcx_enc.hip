@@ -86,6 +86,15 @@ __device__ __forceinline__ void stnt(float4 *p, float4 v) { f32x4 w = { v.x, v.y
 __device__ __forceinline__ void stnt(float2 *p, float2 v) { f32x2 w = { v.x, v.y }; __builtin_nontemporal_store(w, (f32x2 *)p); }
 __device__ __forceinline__ void stnt(float *p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ float ldnt(const float *p) { return __builtin_nontemporal_load(p); }
+// the window-control scratch (envelope planes): hinted like the rest unless built with -DWC_NO_NT (experiment: does the
+// hand-over between the chain kernels stay in the Infinity Cache when the steps are small?)
+#ifdef WC_NO_NT
+__device__ __forceinline__ float4 wc_ld(const float4 *p) { return *p; }
+__device__ __forceinline__ void wc_st(float4 *p, float4 v) { *p = v; }
+#else
+__device__ __forceinline__ float4 wc_ld(const float4 *p) { return ldnt(p); }
+__device__ __forceinline__ void wc_st(float4 *p, float4 v) { stnt(p, v); }
+#endif
 // ---------------------------------------------------------------------------
 // Window control
 // ---------------------------------------------------------------------------
@@ -146,8 +155,8 @@ __global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c, int k0, int k1) 
     for (int ql = wv; ql < 16; ql += 4) {
         const float2 a0 = tile[4 * ql][lane], a1 = tile[4 * ql + 1][lane], a2 = tile[4 * ql + 2][lane], a3 = tile[4 * ql + 3][lane];
         float4 *o = (float4 *)(dst + (size_t)ql * 512 + lane * 4);
-        stnt(o, make_float4(a0.x, a1.x, a2.x, a3.x));
-        stnt(o + 64, make_float4(a0.y, a1.y, a2.y, a3.y));
+        wc_st(o, make_float4(a0.x, a1.x, a2.x, a3.x));
+        wc_st(o + 64, make_float4(a0.y, a1.y, a2.y, a3.y));
     }
 }
 
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c, int k0, int k1)
 #pragma unroll
     for (int g = 0; g < D - 1; g++) {
 #pragma unroll
-        for (int j = 0; j < U; j++) x[g][j] = ldnt(rp + (size_t)j * QS);
+        for (int j = 0; j < U; j++) x[g][j] = wc_ld(rp + (size_t)j * QS);
         rp += U * QS;
     }
     for (int i = 0; i < nq; i += D * U) {
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c, int k0, int k1)
             const bool more = (i + (g + D - 1) * U) < nq;
             const float4 *lp = more ? rp : v;               // past the end: re-read quad 0 (unused)
 #pragma unroll
-            for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = ldnt(lp + (size_t)j * QS);
+            for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = wc_ld(lp + (size_t)j * QS);
             rp += U * QS;
 #pragma unroll
             for (int j = 0; j < U; j++) {
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(64) void k_wc_forward(UlcxEncCtx c, int k0, int k1)
             }
             if (live) {
 #pragma unroll
-                for (int j = 0; j < U; j++) stnt(wp + (size_t)j * QS, x[g][j]);
+                for (int j = 0; j < U; j++) wc_st(wp + (size_t)j * QS, x[g][j]);
             }
             wp += U * QS;
         }
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(NW * 64) void k_wc_ef(UlcxEncCtx c, int k0, int k1)
             d = v.y - env; env += d * cc; v.y = env;
             d = v.z - env; env += d * cc; v.z = env;
             d = v.w - env; env += d * cc; v.w = env;
-            if (live) stnt(wp + (size_t)q * QS, v);
+            if (live) wc_st(wp + (size_t)q * QS, v);
         }
         wp += 16 * QS;
     }
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(64) void k_wc_backward(UlcxEncCtx c, int k0, int k1
 #pragma unroll
     for (int g = 0; g < D - 1; g++) {
 #pragma unroll
-        for (int j = 0; j < U; j++) { xh[g][j] = ldnt(rp - (ptrdiff_t)j * QS); xb[g][j] = ldnt(rp - (ptrdiff_t)j * QS + 64); }
+        for (int j = 0; j < U; j++) { xh[g][j] = wc_ld(rp - (ptrdiff_t)j * QS); xb[g][j] = wc_ld(rp - (ptrdiff_t)j * QS + 64); }
         rp -= U * QS;
     }
     for (int i = 0; i < nq; i += U * D) {
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(64) void k_wc_backward(UlcxEncCtx c, int k0, int k1
             const bool more = (i + (g + D - 1) * U) < nq;
             const float4 *lp = more ? rp : (const float4 *)(e + (size_t)(U - 1) * 512);
 #pragma unroll
-            for (int j = 0; j < U; j++) { xh[(g + D - 1) % D][j] = ldnt(lp - (ptrdiff_t)j * QS); xb[(g + D - 1) % D][j] = ldnt(lp - (ptrdiff_t)j * QS + 64); }
+            for (int j = 0; j < U; j++) { xh[(g + D - 1) % D][j] = wc_ld(lp - (ptrdiff_t)j * QS); xb[(g + D - 1) % D][j] = wc_ld(lp - (ptrdiff_t)j * QS + 64); }
             rp -= U * QS;
             float4 o[U];
 #pragma unroll
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(64) void k_wc_backward(UlcxEncCtx c, int k0, int k1
 #undef WC_BACK_STEP
             }
 #pragma unroll
-            for (int j = 0; j < U; j++) stnt(wp - (ptrdiff_t)j * QS, o[j]);
+            for (int j = 0; j < U; j++) wc_st(wp - (ptrdiff_t)j * QS, o[j]);
             wp -= U * QS;
         }
     }
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(64) void k_wc_integrate(UlcxEncCtx c, int k0, int k
 #pragma unroll
     for (int g = 0; g < D - 1; g++) {
 #pragma unroll
-        for (int j = 0; j < U; j++) x[g][j] = ldnt(rp + (size_t)j * QS);
+        for (int j = 0; j < U; j++) x[g][j] = wc_ld(rp + (size_t)j * QS);
         rp += U * QS;
     }
     const float cBlk = c.cBlk;
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(64) void k_wc_integrate(UlcxEncCtx c, int k0, int k
             const bool more = (i + (g + D - 1) * U) < nq;
             const float4 *lp = more ? rp : v;
 #pragma unroll
-            for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = ldnt(lp + (size_t)j * QS);
+            for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = wc_ld(lp + (size_t)j * QS);
             rp += U * QS;
 #pragma unroll
             for (int j = 0; j < U; j++) {
@@ -2885,6 +2894,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                     int nbk = c.B * (x1 - x0);
                     CK(hipStreamWaitEvent(st, evD[w], 0));
                     if (ev) CK(hipEventRecord(aux.evXf[2 * jx], st));
+                    if (!(ULCX_DBG(c) & 0x2000))               // (ablation build: window control alone)
                     launch_xf(c, ((nbk + 7) / 8) * 8, lds, st, x0, x1);
                     if (ev) CK(hipEventRecord(aux.evXf[2 * jx + 1], st));
                     if (cplxEarly) CK(hipEventRecord(evX[jx], st));
@@ -2906,6 +2916,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             }
         }
     }
+    if (ULCX_DBG(c) & 0x6000) { MARK(); return ULCX_OK; }     // (ablation build: stop behind window control / transform)
     int nUnits = NB * c.C * 4;
     // (the noise log-spectrum does not feed the keys: it is launched after the selection so that the
     //  main stream has work to run beside the side-stream heapsort of tie-straddle blocks)
