@@ -37,9 +37,11 @@ BS, CH, RATE, QUALITY = 2048, 2, 44100, 50.0          # the headline workload (t
 
 CONFIGS = {
     #               BlockSize rate   mode  param  streams/GPU  total streams  bursts/s  decades  BASELINE.json
-    "vbr50":        dict(bs=2048, rate=44100, mode="vbr", p0=50.0, per_gpu=4096, total=None,  bursts=4.0, decades=2.0, ref="configs[1] encode, configs[2] decode"),
-    "cbr64_48k":    dict(bs=2048, rate=48000, mode="cbr", p0=64.0, per_gpu=None, total=32768, bursts=4.0, decades=2.0, ref="configs[3]"),
-    "wswitch_4096": dict(bs=4096, rate=44100, mode="vbr", p0=50.0, per_gpu=None, total=16384, bursts=6.0, decades=3.0, ref="configs[4]"),
+    # blocks: consecutive blocks per stream per step.  vbr50: 32, the figure SURVEY.md 8(d) writes for config 2 ("4096 stereo streams
+    # x (>= 32 blocks each)"; rounds 1-2 ran 16: `--blocks 16` reproduces those lines); the fixed-total configurations keep 16.
+    "vbr50":        dict(bs=2048, rate=44100, mode="vbr", p0=50.0, per_gpu=4096, total=None,  bursts=4.0, decades=2.0, blocks=32, ref="configs[1] encode, configs[2] decode"),
+    "cbr64_48k":    dict(bs=2048, rate=48000, mode="cbr", p0=64.0, per_gpu=None, total=32768, bursts=4.0, decades=2.0, blocks=16, ref="configs[3]"),
+    "wswitch_4096": dict(bs=4096, rate=44100, mode="vbr", p0=50.0, per_gpu=None, total=16384, bursts=6.0, decades=3.0, blocks=16, ref="configs[4]"),
 }
 
 
@@ -172,9 +174,10 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="vbr50")
     ap.add_argument("--mode", choices=["both", "encode", "decode"], default="both")
     ap.add_argument("--streams", type=int, default=0, help="independent streams per GPU (default: the config's; fixed-total configs split their total over the GPUs)")
-    ap.add_argument("--blocks", type=int, default=16, help="consecutive blocks per stream per step")
+    ap.add_argument("--blocks", type=int, default=0, help="consecutive blocks per stream per step (default: the config's: 32 for vbr50, 16 otherwise)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--pmc-summary", default="", help="tools/pmc_summary.py output of a rocprofv3 --pmc run of THIS command: fills roofline.traffic (else null)")
+    ap.add_argument("--pmc-summary", default="", help="tools/pmc_summary.py output of a rocprofv3 --pmc run of THIS command: fills roofline.traffic "
+                    "(default: the committed profiles/r03_pmc_summary.json when it was taken on this very configuration; else null)")
     ap.add_argument("--pcm16", action="store_true", help="separate configuration (SURVEY.md 8f rank 4): PCM16 ingest and PCM16 output "
                     "fused into the first/last kernel instead of the C API's f32; NOT the headline line")
     args = ap.parse_args()
@@ -227,7 +230,7 @@ def main():
     else:
         B = args.streams or cfg["per_gpu"] or 4096
         first_id = shard.weak_scaling_ids(B, rank)[0]
-    K = args.blocks
+    K = args.blocks or cfg["blocks"]
     n = K * bs
     pcm = make_pcm(torch, B, n, dev, seed=1234 + first_id, bursts_per_s=cfg["bursts"], decades=cfg["decades"])
     enc = ulc_amd.BatchEncoder(B, CH, bs, rate, K, device=dev.index)
@@ -328,15 +331,24 @@ def main():
     # kms is the kernel's time per step; a kernel launched n times per step (k_xf: one launch per chunk of blocks of
     # the window-control pipeline) has kms = sum of its n launches, each timed by its own hipEvent pair on its stream.
     launches = float(enc.xf_launches()) if kname == "k_xf" else 1.0      # from the library: chunks of the last call
-    traffic = None                                                       # HBM bytes per launch: only from a PMC pass of this very command
-    if args.pmc_summary and os.path.exists(args.pmc_summary):
+    # HBM bytes per launch of the roofline kernel: from the two PMC passes of THIS command (FETCH_SIZE / WRITE_SIZE cannot
+    # be collected inside a timed run) - handed in with --pmc-summary, or the summary committed under profiles/ when its
+    # recorded configuration is the one running (its git revision goes into the line)
+    traffic, traffic_src = None, None
+    pmc_path = args.pmc_summary or os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+    if os.path.exists(pmc_path):
         try:
-            ent = json.load(open(args.pmc_summary)).get(kname, {})
+            js = json.load(open(pmc_path))
+            meta = js.get("_meta", {})
+            same = bool(args.pmc_summary) or (meta.get("config") == args.config and meta.get("blocks") == K and meta.get("streams") == B
+                                              and meta.get("mode") == args.mode and not args.pcm16)
+            ent = js.get(kname, {}) if same else {}
             traffic = ent.get("hbm_bytes_per_launch")
             if traffic is not None:
                 traffic = traffic / launches
+                traffic_src = os.path.relpath(pmc_path, ROOT) + (" (git %s)" % meta["git"] if meta.get("git") else "")
         except Exception:
-            traffic = None
+            traffic, traffic_src = None, None
     launch_bytes = alg_bytes_block * B * K / launches
     kms_launch = kms / launches
     achieved = launch_bytes / (kms_launch * 1e-3) / 1e9
@@ -367,7 +379,7 @@ def main():
                        "parallelism": f"batch split over {world} GPU(s), no collective on the data path",
                        "per_rank_ms_per_step": [round(float(x), 4) for x in per_rank_ms]},
             "roofline": {"bound": "hbm", "kernel": f"{kname} ({side})", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_block": alg_bytes_block, "blocks_per_launch": B * K / launches,
                          "launches_per_step": launches, "kernel_ms": kms_launch,
                          # the pipeline, not only its largest kernel: every leg moves the same algorithmic bytes

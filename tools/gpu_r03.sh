@@ -2,14 +2,15 @@
 # Round artefacts -> gpurun_out/$TAG (copy what is to be judged into profiles/): smoke, bench lines (headline, per mode,
 # K = 32, the other configurations), rocprofv3 kernel stats of the headline command, PMC traffic passes of the same
 # command (FETCH_SIZE / WRITE_SIZE in separate runs), SQ counter passes (single-stream mode: clean per-kernel numbers),
-# one step's kernel timeline, the drop-in's single-stream rate.   usage: tools/gpu_r03.sh [tag]
+# one step's kernel timeline, the drop-in's single-stream rate.   usage: GIT_REV=$(git rev-parse --short HEAD) gpurun ... tools/gpu_r03.sh [tag]
+# (the GPU box has no .git: the revision the numbers belong to is handed in)
 cd "$(dirname "$0")/.."
 TAG=${1:-r03}; O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?" >> $O/smoke.txt
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --mode encode --no-cpu > $O/bench_encode.json 2>> $O/bench.err
 python bench.py --mode decode --no-cpu > $O/bench_decode.json 2>> $O/bench.err
-python bench.py --blocks 32 --no-cpu > $O/bench_blocks32.json 2>> $O/bench.err
+python bench.py --blocks 16 --no-cpu > $O/bench_blocks16.json 2>> $O/bench.err
 python bench.py --config cbr64_48k --steps 3 --warmup 1 --no-cpu > $O/bench_cbr64_48k.json 2>> $O/bench.err
 python bench.py --config wswitch_4096 --steps 3 --warmup 1 --no-cpu > $O/bench_wswitch_4096.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --no-cpu > $O/bench_under_rocprof.json 2> $O/prof.err
@@ -18,7 +19,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_rd -- py
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_wr -- python3 bench.py --steps 2 --warmup 1 --no-cpu > /dev/null 2> $O/pmc_wr.err
 cp $(find $O/pmc_rd -name "*counter_collection.csv" | head -1) $O/pmc_fetch.csv
 cp $(find $O/pmc_wr -name "*counter_collection.csv" | head -1) $O/pmc_write.csv
-python tools/pmc_summary.py $O/pmc_fetch.csv $O/pmc_write.csv $O/pmc_summary.json > $O/pmc_summary.txt
+python tools/pmc_summary.py $O/pmc_fetch.csv $O/pmc_write.csv $O/pmc_summary.json config=vbr50 blocks=32 streams=4096 mode=both git=${GIT_REV:-unknown} > $O/pmc_summary.txt
 python bench.py --no-cpu --pmc-summary $O/pmc_summary.json > $O/bench_with_traffic.json 2>> $O/bench.err
 # SQ counters, everything on one stream (ULCX_ASYNC_FB=0 ULCX_WC_PIPE=1): two passes of 8 counters
 export ULCX_ASYNC_FB=0 ULCX_WC_PIPE=1

@@ -19,6 +19,9 @@ def load(path, counter):
 
 def main():
     fetch_csv, write_csv, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    meta = dict(kv.split("=", 1) for kv in sys.argv[4:])          # config=vbr50 blocks=32 streams=4096 mode=both git=abc123: what the passes ran
+    for k in ("blocks", "streams"):
+        if k in meta: meta[k] = int(meta[k])
     f, fc = load(fetch_csv, "FETCH_SIZE")
     w, wc = load(write_csv, "WRITE_SIZE")
     steps_f = max(fc.get("k_state_update<float>", 0), 1); steps_w = max(wc.get("k_state_update<float>", 0), 1)
@@ -34,8 +37,9 @@ def main():
     for alias, real in (("k_select", "k_select_wave<64>"), ("k_encode_wave", "k_encode_wave<true>"), ("k_xf", "k_xf<true, float>"),
                         ("k_wc_energy", "k_wc_energy<float>"), ("k_state_update", "k_state_update<float>"), ("k_dsyn", "k_dsyn<float, 16, false>"), ("k_wc_forward", "k_wc_ef<9, float>")):
         if real in res: res[alias] = res[real]
+    if meta: res["_meta"] = meta
     json.dump(res, open(out, "w"), indent=1)
-    for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+    for k, v in sorted(((k, v) for k, v in res.items() if k != "_meta"), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
         print("%-24s %8.1f MB/step  (fetch x2 %8.1f + write %8.1f)  launches/step %.1f" % (k, v["hbm_bytes_per_launch"] / 1e6, 2 * v["FETCH_SIZE_bytes_raw_per_step"] / 1e6, v["WRITE_SIZE_bytes_per_step"] / 1e6, v["launches_per_step"]))
 
 if __name__ == "__main__":

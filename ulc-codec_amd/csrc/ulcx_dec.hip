@@ -646,24 +646,27 @@ struct DsynLds { int zFloats, lapFloats, twFloats, listFloats; };
 __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int twInLds) {
     DsynLds l;
     l.zFloats = (fast ? 2 : 1) * 2 * FFT_PADDEDS(BS / 2, DPS);
-    l.lapFloats = (fast && BS <= 2048) ? 2 * (BS / 2) : 0;      // (above 2048 the stereo kernel keeps the lapping state in global memory: a third workgroup per CU)
-    l.twFloats = (fast && BS <= 2048) ? BS / 2 : 0;               // (likewise the FFT twiddles: read from the tables in global memory, L1/L2-hot, a fourth workgroup per CU)
+    l.lapFloats = (fast && BS <= 2048 && twInLds) ? 2 * (BS / 2) : 0;      // (above 2048 the stereo kernel keeps the lapping state in global memory: a third workgroup per CU)
+    l.twFloats = (fast && BS <= 2048 && twInLds) ? BS / 2 : 0;               // (likewise the FFT twiddles: read from the tables in global memory, L1/L2-hot, a fourth workgroup per CU)
     l.listFloats = 2 * (64 + DSYN_PWORDS(BS)) + 128;             // per wave: prefix counts, sign-parity stream; per workgroup: 128 block / channel RNG states
-    (void)C; (void)twInLds;
+    (void)C;
     return l;
 }
 
 // ---------------------------------------------------------------------------
 // Stereo streams (BlockSize <= 4096): one workgroup = one stream, one wave per channel up to the end of the FFTs.
 // ---------------------------------------------------------------------------
+#ifndef DSYN_LAPG_WAVES
+#define DSYN_LAPG_WAVES 3
+#endif
 template <typename OUT, int DEC_MAXT, bool LAPG>
-__global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
+__global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3) void k_dsyn(UlcxDecCtx c) {
     extern __shared__ float lds[];
     const int BS = c.BS, H2 = BS / 2;
     constexpr int C = 2;
     const int s = c.s0 + blockIdx.x, tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const DsynLds L = dsyn_lds(BS, C, 1, 1);
+    const DsynLds L = dsyn_lds(BS, C, 1, LAPG ? 0 : 1);
     float2 *z    = (float2 *)lds;
     float *glap = c.lap + (size_t)s * C * H2;
     // lapping state: in LDS for the stream's blocks of this call, or (LAPG: BlockSize 4096) used where it lives.  Every
@@ -766,7 +769,7 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                     zj[pn2] = cmulc(make_float2(b.x, a.y), pre[n2]);
                 }
                 STAMP(11);
-                if constexpr (LAPG) fft_wave_dif(zj, M, c.T.tw[d], lane, DPS);
+                if constexpr (LAPG) { if (M == 1024) fft_wave_dif_ct<1024, DPS>(zj, c.T.tw[0], lane); else fft_wave_dif(zj, M, c.T.tw[d], lane, DPS); }
                 else if (M == 1024) fft_wave_dif_ct<1024, DPS>(zj, twl, lane);     // (BlockSize 2048, un-decimated: index arithmetic folded at compile time)
                 else fft_wave_dif(zj, M, twl + (d <= 1 ? 0 : d == 2 ? BS / 8 : 3 * BS / 16), lane, DPS);
                 }
@@ -1033,11 +1036,12 @@ int ulcx_dec_launch(const UlcxDecCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     int stage = 0;
     if (ev) CK(hipEventRecord(ev[stage++], st));
     UlcxDecCtx c = cIn;
-    size_t lds = ulcx_dec_lds_bytes(c.BS, c.C, c.fastOK, c.twInLds);
+    size_t lds = ulcx_dec_lds_bytes(c.BS, c.C, c.fastOK, c.twInLds) + (size_t)aux.ldsPad;     // (ldsPad: experiment, fewer workgroups per CU)
     const bool small = c.BS <= 2048;                      // register slots of the decimated-block path (dec_time_wave)
+    const bool lapg16 = small && c.fastOK && !c.twInLds && !c.pcm16;      // (experiment, ULCX_DSYN_LAPG=1: BlockSize <= 2048 with the lapping state and twiddles in global memory)
     const void *fn = !c.fastOK ? (c.pcm16 ? (const void *)k_dgen<int16_t> : (const void *)k_dgen<float>)
                    : c.pcm16 ? (small ? (const void *)k_dsyn<int16_t, 16, false> : (const void *)k_dsyn<int16_t, 32, true>)
-                             : (small ? (const void *)k_dsyn<float, 16, false> : (const void *)k_dsyn<float, 32, true>);
+                             : (lapg16 ? (const void *)k_dsyn<float, 16, true> : small ? (const void *)k_dsyn<float, 16, false> : (const void *)k_dsyn<float, 32, true>);
     if (lds > 48 * 1024) CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     auto scan = [&](hipStream_t s2, int s0, int s1) {
         UlcxDecCtx cc = c; cc.s0 = s0; cc.s1 = s1;
@@ -1050,7 +1054,7 @@ int ulcx_dec_launch(const UlcxDecCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         if (ULCX_DBG(c) & 8) {}
         else if (!c.fastOK) { if (c.pcm16) hipLaunchKernelGGL(k_dgen<int16_t>, dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL(k_dgen<float>, dim3(g), dim3(WG), lds, s2, cc); }
         else if (c.pcm16) { if (small) hipLaunchKernelGGL((k_dsyn<int16_t, 16, false>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<int16_t, 32, true>), dim3(g), dim3(WG), lds, s2, cc); }
-        else { if (small) hipLaunchKernelGGL((k_dsyn<float, 16, false>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<float, 32, true>), dim3(g), dim3(WG), lds, s2, cc); }
+        else { if (lapg16) hipLaunchKernelGGL((k_dsyn<float, 16, true>), dim3(g), dim3(WG), lds, s2, cc); else if (small) hipLaunchKernelGGL((k_dsyn<float, 16, false>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<float, 32, true>), dim3(g), dim3(WG), lds, s2, cc); }
     };
     int nCh = (aux.side && aux.nChunks > 1) ? aux.nChunks : 1;
     if (nCh > ULCX_DEC_MAXCH) nCh = ULCX_DEC_MAXCH;
