@@ -769,7 +769,7 @@ __global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3)
                     zj[pn2] = cmulc(make_float2(b.x, a.y), pre[n2]);
                 }
                 STAMP(11);
-                if constexpr (LAPG) { if (M == 1024) fft_wave_dif_ct<1024, DPS>(zj, c.T.tw[0], lane); else fft_wave_dif(zj, M, c.T.tw[d], lane, DPS); }
+                if constexpr (LAPG) { if (M == 1024) fft_wave_dif_ct<1024, DPS>(zj, c.T.tw[d], lane); else fft_wave_dif(zj, M, c.T.tw[d], lane, DPS); }
                 else if (M == 1024) fft_wave_dif_ct<1024, DPS>(zj, twl, lane);     // (BlockSize 2048, un-decimated: index arithmetic folded at compile time)
                 else fft_wave_dif(zj, M, twl + (d <= 1 ? 0 : d == 2 ? BS / 8 : 3 * BS / 16), lane, DPS);
                 }

@@ -580,37 +580,55 @@ __device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int
     float *ampO = c.amp2 + (size_t)blk * (BS / 2);
     constexpr float norm = 2.0f / S;
     int nnz = 0;
+    // A thread takes TWO neighbouring post-twiddle indices (kk = 2 tid, 2 tid + 1: M/2 = 2 WG of them), so that what it
+    // writes is contiguous: coefficients 4 tid .. 4 tid + 3 and BS - 4 - 4 tid .. BS - 1 - 4 tid of each channel as 16-byte
+    // stores, line energies as 8-byte stores (one index per thread gave 8- and 4-byte stores: twice the store instructions).
+    {
+        const int kA = 2 * tid, kB = 2 * tid + 1;                 // k1 of the two; their mirrors k2 = M-1-kA, M-1-kB = (M-1-kA) - 1
+        const int kk2[2] = { kA, kB };
+        float re[2][2][4];                                        // [channel][0: the k1 side, 1: the k2 side][4 consecutive coefficients]
+        float ns[2][2][2];                                        // [channel][side][2 consecutive lines]
+        float am[2][2] = { { 0.0f, 0.0f }, { 0.0f, 0.0f } };      // [side][line]
 #pragma unroll
-    for (int kk0 = 0; kk0 < M / 2; kk0 += WG) {
-        const int kk = kk0 + tid;
-        const int k1 = kk, k2 = M - 1 - kk;
-        const int r1 = (int)(__brev((unsigned)k1) >> 22), r2 = (int)(__brev((unsigned)k2) >> 22);
-        const float2 P1 = pre[k1], P2 = pre[k2];
-        const fft_v2f Pv1 = { P1.x, P1.y }, Pv2 = { P2.x, P2.y };
-        float am1 = 0.0f, am2 = 0.0f;
+        for (int u = 0; u < 2; u++) {
+            const int k1 = kk2[u], k2 = M - 1 - k1;
+            const int r1 = (int)(__brev((unsigned)k1) >> 22), r2 = (int)(__brev((unsigned)k2) >> 22);
+            const float2 P1 = pre[k1], P2 = pre[k2];
+            const fft_v2f Pv1 = { P1.x, P1.y }, Pv2 = { P2.x, P2.y };
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const float2 *zc = q ? zc1 : zc0, *zs = q ? zs1 : zs0;
-            auto cm = [](float2 d, fft_v2f w) { const fft_v2f dv = { d.x, d.y }; const fft_v2f r = fft_cmulc_post_pk(dv, w); return make_float2(r.x, r.y); };
-            const float2 yc1 = cm(zc[FFT_PADS(r1, PS)], Pv1), yc2 = cm(zc[FFT_PADS(r2, PS)], Pv2);
-            const float2 ys1 = cm(zs[FFT_PADS(r1, PS)], Pv1), ys2 = cm(zs[FFT_PADS(r2, PS)], Pv2);
-            const float mdct[4] = { yc1.x, yc2.y, yc2.x, yc1.y };
-            const float mdst[4] = { ys1.x, ys2.y, ys2.x, ys1.y };
+            for (int q = 0; q < 2; q++) {
+                const float2 *zc = q ? zc1 : zc0, *zs = q ? zs1 : zs0;
+                auto cm = [](float2 d, fft_v2f w) { const fft_v2f dv = { d.x, d.y }; const fft_v2f r = fft_cmulc_post_pk(dv, w); return make_float2(r.x, r.y); };
+                const float2 yc1 = cm(zc[FFT_PADS(r1, PS)], Pv1), yc2 = cm(zc[FFT_PADS(r2, PS)], Pv2);
+                const float2 ys1 = cm(zs[FFT_PADS(r1, PS)], Pv1), ys2 = cm(zs[FFT_PADS(r2, PS)], Pv2);
+                const float mdct[4] = { yc1.x, yc2.y, yc2.x, yc1.y };
+                const float mdst[4] = { ys1.x, ys2.y, ys2.x, ys1.y };
 #pragma unroll
-            for (int p = 0; p < 2; p++) {
-                const float re0 = mdct[2*p] * norm,   im0 = mdst[2*p] * norm;
-                const float re1 = mdct[2*p+1] * norm, im1 = mdst[2*p+1] * norm;
-                const float re0s = re0 * re0, im0s = im0 * im0, re1s = re1 * re1, im1s = im1 * im1;
-                const float a0 = re0s + im0s, a1 = re1s + im1s;
-                nnz += (fabsf(re0) < 0.5f * ULCX_COEF_EPS) ? 0 : 1;
-                nnz += (fabsf(re1) < 0.5f * ULCX_COEF_EPS) ? 0 : 1;
-                const int j = p ? k2 : k1;
-                stnt((float2 *)(coefO + q * BS + 2 * j), make_float2(re0, re1));
-                stnt(nsumO + q * (BS / 2) + j, a0 + a1);
-                if (p) { am2 += a0; am2 += a1; } else { am1 += a0; am1 += a1; }
+                for (int p = 0; p < 2; p++) {                     // p = 0: pair j = k1 (coefficients 2 k1, 2 k1 + 1); p = 1: pair j = k2
+                    const float re0 = mdct[2*p] * norm,   im0 = mdst[2*p] * norm;
+                    const float re1 = mdct[2*p+1] * norm, im1 = mdst[2*p+1] * norm;
+                    const float re0s = re0 * re0, im0s = im0 * im0, re1s = re1 * re1, im1s = im1 * im1;
+                    const float a0 = re0s + im0s, a1 = re1s + im1s;
+                    nnz += (fabsf(re0) < 0.5f * ULCX_COEF_EPS) ? 0 : 1;
+                    nnz += (fabsf(re1) < 0.5f * ULCX_COEF_EPS) ? 0 : 1;
+                    // k1 side: pairs kA, kB ascending; k2 side: pairs k2(kB) = k2(kA) - 1 then k2(kA): ascending too
+                    const int slot = p ? (1 - u) : u;
+                    re[q][p][2 * slot] = re0; re[q][p][2 * slot + 1] = re1;
+                    ns[q][p][slot] = a0 + a1;                     // (0 + a0) + a1
+                    am[p][slot] += a0; am[p][slot] += a1;         // channel order preserved (q = 0 first)
+                }
             }
         }
-        ampO[k1] = am1; ampO[k2] = am2;
+        const int j1 = kA, j2 = M - 1 - kB;                       // first pair index of each side
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            stnt((float4 *)(coefO + q * BS + 2 * j1), make_float4(re[q][0][0], re[q][0][1], re[q][0][2], re[q][0][3]));
+            stnt((float4 *)(coefO + q * BS + 2 * j2), make_float4(re[q][1][0], re[q][1][1], re[q][1][2], re[q][1][3]));
+            stnt((float2 *)(nsumO + q * (BS / 2) + j1), make_float2(ns[q][0][0], ns[q][0][1]));
+            stnt((float2 *)(nsumO + q * (BS / 2) + j2), make_float2(ns[q][1][0], ns[q][1][1]));
+        }
+        *(float2 *)(ampO + j1) = make_float2(am[0][0], am[0][1]);
+        *(float2 *)(ampO + j2) = make_float2(am[1][0], am[1][1]);
     }
     return nnz;
 }
