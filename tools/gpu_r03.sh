@@ -36,3 +36,11 @@ python tools/timeline.py $(find $O/tl -name "*kernel_trace.csv" | head -1) > $O/
 rm -rf $O/prof $O/prof1 $O/pmc_rd $O/pmc_wr $O/tl $O/sq1 $O/sq2
 python tools/dropin_rate.py > $O/dropin_rate.txt 2>&1
 ls -la $O; head -c 600 $O/bench.json; echo; tail -2 $O/smoke.txt; head -12 $O/pmc_summary.txt
+# keep only this library's kernels in the counter files (the PyTorch kernels of the input generator are most of the rows)
+python3 - $O/sq_pass1.csv $O/sq_pass2.csv <<'PY'
+import csv, sys
+for f in sys.argv[1:]:
+    rows = list(csv.DictReader(open(f)))
+    keep = [r for r in rows if r["Kernel_Name"].replace("void ", "").startswith("k_")]
+    w = csv.DictWriter(open(f, "w", newline=""), fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
+PY
