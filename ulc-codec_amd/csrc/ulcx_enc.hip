@@ -2971,6 +2971,12 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         launch_state_update(c, side3);
         CK(hipEventRecord(evState, side3));
     } else { hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c, 0, c.K);                 MARK(); }
+    const bool noiseEarly = noiseAside && aux.noiseEarly;      // the noise chain right behind the transform (it only needs nsum), beside the masking sums
+    if (noiseEarly) {
+        CK(hipStreamWaitEvent(side2, evN0, 0));
+        int rcn = launch_noise(side2, false); if (rcn) return rcn;
+        CK(hipEventRecord(evNoise, side2));
+    }
     {
         const bool uniP = c.barkRing && aux.barkUniP;       // (psycho sums: one wave per SIMD either way, no gain measured)
         if (uniP) {
@@ -2978,7 +2984,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             hipLaunchKernelGGL(k_bark_levels<false>, dim3((unsigned)(((size_t)NB * 32 + WG - 1) / WG)), dim3(WG), 0, st, c);
         }
         hipLaunchKernelGGL(k_pbark, dim3((NB * 4 + 63) / 64), dim3(64), 0, st, c, uniP ? 1 : 0);          MARK();
-        if (noiseAside) {
+        if (noiseAside && !noiseEarly) {
             CK(hipEventRecord(evTail0, st));                       // (reused: behind k_pbark)
             CK(hipStreamWaitEvent(side2, evTail0, 0));
             int rcn = launch_noise(side2, false); if (rcn) return rcn;
