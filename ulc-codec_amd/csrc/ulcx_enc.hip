@@ -1253,7 +1253,12 @@ __global__ __launch_bounds__(64) void k_pbark(UlcxEncCtx c, int useList) {
 // FastLog of every value and leave {v, log v} pairs in LDS; wave 0 only walks its rows through the finished tile - two
 // conversions, the product and the three ordered sums per line (7 instructions) - while the others prepare the next tile
 // in the second buffer.  One barrier per tile.  Same sums, same order.
-#define BK_TL 32                                           // lines per tile
+#ifndef BK_TL
+#define BK_TL 32                                           // lines per tile (32 or 64; BlockSize / 2 must be a multiple)
+#endif
+#define BK_PPR (BK_TL / 4)                                 // 16-byte pieces per row of a tile
+#define BK_PIECES (64 * BK_PPR)
+#define BK_NPC ((BK_PIECES + 191) / 192)                   // pieces per producer lane
 #ifndef BK_AHEAD
 #define BK_AHEAD 4                                         // tiles of loads the producer waves keep in flight
 #endif
@@ -1280,22 +1285,22 @@ __global__ __launch_bounds__(256) void k_bark_uniform(UlcxEncCtx c) {
         // BK_AHEAD tiles of loads in flight (a tile is consumed in well under a microsecond, a load from HBM takes two or
         // three beside the other kernels of the step): register sets rotate by unrolling the tile loop BK_AHEAD times
         constexpr int AH = BK_AHEAD;
-        float4 nx[AH][3];
-        auto fetch = [&](float4 (&r)[3], int t) {
+        float4 nx[AH][BK_NPC];
+        auto fetch = [&](float4 (&r)[BK_NPC], int t) {
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
+            for (int i = 0; i < BK_NPC; i++) {
                 const int pc = p0 + 192 * i;
-                if (pc < 512) r[i] = *(const float4 *)(src + (size_t)min(row0 + (pc >> 3), nRows - 1) * half + t * BK_TL + (pc & 7) * 4);
+                if (pc < BK_PIECES) r[i] = *(const float4 *)(src + (size_t)min(row0 + pc / BK_PPR, nRows - 1) * half + t * BK_TL + (pc % BK_PPR) * 4);
             }
         };
-        auto put = [&](const float4 (&r)[3], int t) {
+        auto put = [&](const float4 (&r)[BK_NPC], int t) {
             float *tile = tiles + (t & 1) * BK_TILE_FLOATS;
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
+            for (int i = 0; i < BK_NPC; i++) {
                 const int pc = p0 + 192 * i;
-                if (pc < 512) {
+                if (pc < BK_PIECES) {
                     const float4 v = r[i];
-                    float4 *o = (float4 *)(tile + (pc >> 3) * BK_RS + (pc & 7) * 8);
+                    float4 *o = (float4 *)(tile + (pc / BK_PPR) * BK_RS + (pc % BK_PPR) * 8);
                     o[0] = make_float4(v.x, fastlog(0x1.0p-126f + v.x), v.y, fastlog(0x1.0p-126f + v.y));
                     o[1] = make_float4(v.z, fastlog(0x1.0p-126f + v.z), v.w, fastlog(0x1.0p-126f + v.w));
                 }
@@ -1351,14 +1356,16 @@ __global__ __launch_bounds__(256) void k_bark_uniform(UlcxEncCtx c) {
     __syncthreads();                                             // tile 0 is in place
     for (int t = 0; t < nT; t++) {
         const float4 *mineRow = (const float4 *)(tiles + (t & 1) * BK_TILE_FLOATS + lane * BK_RS);
-        float4 q[BK_TL / 2];
+        for (int hh = 0; hh < BK_TL / 32; hh++) {                // 32 lines at a time: sixteen 16-byte reads in registers
+            float4 q[16];
 #pragma unroll
-        for (int j = 0; j < BK_TL / 2; j++) q[j] = mineRow[j];
+            for (int j = 0; j < 16; j++) q[j] = mineRow[hh * 16 + j];
 #pragma unroll
-        for (int i = 0; i < BK_TL; i++) {
-            edges_at(t * BK_TL + i);
-            const float4 qq = q[i >> 1];
-            add_line((i & 1) ? qq.z : qq.x, (i & 1) ? qq.w : qq.y);
+            for (int i = 0; i < 32; i++) {
+                edges_at(t * BK_TL + hh * 32 + i);
+                const float4 qq = q[i >> 1];
+                add_line((i & 1) ? qq.z : qq.x, (i & 1) ? qq.w : qq.y);
+            }
         }
         __syncthreads();
     }
