@@ -384,7 +384,7 @@ def test_pcm16_ingest_and_output_match_the_wav_io_conversions(bs, ch, rate, call
     {"ULCX_GAPSUMS": "0"},                         # no speculative noise sums
     {"ULCX_CPLX_EARLY": "1"},                      # complexity sums per transform chunk
     {"ULCX_BARK_UNIFORM": "0"},                    # noise Bark sums of every block on the lane-per-subblock kernel
-    {"ULCX_BARK_UNIFORM_P": "1"},                  # the masking Bark sums on the geometry-uniform kernel too
+    {"ULCX_BARK_UNIFORM_P": "0"},                  # the masking Bark sums of every block on the lane-per-subblock kernel
     {"ULCX_ASYNC_FB": "0", "ULCX_WC_PIPE": "1", "ULCX_WAVE": "0", "ULCX_GAPSUMS": "0"},
 ])
 def test_runtime_switches_keep_parity(env):
@@ -420,6 +420,49 @@ def test_runtime_switches_keep_parity(env):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+@pytest.mark.parametrize("env,B,K", [
+    ({"ULCX_XF_RUN": "3"}, 6, 16),                 # steady-state blocks on k_xf_fast, runs of 3 with the half-frame carry
+    ({"ULCX_XF_RUN": "16", "ULCX_WC_PIPE": "1"}, 6, 16),
+    ({"ULCX_WC_LADDER": "1,2,5,8"}, 6, 16),        # explicit window-control / transform ladder
+    ({"ULCX_WC_LADDER": "1,1,2,2,2,2,2,2,2", "ULCX_XF_LADDER": "1,3,4,4,4"}, 6, 16),
+    ({"ULCX_NOISE_EARLY": "0"}, 6, 16),            # noise chain behind the masking sums (the round-2 order)
+    ({"ULCX_DEC_PIPE": "2"}, 130, 4),              # syntax walk of the next chunk of streams beside the synthesis
+    ({"ULCX_DSYN_LAPG": "1"}, 6, 16),              # synthesis with lapping state + twiddles in global memory
+    ({"ULCX_DSYN_PAD": "8192"}, 6, 16),
+])
+def test_round3_switches_keep_parity(env, B, K):
+    """The switches round 3 added, on the headline geometry - stereo, BlockSize 2048, where the transform's
+    steady-state path and its run kernel exist: encode vs the oracle over two calls (state carry), decode vs the oracle."""
+    amd = _amd()
+    bs, ch, rate = 2048, 2, 44100
+    pcm = _streams(B, 2 * K, bs, ch, rate, True, seed=4242)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        enc = amd.BatchEncoder(B, ch, bs, rate, K)
+        dec = amd.BatchDecoder(B, ch, bs, K)
+        check = range(B) if B <= 8 else (0, 63, 64, 65, B - 1)
+        refs = {s: oracle_encode_debug(pcm[s], bs, rate, 0, 50.0, slot=enc.slot) for s in check}
+        outs = []
+        for call in range(2):
+            res = enc.encode(pcm[:, call * K * bs:(call + 1) * K * bs], amd.MODE_VBR, 50.0)
+            for s in check:
+                _compare_encode(res, refs[s], s, call * K, K, None, f"{env}")
+            outs.append(dec.decode(res[0]))
+        for s in check:
+            rc, ref_pcm, ref_bits = oracle_decode_stream(refs[s]["out"], ch, bs)
+            assert rc == 0
+            got = np.concatenate([o[0][s] for o in outs])
+            assert np.array_equal(got.view(np.uint32), ref_pcm.view(np.uint32)), f"{env}: decoded PCM differs (stream {s})"
+        enc.close(); dec.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
 
 
 def test_timing_events_can_be_switched_off():

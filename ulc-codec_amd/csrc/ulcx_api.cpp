@@ -23,7 +23,7 @@ struct ulcx_encoder {
     hipStream_t side; hipEvent_t evFork, evJoin, evFork2; bool sideOk; bool timing;
     hipEvent_t evWC[7 + 3 * ULCX_WC_MAXCH + ULCX_XF_MAXCH + 1]; int wcPipe; hipStream_t side2, side3, side4; hipEvent_t evE[ULCX_WC_MAXCH]; hipEvent_t evXf[2 * ULCX_XF_MAXCH]; int nXf;      // window-control / transform chunk pipeline (ULCX_WC_PIPE chunks, default 4)
     bool keysFinal;
-    int wcSteps, cplxEarly, wcFuse, barkUniP, noiseEarly; bool wcEStream;      // environment switches, read once at create
+    int wcSteps, cplxEarly, wcFuse, barkUniP, noiseEarly, xfRun; bool wcEStream;      // environment switches, read once at create
     int nWcLad, nXfLad, wcLad[ULCX_WC_MAXCH], xfLad[ULCX_XF_MAXCH];   // ULCX_WC_LADDER / ULCX_XF_LADDER: step sizes in blocks
     // staging for the host-pointer API
     float *d_pcm; uint8_t *d_out; int32_t *d_bits, *d_wc; float *d_cplx;
@@ -236,6 +236,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
         { const char *v = getenv("ULCX_BARK_UNIFORM_P"); e->barkUniP = (v && v[0] == '0') ? 0 : 1; }     // masking sums of un-decimated blocks on the uniform kernel too (round 3; =0: k_pbark for every block)
         auto parse_ladder = [](const char *v, int *dst, int cap) { int n = 0; while (v && *v && n < cap) { int x = atoi(v); if (x < 1) return 0; dst[n++] = x; while (*v && *v != ',') v++; if (*v == ',') v++; } return n; };
         { const char *v = getenv("ULCX_NOISE_EARLY"); e->noiseEarly = (v && v[0] == '0') ? 0 : 1; }     // default on (round 3: 10.35 vs 10.41 ms per encode of 131072 blocks)
+        e->xfRun = 0; if (const char *v = getenv("ULCX_XF_RUN")) { int n = atoi(v); if (n >= 0 && n <= 64) e->xfRun = n; }
         e->nWcLad = parse_ladder(getenv("ULCX_WC_LADDER"), e->wcLad, ULCX_WC_MAXCH);
         e->nXfLad = parse_ladder(getenv("ULCX_XF_LADDER"), e->xfLad, ULCX_XF_MAXCH);
     }
@@ -272,7 +273,7 @@ static int encode_dev_any(ulcx_encoder *e, int mode, float p0, float p1, const f
     aux.side = e->sideOk ? e->side : nullptr; aux.side2 = e->sideOk ? e->side2 : nullptr; aux.side3 = e->sideOk ? e->side3 : nullptr; aux.side4 = (e->sideOk && e->wcEStream) ? e->side4 : nullptr; aux.evE = e->evE;
     aux.evFork = e->evFork; aux.evJoin = e->evJoin; aux.evFork2 = e->evFork2; aux.evWC = e->evWC; aux.evXf = e->evXf;
     aux.wcPipe = (nBlocks >= 2 * e->wcPipe) ? e->wcPipe : (nBlocks >= 6 && e->wcPipe > 1 ? 3 : 1); aux.nXf = &e->nXf;
-    aux.wcSteps = e->wcSteps; aux.cplxEarly = e->cplxEarly; aux.wcFuse = e->wcFuse; aux.barkUniP = e->barkUniP; aux.noiseEarly = e->noiseEarly;
+    aux.wcSteps = e->wcSteps; aux.cplxEarly = e->cplxEarly; aux.wcFuse = e->wcFuse; aux.barkUniP = e->barkUniP; aux.noiseEarly = e->noiseEarly; aux.xfRun = e->xfRun;
     aux.nWcCut = aux.nXfCut = 0;
     if (aux.wcPipe > 1) {
         // schedules as cumulative block counts; a ladder applies when it sums to this call's block count and every transform

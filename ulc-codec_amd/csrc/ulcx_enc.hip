@@ -520,8 +520,13 @@ __device__ __forceinline__ float win_apply(float x, int i, int S, int aL, int ov
 // block between two full-overlap neighbours (PCM16 ingest: from the call's third block on).  Same arithmetic, same
 // order as the general body of k_xf below (which documents it) - only the index arithmetic, the loop bounds and the window
 // selects fold away, and the four 1024-point transforms run the compile-time passes (fft_wave_dif_ct).
-template <typename IN>
-__device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int s, int k, int blk, int tid) {
+// XfCarry: what a workgroup that transforms CONSECUTIVE blocks of one stream keeps in registers from one block to the next.
+// Block k's frame is input blocks k-2 and k-1, block k+1's is k-1 and k: the samples a thread folds in the second half of
+// one frame (positions S + 2jj, 2S - 2 - 2jj and their neighbours) are the ones it folds in the first half of the next
+// (positions 2jj, S - 2 - 2jj) - after the M/S step, before the window.  Two fold trips x four positions x (M, S).
+struct XfCarry { float2 raw[2][4]; bool valid; };
+template <typename IN, bool CARRY>
+__device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int s, int k, int blk, int tid, XfCarry &cy) {
     constexpr int BS = 2048, S = 2048, M = 1024, PS = 4, Mp = FFT_PADDEDS(M, PS);
     static_assert(WG == 256, "two fold / epilogue trips per thread");
     float2 *z = (float2 *)lds;
@@ -529,6 +534,12 @@ __device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int
     float2 *zc0 = z, *zs0 = z + Mp, *zc1 = z + 2 * Mp, *zs1 = z + 3 * Mp;
     const float2 *pre = c.T.pre[0];
     const float *rise = c.T.winRise + S, *fall = c.T.winFall + S;
+    if (CARRY) {
+        // (inside a loop over the run's blocks: the table loads below do not depend on the block, and hoisted out of the
+        //  loop they cost more registers than the 128-register cap has - opaque pointers keep them where they are)
+        asm volatile("" : "+s"(pre), "+s"(rise), "+s"(fall));
+        asm volatile("" : "+v"(tid));                          // (likewise every index that only depends on the thread)
+    }
     // frame = [(k-2) BS, k BS): its first half (positions < S) is block k-2, its second half block k-1 of the stream's
     // timeline; blocks -2 and -1 are the two the encoder keeps from the previous call (c.hist, always float)
     const IN *pcmS = pcm_base<IN>(c) + (size_t)s * c.K * BS * 2;
@@ -538,20 +549,31 @@ __device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int
         if (k < 2) frameLo = histS + (size_t)k * BS * 2;                      // block k-2 = history block k
         if (k < 1) frameHi = histS;                                            // block k-1 = history block 1: (hist + BS*2) - S*2
     }
+    const bool reuse = CARRY && cy.valid;                      // (workgroup-uniform: the previous block of this workgroup's run took this path)
+    if (!reuse) {                                              // (otherwise the full-size twiddles are still in LDS)
 #pragma unroll
-    for (int i = tid; i < M / 2; i += WG) twl[i] = c.T.tw[0][i];
+        for (int i = tid; i < M / 2; i += WG) twl[i] = c.T.tw[0][i];
+    }
 #pragma unroll
     for (int jj0 = 0; jj0 < M / 2; jj0 += WG) {
         const int jj = jj0 + tid;
+        const int trip = jj0 / WG;
         const int iA = 2 * jj, iB = S - 2 - 2 * jj, iC = S + 2 * jj, iD = 2 * S - 2 - 2 * jj;
         const int ip[4] = { iA, iB, iC, iD };
         float2 xs[8];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const float4 v = ld4((r < 2 ? frameLo : frameHi) + (size_t)ip[r] * 2);
+            float2 m0, m1;                                     // the two positions ip[r], ip[r] + 1 after M/S
+            if (CARRY && r < 2 && reuse) { m0 = cy.raw[trip][2 * r]; m1 = cy.raw[trip][2 * r + 1]; }
+            else {
+                const float4 v = ld4((r < 2 ? frameLo : frameHi) + (size_t)ip[r] * 2);
+                m0 = make_float2((v.x + v.y) * 0.5f, (v.x - v.y) * 0.5f);
+                m1 = make_float2((v.z + v.w) * 0.5f, (v.z - v.w) * 0.5f);
+            }
+            if (CARRY && r >= 2) { cy.raw[trip][2 * (r - 2)] = m0; cy.raw[trip][2 * (r - 2) + 1] = m1; }     // the next block's first half
             const float2 fw = (r < 2) ? *(const float2 *)(rise + ip[r]) : *(const float2 *)(fall + ip[r] - S);     // (even positions: 8-byte aligned)
-            xs[2 * r]     = make_float2(((v.x + v.y) * 0.5f) * fw.x, ((v.x - v.y) * 0.5f) * fw.x);
-            xs[2 * r + 1] = make_float2(((v.z + v.w) * 0.5f) * fw.y, ((v.z - v.w) * 0.5f) * fw.y);
+            xs[2 * r]     = make_float2(m0.x * fw.x, m0.y * fw.x);
+            xs[2 * r + 1] = make_float2(m1.x * fw.y, m1.y * fw.y);
         }
 #pragma unroll
         for (int hsel = 0; hsel < 2; hsel++) {
@@ -630,12 +652,64 @@ __device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int
         *(float2 *)(ampO + j1) = make_float2(am[0][0], am[0][1]);
         *(float2 *)(ampO + j2) = make_float2(am[1][0], am[1][1]);
     }
+    if (CARRY) cy.valid = true;
     return nnz;
+}
+
+// which blocks take the steady-state path: stereo BlockSize 2048 (the caller's business), un-decimated, full overlap on
+// both sides; PCM16 ingest from the call's third block on (its history halves are float)
+template <typename IN>
+__device__ __forceinline__ bool xf_is_fast(const UlcxEncCtx &c, int s, int k) {
+#ifdef XF_NO_FAST
+    return false;
+#endif
+    const int BS = c.BS;
+    const int *wrow = c.wcArr + (size_t)s * (c.maxK + 2) + k;
+    const int wcPrev = wrow[0], wc = wrow[1], wcNext = wrow[2];
+    if (!(k >= 2 || std::is_same<IN, float>::value) || (ulcx_pattern(wc) >> 4) != 0) return false;
+    unsigned pp = ulcx_pattern(wcPrev);
+    int lastS = BS;
+    do { lastS = BS >> (pp & 7); } while (pp >>= 4);
+    int ovFirst = first_overlap(wc, BS);
+    if (ovFirst > lastS) ovFirst = lastS;
+    return ovFirst == BS && first_overlap(wcNext, BS) >= BS;
+}
+// The steady-state blocks as a kernel of their own (round 3): a workgroup takes a RUN of consecutive blocks of one stream
+// and keeps the half frame two neighbours share in registers (XfCarry: half the input loads, half the M/S arithmetic);
+// blocks of the run that do not qualify are left to k_xf (launched behind it with skipFast = 1).  In one kernel with the
+// general body the carry's 16 registers spill (128-register cap of four workgroups per CU: 2x slower); alone this path
+// has room.  Workgroups are dealt round-robin over the 8 XCDs: runs of one stream follow each other on one XCD.
+template <typename IN>
+__global__ __launch_bounds__(WG, 4) void k_xf_fast(UlcxEncCtx c, int k0, int k1, int run) {
+    extern __shared__ float lds[];
+    const int kc = k1 - k0;
+    const int nr = (kc + run - 1) / run;
+    const int units = c.B * nr;
+    const int per = (units + 7) / 8;
+    const int vu = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+    if (vu >= units) return;
+    const int s = vu / nr;
+    const int kA = k0 + (vu % nr) * run, kB = (kA + run < k1) ? kA + run : k1;
+    const int tid = threadIdx.x;
+    int &s_nnz = *(int *)(lds + 4 * FFT_PADDEDS(2048, 4) + 2048 / 2);
+    XfCarry cy; cy.valid = false;
+    for (int k = kA; k < kB; k++) {
+        if (!xf_is_fast<IN>(c, s, k)) { cy.valid = false; continue; }
+        const int blk = s * c.K + k;
+        if (tid == 0) s_nnz = 0;
+        __syncthreads();
+        int nnz = xf_fast_2048<IN, true>(c, lds, s, k, blk, tid, cy);
+        for (int o = 32; o > 0; o >>= 1) nnz += __shfl_down(nnz, o);
+        if ((tid & 63) == 0) atomicAdd(&s_nnz, nnz);
+        __syncthreads();
+        if (tid == 0) c.nnz[blk] = s_nnz;
+        __syncthreads();
+    }
 }
 
 // ST: stereo instantiation (C = 2 as a compile-time constant: one channel pair, no per-pair branches)
 template <bool ST, typename IN>
-__global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
+__global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1, int skipFast) {
     extern __shared__ float lds[];
     const int BS = c.BS, C = ST ? 2 : c.C;
     // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its own L2).
@@ -679,12 +753,9 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
     __syncthreads();
 
     // the steady state of the headline geometry takes the all-constants path (xf_fast_2048)
-    const bool fastBlk = ST && BS == 2048 && (k >= 2 || std::is_same<IN, float>::value) && (ulcx_pattern(wc) >> 4) == 0 && ovFirst == BS && nextOv >= BS
-#ifdef XF_NO_FAST
-                         && false
-#endif
-                         ;
-    if (fastBlk) nnz = xf_fast_2048<IN>(c, lds, s, k, blk, tid);
+    const bool fastBlk = ST && BS == 2048 && xf_is_fast<IN>(c, s, k);
+    XfCarry noCarry;
+    if (fastBlk) { if (skipFast) return; nnz = xf_fast_2048<IN, false>(c, lds, s, k, blk, tid, noCarry); }     // (skipFast: k_xf_fast has transformed it)
     else
     for (int ch0 = 0; ch0 < C; ch0 += 2) {             // one M/S pair (or a trailing single channel) at a time
         const int nch = ST ? 2 : ((ch0 + 1 < C) ? 2 : 1);
@@ -2783,18 +2854,28 @@ static void launch_wc_ef(const UlcxEncCtx &c, hipStream_t st, int k0, int k1) {
     if (c.pcm16) hipLaunchKernelGGL((k_wc_ef<EF_NW, int16_t>), dim3((c.B + EF_SPW - 1) / EF_SPW), dim3(EF_NW * 64), EF_LDS_BYTES, st, c, k0, k1);
     else hipLaunchKernelGGL((k_wc_ef<EF_NW, float>), dim3((c.B + EF_SPW - 1) / EF_SPW), dim3(EF_NW * 64), EF_LDS_BYTES, st, c, k0, k1);
 }
-static void launch_xf(const UlcxEncCtx &c, unsigned grid, size_t lds, hipStream_t st, int k0, int k1) {
+static void launch_xf(const UlcxEncCtx &c, unsigned grid, size_t lds, hipStream_t st, int k0, int k1, int run = 0) {
     if (c.BS > 8192) {                                      // one array at a time (k_xf_big)
         if (c.pcm16) hipLaunchKernelGGL(k_xf_big<int16_t>, dim3(grid), dim3(WG), lds, st, c, k0, k1);
         else hipLaunchKernelGGL(k_xf_big<float>, dim3(grid), dim3(WG), lds, st, c, k0, k1);
         return;
     }
+    // run > 0: the steady-state blocks on k_xf_fast in runs of `run` consecutive blocks per workgroup, the rest behind it
+    int skipFast = 0;
+    if (run > 0 && c.C == 2 && c.BS == 2048 && k1 - k0 >= 2) {
+        if (run > k1 - k0) run = k1 - k0;
+        const int units = c.B * ((k1 - k0 + run - 1) / run);
+        const unsigned g2 = (unsigned)(((units + 7) / 8) * 8);
+        if (c.pcm16) hipLaunchKernelGGL(k_xf_fast<int16_t>, dim3(g2), dim3(WG), lds, st, c, k0, k1, run);
+        else hipLaunchKernelGGL(k_xf_fast<float>, dim3(g2), dim3(WG), lds, st, c, k0, k1, run);
+        skipFast = 1;
+    }
     if (c.pcm16) {
-        if (c.C == 2) hipLaunchKernelGGL((k_xf<true, int16_t>), dim3(grid), dim3(WG), lds, st, c, k0, k1);
-        else hipLaunchKernelGGL((k_xf<false, int16_t>), dim3(grid), dim3(WG), lds, st, c, k0, k1);
+        if (c.C == 2) hipLaunchKernelGGL((k_xf<true, int16_t>), dim3(grid), dim3(WG), lds, st, c, k0, k1, skipFast);
+        else hipLaunchKernelGGL((k_xf<false, int16_t>), dim3(grid), dim3(WG), lds, st, c, k0, k1, skipFast);
     } else {
-        if (c.C == 2) hipLaunchKernelGGL((k_xf<true, float>), dim3(grid), dim3(WG), lds, st, c, k0, k1);
-        else hipLaunchKernelGGL((k_xf<false, float>), dim3(grid), dim3(WG), lds, st, c, k0, k1);
+        if (c.C == 2) hipLaunchKernelGGL((k_xf<true, float>), dim3(grid), dim3(WG), lds, st, c, k0, k1, skipFast);
+        else hipLaunchKernelGGL((k_xf<false, float>), dim3(grid), dim3(WG), lds, st, c, k0, k1, skipFast);
     }
 }
 static void launch_state_update(const UlcxEncCtx &c, hipStream_t st) {
@@ -2857,7 +2938,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         };
         if (nCh <= 1) {
             int rc = launch_wc(st, 0, c.K, true); if (rc) return rc;
-            launch_xf(c, ((NB + 7) / 8) * 8, lds, st, 0, c.K);
+            launch_xf(c, ((NB + 7) / 8) * 8, lds, st, 0, c.K, aux.xfRun);
             MARK();
         } else {
             for (int i = 0; i < 5; i++) MARK();                    // (window-control stages: hidden in the k_xf interval in this mode)
@@ -2920,7 +3001,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                     CK(hipStreamWaitEvent(st, evD[w], 0));
                     if (ev) CK(hipEventRecord(aux.evXf[2 * jx], st));
                     if (!(ULCX_DBG(c) & 0x2000))               // (ablation build: window control alone)
-                    launch_xf(c, ((nbk + 7) / 8) * 8, lds, st, x0, x1);
+                    launch_xf(c, ((nbk + 7) / 8) * 8, lds, st, x0, x1, aux.xfRun);
                     if (ev) CK(hipEventRecord(aux.evXf[2 * jx + 1], st));
                     if (cplxEarly) CK(hipEventRecord(evX[jx], st));
                     jx++;

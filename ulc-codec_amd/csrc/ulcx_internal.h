@@ -171,6 +171,7 @@ struct UlcxEncAux {
     int wcPipe;                          // chunks of blocks pipelined between window control and transform; 1 = off
     int wcSteps;                         // fine steps of the window-control kernels per call (ULCX_WC_STEPS)
     int cplxEarly, wcFuse, barkUniP;     // ULCX_CPLX_EARLY / ULCX_WC_FUSE / ULCX_BARK_UNIFORM_P, read once when the encoder is created
+    int xfRun;                           // ULCX_XF_RUN: consecutive blocks of a stream one k_xf_fast workgroup takes (0: no separate kernel)
     int noiseEarly;                      // ULCX_NOISE_EARLY: noise log-spectrum chain starts behind the transform, not behind the masking sums
     int nWcCut, nXfCut;                  // explicit schedules (0 = derive from wcSteps / wcPipe): cumulative block counts, last = K
     int wcCut[ULCX_WC_MAXCH + 1], xfCut[ULCX_XF_MAXCH + 1];
