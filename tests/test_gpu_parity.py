@@ -428,7 +428,8 @@ def test_runtime_switches_keep_parity(env):
     ({"ULCX_WC_LADDER": "1,1,2,2,2,2,2,2,2", "ULCX_XF_LADDER": "1,3,4,4,4"}, 6, 16),
     ({"ULCX_NOISE_EARLY": "0"}, 6, 16),            # noise chain behind the masking sums (the round-2 order)
     ({"ULCX_DEC_PIPE": "2"}, 130, 4),              # syntax walk of the next chunk of streams beside the synthesis
-    ({"ULCX_DSYN_LAPG": "1"}, 6, 16),              # synthesis with lapping state + twiddles in global memory
+    ({"ULCX_DSYN_LAPG": "0"}, 6, 16),              # synthesis with lapping state + twiddles in LDS (rounds 1-2; default: twiddles only)
+    ({"ULCX_DSYN_LAPG": "1"}, 6, 16),              # ... both in global memory
     ({"ULCX_DSYN_PAD": "8192"}, 6, 16),
 ])
 def test_round3_switches_keep_parity(env, B, K):

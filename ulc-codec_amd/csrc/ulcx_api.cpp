@@ -538,8 +538,10 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     // per channel (k_dsyn); everything else takes the general kernel (k_dgen: one array, state in HBM)
     c.fastOK = (nChan == 2 && BlockSize <= 4096) ? 1 : 0;
     if (const char *ev = getenv("ULCX_DEC_FAST")) c.fastOK = c.fastOK && (ev[0] != '0');
-    c.twInLds = c.fastOK;
-    if (const char *ev = getenv("ULCX_DSYN_LAPG")) { if (ev[0] == '1' && BlockSize <= 2048) c.twInLds = 0; }     // experiment: lapping state + twiddles in global memory, more workgroups per CU
+    // stereo, BlockSize <= 2048: twiddles in LDS, lapping state in global memory (mode 2: six synthesis workgroups per CU;
+    // round 3: 1.00 -> 0.92 ms per 65536 blocks); ULCX_DSYN_LAPG=0 both in LDS (rounds 1-2), =1 both in global memory
+    c.twInLds = c.fastOK ? ((BlockSize <= 2048) ? 2 : 1) : 0;
+    if (const char *ev = getenv("ULCX_DSYN_LAPG")) { if (c.fastOK && BlockSize <= 2048) c.twInLds = ev[0] == '0' ? 1 : ev[0] == '1' ? 0 : 2; }
     rc = ulcx_tables_build(&c.T, &e->tables, BlockSize, 44100, false);
     if (rc) { cleanup(e); return rc; }
     size_t B = nStreams, NB = B * maxBlocksPerCall;

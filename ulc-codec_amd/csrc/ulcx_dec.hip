@@ -646,8 +646,9 @@ struct DsynLds { int zFloats, lapFloats, twFloats, listFloats; };
 __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int twInLds) {
     DsynLds l;
     l.zFloats = (fast ? 2 : 1) * 2 * FFT_PADDEDS(BS / 2, DPS);
-    l.lapFloats = (fast && BS <= 2048 && twInLds) ? 2 * (BS / 2) : 0;      // (above 2048 the stereo kernel keeps the lapping state in global memory: a third workgroup per CU)
-    l.twFloats = (fast && BS <= 2048 && twInLds) ? BS / 2 : 0;               // (likewise the FFT twiddles: read from the tables in global memory, L1/L2-hot, a fourth workgroup per CU)
+    // twInLds: 1 = lapping state and twiddles in LDS, 0 = both in global memory, 2 = twiddles in LDS, lapping state in global memory
+    l.lapFloats = (fast && BS <= 2048 && twInLds == 1) ? 2 * (BS / 2) : 0;      // (above 2048 the stereo kernel keeps the lapping state in global memory: a third workgroup per CU)
+    l.twFloats = (fast && BS <= 2048 && twInLds != 0) ? BS / 2 : 0;               // (likewise the FFT twiddles: read from the tables in global memory, L1/L2-hot, a fourth workgroup per CU)
     l.listFloats = 2 * (64 + DSYN_PWORDS(BS)) + 128;             // per wave: prefix counts, sign-parity stream; per workgroup: 128 block / channel RNG states
     (void)C;
     return l;
@@ -659,14 +660,14 @@ __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int 
 #ifndef DSYN_LAPG_WAVES
 #define DSYN_LAPG_WAVES 3
 #endif
-template <typename OUT, int DEC_MAXT, bool LAPG>
+template <typename OUT, int DEC_MAXT, bool LAPG, bool TWL = !LAPG>          // LAPG: lapping state in global memory; TWL: twiddles in LDS
 __global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3) void k_dsyn(UlcxDecCtx c) {
     extern __shared__ float lds[];
     const int BS = c.BS, H2 = BS / 2;
     constexpr int C = 2;
     const int s = c.s0 + blockIdx.x, tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const DsynLds L = dsyn_lds(BS, C, 1, LAPG ? 0 : 1);
+    const DsynLds L = dsyn_lds(BS, C, 1, LAPG ? (TWL ? 2 : 0) : 1);
     float2 *z    = (float2 *)lds;
     float *glap = c.lap + (size_t)s * C * H2;
     // lapping state: in LDS for the stream's blocks of this call, or (LAPG: BlockSize 4096) used where it lives.  Every
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3)
     uint32_t *bseed = (uint32_t *)(lds + L.zFloats + L.lapFloats + L.twFloats + 2 * (64 + DSYN_PWORDS(BS)));   // [0,64): RNG state at each block's start, [64,128): at its second channel
     sw.lane = lane;
     if (!LAPG) for (int i = tid; i < 2 * H2; i += WG) lap[i] = glap[i];
-    if (!LAPG) for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
+    if (TWL) for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
     bool twFull = true;
     int lastSub = c.lastSub[s];
     int dead = c.dead[s];
@@ -698,7 +699,14 @@ __global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3)
 #endif
     __syncthreads();
 
+    const int laneOuter = lane, tidOuter = tid;
     for (int k = 0; k < c.K; k++) {
+        // Inside this loop over the stream's blocks the compiler hoists every load and index that depends on the thread only
+        // (pre-twiddles, window factors, bit-reversed positions, padded FFT addresses) out of the loop - registers held
+        // across all blocks.  Opaque copies of the thread's indices keep them where they are used.
+        int lane = laneOuter, tid = tidOuter;
+        asm volatile("" : "+v"(lane), "+v"(tid));
+        sw.lane = lane;                                              // (round 3: 168 registers with spills -> 156 without, 1.05 -> 1.00 ms)
         const int blk = s * c.K + k;
         if ((k & 63) == 0) {
             // The stream's one RNG chain (ulcDecoder.c:75-81) for the next 64 blocks at once: a block starts draws-of-its-
@@ -735,7 +743,7 @@ __global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3)
         int nsub = 1;
         if (!whole) { nsub = 0; unsigned q = pat0; do nsub++; while (q >>= 4); }
         auto unit_draws = [&](int ch, int j) { return ((j + 1 < nsub) ? udraw[ch * 4 + j + 1] : (ch + 1 < C) ? udraw[(ch + 1) * 4] : c.draws[blk]) - udraw[ch * 4 + j]; };
-        if (!LAPG && whole != twFull) {
+        if (TWL && whole != twFull) {
             // twiddle tables for this block's transform sizes: the full-size one, or those of N/2, N/4, N/8 back to back
             if (whole) for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
             else for (int i = tid; i < 7 * BS / 32; i += WG) {
@@ -769,7 +777,7 @@ __global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3)
                     zj[pn2] = cmulc(make_float2(b.x, a.y), pre[n2]);
                 }
                 STAMP(11);
-                if constexpr (LAPG) { if (M == 1024) fft_wave_dif_ct<1024, DPS>(zj, c.T.tw[d], lane); else fft_wave_dif(zj, M, c.T.tw[d], lane, DPS); }
+                if constexpr (!TWL) { if (M == 1024) fft_wave_dif_ct<1024, DPS>(zj, c.T.tw[d], lane); else fft_wave_dif(zj, M, c.T.tw[d], lane, DPS); }
                 else if (M == 1024) fft_wave_dif_ct<1024, DPS>(zj, twl, lane);     // (BlockSize 2048, un-decimated: index arithmetic folded at compile time)
                 else fft_wave_dif(zj, M, twl + (d <= 1 ? 0 : d == 2 ? BS / 8 : 3 * BS / 16), lane, DPS);
                 }
@@ -1038,10 +1046,14 @@ int ulcx_dec_launch(const UlcxDecCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     UlcxDecCtx c = cIn;
     size_t lds = ulcx_dec_lds_bytes(c.BS, c.C, c.fastOK, c.twInLds) + (size_t)aux.ldsPad;     // (ldsPad: experiment, fewer workgroups per CU)
     const bool small = c.BS <= 2048;                      // register slots of the decimated-block path (dec_time_wave)
-    const bool lapg16 = small && c.fastOK && !c.twInLds && !c.pcm16;      // (experiment, ULCX_DSYN_LAPG=1: BlockSize <= 2048 with the lapping state and twiddles in global memory)
+    // stereo, BlockSize <= 2048: where the lapping state and the FFT twiddles live (c.twInLds: 1 both in LDS - rounds 1-2 -,
+    // 2 twiddles in LDS and the lapping state in global memory: 23 KB, six workgroups per CU instead of five - round 3, the
+    // default -, 0 both in global memory)
+    const int mode = small ? c.twInLds : 0;
     const void *fn = !c.fastOK ? (c.pcm16 ? (const void *)k_dgen<int16_t> : (const void *)k_dgen<float>)
-                   : c.pcm16 ? (small ? (const void *)k_dsyn<int16_t, 16, false> : (const void *)k_dsyn<int16_t, 32, true>)
-                             : (lapg16 ? (const void *)k_dsyn<float, 16, true> : small ? (const void *)k_dsyn<float, 16, false> : (const void *)k_dsyn<float, 32, true>);
+                   : !small ? (c.pcm16 ? (const void *)k_dsyn<int16_t, 32, true> : (const void *)k_dsyn<float, 32, true>)
+                   : c.pcm16 ? (mode == 2 ? (const void *)k_dsyn<int16_t, 16, true, true> : mode == 0 ? (const void *)k_dsyn<int16_t, 16, true> : (const void *)k_dsyn<int16_t, 16, false>)
+                             : (mode == 2 ? (const void *)k_dsyn<float, 16, true, true> : mode == 0 ? (const void *)k_dsyn<float, 16, true> : (const void *)k_dsyn<float, 16, false>);
     if (lds > 48 * 1024) CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     auto scan = [&](hipStream_t s2, int s0, int s1) {
         UlcxDecCtx cc = c; cc.s0 = s0; cc.s1 = s1;
@@ -1053,8 +1065,16 @@ int ulcx_dec_launch(const UlcxDecCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         const unsigned g = (unsigned)(s1 - s0);
         if (ULCX_DBG(c) & 8) {}
         else if (!c.fastOK) { if (c.pcm16) hipLaunchKernelGGL(k_dgen<int16_t>, dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL(k_dgen<float>, dim3(g), dim3(WG), lds, s2, cc); }
-        else if (c.pcm16) { if (small) hipLaunchKernelGGL((k_dsyn<int16_t, 16, false>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<int16_t, 32, true>), dim3(g), dim3(WG), lds, s2, cc); }
-        else { if (lapg16) hipLaunchKernelGGL((k_dsyn<float, 16, true>), dim3(g), dim3(WG), lds, s2, cc); else if (small) hipLaunchKernelGGL((k_dsyn<float, 16, false>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<float, 32, true>), dim3(g), dim3(WG), lds, s2, cc); }
+        else if (!small) { if (c.pcm16) hipLaunchKernelGGL((k_dsyn<int16_t, 32, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<float, 32, true>), dim3(g), dim3(WG), lds, s2, cc); }
+        else if (c.pcm16) {
+            if (mode == 2) hipLaunchKernelGGL((k_dsyn<int16_t, 16, true, true>), dim3(g), dim3(WG), lds, s2, cc);
+            else if (mode == 0) hipLaunchKernelGGL((k_dsyn<int16_t, 16, true>), dim3(g), dim3(WG), lds, s2, cc);
+            else hipLaunchKernelGGL((k_dsyn<int16_t, 16, false>), dim3(g), dim3(WG), lds, s2, cc);
+        } else {
+            if (mode == 2) hipLaunchKernelGGL((k_dsyn<float, 16, true, true>), dim3(g), dim3(WG), lds, s2, cc);
+            else if (mode == 0) hipLaunchKernelGGL((k_dsyn<float, 16, true>), dim3(g), dim3(WG), lds, s2, cc);
+            else hipLaunchKernelGGL((k_dsyn<float, 16, false>), dim3(g), dim3(WG), lds, s2, cc);
+        }
     };
     int nCh = (aux.side && aux.nChunks > 1) ? aux.nChunks : 1;
     if (nCh > ULCX_DEC_MAXCH) nCh = ULCX_DEC_MAXCH;
