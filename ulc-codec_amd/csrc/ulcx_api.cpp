@@ -42,7 +42,7 @@ struct ulcx_decoder {
     bool evOk, evRecorded, timing;
     uint8_t *d_in; size_t d_in_bytes; float *d_pcm; int32_t *d_bits;
     uint8_t *d_pay; int32_t *d_payBytes; long long payStride;     // resident packed payloads (ulcx_decoder_upload_payload)
-    hipStream_t side; hipEvent_t evFork, evScan[ULCX_DEC_MAXCH]; bool sideOk; int nChunks; int ldsPad;   // walk / synthesis pipeline (ULCX_DEC_PIPE chunks)
+    hipStream_t side; hipEvent_t evFork, evScan[ULCX_DEC_MAXCH]; bool sideOk; int nChunks; int ldsPad, scanLpw;   // walk / synthesis pipeline (ULCX_DEC_PIPE chunks)
     // single-block path (ulcx_decode_block1)
     hipStream_t b1Stream; hipGraph_t b1Graph; hipGraphExec_t b1Exec; bool b1Init, b1Graphed, b1NoGraph; int b1Slot;
     uint8_t *pinIn; float *pinPcm; int32_t *pinMeta;
@@ -511,7 +511,7 @@ static void build_rng_tables(std::vector<uint32_t> &jumpT) {
 
 static UlcxDecAux dec_aux(ulcx_decoder *e) {
     UlcxDecAux a; a.side = e->sideOk ? e->side : nullptr; a.evFork = e->evFork; a.evScan = e->evScan; a.nChunks = e->nChunks;
-    a.ldsPad = e->ldsPad;
+    a.ldsPad = e->ldsPad; a.scanLpw = e->scanLpw;
     return a;
 }
 
@@ -526,6 +526,7 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->timing = true;
     e->d_in = nullptr; e->d_in_bytes = 0; e->d_pcm = nullptr; e->d_bits = nullptr; e->d_pay = nullptr; e->d_payBytes = nullptr; e->payStride = 0;
     e->sideOk = false; e->side = nullptr; e->nChunks = 1;
+    e->scanLpw = 64; if (const char *pv = getenv("ULCX_DSCAN_LPW")) { int n = atoi(pv); if (n == 16 || n == 32 || n == 64) e->scanLpw = n; }
     e->ldsPad = 0; if (const char *pv = getenv("ULCX_DSYN_PAD")) { int n = atoi(pv); if (n > 0 && n < 120 * 1024) e->ldsPad = n & ~15; }
     e->b1Init = e->b1Graphed = e->b1NoGraph = false; e->pinIn = nullptr; e->pinPcm = nullptr; e->pinMeta = nullptr; e->b1Slot = 0;
     UlcxDecCtx &c = e->ctx;

@@ -303,8 +303,9 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
 }
 
 // Pass 1 - one lane per block.
-__global__ __launch_bounds__(64) void k_dscan(UlcxDecCtx c) {
-    int blk = c.s0 * c.K + blockIdx.x * 64 + threadIdx.x;          // streams [s0, s1) of the batch (ulcx_dec_launch pipelines chunks)
+__global__ __launch_bounds__(64) void k_dscan(UlcxDecCtx c, int lpw) {
+    if ((int)threadIdx.x >= lpw) return;                           // (lpw < 64: half- or quarter-filled waves, more of them per SIMD)
+    int blk = c.s0 * c.K + blockIdx.x * lpw + threadIdx.x;         // streams [s0, s1) of the batch (ulcx_dec_launch pipelines chunks)
     if (blk >= c.s1 * c.K) return;
     scan_block(c, blk, c.in + (size_t)blk * c.slot, c.slot * 8, c.slot, c.in, c.in + c.inBytes);
 }
@@ -1058,7 +1059,7 @@ int ulcx_dec_launch(const UlcxDecCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     auto scan = [&](hipStream_t s2, int s0, int s1) {
         UlcxDecCtx cc = c; cc.s0 = s0; cc.s1 = s1;
         if (c.packed) hipLaunchKernelGGL(k_dscan_packed, dim3((s1 - s0 + 63) / 64), dim3(64), 0, s2, cc);
-        else hipLaunchKernelGGL(k_dscan, dim3(((s1 - s0) * c.K + 63) / 64), dim3(64), 0, s2, cc);
+        else { const int lpw = aux.scanLpw > 0 ? aux.scanLpw : 64; hipLaunchKernelGGL(k_dscan, dim3(((s1 - s0) * c.K + lpw - 1) / lpw), dim3(64), 0, s2, cc, lpw); }
     };
     auto syn = [&](hipStream_t s2, int s0, int s1) {
         UlcxDecCtx cc = c; cc.s0 = s0; cc.s1 = s1;

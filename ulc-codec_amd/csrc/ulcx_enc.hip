@@ -1498,6 +1498,19 @@ __device__ __forceinline__ float key0_of(float re) {
     asm volatile("" : "+v"(k));
     return (fabsf(re) < 0.5f * ULCX_COEF_EPS) ? __uint_as_float(0xff800000u) : k;
 }
+// The same key as key_ord(final_key(key0_of(re), m, ch)) for the wave selection (round 3: 30 -> 21 vector instructions per
+// key).  2*v is exact, so fma(v, 2, m) rounds once where 2*v + m rounds once: identical.  The key is never -0.0 (a sum is -0
+// only if both terms are, and ln2 * (float)e is +0 for e = 0; the channel constant is not 0), so the map needs no zero
+// test: two instructions, arithmetic shift + one three-input bit operation.
+__device__ __forceinline__ uint32_t sel_key(float re, float m, int ch) {
+    float k = fastlog(re * re);                            // (evaluated unconditionally: a select, not a branch per coefficient)
+    asm("" : "+v"(k));
+    k = (fabsf(re) < 0.5f * ULCX_COEF_EPS) ? __uint_as_float(0xff800000u) : k;
+    float t = __builtin_fmaf(k, 2.0f, m);
+    if (ch & 1) t = t + -0x1.62E430p0f;
+    const uint32_t u = __float_as_uint(t);
+    return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
+}
 // Psyopt.c:140-150: masking level of line pair jp (0 <= jp < BS/2) of a block: interpolation between the Bark levels of
 // its subblock (bark4 = the block's [4][25] levels from k_pbark).  Evaluated where the keys are formed: no array of it in HBM.
 __device__ __forceinline__ float mask_level(const UlcxEncCtx &c, const float *bark4, int wc, int jp) {
@@ -1648,7 +1661,7 @@ __global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
 
 // One WAVE per block, keys held in registers (R = N/64 per lane): no workgroup barriers,
 // the 256-bin histogram of each radix pass lives in a private 1 KB LDS slice.
-template <int R>
+template <int R, int LGBS = 0>                           // LGBS: log2(BlockSize) as a compile-time constant (0: read from the context)
 __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass) {
     if (probes_over(c, finalPass)) return;
     int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1667,6 +1680,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
     extern __shared__ float sel_lds[];                        // per wave: BS/2 masking levels + the block's 4 x 25 Bark levels; later the candidate lists
     const int selStride = ulcx_sel_lds_words(c.BS);
     uint32_t u[R];
+    const int lgK = LGBS ? LGBS : c.lgBS, bsK = LGBS ? (1 << LGBS) : c.BS;   // (constants: channel and LDS offsets of a key fold per register)
     {
         // the block's masking level per line (Psyopt.c:140-150), formed by the wave into LDS (BS/2 <= 32 R values) instead of
         // being read from an array another kernel wrote
@@ -1685,9 +1699,9 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
         for (int r0 = 0; r0 < R; r0 += 8) {
             float cv[8], mv[8];
 #pragma unroll
-            for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; cv[q] = ldnt(coef + i); mv[q] = msk[(i & (c.BS - 1)) >> 1]; }
+            for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; cv[q] = ldnt(coef + i); mv[q] = msk[(i & (bsK - 1)) >> 1]; }
 #pragma unroll
-            for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; u[r0 + q] = key_ord(final_key(key0_of(cv[q]), mv[q], i >> c.lgBS)); }
+            for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; u[r0 + q] = sel_key(cv[q], mv[q], i >> lgK); }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1951,7 +1965,11 @@ __global__ __launch_bounds__(WG) void k_keep_ranks(UlcxEncCtx c, int finalPass) 
 // the serial kernel would compute; it checks the assumption and recomputes if it is off
 // (a kept coefficient collapsed, a noise run fell back to a zero run, ...).
 // ---------------------------------------------------------------------------
-#define E_GAPCAP 1024      // gaps >= 16 per block: at most N/17 of them; N <= 16384 here
+#ifdef GAPCAP_OLD
+#define E_GAPCAP(N) 1024
+#else
+#define E_GAPCAP(N) ((N) / 16)      // gaps >= 16 per block: at most N/17 of them (round 3: was a fixed 1024 - 8 KB of LDS, six workgroups per CU instead of eight)
+#endif
 __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
     extern __shared__ uint32_t gsm[];
     int tid = threadIdx.x;
@@ -1973,7 +1991,8 @@ __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
     // kept coefficients whose gap is long enough for a noise run; pass 2: one queued gap per
     // thread, so a wave's time is its longest gap once, not once per strided slot.
     uint32_t *wl = kw + N / 32;                            // work list: (start << 16 | i - start) ... stored as two words
-    int *wcount = (int *)(wl + 2 * E_GAPCAP);
+    const int gapCap = E_GAPCAP(N);
+    int *wcount = (int *)(wl + 2 * gapCap);
     if (tid == 0) *wcount = 0;
     __syncthreads();
     for (int hw = tid; hw < N / 16; hw += WG) {              // 16 coefficient slots per step: only set bits are visited
@@ -2002,12 +2021,12 @@ __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
         int start = prev + 1, zr = i - start;
         if (zr < 16) continue;
         int slot = atomicAdd(wcount, 1);
-        if (slot < E_GAPCAP) { wl[2 * slot] = (uint32_t)i; wl[2 * slot + 1] = (uint32_t)start; }
+        if (slot < gapCap) { wl[2 * slot] = (uint32_t)i; wl[2 * slot + 1] = (uint32_t)start; }
         else gs[i] = make_float2(-2.0f, 0.0f);             // list full (cannot happen for N/16 <= cap): mark "not computed"
       }
     }
     __syncthreads();
-    int nw = *wcount; if (nw > E_GAPCAP) nw = E_GAPCAP;
+    int nw = *wcount; if (nw > gapCap) nw = gapCap;
     for (int t = tid; t < nw; t += WG) {
         int i = (int)wl[2 * t], start = (int)wl[2 * t + 1];
         int zr = i - start;
@@ -2485,7 +2504,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
     }
     bool overflow = nK > E2_KCAP;
     WAVE_SYNC();
-    if ((ULCX_DBG(c) >> 8) == 1) return;
+    if ((ULCX_DBG(c) >> 8) == 1) { if (lane == 0) c.unitNyb[gid] = 0; return; }
 
     // C. zone segmentation: the greedy scan of Encode.c:218-269 (a zone breaks at the first coefficient whose level puts
     //    max > 4*min over the zone so far), without walking the coefficients one by one:
@@ -2543,7 +2562,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
         if (nZ > E2_ZCAP) overflow = true;
     }
     WAVE_SYNC();
-    if ((ULCX_DBG(c) >> 8) == 2) return;
+    if ((ULCX_DBG(c) >> 8) == 2) { if (lane == 0) c.unitNyb[gid] = 0; return; }
 
     // D. quantizer per zone + nybbles of its change code (Encode.c:240-244, 32-45)
     if (!overflow) {
@@ -2564,7 +2583,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
         }
     }
     WAVE_SYNC();
-    if ((ULCX_DBG(c) >> 8) == 3) return;
+    if ((ULCX_DBG(c) >> 8) == 3) { if (lane == 0) c.unitNyb[gid] = 0; return; }
 
     // E. quantise kept items, drop the ones that collapse (Encode.c:114), compact in place.
     //    Bit 15 of the compacted index records "the kept item right before me was coded too",
@@ -2593,7 +2612,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
         }
     }
     WAVE_SYNC();
-    if ((ULCX_DBG(c) >> 8) == 4) return;
+    if ((ULCX_DBG(c) >> 8) == 4) { if (lane == 0) c.unitNyb[gid] = 0; return; }
 
     // F+H. gaps -> run codes; positions by prefix sum; emission
     int total = 0;
@@ -2633,7 +2652,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
         }
         overflow = __any(overflow);
     }
-    if ((ULCX_DBG(c) >> 8) == 5) return;
+    if ((ULCX_DBG(c) >> 8) == 5) { if (lane == 0) c.unitNyb[gid] = 0; return; }
 
     // G. tail (Encode.c:271-312)
     if (!overflow) {
@@ -3108,12 +3127,15 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     if (selLds > 48 * 1024 && selLds <= ULCX_LDS_LIMIT && (N / 64 == 128 || N / 64 == 64)) {   // (mono BlockSize 8192: 67 KB)
         CK(hipFuncSetAttribute((const void *)k_select_wave<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)selLds));
         CK(hipFuncSetAttribute((const void *)k_select_wave<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)selLds));
+        CK(hipFuncSetAttribute((const void *)k_select_wave<64, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)selLds));
     }
     auto launch_select = [&](int fin) {
         int R = N / 64;
         switch (R) {
             case 128: hipLaunchKernelGGL(k_select_wave<128>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;   // (BlockSize 4096 stereo: ~200 VGPRs, one wave per SIMD)
-            case 64: hipLaunchKernelGGL(k_select_wave<64>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;
+            case 64: if (c.lgBS == 11) hipLaunchKernelGGL((k_select_wave<64, 11>), dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin);     // (stereo BlockSize 2048)
+                     else hipLaunchKernelGGL(k_select_wave<64>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin);
+                     return true;
             case 32: hipLaunchKernelGGL(k_select_wave<32>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;
             case 16: hipLaunchKernelGGL(k_select_wave<16>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;
             case 8:  hipLaunchKernelGGL(k_select_wave<8>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;
@@ -3138,7 +3160,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         const bool fb2 = (cc.fbMode == 2);                 // exact path: small grids that walk the list of owned blocks
         const int fbW = NB < 128 ? NB : 128;
         if (cc.useGapSums) {
-            size_t glds = (size_t)N * 4 + N / 8 + 8 * E_GAPCAP + 16;
+            size_t glds = (size_t)N * 4 + N / 8 + 8 * E_GAPCAP(N) + 16;
             if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
             // the two speculative-sum kernels are independent and both latency-bound: on the main path k_tailsums
             // runs on a side stream beside k_gapsums

@@ -184,6 +184,7 @@ struct UlcxDecAux {
     hipEvent_t evFork, *evScan;          // [ULCX_DEC_MAXCH]
     int nChunks;
     int ldsPad;                          // ULCX_DSYN_PAD: extra dynamic LDS bytes per synthesis workgroup (occupancy experiments)
+    int scanLpw;                         // blocks (= live lanes) per wave of the syntax walk: 64, 32 or 16
 };
 int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev, const UlcxDecAux &aux);
 size_t ulcx_dec_lds_bytes(int BS, int C, int fast, int twInLds);
