@@ -19,6 +19,7 @@
 // All float arithmetic is written in the reference's operation order and this file is
 // compiled with -ffp-contract=off: no fused multiply-add is formed anywhere except the
 // explicit ones inside the glibc restatements (ulcx_libm.h).
+#include <utility>
 #include "ulcx_internal.h"
 #include <type_traits>
 #include "ulcx_libm.h"
@@ -1239,39 +1240,48 @@ __global__ __launch_bounds__(64) void k_nbark(UlcxEncCtx c, int useList) {
 }
 
 // Psyopt.c:236-248: per-line interpolation + {w, w*(log+ln2)} pairs.
-// One workgroup per (block, channel): the unit's Bark levels sit in LDS, every thread does
-// BS/512 line pairs (independent chains of table gathers + expf to overlap).
+// One workgroup per block, NLINE_CH channels at a time: their Bark levels sit in LDS, every thread takes two neighbouring
+// line pairs per trip and, for them, the geometry and the two table entries ONCE for all channels (round 3: a workgroup per
+// (block, channel) was capped by the eight waves a SIMD holds - 5 us of latency per 8 KB written).
+#define NLINE_CH 2
 __global__ __launch_bounds__(WG) void k_nline(UlcxEncCtx c) {
-    __shared__ float sbark[4 * ULCX_NBARK];
-    int bc = blockIdx.x, tid = threadIdx.x;
-    int blk = bc / c.C, ch = bc - blk * c.C;
-    int half = c.BS / 2;
-    int s = blk / c.K, k = blk % c.K;
-    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
-    if (tid < 4 * ULCX_NBARK) sbark[tid] = c.barkN[(size_t)(blk * c.C + ch) * 4 * ULCX_NBARK + tid];
-    __syncthreads();
-    float2 *dst = (float2 *)(c.npair + (size_t)blk * (c.C * c.BS) + (size_t)ch * c.BS);
-    // two neighbouring line pairs per thread: one 16-byte store (subblocks are multiples of 32 lines: both are in the same one)
-    for (int jp = 2 * tid; jp < half; jp += 2 * WG) {
-        unsigned pat = ulcx_pattern(wc);
-        int off = 0, d = 0, S = c.BS, j = 0;
-        for (;; j++) { d = pat & 7; S = c.BS >> d; if (2 * jp < off + S) break; off += S; pat >>= 4; }
-        int line = jp - off / 2;
-        const float *bark = sbark + j * ULCX_NBARK;
-        const int2 bi2 = *(const int2 *)(c.T.bandIdx[d] + line);
-        const float2 fr2 = *(const float2 *)(c.T.bandFrac[d] + line);
-        float o[4];
+    __shared__ float sbark[NLINE_CH * 4 * ULCX_NBARK];
+    const int blk = blockIdx.x, tid = threadIdx.x;
+    const int half = c.BS / 2;
+    const int s = blk / c.K, k = blk % c.K;
+    const int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+    for (int ch0 = 0; ch0 < c.C; ch0 += NLINE_CH) {
+        const int nch = (c.C - ch0 < NLINE_CH) ? c.C - ch0 : NLINE_CH;
+        if (ch0) __syncthreads();
+        for (int i = tid; i < nch * 4 * ULCX_NBARK; i += WG) sbark[i] = c.barkN[(size_t)(blk * c.C + ch0) * 4 * ULCX_NBARK + i];
+        __syncthreads();
+        // two neighbouring line pairs per thread: one 16-byte store (subblocks are multiples of 32 lines: both are in the same one)
+        for (int jp = 2 * tid; jp < half; jp += 2 * WG) {
+            unsigned pat = ulcx_pattern(wc);
+            int off = 0, d = 0, S = c.BS, j = 0;
+            for (;; j++) { d = pat & 7; S = c.BS >> d; if (2 * jp < off + S) break; off += S; pat >>= 4; }
+            const int line = jp - off / 2;
+            const int2 bi2 = *(const int2 *)(c.T.bandIdx[d] + line);
+            const float2 fr2 = *(const float2 *)(c.T.bandFrac[d] + line);
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            int bi = q ? bi2.y : bi2.x;
-            float fr = q ? fr2.y : fr2.x;
-            float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
-            float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
-            float noise = L * (1.0f - fr) + R * fr;
-            float w = ulcx_expf(0.5f * noise);
-            o[2 * q] = w; o[2 * q + 1] = w * (noise + 0x1.62E430p-1f);
+            for (int cc = 0; cc < NLINE_CH; cc++) {
+                if (cc >= nch) break;
+                const float *bark = sbark + (cc * 4 + j) * ULCX_NBARK;
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    int bi = q ? bi2.y : bi2.x;
+                    float fr = q ? fr2.y : fr2.x;
+                    float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
+                    float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
+                    float noise = L * (1.0f - fr) + R * fr;
+                    float w = ulcx_expf(0.5f * noise);
+                    o[2 * q] = w; o[2 * q + 1] = w * (noise + 0x1.62E430p-1f);
+                }
+                float2 *dst = (float2 *)(c.npair + (size_t)blk * (c.C * c.BS) + (size_t)(ch0 + cc) * c.BS);
+                stnt((float4 *)(dst + jp), make_float4(o[0], o[1], o[2], o[3]));
+            }
         }
-        stnt((float4 *)(dst + jp), make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
@@ -1659,6 +1669,16 @@ __global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
     }
 }
 
+// The 64-bit ballot of key register I into lane I of (klo, khi): v_writelane_b32 with an immediate lane.  (No builtin for it in
+// this compiler; the s_nop covers the two wait states gfx940+ wants between a vector compare's scalar result and a
+// vector instruction that reads it - the hazard recogniser does not look inside inline assembly.)
+template <int L> __device__ __forceinline__ void writelane2_imm(uint32_t &lo, uint32_t &hi, unsigned long long m) {
+    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(lo), "+v"(hi) : "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "n"(L));
+}
+template <int R, int... I>
+__device__ __forceinline__ void sel_gather_keep(const uint32_t (&u)[R], uint32_t T, uint32_t &klo, uint32_t &khi, std::integer_sequence<int, I...>) {
+    ((void)[&] { writelane2_imm<I>(klo, khi, __ballot(u[I] >= T)); }(), ...);
+}
 // One WAVE per block, keys held in registers (R = N/64 per lane): no workgroup barriers,
 // the 256-bin histogram of each radix pass lives in a private 1 KB LDS slice.
 template <int R, int LGBS = 0>                           // LGBS: log2(BlockSize) as a compile-time constant (0: read from the context)
@@ -1718,6 +1738,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
     constexpr int SEL_CAP = ULCX_SEL_CAP, SEL_CAND = ULCX_SEL_CAND;
     constexpr bool SEL_COMPACT = R > 2 * SEL_CAP;         // (few keys per lane: the full probes are as cheap)
     uint32_t T = 0;
+    int cntT = N;                                         // keys >= T (the search keeps it: no counting pass at the end)
     {
         uint32_t mn = 0xFFFFFFFFu, mx = 0u;
 #pragma unroll
@@ -1755,7 +1776,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
 #pragma unroll
                         for (int j = 0; j < SEL_CAP; j++) { uint32_t v = (cd[j] >= t) ? cd[j] : 0xFFFFFFFFu; m2 = v < m2 ? v : m2; }
                     }
-                    T = wave_min_u32(m2);
+                    T = wave_min_u32(m2); cntLo = kSel;
                     break;
                 }
                 if (cnt > kSel) { T = t; cntLo = cnt; } else if (!compacted) cntHi = cnt;
@@ -1779,19 +1800,24 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
                     }
                 }
             }
+            cntT = cntLo;
         }
     }
-    int g = 0, e = 0;
+    // the tie group at T straddles the cut iff more than kSel keys are >= T (kSel - #(u > T) < #(u == T))
+    const bool straddle = kSel < cntT;
+    // keep bitmap: the ballot of register r is the pair of words 2r, 2r+1 - gathered into lane r (R <= 64) or lanes r, r - 64
+    // and stored once per lane instead of twice per register
+    if constexpr (R <= 64) {
+        uint32_t klo = 0, khi = 0;
+        sel_gather_keep(u, T, klo, khi, std::make_integer_sequence<int, R>());
+        if (lane < R) *(uint2 *)(keep + 2 * lane) = make_uint2(klo, khi);
+    } else {
 #pragma unroll
-    for (int r = 0; r < R; r++) { g += (u[r] > T) ? 1 : 0; e += (u[r] == T) ? 1 : 0; }
-    for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o); e += __shfl_xor(e, o); }
-    int need = kSel - g;                                  // how many of the e keys tied at T belong to the kept set
-    bool straddle = (need < e);
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        unsigned long long m = __ballot(u[r] >= T);
-        if (lane == 0)  keep[2 * r] = (uint32_t)m;
-        if (lane == 32) keep[2 * r + 1] = (uint32_t)(m >> 32);
+        for (int r = 0; r < R; r++) {
+            unsigned long long m = __ballot(u[r] >= T);
+            if (lane == 0)  keep[2 * r] = (uint32_t)m;
+            if (lane == 32) keep[2 * r + 1] = (uint32_t)(m >> 32);
+        }
     }
     if (straddle && lane == 0) {
         int slot = atomicAdd(c.fbCount, 1);
@@ -3056,7 +3082,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             hipLaunchKernelGGL(k_bark_levels<true>, dim3((unsigned)(((size_t)NB * c.C * 32 + WG - 1) / WG)), dim3(WG), 0, s2, c);
         }
         hipLaunchKernelGGL(k_nbark, dim3((nUnits + 63) / 64), dim3(64), 0, s2, c, c.barkRing ? 1 : 0);    if (ev0) MARK();
-        hipLaunchKernelGGL(k_nline, dim3(NB * c.C), dim3(WG), 0, s2, c);                                   if (ev0) MARK();
+        hipLaunchKernelGGL(k_nline, dim3(NB), dim3(WG), 0, s2, c);                                   if (ev0) MARK();
         return ULCX_OK;
     };
     // The noise log-spectrum (k_nbark: lane-serial ordered sums, latency-bound; k_nline) depends on the
