@@ -195,6 +195,8 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.gapSum, NB * cb, false);
     DA(c.tailSum, NB * nChan * 4 * 8, true);
     if (const char *ev = getenv("ULCX_WAVE")) c.useWave = (ev[0] != '0');
+    c.directPack = 1;
+    if (const char *ev = getenv("ULCX_DIRECT_PACK")) c.directPack = (ev[0] != '0');
     c.dbgSkip = 0;
 #ifdef ULCX_ABLATE
     if (const char *ev = getenv("ULCX_DBG_SKIP")) c.dbgSkip = atoi(ev);   // timing experiments only (breaks results)

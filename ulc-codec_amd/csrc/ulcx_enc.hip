@@ -2473,8 +2473,14 @@ __device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const flo
 // wave-local ordering of LDS traffic (all 64 lanes run in lockstep; LDS ops of one wave complete in order)
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
+// Direct packing (round 3): in the final pass of a stereo, un-decimated block - one unit per channel - the two waves of
+// the block write their bytes straight into the output slot instead of staging rows that k_pack shifts into place
+// (Encode.c:329-359: header nybble, channel 0, channel 1, byte aligned).  xch: the pair's LDS word, through which the
+// channel-0 wave tells its partner {nybbles of channel 0, its last nybble, failed, trip number}.
+#define XCH_WORD(total, last, fail, seq) ((unsigned long long)((uint32_t)(total) | ((uint32_t)(last) << 16) | ((uint32_t)(fail) << 20)) | ((unsigned long long)(uint32_t)(seq) << 32))
 template <bool SMALL>
-__device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, int ch, int j, int wc, int lane, float *e2, const WaveCaps caps, int failBit) {
+__device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, int ch, int j, int wc, int lane, float *e2, const WaveCaps caps, int failBit,
+                                 unsigned long long *xch = nullptr, int seq = 0) {
     // SMALL: the ordinary-block capacities as compile-time constants (constant LDS offsets); else the launch's
     const int E2_KCAP = SMALL ? WAVE_SK : caps.k, E2_ZCAP = SMALL ? WAVE_SZ : caps.z, E2_NYBCAP = SMALL ? WAVE_SN : caps.nyb;
     int gid = (blk * c.C + ch) * 4 + j;
@@ -2735,7 +2741,9 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
         total += qtail + tailN;
         if (total > E2_NYBCAP) overflow = true;
     }
+    const bool direct = xch != nullptr;                      // (wave-uniform: final pass, stereo, un-decimated block, unit 0)
     if (overflow) {                                          // hand the whole block to the serial kernel
+        if (direct && ch == 0 && lane == 0) __hip_atomic_store(xch, XCH_WORD(0, 0, 1, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (lane == 0) {
             int old = atomicOr(&c.slow[blk], failBit);
             if (failBit == 1 && !(old & 1)) {              // first failure of this block: queue it for the full-capacity retry launch
@@ -2749,6 +2757,37 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
     WAVE_SYNC();
     if (lane == 0) c.unitNyb[gid] = total;
     if (!finalPass) return;
+    if (direct) {
+        int o = 1; uint32_t prevNyb = (uint32_t)wc & 0xFu;   // block nybble this unit starts at, the nybble in front of it
+        bool ok = true;
+        if (ch == 0) {
+            if (lane == 0) __hip_atomic_store(xch, XCH_WORD(total, total ? nyb[total - 1] : prevNyb, 0, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            unsigned long long v64;
+            for (;;) {
+                v64 = __hip_atomic_load(xch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((uint32_t)(v64 >> 32) == (uint32_t)seq) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v64);
+            ok = !((v >> 20) & 1u);
+            o = 1 + (int)(v & 0xFFFFu); prevNyb = (v >> 16) & 0xFu;
+        }
+        if (ok) {
+            // bytes [o/2, bEnd) of the block: channel 0 leaves a last half-filled byte to channel 1, channel 1 pads its own
+            const int end = o + total;
+            const int bEnd = ch == 0 ? end >> 1 : (end + 1) >> 1;
+            uint8_t *outB = c.out + (size_t)blk * c.slot;
+            for (int b = (o >> 1) + lane; b < bEnd; b += 64) {
+                const int q0 = 2 * b - o;
+                const unsigned lo4 = q0 >= 0 ? nyb[q0] : prevNyb;
+                const unsigned hi4 = q0 + 1 < total ? nyb[q0 + 1] : 0u;
+                if (b < c.slot) outB[b] = (uint8_t)(lo4 | (hi4 << 4));
+            }
+            if (ch == 1 && lane == 0) { c.bits[blk] = (end * 4 + 7) & ~7; atomicOr(&c.slow[blk], 4); }      // bit 2: packed, k_pack passes
+            return;
+        }
+    }
     // I. nybbles -> bytes in the unit's staging row (same layout k_encode_units writes)
     uint8_t *dst = c.unitBuf + (size_t)blk * c.C * c.unitCap + (size_t)ch * c.unitCap + 2 * off + 8 * j;
     int nb = (total + 1) / 2;
@@ -2775,7 +2814,13 @@ __global__ __launch_bounds__(256) void k_encode_wave(UlcxEncCtx c, int finalPass
     const int NBq = c.B * c.K, which = (c.fbMode == 2) ? 1 : 0;
     const int *queue = c.slow + NBq + 2 + which * NBq;
     int nBlk = (phase == 1) ? c.slow[NBq + which] : (c.fbMode == 2) ? fb_count(c) : NBq;
+    // direct packing: waves 2p, 2p+1 of the workgroup are the two channels of one block
+    unsigned long long *xchAll = (unsigned long long *)((char *)e2all + 4 * (size_t)ldsPerWave);
+    const bool directOK = finalPass && c.C == 2 && phase != 1 && c.directPack;
+    if (directOK) { if (threadIdx.x < 2) xchAll[threadIdx.x] = 0; __syncthreads(); }
+    int seq = 0;
     for (int u = blockIdx.x * 4 + wv; u < nBlk * c.C; u += gridDim.x * 4) {      // (block, channel) index; one trip for the full-batch launch
+        seq++;
         int blk = u / c.C, ch = u - blk * c.C;
         if (phase == 1) blk = queue[blk];
         else {
@@ -2784,8 +2829,9 @@ __global__ __launch_bounds__(256) void k_encode_wave(UlcxEncCtx c, int finalPass
         }
         int s = blk / c.K, k = blk % c.K;
         int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+        const bool whole = (c.BS >> (ulcx_pattern(wc) & 7)) == c.BS;          // one unit per channel
         for (int j = 0; j < 4; j++) {
-            encode_unit_wave<SMALL>(c, finalPass, blk, ch, j, wc, lane, e2, caps, phase ? 2 : 1);
+            encode_unit_wave<SMALL>(c, finalPass, blk, ch, j, wc, lane, e2, caps, phase ? 2 : 1, (directOK && whole && j == 0) ? xchAll + (wv >> 1) : nullptr, seq);
             WAVE_SYNC();
         }
     }
@@ -2796,6 +2842,7 @@ __global__ __launch_bounds__(256) void k_encode_wave(UlcxEncCtx c, int finalPass
 __device__ void pack_block(const UlcxEncCtx &c, int finalPass, int blk) {
     int lane = threadIdx.x;
     if (skip_block(c, blk, finalPass)) return;
+    if (finalPass && c.useWave && (c.slow[blk] & 4)) return;        // the wave writer packed this block itself
     int s = blk / c.K, k = blk % c.K;
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     int nU = c.C * 4;
@@ -3181,7 +3228,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     // instead of 1), and what even they cannot hold goes to k_encode_units
     WaveCaps capM = { 1024, 512, 4096 };
     const bool haveMid = capM.k < capF.k;
-    if (haveFull && (size_t)wavecaps_lds(capF) * 4 > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_encode_wave<false>, hipFuncAttributeMaxDynamicSharedMemorySize, wavecaps_lds(capF) * 4));
+    if (haveFull && (size_t)wavecaps_lds(capF) * 4 > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_encode_wave<false>, hipFuncAttributeMaxDynamicSharedMemorySize, wavecaps_lds(capF) * 4 + 16));
     auto launch_encode = [&](UlcxEncCtx cc, hipStream_t s2, int fin, bool ev0, bool bigFirst) -> int {
         const bool fb2 = (cc.fbMode == 2);                 // exact path: small grids that walk the list of owned blocks
         const int fbW = NB < 128 ? NB : 128;
@@ -3208,14 +3255,14 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             // early CBR probes keep ~N/2 coefficients per block: go straight to the full-size caps there
             WaveCaps first = (bigFirst && haveFull) ? capF : capS;
             bool twoPhase = haveFull && !bigFirst;
-            if (bigFirst && haveFull) hipLaunchKernelGGL(k_encode_wave<false>, dim3(fb2 ? fbW : (nBC + 3) / 4), dim3(256), (size_t)wavecaps_lds(first) * 4, s2, cc, fin, first, 2);
-            else hipLaunchKernelGGL(k_encode_wave<true>, dim3(fb2 ? fbW : (nBC + 3) / 4), dim3(256), (size_t)wavecaps_lds(first) * 4, s2, cc, fin, first, twoPhase ? 0 : 2);
+            if (bigFirst && haveFull) hipLaunchKernelGGL(k_encode_wave<false>, dim3(fb2 ? fbW : (nBC + 3) / 4), dim3(256), (size_t)wavecaps_lds(first) * 4 + 16, s2, cc, fin, first, 2);
+            else hipLaunchKernelGGL(k_encode_wave<true>, dim3(fb2 ? fbW : (nBC + 3) / 4), dim3(256), (size_t)wavecaps_lds(first) * 4 + 16, s2, cc, fin, first, twoPhase ? 0 : 2);
             if (twoPhase)
             {
                 // (the exact path's few blocks also retry with the medium capacities: a full-capacity workgroup needs a whole
                 //  CU's LDS and would wait for the main path's kernel to drain)
                 const WaveCaps capR = (haveMid && (fb2 || (probes > 0 && !fin))) ? capM : capF;
-                hipLaunchKernelGGL(k_encode_wave<false>, dim3(fb2 ? fbW : ((nBC + 3) / 4 < 512 ? (nBC + 3) / 4 : 512)), dim3(256), (size_t)wavecaps_lds(capR) * 4, s2, cc, fin, capR, 1);
+                hipLaunchKernelGGL(k_encode_wave<false>, dim3(fb2 ? fbW : ((nBC + 3) / 4 < 512 ? (nBC + 3) / 4 : 512)), dim3(256), (size_t)wavecaps_lds(capR) * 4 + 16, s2, cc, fin, capR, 1);
             }
         }
         if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));

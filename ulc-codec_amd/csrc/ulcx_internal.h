@@ -99,6 +99,7 @@ struct UlcxEncCtx {
     int     rankSlots, fbLo, fbHi;       // resident rank slots; slot window of the current exact-path launch
     int     fbMode;                      // 0 = all blocks, 1 = skip isFb blocks, 2 = only isFb blocks
     int     useWave;                     // wave-per-unit encode pass (k_encode_wave); serial kernel only for overflow blocks
+    int     directPack;                  // the wave writer packs stereo un-decimated blocks into the output slot itself (ULCX_DIRECT_PACK=0: k_pack does all)
     void   *heapScratch;                 // [ULCX_HEAP_GRID][C*BS] {key,idx} heaps, only when C*BS*8 exceeds the LDS budget
 };
 
