@@ -2539,56 +2539,52 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
     if ((ULCX_DBG(c) >> 8) == 1) { if (lane == 0) c.unitNyb[gid] = 0; return; }
 
     // C. zone segmentation: the greedy scan of Encode.c:218-269 (a zone breaks at the first coefficient whose level puts
-    //    max > 4*min over the zone so far), without walking the coefficients one by one:
-    //    1. every kept coefficient i finds, in parallel, where a zone STARTED at i would break ("next break", kept in kz);
-    //    2. the zone starts are the chain 0 -> nb[0] -> nb[nb[0]] ... : one wave-uniform step per zone, marking bit 15;
-    //    3. a coefficient's zone index is the number of starts up to it; a zone's maximum is an LDS max over its members
-    //       (levels are non-negative floats, so they order as their bit patterns).
+    //    max > 4*min over the zone so far), one ZONE per trip instead of one coefficient: a window of 64 kept levels sits in
+    //    the lanes, the running minimum / maximum from the zone's start are two inclusive prefix scans (DPP; levels are
+    //    non-negative floats, they order as their bit patterns), the break is the first lane whose prefixes fail the test,
+    //    the zone's maximum the prefix maximum of the lane in front of it.  A zone that reaches the window's end carries
+    //    its minimum / maximum into the next window.  (Round 3: every kept coefficient used to scan ahead for the break of
+    //    a zone started at it - the longest of 64 such scans per round, 49 steps on the bench's blocks against 10 zones a
+    //    unit - followed by a chain walk through LDS.)
     int nZ = 0;
     if (!overflow && nK > 0) {
-        if (lane == 0) kval[nK] = __uint_as_float(0x7F800000u);   // +inf breaks any zone: the last one ends at nK (kval[E2_KCAP] is zmax[0], cleared below)
-        WAVE_SYNC();
+        const uint32_t INFB = 0x7F800000u;
+        uint32_t cmn = 0u, cmx = 0u;                         // the open zone's minimum / maximum so far (bit patterns)
+        bool open = false;                                   // a zone continues from the previous window (wave-uniform)
         for (int base = 0; base < nK; base += 64) {
             const int i = base + lane;
-            if (i < nK) {
-                float mn = fabsf(kval[i]), mx = mn;
-                if (i == 0) mn = (mn < 1000.0f) ? mn : 1000.0f;    // the reference's initial QuantMin (Encode.c:219)
-                const float *nx = kval + i + 1;
-                int t = 0;
-                // min/max against |l| (no NaNs here: plain v_min/v_max are exact); four levels fetched per trip (reads past the
-                // sentinel stay inside this wave's LDS and are never reached by the comparisons)
-#define ZONE_STEP(l) { float nmn, nmx; \
-                    asm("v_min_f32 %0, |%1|, %2" : "=v"(nmn) : "v"(l), "v"(mn)); \
-                    asm("v_max_f32 %0, |%1|, %2" : "=v"(nmx) : "v"(l), "v"(mx)); \
-                    if (nmx > nmn * 4.0f) break; \
-                    mn = nmn; mx = nmx; t++; }
-                for (;;) {
-                    const float l0 = nx[t], l1 = nx[t + 1], l2 = nx[t + 2], l3 = nx[t + 3];
-                    ZONE_STEP(l0) ZONE_STEP(l1) ZONE_STEP(l2) ZONE_STEP(l3)
+            const uint32_t lv = (i < nK) ? (__float_as_uint(kval[i]) & 0x7FFFFFFFu) : INFB;     // +inf behind the list: it breaks any zone
+            int myz = 0;
+            int s = 0;                                       // lane the current zone starts at (0 when it is carried in)
+            for (;;) {
+                uint32_t a = lv;
+                if (base == 0 && s == 0 && lane == 0) a = (__uint_as_float(lv) < 1000.0f) ? lv : __float_as_uint(1000.0f);   // the reference's initial QuantMin (Encode.c:219)
+                a = (lane >= s) ? a : 0xFFFFFFFFu;
+                uint32_t b = (lane >= s) ? lv : 0u;
+#define STEP(ctl, rmask) { uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)a, ctl, rmask, 0xf, false); a = o < a ? o : a; \
+                           uint32_t q = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, ctl, rmask, 0xf, false); b = q > b ? q : b; }
+                ULCX_DPP_STEPS(STEP)
+#undef STEP
+                if (open) { a = cmn < a ? cmn : a; b = cmx > b ? cmx : b; }
+                const bool brk = (__uint_as_float(b) > __uint_as_float(a) * 4.0f) && (open || lane > s);
+                const unsigned long long m = __ballot(brk);
+                if (m == 0ull) {                             // no break in this window: the zone goes on in the next one
+                    if (lane >= s) myz = nZ;
+                    cmn = (uint32_t)__builtin_amdgcn_readlane((int)a, 63); cmx = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
+                    open = true;
+                    break;
                 }
-#undef ZONE_STEP
-                kz[i] = (uint16_t)(i + 1 + t);
+                const int t = __builtin_ctzll(m);            // first coefficient of the next zone
+                if (lane >= s && lane < t) myz = nZ;
+                const uint32_t zm = t > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)b, t - 1) : cmx;
+                if (lane == 0 && nZ < E2_ZCAP) ((uint32_t *)zmax)[nZ] = zm;
+                nZ++;
+                s = t; open = false;
+                if (base + t >= nK) break;                   // that was the sentinel behind the list
             }
+            if (i < nK) kz[i] = (uint16_t)myz;
         }
-        WAVE_SYNC();
-        for (int z = lane; z < E2_ZCAP; z += 64) ((uint32_t *)zmax)[z] = 0u;
-        for (int i = 0; i < nK; ) {                          // (wave-uniform chain walk)
-            const int nxt = __builtin_amdgcn_readfirstlane((int)kz[i]);
-            if (lane == 0) kz[i] = (uint16_t)(nxt | 0x8000);
-            i = nxt;
-        }
-        WAVE_SYNC();
-        for (int base = 0; base < nK; base += 64) {
-            const int i = base + lane;
-            const bool have = i < nK;
-            const unsigned long long m = __ballot(have && (kz[i] & 0x8000));
-            const int myz = nZ + __popcll(m & ((2ull << lane) - 1ull)) - 1;
-            if (have) {
-                kz[i] = (uint16_t)myz;
-                if (myz < E2_ZCAP) atomicMax((uint32_t *)zmax + myz, __float_as_uint(kval[i]) & 0x7FFFFFFFu);
-            }
-            nZ += __popcll(m);
-        }
+        if (open) { if (lane == 0 && nZ < E2_ZCAP) ((uint32_t *)zmax)[nZ] = cmx; nZ++; }
         WAVE_SYNC();
         if (nZ <= E2_ZCAP && __builtin_amdgcn_readfirstlane((int)((uint32_t *)zmax)[nZ - 1]) == 0) nZ--;   // end sentinel: a last zone of zero levels is not closed (Encode.c:226-238)
         if (nZ > E2_ZCAP) overflow = true;
