@@ -2012,46 +2012,61 @@ __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
         for (int i = tid; i < N / 4; i += WG) ((float4 *)pairs)[i] = ldnt(pg + i);
     }
     __syncthreads();
+    if (ULCX_DBG(c) & 0x10000) return;                     // (ablation build: the loads alone)
     float2 *gs = c.gapSum + (size_t)blk * N;
-    // gaps in front of kept coefficients.  Pass 1: every thread scans its slots and queues the
-    // kept coefficients whose gap is long enough for a noise run; pass 2: one queued gap per
-    // thread, so a wave's time is its longest gap once, not once per strided slot.
-    uint32_t *wl = kw + N / 32;                            // work list: (start << 16 | i - start) ... stored as two words
+    // gaps in front of kept coefficients.  Pass 1 lists the kept coefficients whose gap is long enough for a noise run,
+    // pass 2 takes one listed gap per thread (a wave's time is its longest gap once).  Pass 1 is per keep WORD, not per
+    // kept coefficient (round 3: a loop over the set bits, a walk back to the previous kept coefficient for each, was
+    // 0.44 of the kernel's 0.96 ms): a gap of >= 16 zeros either ends at the word's first set bit - the previous kept
+    // coefficient is the top bit of the last non-zero word, found in a bit mask of the non-zero words - or lies inside the
+    // word between two set bits, and only one such run fits in 32 bits.
+    uint32_t *wl = kw + N / 32;                            // work list: (kept coefficient, start of its gap) pairs
     const int gapCap = E_GAPCAP(N);
     int *wcount = (int *)(wl + 2 * gapCap);
+    unsigned long long *nzw = (unsigned long long *)(wcount + 2);      // bit w % 64 of nzw[w / 64]: keep word w is not 0
+    const int nW = N / 32;
     if (tid == 0) *wcount = 0;
-    __syncthreads();
-    for (int hw = tid; hw < N / 16; hw += WG) {              // 16 coefficient slots per step: only set bits are visited
-      uint32_t bitsHere = (kw[hw >> 1] >> (16 * (hw & 1))) & 0xFFFFu;
-      while (bitsHere) {
-        int i = hw * 16 + __ffs(bitsHere) - 1;
-        bitsHere &= bitsHere - 1;
-        // start of the unit containing i
-        int ch = i / c.BS, r = i - ch * c.BS;
-        unsigned pat = ulcx_pattern(wc);
-        int off = 0;
-        for (;;) { int S = c.BS >> (pat & 7); if (r < off + S) break; off += S; pat >>= 4; }
-        int us = ch * c.BS + off;
-        // previous kept index in [us, i)
-        int prev = us - 1;
-        {
-            int w = i >> 5;
-            uint32_t m = kw[w] & ((1u << (i & 31)) - 1);
-            for (;;) {
-                if (m) { prev = (w << 5) + 31 - __clz(m); break; }
-                if ((w << 5) <= us) break;
-                w--; m = kw[w];
-            }
-            if (prev < us) prev = us - 1;
-        }
-        int start = prev + 1, zr = i - start;
-        if (zr < 16) continue;
-        int slot = atomicAdd(wcount, 1);
-        if (slot < gapCap) { wl[2 * slot] = (uint32_t)i; wl[2 * slot + 1] = (uint32_t)start; }
-        else gs[i] = make_float2(-2.0f, 0.0f);             // list full (cannot happen for N/16 <= cap): mark "not computed"
-      }
+    for (int w0 = 0; w0 < nW; w0 += WG) {
+        const int w = w0 + tid;
+        const unsigned long long bm = __ballot(w < nW && kw[w] != 0u);
+        if ((tid & 63) == 0 && w < nW) nzw[w >> 6] = bm;
     }
     __syncthreads();
+    for (int w = tid; w < nW; w += WG) {
+        const uint32_t m = kw[w];
+        if (m == 0u) continue;
+        // start of the unit that holds this word (unit bounds are multiples of 32)
+        const int i0 = w * 32, ch = i0 / c.BS, r0 = i0 - ch * c.BS;
+        unsigned pat = ulcx_pattern(wc);
+        int off = 0;
+        for (;;) { int S = c.BS >> (pat & 7); if (r0 < off + S) break; off += S; pat >>= 4; }
+        const int us = ch * c.BS + off, usw = us >> 5;
+        // previous kept coefficient in front of this word, inside the unit
+        int prev = us - 1;
+        for (int q = w >> 6; q >= (usw >> 6); q--) {
+            unsigned long long mk = nzw[q];
+            if (q == (w >> 6)) mk &= (1ull << (w & 63)) - 1ull;
+            if (mk) { const int wp = q * 64 + 63 - __clzll(mk); if (wp >= usw) prev = wp * 32 + 31 - __clz(kw[wp]); break; }
+        }
+        const int f = __ffs(m) - 1;
+        int nIt = 0, it0 = 0, st0 = 0, it1 = 0, st1 = 0;
+        if (i0 + f - (prev + 1) >= 16) { it0 = i0 + f; st0 = prev + 1; nIt = 1; }
+        uint32_t z = ~m, rr = z & (z >> 1); rr &= rr >> 2; rr &= rr >> 4; rr &= rr >> 8;      // bit k: bits k..k+15 of the word are 0
+        rr &= ~((2u << f) - 1u);                           // runs above the first set bit only
+        if (rr) {
+            const int k = __ffs(rr) - 1;                   // the run starts behind a set bit
+            const uint32_t up = m >> k;
+            if (up) { it1 = i0 + k + __ffs(up) - 1; st1 = i0 + k; nIt |= 2; }
+        }
+        if (nIt) {
+            const int n = (nIt & 1) + (nIt >> 1);
+            const int slot = atomicAdd(wcount, n);
+            if (nIt & 1) { wl[2 * slot] = (uint32_t)it0; wl[2 * slot + 1] = (uint32_t)st0; }
+            if (nIt & 2) { const int s2 = slot + (nIt & 1); wl[2 * s2] = (uint32_t)it1; wl[2 * s2 + 1] = (uint32_t)st1; }
+        }
+    }
+    __syncthreads();
+    if (ULCX_DBG(c) & 0x20000) return;                     // (ablation build: loads + gap list)
     int nw = *wcount; if (nw > gapCap) nw = gapCap;
     for (int t = tid; t < nw; t += WG) {
         int i = (int)wl[2 * t], start = (int)wl[2 * t + 1];
@@ -3236,7 +3251,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         const bool fb2 = (cc.fbMode == 2);                 // exact path: small grids that walk the list of owned blocks
         const int fbW = NB < 128 ? NB : 128;
         if (cc.useGapSums) {
-            size_t glds = (size_t)N * 4 + N / 8 + 8 * E_GAPCAP(N) + 16;
+            size_t glds = (size_t)N * 4 + N / 8 + 8 * E_GAPCAP(N) + 16 + 8 * ((N / 32 + 63) / 64);
             if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
             // the two speculative-sum kernels are independent and both latency-bound: on the main path k_tailsums
             // runs on a side stream beside k_gapsums
