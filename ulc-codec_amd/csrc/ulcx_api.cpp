@@ -233,7 +233,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
         if (const char *pv = getenv("ULCX_WC_PIPE")) { int n = atoi(pv); if (n >= 1 && n <= ULCX_XF_MAXCH && n != 2 && (n == 1 || e->sideOk)) e->wcPipe = n; }
         e->wcSteps = -1; if (const char *sv = getenv("ULCX_WC_STEPS")) e->wcSteps = atoi(sv);      // -1: default; 0: the transform's chunks
         e->wcEStream = getenv("ULCX_WC_ESTREAM") != nullptr;
-        { const char *v = getenv("ULCX_CPLX_EARLY"); e->cplxEarly = (v && v[0] == '1') ? 1 : 0; }
+        { const char *v = getenv("ULCX_CPLX_EARLY"); e->cplxEarly = (v && v[0] == '0') ? 0 : 1; }      // (round 3: on - the last transform chunk runs alone and leaves room beside it)
         { const char *v = getenv("ULCX_WC_FUSE"); e->wcFuse = (v && v[0] == '0') ? 0 : 1; }
         { const char *v = getenv("ULCX_BARK_UNIFORM_P"); e->barkUniP = (v && v[0] == '0') ? 0 : 1; }     // masking sums of un-decimated blocks on the uniform kernel too (round 3; =0: k_pbark for every block)
         auto parse_ladder = [](const char *v, int *dst, int cap) { int n = 0; while (v && *v && n < cap) { int x = atoi(v); if (x < 1) return 0; dst[n++] = x; while (*v && *v != ',') v++; if (*v == ',') v++; } return n; };

@@ -2858,7 +2858,7 @@ __global__ __launch_bounds__(256) void k_encode_wave(UlcxEncCtx c, int finalPass
 // Encode.c:329-359: header nybble(s) + units in (channel, subblock) order, byte aligned.
 // One wave per block.
 __device__ void pack_block(const UlcxEncCtx &c, int finalPass, int blk) {
-    int lane = threadIdx.x;
+    int lane = threadIdx.x & 63;
     if (skip_block(c, blk, finalPass)) return;
     if (finalPass && c.useWave && (c.slow[blk] & 4)) return;        // the wave writer packed this block itself
     int s = blk / c.K, k = blk % c.K;
@@ -2910,11 +2910,14 @@ __device__ void pack_block(const UlcxEncCtx &c, int finalPass, int blk) {
     }
     if (lane == 0) c.bits[blk] = bitsTot;
 }
-__global__ __launch_bounds__(64) void k_pack(UlcxEncCtx c, int finalPass) {
+// (four blocks per workgroup: since the wave writer packs most blocks itself this kernel is mostly waves that leave at
+//  once, and single-wave workgroups are bound by the dispatch rate)
+__global__ __launch_bounds__(256) void k_pack(UlcxEncCtx c, int finalPass) {
     if (probes_over(c, finalPass)) return;
-    if (c.fbMode != 2) { pack_block(c, finalPass, blockIdx.x); return; }
+    const int wv = threadIdx.x >> 6;
+    if (c.fbMode != 2) { const int blk = blockIdx.x * 4 + wv; if (blk < c.B * c.K) pack_block(c, finalPass, blk); return; }
     int n = fb_count(c);
-    for (int v = blockIdx.x; v < n; v += gridDim.x) pack_block(c, finalPass, c.fbList[c.fbLo + v]);
+    for (int v = blockIdx.x * 4 + wv; v < n; v += gridDim.x * 4) pack_block(c, finalPass, c.fbList[c.fbLo + v]);
 }
 
 // ---------------------------------------------------------------------------
@@ -3286,7 +3289,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
         hipLaunchKernelGGL(k_encode_units, dim3(fb2 ? fbW : (nUnits + 63) / 64), dim3(64), 0, s2, cc, fin);
         if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
-        hipLaunchKernelGGL(k_pack, dim3(fb2 ? fbW : NB), dim3(64), 0, s2, cc, fin);
+        hipLaunchKernelGGL(k_pack, dim3(fb2 ? (fbW + 3) / 4 : (NB + 3) / 4), dim3(256), 0, s2, cc, fin);
         if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
         return ULCX_OK;
     };
