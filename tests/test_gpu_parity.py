@@ -139,6 +139,47 @@ def test_decode_bit_exact(bs, ch, rate, q):
     dec.close()
 
 
+@pytest.mark.parametrize("bs,rate", [(2048, 44100), (4096, 48000), (1024, 44100)])
+def test_decode_few_long_streams_cut_evenly(bs, rate):
+    """Round 3: a batch that does not fill the machine with one workgroup per stream - here 3 stereo streams of 40 blocks per
+    call - is synthesised over an even cut of its (stream, block) pairs: a workgroup that starts inside a stream rebuilds the
+    lapping state from the block in front of its range, jumps the RNG, and takes LastSubBlockSize from the previous window
+    code.  Two calls (the state arrays swap), window switching, a corrupt block in the middle of one stream; against the
+    oracle, and against the same decoder with the cut switched off."""
+    amd = _amd()
+    B, calls, K, ch = 3, 2, 40, 2
+    pcm = _streams(B, calls * K, bs, ch, rate, True, seed=77)
+    slot = 2 * ch * bs + 16
+    refs = [oracle_encode_debug(pcm[s], bs, rate, 0, 50.0, slot=slot) for s in range(B)]
+    blocks = np.stack([r["out"] for r in refs]).copy()
+    blocks[1, K + 11, 2:40] = 0x11                                # stream 1 dies in the second call (long zero runs overrunning the subblock)
+    outs = {}
+    for split in ("1", "0"):
+        old = os.environ.get("ULCX_DSYN_SPLIT")
+        os.environ["ULCX_DSYN_SPLIT"] = split
+        try:
+            dec = amd.BatchDecoder(B, ch, bs, K)
+            got, gbits = [], []
+            for c in range(calls):
+                p, b = dec.decode(blocks[:, c * K:(c + 1) * K])
+                got.append(p); gbits.append(b)
+            outs[split] = (np.concatenate(got, axis=1), np.concatenate(gbits, axis=1))
+            dec.close()
+        finally:
+            if old is None: os.environ.pop("ULCX_DSYN_SPLIT", None)
+            else: os.environ["ULCX_DSYN_SPLIT"] = old
+    assert np.array_equal(outs["1"][1], outs["0"][1]) and np.array_equal(outs["1"][0], outs["0"][0]), "even cut and one workgroup per stream disagree"
+    for s in range(B):
+        rc, ref_pcm, ref_bits = oracle_decode_stream(blocks[s], ch, bs)
+        n = calls * K
+        got, gb = outs["1"][0][s], outs["1"][1][s]
+        if s == 1:
+            assert (gb[K + 11:] == 0).all() and not got[(K + 11) * bs:].any(), "a dead stream must stay silent"
+            n = K + 11
+        assert np.array_equal(gb[:n], ref_bits[:n]), f"stream {s}: bits consumed differ"
+        assert np.array_equal(got[:n * bs], ref_pcm[:n * bs]), f"stream {s}: decoded PCM differs"
+
+
 @pytest.mark.parametrize("bs,ch,rate,q", [(2048, 2, 44100, 50.0), (512, 1, 48000, 70.0)])
 def test_decode_block_filling_its_slot_exactly(bs, ch, rate, q):
     """slotBytes = the byte count of the call's largest block (what a caller sizing slots to the container's MaxBlockSize

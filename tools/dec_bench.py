@@ -1,11 +1,13 @@
-"""GPU: decode-only timing of the bench batch (4096 x 16 blocks) for the library currently in the tree."""
+"""GPU: decode-only timing of a batch (default the 4096 streams x 16 blocks of rounds 1-2; argv: tag B K) for the library
+currently selected (ULC_AMD_LIB)."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ulc-codec_amd")); sys.path.insert(0, ROOT)
 import ulc_amd, bench
 dev = torch.device("cuda", 0)
-B, K = 4096, 16
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 pcm = bench.make_pcm(torch, B, K * 2048, dev, seed=1234)
 enc = ulc_amd.BatchEncoder(B, 2, 2048, 44100, K); dec = ulc_amd.BatchDecoder(B, 2, 2048, K)
 slot = enc.slot

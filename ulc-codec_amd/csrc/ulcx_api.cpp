@@ -43,6 +43,9 @@ struct ulcx_decoder {
     uint8_t *d_in; size_t d_in_bytes; float *d_pcm; int32_t *d_bits;
     uint8_t *d_pay; int32_t *d_payBytes; long long payStride;     // resident packed payloads (ulcx_decoder_upload_payload)
     hipStream_t side; hipEvent_t evFork, evScan[ULCX_DEC_MAXCH]; bool sideOk; int nChunks; int ldsPad, scanLpw;   // walk / synthesis pipeline (ULCX_DEC_PIPE chunks)
+    // k_dsyn over an even cut of the call's (stream, block) pairs: the second set of state arrays, the resident
+    // workgroups of the kernel on this device, ULCX_DSYN_SPLIT=0 switches it off
+    float *lap2; int *lastSub2; uint32_t *seed2; int *dead2; int synSlots; bool splitOK;
     // single-block path (ulcx_decode_block1)
     hipStream_t b1Stream; hipGraph_t b1Graph; hipGraphExec_t b1Exec; bool b1Init, b1Graphed, b1NoGraph; int b1Slot;
     uint8_t *pinIn; float *pinPcm; int32_t *pinMeta;
@@ -513,8 +516,33 @@ static void build_rng_tables(std::vector<uint32_t> &jumpT) {
 
 static UlcxDecAux dec_aux(ulcx_decoder *e) {
     UlcxDecAux a; a.side = e->sideOk ? e->side : nullptr; a.evFork = e->evFork; a.evScan = e->evScan; a.nChunks = e->nChunks;
-    a.ldsPad = e->ldsPad; a.scanLpw = e->scanLpw;
+    a.ldsPad = e->ldsPad; a.scanLpw = e->scanLpw; a.synGrid = 0;
     return a;
+}
+
+// One decode launch.  When the batch does not fill the machine in whole rounds of one workgroup per stream - 4096 streams on
+// 1536 resident workgroups, or a few long streams - the synthesis takes an even cut of the (stream, block) pairs instead: a
+// workgroup then runs one extra block (the one in front of its range, for the lapping state), so the cut must pay for that.
+static int dec_launch(ulcx_decoder *e, UlcxDecCtx &c, hipStream_t st) {
+    UlcxDecAux a = dec_aux(e);
+    a.synGrid = 0;
+    c.lapO = c.lap; c.lastSubO = c.lastSub; c.seedO = c.seed; c.deadO = c.dead;
+    if (e->splitOK && a.nChunks <= 1 && e->synSlots > 0) {
+        const long long T = (long long)e->B * c.K;
+        long long per = (T + e->synSlots - 1) / e->synSlots; if (per < 8) per = 8;
+        const long long grid = T / per;
+        const long long costStream = (((long long)e->B + e->synSlots - 1) / e->synSlots) * c.K;     // block times, one workgroup per stream
+        if (grid >= 1 && grid != e->B && (per + 1) * 3 < costStream * 2) {       // (1.5 x: an even cut of uneven streams ends with its slowest workgroup, measured on the bench batch)
+            a.synGrid = (int)grid;
+            if (getenv("ULCX_DEBUG_PRINT")) fprintf(stderr, "[ulcx] synthesis: %lld (stream, block) pairs over %lld workgroups (%d resident), %lld + 1 blocks each\n", T, grid, e->synSlots, per);
+            c.lapO = e->lap2; c.lastSubO = e->lastSub2; c.seedO = e->seed2; c.deadO = e->dead2;
+        }
+    }
+    const int rc = ulcx_dec_launch(c, st, e->timing ? e->ev : nullptr, a);
+    if (rc == ULCX_OK && a.synGrid) {
+        std::swap(e->ctx.lap, e->lap2); std::swap(e->ctx.lastSub, e->lastSub2); std::swap(e->ctx.seed, e->seed2); std::swap(e->ctx.dead, e->dead2);
+    }
+    return rc;
 }
 
 extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams, int nChan, int BlockSize, int maxBlocksPerCall) {
@@ -528,6 +556,7 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->timing = true;
     e->d_in = nullptr; e->d_in_bytes = 0; e->d_pcm = nullptr; e->d_bits = nullptr; e->d_pay = nullptr; e->d_payBytes = nullptr; e->payStride = 0;
     e->sideOk = false; e->side = nullptr; e->nChunks = 1;
+    e->lap2 = nullptr; e->lastSub2 = nullptr; e->seed2 = nullptr; e->dead2 = nullptr; e->synSlots = 0; e->splitOK = false;
     e->scanLpw = 64; if (const char *pv = getenv("ULCX_DSCAN_LPW")) { int n = atoi(pv); if (n == 16 || n == 32 || n == 64) e->scanLpw = n; }
     e->ldsPad = 0; if (const char *pv = getenv("ULCX_DSYN_PAD")) { int n = atoi(pv); if (n > 0 && n < 120 * 1024) e->ldsPad = n & ~15; }
     e->b1Init = e->b1Graphed = e->b1NoGraph = false; e->pinIn = nullptr; e->pinPcm = nullptr; e->pinMeta = nullptr; e->b1Slot = 0;
@@ -552,6 +581,20 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     DA(c.lastSub, B, true);
     DA(c.seed, B, true);
     DA(c.dead, B, true);
+    c.lapO = c.lap; c.lastSubO = c.lastSub; c.seedO = c.seed; c.deadO = c.dead; c.lapScratch = nullptr; c.k0 = 0; c.k1 = 0;
+    if (c.fastOK && (BlockSize > 2048 || c.twInLds != 1)) {               // the kernels that keep the lapping state in global memory
+        bool want = true;
+        if (const char *ev = getenv("ULCX_DSYN_SPLIT")) want = ev[0] != '0';
+        e->synSlots = want ? ulcx_dec_syn_slots(c) : 0;
+        if (e->synSlots > 0) {
+            DA(e->lap2, B * nChan * (BlockSize / 2), true);
+            DA(e->lastSub2, B, true);
+            DA(e->seed2, B, true);
+            DA(e->dead2, B, true);
+            DA(c.lapScratch, (size_t)e->synSlots * nChan * (BlockSize / 2), true);
+            e->splitOK = true;
+        }
+    }
     DA(c.wcScan, NB, true);
     DA(c.draws, NB, true);
     DA(c.packOff, B, true);
@@ -607,7 +650,7 @@ static int decode_dev_any(ulcx_decoder *e, const uint8_t *d_in, int slotBytes, i
     UlcxDecCtx c = e->ctx;
     c.K = nBlocks; c.slot = slotBytes; c.in = d_in; c.pcm = d_pcm; c.pcm16 = d_pcm16; c.bits = d_bits;
     c.inBytes = (long long)e->B * nBlocks * slotBytes;
-    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->timing ? e->ev : nullptr, dec_aux(e));
+    int rc = dec_launch(e, c, (hipStream_t)hipStream);
     e->evRecorded = (rc == ULCX_OK) && e->timing;
     return rc;
 }
@@ -731,7 +774,7 @@ extern "C" int ulcx_decode_packed_dev(ulcx_decoder *e, const uint8_t *d_payload,
     c.K = nBlocks; c.slot = 0; c.in = d_payload; c.pcm = d_pcm; c.pcm16 = nullptr; c.bits = d_bits;
     c.packed = 1; c.payStride = payloadStride; c.payBytes = d_payloadBytes;
     c.inBytes = (long long)e->B * payloadStride;
-    int rc = ulcx_dec_launch(c, (hipStream_t)hipStream, e->timing ? e->ev : nullptr, dec_aux(e));
+    int rc = dec_launch(e, c, (hipStream_t)hipStream);
     e->evRecorded = (rc == ULCX_OK) && e->timing;
     return rc;
 }

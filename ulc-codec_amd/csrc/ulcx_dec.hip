@@ -661,37 +661,37 @@ __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int 
 #ifndef DSYN_LAPG_WAVES
 #define DSYN_LAPG_WAVES 3
 #endif
-template <typename OUT, int DEC_MAXT, bool LAPG, bool TWL = !LAPG>          // LAPG: lapping state in global memory; TWL: twiddles in LDS
+// LAPG: lapping state in global memory; TWL: twiddles in LDS; SPLIT: the grid is an even cut of the (stream, block) pairs
+// (else one workgroup per stream: the index arithmetic and the choice of the lapping rows below fold away)
+template <typename OUT, int DEC_MAXT, bool LAPG, bool TWL = !LAPG, bool SPLIT = false>
 __global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3) void k_dsyn(UlcxDecCtx c) {
+    static_assert(LAPG || !SPLIT, "an even cut needs the lapping state in global memory");
     extern __shared__ float lds[];
     const int BS = c.BS, H2 = BS / 2;
     constexpr int C = 2;
-    const int s = c.s0 + blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const DsynLds L = dsyn_lds(BS, C, 1, LAPG ? (TWL ? 2 : 0) : 1);
     float2 *z    = (float2 *)lds;
-    float *glap = c.lap + (size_t)s * C * H2;
-    // lapping state: in LDS for the stream's blocks of this call, or (LAPG: BlockSize 4096) used where it lives.  Every
-    // element is read and rewritten by the same thread in un-decimated blocks and by the same wave in decimated ones;
-    // the barriers between the two kinds of block order the rest.
-    float  *lap;
-    if constexpr (LAPG) lap = glap; else lap = lds + L.zFloats;
+    // lapping state: in LDS for the stream's blocks of this launch, or (LAPG) in global memory: the arrays a stream's state
+    // is read from / written to at its first / last block of the launch, the workgroup's own scratch rows in between.
+    // Every element is read and rewritten by the same thread in un-decimated blocks and by the same wave in decimated
+    // ones; the barriers between the two kinds of block order the rest.
+    float  *ldsLap = lds + L.zFloats;
+    // (one workgroup per stream - grid = streams -: the stream's own rows serve, nothing else touches them during the launch)
+    float  *scr = !LAPG ? ldsLap : !SPLIT ? c.lapO + (size_t)(c.s0 + blockIdx.x) * C * H2 : c.lapScratch + (size_t)blockIdx.x * C * H2;
     float2 *twl  = (float2 *)(lds + L.zFloats + L.lapFloats);        // FFT twiddles: the full-size table, or the three of a decimated block's sizes
     SynWave sw;
     sw.pre  = (int *)(lds + L.zFloats + L.lapFloats + L.twFloats) + wv * (64 + DSYN_PWORDS(BS));
     sw.seedTab = (uint32_t *)(sw.pre + 64);
     uint32_t *bseed = (uint32_t *)(lds + L.zFloats + L.lapFloats + L.twFloats + 2 * (64 + DSYN_PWORDS(BS)));   // [0,64): RNG state at each block's start, [64,128): at its second channel
     sw.lane = lane;
-    if (!LAPG) for (int i = tid; i < 2 * H2; i += WG) lap[i] = glap[i];
     if (TWL) for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
     bool twFull = true;
-    int lastSub = c.lastSub[s];
-    int dead = c.dead[s];
-    uint32_t seed = c.seed[s];
     const int M0 = BS >> 1, Mp0 = FFT_PADDEDS(M0, DPS);
     float2 *zc = z + wv * Mp0;                                       // this wave's channel
 #ifdef ULCX_DSYN_STAMPS
-    // diagnostic build only: shader cycles per phase, summed over the stream's blocks
+    // diagnostic build only: shader cycles per phase, summed over the workgroup's blocks
     DsynStamps stq; for (int i = 0; i < 12; i++) stq.t[i] = 0; stq.t0 = __builtin_amdgcn_s_memtime();
     sw.stp = &stq;
 #define STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stq.t[i] += t_ - stq.t0; stq.t0 = t_; } while (0)
@@ -700,22 +700,68 @@ __global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3)
 #endif
     __syncthreads();
 
+    // The (stream, block) pairs of the launch in stream-major order, cut evenly over the grid (round 3).  One workgroup
+    // per stream is the special case grid = streams.  A workgroup that enters a stream behind its first block of the
+    // launch runs the block in front of its range without output first: the lapping state a block leaves depends on that
+    // block alone (the pending list is rewritten in full: dec_time_wave, and the un-decimated epilogue below), the RNG
+    // state is reached by a jump over the draws of the blocks in front, LastSubBlockSize follows from the previous
+    // block's window code.  So 4096 streams need not come in rounds of the machine's 1536 workgroup slots (2.67 rounds,
+    // the last one a third full), and a few long streams fill the machine too.
+    const int Kc = c.k1 - c.k0;
+    const long long T = (long long)(c.s1 - c.s0) * Kc;
+    const long long f0 = SPLIT ? T * blockIdx.x / gridDim.x : (long long)blockIdx.x * Kc, f1 = SPLIT ? T * (blockIdx.x + 1) / gridDim.x : f0 + Kc;
+    if (f0 >= f1) return;
+    bool warm = SPLIT && (f0 % Kc) != 0;
+    int nTrip = (int)(f1 - f0) + (warm ? 1 : 0);
+    int s = c.s0 + (int)((f0 - (warm ? 1 : 0)) / Kc), k = c.k0 + (int)((f0 - (warm ? 1 : 0)) % Kc) - 1;
+    int sCur = -1, lastSub = 0, dead = 0, chunkK = -1;
+    uint32_t seed = 0;
     const int laneOuter = lane, tidOuter = tid;
-    for (int k = 0; k < c.K; k++) {
-        // Inside this loop over the stream's blocks the compiler hoists every load and index that depends on the thread only
+    for (; nTrip > 0; nTrip--, warm = false) {
+        // Inside this loop over the blocks the compiler hoists every load and index that depends on the thread only
         // (pre-twiddles, window factors, bit-reversed positions, padded FFT addresses) out of the loop - registers held
         // across all blocks.  Opaque copies of the thread's indices keep them where they are used.
         int lane = laneOuter, tid = tidOuter;
         asm volatile("" : "+v"(lane), "+v"(tid));
         sw.lane = lane;                                              // (round 3: 168 registers with spills -> 156 without, 1.05 -> 1.00 ms)
+        if (++k == c.k1) { k = c.k0; s++; }
         const int blk = s * c.K + k;
-        if ((k & 63) == 0) {
+        if (s != sCur) {
+            // entering a stream, at its first block of the launch or behind it: the state in front of block k
+            if (!LAPG && sCur >= 0) { __syncthreads(); float *go = c.lapO + (size_t)sCur * C * H2; for (int i = tid; i < 2 * H2; i += WG) go[i] = ldsLap[i]; __syncthreads(); }
+            sCur = s;
+            if (!LAPG) { const float *gi = c.lap + (size_t)s * C * H2; for (int i = tid; i < 2 * H2; i += WG) ldsLap[i] = gi[i]; }
+            __syncthreads();
+            int bad = 0; uint32_t dsum = 0;
+            for (int j = c.k0 + tid; j < k; j += WG) {               // blocks of the launch in front of k (none at the stream's start)
+                const int bj = s * c.K + j;
+                if (c.wcScan[bj] == 0) bad = 1;
+                dsum += (uint32_t)c.draws[bj];
+            }
+            bad = __syncthreads_or(bad);
+            dead = c.dead[s] | bad;                                  // (a corrupt block in front: the stream is dead, no other state matters)
+            lastSub = c.lastSub[s];
+            seed = c.seed[s];
+            if (k > c.k0) {
+                const uint32_t ws = wave_scan_add(dsum);             // (lane 63: the wave's sum)
+                if (lane == 63) bseed[wv] = ws;
+                __syncthreads();
+                seed = rng_jump(c.jumpT, seed, bseed[0] + bseed[1]);
+                __syncthreads();
+                const unsigned pp0 = ulcx_pattern(c.wcScan[blk - 1]);        // LastSubBlockSize as block k-1 left it (ulcDecoder.c:300)
+                unsigned pp = pp0; int ls = BS;
+                if ((BS >> (pp0 & 7)) != BS) do { ls = BS >> (pp & 7); } while (pp >>= 4);
+                lastSub = ls;
+            }
+            chunkK = -1;
+        }
+        if (chunkK < 0 || k >= chunkK + 64) {
             // The stream's one RNG chain (ulcDecoder.c:75-81) for the next 64 blocks at once: a block starts draws-of-its-
             // predecessors after the chunk's first state - one lane per block, prefix sum, one jump each (wave 1: the
             // state at each block's second channel).  A corrupt block ends the stream: it and its successors draw nothing.
             __syncthreads();
-            const int kk = k + lane, bk = s * c.K + (kk < c.K ? kk : k);
-            const bool on = kk < c.K;
+            const int kk = k + lane, bk = s * c.K + (kk < c.k1 ? kk : k);
+            const bool on = kk < c.k1;
             int dr = on ? c.draws[bk] : 0;
             const unsigned long long badm = __ballot(on && c.wcScan[bk] == 0);
             if (badm && lane >= __builtin_ctzll(badm)) dr = 0;
@@ -724,14 +770,24 @@ __global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3)
             bseed[wv * 64 + lane] = rng_jump(c.jumpT, seed, before);
             const uint32_t chunkDraws = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             __syncthreads();
-            seed = rng_jump(c.jumpT, seed, chunkDraws);            // state after the chunk: the next chunk's start / the stream's state for the next call
+            seed = rng_jump(c.jumpT, seed, chunkDraws);            // state after the chunk: the next chunk's start / the stream's state behind the launch
+            chunkK = k;
         }
+        const int kb = k - chunkK;                                   // this block's slot in the chunk's seed table
         const int wc = c.wcScan[blk];
         if (wc == 0) dead = 1;                                       // a corrupt block ends the stream (ulcDecodeTool.c:154-157)
+        const bool lastOfStream = k == c.k1 - 1;
         OUT *outp = out_base<OUT>(c) + (size_t)blk * C * BS;
+        // where this block finds and leaves the lapping state
+        const float *lapR = !SPLIT ? scr : (k == c.k0 ? c.lap + (size_t)s * C * H2 : scr);
+        float *lapW = !SPLIT ? scr : (lastOfStream ? c.lapO + (size_t)s * C * H2 : scr);
         if (dead) {
-            for (int i = tid; i < C * BS; i += WG) st1(outp + i, 0.0f);
-            if (tid == 0) c.bits[blk] = 0;
+            if (!warm) {
+                for (int i = tid; i < C * BS; i += WG) st1(outp + i, 0.0f);
+                if (tid == 0) c.bits[blk] = 0;
+            }
+            if (lastOfStream && tid == 0) { c.lastSubO[s] = lastSub; c.seedO[s] = seed; c.deadO[s] = 1; }
+            if (LAPG && lastOfStream) for (int i = tid; i < 2 * H2; i += WG) lapW[i] = 0.0f;     // (never read again: the stream stays dead)
             continue;
         }
         const int *udraw = c.unitDraws + (size_t)blk * C * 4;
@@ -762,7 +818,7 @@ __global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3)
                 const int d = pat & 7, S = BS >> d, M = S >> 1, Mp = FFT_PADDEDS(M, DPS);
                 float2 *zj = zc + FFT_PADS(off >> 1, DPS);
                 sw.A = (float *)zj;
-                const uint32_t unitSeed = (j == 0) ? bseed[wv * 64 + (k & 63)] : rng_jump(c.jumpT, bseed[k & 63], (uint32_t)udraw[wv * 4 + j]);
+                const uint32_t unitSeed = (j == 0) ? bseed[wv * 64 + kb] : rng_jump(c.jumpT, bseed[kb], (uint32_t)udraw[wv * 4 + j]);
                 STAMP(1);
                 if (!(ULCX_DBG(c) & 1)) synth_unit(c, sw, S, prec, nrec, urec[wv * 4 + j], unitSeed, unit_draws(wv, j), utail[wv * 4 + j].y, tmag + (size_t)(wv * 4 + j) * c.tailStride, Mp);
                 else for (int i = lane; i < Mp; i += 64) zj[i] = make_float2(0.0f, 0.0f);
@@ -801,7 +857,8 @@ __global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3)
                 const int a = (S - ov) >> 1;
                 const float *fall = c.T.winFall + ov, *rise = c.T.winRise + ov;
                 const int bits = 31 - __clz(M);
-                float *L0 = lap, *L1 = lap + H2;
+                const float *R0 = lapR, *R1 = lapR + H2;
+                float *L0 = lapW, *L1 = lapW + H2;
                 for (int kk = tid; kk < M / 2; kk += WG) {
                     const int k1 = kk, k2 = M - 1 - kk;
                     int r1 = (int)(__brev((unsigned)k1) >> (32 - bits));
@@ -810,7 +867,8 @@ __global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3)
                     const float2 P1 = pre[k1], P2 = pre[k2];
                     const float2 ya1 = cmulc_post(z0[r1], P1), ya2 = cmulc_post(z0[r2], P2);     // channel 0 (M): (Re y, -Im y)
                     const float2 yb1 = cmulc_post(z1[r1], P1), yb2 = cmulc_post(z1[r2], P2);     // channel 1 (S)
-                    const float A0m = L0[2 * k1], A1m = L0[2 * k1 + 1], A0s = L1[2 * k1], A1s = L1[2 * k1 + 1];
+                    if (!warm) {
+                    const float A0m = R0[2 * k1], A1m = R0[2 * k1 + 1], A0s = R1[2 * k1], A1s = R1[2 * k1 + 1];
                     const float Bm[2] = { ya1.y, ya2.x }, Bs[2] = { yb1.y, yb2.x };
                     const float Am[2] = { A0m, A1m }, As[2] = { A0s, A1s };
                     const int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
@@ -835,6 +893,7 @@ __global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3)
                     // positions pv[1] = pv[0]-1 and S-1-pv[0], S-pv[0] are neighbours: two aligned 16-byte stores
                     st4(outp + 2 * pv[1], lo2[1].x, lo2[1].y, lo2[0].x, lo2[0].y);
                     st4(outp + 2 * (S - 1 - pv[0]), hi2[0].x, hi2[0].y, hi2[1].x, hi2[1].y);
+                    }
                     L0[2 * k1] = ya1.x; L0[2 * k1 + 1] = ya2.y;
                     L1[2 * k1] = yb1.x; L1[2 * k1 + 1] = yb2.y;
                 }
@@ -846,12 +905,16 @@ __global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3)
         } else {
             // ---- decimated block: each wave finishes its channel in LDS, then both channels together:
             //      inverse M/S (ulcDecoder.c:281-289) + interleave (:292-297)
+            // (the time-domain pass works on the lapping state in place: in the workgroup's own rows)
+            if (LAPG && lapR != scr && !warm) { for (int i = tid; i < 2 * H2; i += WG) scr[i] = lapR[i]; __syncthreads(); }
+            float *lapD = LAPG ? scr : ldsLap;
             WAVE_SYNC();
-            const int newLast = dec_time_wave<DEC_MAXT>(c, zc, lap + wv * H2, wc, pat0, nsub, lastSub, lane);
+            const int newLast = dec_time_wave<DEC_MAXT>(c, zc, lapD + wv * H2, wc, pat0, nsub, lastSub, lane);
             __syncthreads();
             // output = times [-BS/2, BS/2) of both channels: the old pending lists (time -1-i at lap[i]), then the arrays
             const float *t0 = (const float *)z, *t1 = (const float *)(z + Mp0);
-            const float *L0 = lap, *L1 = lap + H2;
+            const float *L0 = lapD, *L1 = lapD + H2;
+            if (!warm) {
             for (int n = 2 * tid; n < H2; n += 2 * WG) {
                 const float mx = L0[H2 - 1 - n], my = L0[H2 - 2 - n], sx = L1[H2 - 1 - n], sy = L1[H2 - 2 - n];
                 st4(outp + 2 * n, mx + sx, mx - sx, my + sy, my - sy);
@@ -860,22 +923,23 @@ __global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3)
                 const float2 m = *(const float2 *)(t0 + padf(n)), sd = *(const float2 *)(t1 + padf(n));
                 st4(outp + 2 * (H2 + n), m.x + sd.x, m.x - sd.x, m.y + sd.y, m.y - sd.y);
             }
+            }
             __syncthreads();
             // new pending lists: times [BS/2, BS) of the arrays
             for (int i = tid; i < 2 * H2; i += WG) {
                 const int ch = i >= H2 ? 1 : 0, m = i - ch * H2;
-                lap[ch * H2 + H2 - 1 - m] = ((const float *)(z + ch * Mp0))[padf(H2 + m)];
+                lapW[ch * H2 + H2 - 1 - m] = ((const float *)(z + ch * Mp0))[padf(H2 + m)];
             }
             __syncthreads();
             lastSub = newLast;
             STAMP(7);
         }
+        if (lastOfStream && tid == 0) { c.lastSubO[s] = lastSub; c.seedO[s] = seed; c.deadO[s] = dead; }
     }
 #ifdef ULCX_DSYN_STAMPS
     if (lane == 0) for (int i = 0; i < 12; i++) ((unsigned long long *)(c.scratch + (size_t)s * 4 * BS))[wv * 12 + i] = stq.t[i];
 #endif
-    if (!LAPG) for (int i = tid; i < 2 * H2; i += WG) glap[i] = lap[i];
-    if (tid == 0) { c.lastSub[s] = lastSub; c.seed[s] = seed; c.dead[s] = dead; }
+    if (!LAPG && sCur >= 0) { __syncthreads(); float *go = c.lapO + (size_t)sCur * C * H2; for (int i = tid; i < 2 * H2; i += WG) go[i] = ldsLap[i]; }
 }
 
 // ---------------------------------------------------------------------------
@@ -1041,6 +1105,21 @@ size_t ulcx_dec_lds_bytes(int BS, int C, int fast, int twInLds) {
 // The syntax walk (k_dscan: one wave per 64 blocks, a chain of dependent instructions - it leaves most of the machine idle)
 // and the synthesis (k_dsyn: instruction-issue bound) are pipelined over chunks of streams: the walk of chunk i+1 runs on a
 // side stream beside the synthesis of chunk i.  aux.side == NULL (or a small batch): one chunk, everything on the caller's stream.
+// resident workgroups of the stereo synthesis kernel this context runs (float output; the PCM16 instantiation has the same
+// resources): what an even cut of the batch is sized for
+int ulcx_dec_syn_slots(const UlcxDecCtx &c) {
+    if (!c.fastOK) return 0;
+    const bool small = c.BS <= 2048;
+    const int mode = small ? c.twInLds : 0;
+    const void *fn = !small ? (const void *)k_dsyn<float, 32, true> : mode == 2 ? (const void *)k_dsyn<float, 16, true, true> : mode == 0 ? (const void *)k_dsyn<float, 16, true> : (const void *)k_dsyn<float, 16, false>;
+    const size_t lds = ulcx_dec_lds_bytes(c.BS, c.C, c.fastOK, c.twInLds);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int dev = 0, cus = 0, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, WG, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return cus * per;
+}
+
 int ulcx_dec_launch(const UlcxDecCtx &cIn, hipStream_t st, hipEvent_t *ev, const UlcxDecAux &aux) {
     int stage = 0;
     if (ev) CK(hipEventRecord(ev[stage++], st));
@@ -1062,18 +1141,23 @@ int ulcx_dec_launch(const UlcxDecCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         else { const int lpw = aux.scanLpw > 0 ? aux.scanLpw : 64; hipLaunchKernelGGL(k_dscan, dim3(((s1 - s0) * c.K + lpw - 1) / lpw), dim3(64), 0, s2, cc, lpw); }
     };
     auto syn = [&](hipStream_t s2, int s0, int s1) {
-        UlcxDecCtx cc = c; cc.s0 = s0; cc.s1 = s1;
-        const unsigned g = (unsigned)(s1 - s0);
+        UlcxDecCtx cc = c; cc.s0 = s0; cc.s1 = s1; cc.k0 = 0; cc.k1 = c.K;
+        const bool lapg = c.fastOK && (!small || mode != 1);       // kernels with the lapping state in global memory: any grid
+        const bool split = lapg && aux.synGrid > 0 && s0 == 0 && s1 == c.B;
+        const unsigned g = split ? (unsigned)aux.synGrid : (unsigned)(s1 - s0);
         if (ULCX_DBG(c) & 8) {}
         else if (!c.fastOK) { if (c.pcm16) hipLaunchKernelGGL(k_dgen<int16_t>, dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL(k_dgen<float>, dim3(g), dim3(WG), lds, s2, cc); }
-        else if (!small) { if (c.pcm16) hipLaunchKernelGGL((k_dsyn<int16_t, 32, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<float, 32, true>), dim3(g), dim3(WG), lds, s2, cc); }
+        else if (!small) {
+            if (c.pcm16) { if (split) hipLaunchKernelGGL((k_dsyn<int16_t, 32, true, false, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<int16_t, 32, true>), dim3(g), dim3(WG), lds, s2, cc); }
+            else { if (split) hipLaunchKernelGGL((k_dsyn<float, 32, true, false, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<float, 32, true>), dim3(g), dim3(WG), lds, s2, cc); }
+        }
         else if (c.pcm16) {
-            if (mode == 2) hipLaunchKernelGGL((k_dsyn<int16_t, 16, true, true>), dim3(g), dim3(WG), lds, s2, cc);
-            else if (mode == 0) hipLaunchKernelGGL((k_dsyn<int16_t, 16, true>), dim3(g), dim3(WG), lds, s2, cc);
+            if (mode == 2) { if (split) hipLaunchKernelGGL((k_dsyn<int16_t, 16, true, true, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<int16_t, 16, true, true>), dim3(g), dim3(WG), lds, s2, cc); }
+            else if (mode == 0) { if (split) hipLaunchKernelGGL((k_dsyn<int16_t, 16, true, false, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<int16_t, 16, true>), dim3(g), dim3(WG), lds, s2, cc); }
             else hipLaunchKernelGGL((k_dsyn<int16_t, 16, false>), dim3(g), dim3(WG), lds, s2, cc);
         } else {
-            if (mode == 2) hipLaunchKernelGGL((k_dsyn<float, 16, true, true>), dim3(g), dim3(WG), lds, s2, cc);
-            else if (mode == 0) hipLaunchKernelGGL((k_dsyn<float, 16, true>), dim3(g), dim3(WG), lds, s2, cc);
+            if (mode == 2) { if (split) hipLaunchKernelGGL((k_dsyn<float, 16, true, true, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<float, 16, true, true>), dim3(g), dim3(WG), lds, s2, cc); }
+            else if (mode == 0) { if (split) hipLaunchKernelGGL((k_dsyn<float, 16, true, false, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<float, 16, true>), dim3(g), dim3(WG), lds, s2, cc); }
             else hipLaunchKernelGGL((k_dsyn<float, 16, false>), dim3(g), dim3(WG), lds, s2, cc);
         }
     };

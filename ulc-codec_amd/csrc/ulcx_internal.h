@@ -117,6 +117,12 @@ struct UlcxDecCtx {
     int   *lastSub;                      // [B] LastSubBlockSize
     uint32_t *seed;                      // [B] noise RNG state (ulcDecoder.c:75-81)
     int   *dead;                         // [B] stream hit a corrupt block
+    // k_dsyn with several workgroups per stream (round 3): the state after the launch goes to a second set of arrays (a
+    // workgroup that enters a stream in the middle reads the state in front of the launch while the one that finishes the
+    // stream writes the new one); the host swaps the two sets afterwards.  Without a split both sets are the same arrays.
+    float *lapO; int *lastSubO; uint32_t *seedO; int *deadO;
+    float *lapScratch;                   // [grid][C][BS/2] a workgroup's own lapping state between its blocks
+    int    k0, k1;                       // blocks [k0, k1) of every stream this synthesis launch works on
     // per-call scratch: what the scan leaves for the synthesis (ulcx_dec.hip)
     int   *wcScan;                       // [NB] WindowCtrl as the scan saw it (0 = corrupt)
     int   *draws;                        // [NB] RNG draws consumed by the block
@@ -186,9 +192,11 @@ struct UlcxDecAux {
     int nChunks;
     int ldsPad;                          // ULCX_DSYN_PAD: extra dynamic LDS bytes per synthesis workgroup (occupancy experiments)
     int scanLpw;                         // blocks (= live lanes) per wave of the syntax walk: 64, 32 or 16
+    int synGrid;                         // > 0: workgroups of the synthesis over an even cut of the (stream, block) pairs; 0: one per stream
 };
 int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev, const UlcxDecAux &aux);
 size_t ulcx_dec_lds_bytes(int BS, int C, int fast, int twInLds);
+int ulcx_dec_syn_slots(const UlcxDecCtx &c);      // resident workgroups of the stereo synthesis kernel on the current device
 int ulcx_pack_launch(int nStreams, int nBlocks, int slotBytes, const uint8_t *d_slots, const int32_t *d_bits, uint8_t *d_payload,
                      long long stride, int32_t *d_payloadBytes, int32_t *d_maxBlock, hipStream_t st);
 size_t ulcx_enc_xf_lds_bytes(int BS, int C);
