@@ -473,6 +473,7 @@ def test_runtime_switches_keep_parity(env):
     ({"ULCX_DSYN_LAPG": "0"}, 6, 16),              # synthesis with lapping state + twiddles in LDS (rounds 1-2; default: twiddles only)
     ({"ULCX_DSYN_LAPG": "1"}, 6, 16),              # ... both in global memory
     ({"ULCX_DSYN_PAD": "8192"}, 6, 16),
+    ({"ULCX_DEC_HALVES": "1"}, 260, 16),           # the walk of the second half of the blocks beside the synthesis of the first (>= 4096 blocks per call)
 ])
 def test_round3_switches_keep_parity(env, B, K):
     """The switches round 3 added, on the headline geometry - stereo, BlockSize 2048, where the transform's

@@ -42,7 +42,7 @@ struct ulcx_decoder {
     bool evOk, evRecorded, timing;
     uint8_t *d_in; size_t d_in_bytes; float *d_pcm; int32_t *d_bits;
     uint8_t *d_pay; int32_t *d_payBytes; long long payStride;     // resident packed payloads (ulcx_decoder_upload_payload)
-    hipStream_t side; hipEvent_t evFork, evScan[ULCX_DEC_MAXCH]; bool sideOk; int nChunks; int ldsPad, scanLpw;   // walk / synthesis pipeline (ULCX_DEC_PIPE chunks)
+    hipStream_t side; hipEvent_t evFork, evScan[ULCX_DEC_MAXCH]; bool sideOk; int nChunks; int ldsPad, scanLpw, kHalves;   // walk / synthesis pipeline (ULCX_DEC_PIPE chunks)
     // k_dsyn over an even cut of the call's (stream, block) pairs: the second set of state arrays, the resident
     // workgroups of the kernel on this device, ULCX_DSYN_SPLIT=0 switches it off
     float *lap2; int *lastSub2; uint32_t *seed2; int *dead2; int synSlots; bool splitOK;
@@ -516,7 +516,7 @@ static void build_rng_tables(std::vector<uint32_t> &jumpT) {
 
 static UlcxDecAux dec_aux(ulcx_decoder *e) {
     UlcxDecAux a; a.side = e->sideOk ? e->side : nullptr; a.evFork = e->evFork; a.evScan = e->evScan; a.nChunks = e->nChunks;
-    a.ldsPad = e->ldsPad; a.scanLpw = e->scanLpw; a.synGrid = 0;
+    a.ldsPad = e->ldsPad; a.scanLpw = e->scanLpw; a.synGrid = 0; a.kHalves = e->kHalves;
     return a;
 }
 
@@ -555,7 +555,7 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     e->device = device; e->B = nStreams; e->C = nChan; e->BS = BlockSize; e->maxK = maxBlocksPerCall;
     e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->timing = true;
     e->d_in = nullptr; e->d_in_bytes = 0; e->d_pcm = nullptr; e->d_bits = nullptr; e->d_pay = nullptr; e->d_payBytes = nullptr; e->payStride = 0;
-    e->sideOk = false; e->side = nullptr; e->nChunks = 1;
+    e->sideOk = false; e->side = nullptr; e->nChunks = 1; e->kHalves = 0;
     e->lap2 = nullptr; e->lastSub2 = nullptr; e->seed2 = nullptr; e->dead2 = nullptr; e->synSlots = 0; e->splitOK = false;
     e->scanLpw = 64; if (const char *pv = getenv("ULCX_DSCAN_LPW")) { int n = atoi(pv); if (n == 16 || n == 32 || n == 64) e->scanLpw = n; }
     e->ldsPad = 0; if (const char *pv = getenv("ULCX_DSYN_PAD")) { int n = atoi(pv); if (n > 0 && n < 120 * 1024) e->ldsPad = n & ~15; }
@@ -624,7 +624,12 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
         int n = pv ? atoi(pv) : 1;                             // default off: measured 1.31 / 1.45 / 1.54 / 2.6 ms per decode for 1 / 2 / 4 / 8 chunks
         if (n < 1) n = 1;
         if (n > ULCX_DEC_MAXCH) n = ULCX_DEC_MAXCH;
-        if (!(fb && fb[0] == '0') && n > 1) {
+        // ULCX_DEC_HALVES=1: the walk of the second half of every stream's blocks beside the synthesis of the first (batches of
+        // >= 4096 blocks).  Off: measured 2.55 vs 2.50 ms per 131072 blocks, 1.28 vs 1.20 per 65536 - the synthesis slows down
+        // by more than the walk it hides, and two launches end in two partly filled rounds
+        const char *hv = getenv("ULCX_DEC_HALVES");
+        e->kHalves = (c.fastOK && hv && hv[0] == '1' && (long long)nStreams * maxBlocksPerCall >= 4096) ? 1 : 0;
+        if (!(fb && fb[0] == '0') && (n > 1 || e->kHalves)) {
             bool ok = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess;
             if (ok) {
                 ok = hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming) == hipSuccess;

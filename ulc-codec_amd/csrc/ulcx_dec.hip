@@ -305,8 +305,9 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
 // Pass 1 - one lane per block.
 __global__ __launch_bounds__(64) void k_dscan(UlcxDecCtx c, int lpw) {
     if ((int)threadIdx.x >= lpw) return;                           // (lpw < 64: half- or quarter-filled waves, more of them per SIMD)
-    int blk = c.s0 * c.K + blockIdx.x * lpw + threadIdx.x;         // streams [s0, s1) of the batch (ulcx_dec_launch pipelines chunks)
-    if (blk >= c.s1 * c.K) return;
+    const int id = blockIdx.x * lpw + threadIdx.x, Kc = c.k1 - c.k0;       // streams [s0, s1), blocks [k0, k1) of each (ulcx_dec_launch pipelines pieces of the batch)
+    if (id >= (c.s1 - c.s0) * Kc) return;
+    const int blk = (c.s0 + id / Kc) * c.K + c.k0 + id % Kc;
     scan_block(c, blk, c.in + (size_t)blk * c.slot, c.slot * 8, c.slot, c.in, c.in + c.inBytes);
 }
 
@@ -1135,13 +1136,13 @@ int ulcx_dec_launch(const UlcxDecCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                    : c.pcm16 ? (mode == 2 ? (const void *)k_dsyn<int16_t, 16, true, true> : mode == 0 ? (const void *)k_dsyn<int16_t, 16, true> : (const void *)k_dsyn<int16_t, 16, false>)
                              : (mode == 2 ? (const void *)k_dsyn<float, 16, true, true> : mode == 0 ? (const void *)k_dsyn<float, 16, true> : (const void *)k_dsyn<float, 16, false>);
     if (lds > 48 * 1024) CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    auto scan = [&](hipStream_t s2, int s0, int s1) {
-        UlcxDecCtx cc = c; cc.s0 = s0; cc.s1 = s1;
+    auto scan = [&](hipStream_t s2, int s0, int s1, int k0 = 0, int k1 = -1) {
+        UlcxDecCtx cc = c; cc.s0 = s0; cc.s1 = s1; cc.k0 = k0; cc.k1 = k1 < 0 ? c.K : k1;
         if (c.packed) hipLaunchKernelGGL(k_dscan_packed, dim3((s1 - s0 + 63) / 64), dim3(64), 0, s2, cc);
-        else { const int lpw = aux.scanLpw > 0 ? aux.scanLpw : 64; hipLaunchKernelGGL(k_dscan, dim3(((s1 - s0) * c.K + lpw - 1) / lpw), dim3(64), 0, s2, cc, lpw); }
+        else { const int lpw = aux.scanLpw > 0 ? aux.scanLpw : 64; hipLaunchKernelGGL(k_dscan, dim3(((s1 - s0) * (cc.k1 - cc.k0) + lpw - 1) / lpw), dim3(64), 0, s2, cc, lpw); }
     };
-    auto syn = [&](hipStream_t s2, int s0, int s1) {
-        UlcxDecCtx cc = c; cc.s0 = s0; cc.s1 = s1; cc.k0 = 0; cc.k1 = c.K;
+    auto syn = [&](hipStream_t s2, int s0, int s1, int k0 = 0, int k1 = -1) {
+        UlcxDecCtx cc = c; cc.s0 = s0; cc.s1 = s1; cc.k0 = k0; cc.k1 = k1 < 0 ? c.K : k1;
         const bool lapg = c.fastOK && (!small || mode != 1);       // kernels with the lapping state in global memory: any grid
         const bool split = lapg && aux.synGrid > 0 && s0 == 0 && s1 == c.B;
         const unsigned g = split ? (unsigned)aux.synGrid : (unsigned)(s1 - s0);
@@ -1164,7 +1165,24 @@ int ulcx_dec_launch(const UlcxDecCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     int nCh = (aux.side && aux.nChunks > 1) ? aux.nChunks : 1;
     if (nCh > ULCX_DEC_MAXCH) nCh = ULCX_DEC_MAXCH;
     if (c.B < 64 * nCh) nCh = 1;                          // (a chunk is at least a wave of the walk)
-    if (nCh == 1) {
+    // The walk of the second half of every stream's blocks beside the synthesis of the first (round 3): the walk is one
+    // wave per SIMD of dependent instructions, the synthesis leaves it its issue slots; a stream's state goes from the first
+    // synthesis launch to the second through the state arrays like from one call to the next.  (Timing: the "k_dscan"
+    // interval is the first half's walk - the exposed one.)
+    const bool halves = nCh == 1 && aux.side && aux.kHalves && c.fastOK && !c.packed && aux.synGrid <= 0 && c.K >= 8 && (long long)c.B * c.K >= 4096;
+    if (halves) {
+        const int kh = c.K / 2;
+        scan(st, 0, c.B, 0, kh);
+        if (ev) CK(hipEventRecord(ev[stage++], st));
+        CK(hipEventRecord(aux.evFork, st));
+        CK(hipStreamWaitEvent(aux.side, aux.evFork, 0));
+        scan(aux.side, 0, c.B, kh, c.K);
+        CK(hipEventRecord(aux.evScan[1], aux.side));
+        syn(st, 0, c.B, 0, kh);
+        CK(hipStreamWaitEvent(st, aux.evScan[1], 0));
+        syn(st, 0, c.B, kh, c.K);
+        if (ev) CK(hipEventRecord(ev[stage++], st));
+    } else if (nCh == 1) {
         scan(st, 0, c.B);
         if (ev) CK(hipEventRecord(ev[stage++], st));
         syn(st, 0, c.B);

@@ -192,6 +192,7 @@ struct UlcxDecAux {
     int nChunks;
     int ldsPad;                          // ULCX_DSYN_PAD: extra dynamic LDS bytes per synthesis workgroup (occupancy experiments)
     int scanLpw;                         // blocks (= live lanes) per wave of the syntax walk: 64, 32 or 16
+    int kHalves;                         // the walk of the second half of the blocks beside the synthesis of the first (ULCX_DEC_HALVES=0: off)
     int synGrid;                         // > 0: workgroups of the synthesis over an even cut of the (stream, block) pairs; 0: one per stream
 };
 int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev, const UlcxDecAux &aux);
