@@ -2433,9 +2433,13 @@ struct WaveCaps { int k, z, nyb; };
 __host__ __device__ static inline int wavecaps_lds(const WaveCaps &w) { return w.k * 4 + w.z * 8 + w.k * 4 + w.z + w.nyb + 64; }
 
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
+    // inclusive prefix by row shifts / row broadcasts (round 3: six ds_bpermute round trips before)
     int x = v;
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(x, o); if (lane >= o) x += t; }
-    total = __shfl(x, 63);
+#define STEP(ctl, rmask) x += __builtin_amdgcn_update_dpp(0, x, ctl, rmask, 0xf, false);
+    ULCX_DPP_STEPS(STEP)
+#undef STEP
+    total = __builtin_amdgcn_readlane(x, 63);
+    (void)lane;
     return x - v;
 }
 
