@@ -23,7 +23,7 @@ struct ulcx_encoder {
     hipStream_t side; hipEvent_t evFork, evJoin, evFork2; bool sideOk; bool timing;
     hipEvent_t evWC[7 + 3 * ULCX_WC_MAXCH + ULCX_XF_MAXCH + 1]; int wcPipe; hipStream_t side2, side3, side4; hipEvent_t evE[ULCX_WC_MAXCH]; hipEvent_t evXf[2 * ULCX_XF_MAXCH]; int nXf;      // window-control / transform chunk pipeline (ULCX_WC_PIPE chunks, default 4)
     bool keysFinal;
-    int wcSteps, cplxEarly, wcFuse, barkUniP, noiseEarly, xfRun; bool wcEStream;      // environment switches, read once at create
+    int wcSteps, cplxEarly, wcFuse, barkUniP, noiseEarly, xfRun, fusedNoise; bool wcEStream;      // environment switches, read once at create
     int nWcLad, nXfLad, wcLad[ULCX_WC_MAXCH], xfLad[ULCX_XF_MAXCH];   // ULCX_WC_LADDER / ULCX_XF_LADDER: step sizes in blocks
     // staging for the host-pointer API
     float *d_pcm; uint8_t *d_out; int32_t *d_bits, *d_wc; float *d_cplx;
@@ -234,6 +234,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
         }
         e->wcPipe = e->sideOk ? 4 : 1;                         // transform chunks per call: 1 block, then thirds (4 vs 5 chunks: 9.50 vs 9.56 ms per bench step)
         if (const char *pv = getenv("ULCX_WC_PIPE")) { int n = atoi(pv); if (n >= 1 && n <= ULCX_XF_MAXCH && n != 2 && (n == 1 || e->sideOk)) e->wcPipe = n; }
+        { const char *v = getenv("ULCX_FUSED_NOISE"); e->fusedNoise = (v && v[0] == '1') ? 1 : 0; }
         e->wcSteps = -1; if (const char *sv = getenv("ULCX_WC_STEPS")) e->wcSteps = atoi(sv);      // -1: default; 0: the transform's chunks
         e->wcEStream = getenv("ULCX_WC_ESTREAM") != nullptr;
         { const char *v = getenv("ULCX_CPLX_EARLY"); e->cplxEarly = (v && v[0] == '0') ? 0 : 1; }      // (round 3: on - the last transform chunk runs alone and leaves room beside it)
@@ -278,7 +279,7 @@ static int encode_dev_any(ulcx_encoder *e, int mode, float p0, float p1, const f
     aux.side = e->sideOk ? e->side : nullptr; aux.side2 = e->sideOk ? e->side2 : nullptr; aux.side3 = e->sideOk ? e->side3 : nullptr; aux.side4 = (e->sideOk && e->wcEStream) ? e->side4 : nullptr; aux.evE = e->evE;
     aux.evFork = e->evFork; aux.evJoin = e->evJoin; aux.evFork2 = e->evFork2; aux.evWC = e->evWC; aux.evXf = e->evXf;
     aux.wcPipe = (nBlocks >= 2 * e->wcPipe) ? e->wcPipe : (nBlocks >= 6 && e->wcPipe > 1 ? 3 : 1); aux.nXf = &e->nXf;
-    aux.wcSteps = e->wcSteps; aux.cplxEarly = e->cplxEarly; aux.wcFuse = e->wcFuse; aux.barkUniP = e->barkUniP; aux.noiseEarly = e->noiseEarly; aux.xfRun = e->xfRun;
+    aux.wcSteps = e->wcSteps; aux.fusedNoise = e->fusedNoise; aux.cplxEarly = e->cplxEarly; aux.wcFuse = e->wcFuse; aux.barkUniP = e->barkUniP; aux.noiseEarly = e->noiseEarly; aux.xfRun = e->xfRun;
     aux.nWcCut = aux.nXfCut = 0;
     if (aux.wcPipe > 1) {
         // schedules as cumulative block counts; a ladder applies when it sums to this call's block count and every transform

@@ -1996,6 +1996,10 @@ __global__ __launch_bounds__(WG) void k_keep_ranks(UlcxEncCtx c, int finalPass) 
 #else
 #define E_GAPCAP(N) ((N) / 16)      // gaps >= 16 per block: at most N/17 of them (round 3: was a fixed 1024 - 8 KB of LDS, six workgroups per CU instead of eight)
 #endif
+// GEN (round 3, ULCX_FUSED_NOISE=1): the workgroup forms the block's {w, w*log} pairs itself from the Bark levels (what
+// k_nline does: Psyopt.c:236-248), leaves them in HBM for the writer's rare fall-backs, and takes the units' five tail sums
+// as further work items (what k_tailsums does: NoiseFill.c:41-62) - two kernels and two reads of the pair array less.
+template <bool GEN>
 __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
     extern __shared__ uint32_t gsm[];
     int tid = threadIdx.x;
@@ -2007,9 +2011,42 @@ __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     const uint32_t *keepB = c.keep + (size_t)blk * (N / 32);
     for (int i = tid; i < N / 32; i += WG) kw[i] = keepB[i];
-    {
+    const int nTailSlots = GEN ? 5 * 4 * c.C : 0;          // work-list slots in front of the gaps: (unit, chain) of the tail sums
+    if (!GEN) {
         const float4 *pg = (const float4 *)(c.npair + (size_t)blk * N);
         for (int i = tid; i < N / 4; i += WG) ((float4 *)pairs)[i] = ldnt(pg + i);
+    } else {
+        float *sbark = (float *)(gsm + N + N / 32 + 2 * (E_GAPCAP(N) + nTailSlots) + 4 + 2 * ((N / 32 + 63) / 64));
+        const int nLev = c.C * 4 * ULCX_NBARK;
+        for (int i = tid; i < nLev; i += WG) sbark[i] = c.barkN[(size_t)blk * nLev + i];
+        __syncthreads();
+        const int half = c.BS / 2;
+        float *gp = c.npair + (size_t)blk * N;
+        for (int jp = 2 * tid; jp < half; jp += 2 * WG) {      // two neighbouring line pairs per thread, every channel (as k_nline)
+            unsigned pat = ulcx_pattern(wc);
+            int off = 0, dd = 0, S = c.BS, j = 0;
+            for (;; j++) { dd = pat & 7; S = c.BS >> dd; if (2 * jp < off + S) break; off += S; pat >>= 4; }
+            const int line = jp - off / 2;
+            const int2 bi2 = *(const int2 *)(c.T.bandIdx[dd] + line);
+            const float2 fr2 = *(const float2 *)(c.T.bandFrac[dd] + line);
+            for (int ch = 0; ch < c.C; ch++) {
+                const float *bark = sbark + (ch * 4 + j) * ULCX_NBARK;
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    int bi = q ? bi2.y : bi2.x;
+                    float fr = q ? fr2.y : fr2.x;
+                    float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
+                    float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
+                    float noise = L * (1.0f - fr) + R * fr;
+                    float w = ulcx_expf(0.5f * noise);
+                    o[2 * q] = w; o[2 * q + 1] = w * (noise + 0x1.62E430p-1f);
+                }
+                const float4 v = make_float4(o[0], o[1], o[2], o[3]);
+                *(float4 *)(pairs + (size_t)ch * c.BS + 2 * jp) = v;
+                stnt((float4 *)(gp + (size_t)ch * c.BS + 2 * jp), v);
+            }
+        }
     }
     __syncthreads();
     if (ULCX_DBG(c) & 0x10000) return;                     // (ablation build: the loads alone)
@@ -2021,17 +2058,40 @@ __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
     // coefficient is the top bit of the last non-zero word, found in a bit mask of the non-zero words - or lies inside the
     // word between two set bits, and only one such run fits in 32 bits.
     uint32_t *wl = kw + N / 32;                            // work list: (kept coefficient, start of its gap) pairs
-    const int gapCap = E_GAPCAP(N);
+    const int gapCap = E_GAPCAP(N) + nTailSlots;
     int *wcount = (int *)(wl + 2 * gapCap);
     unsigned long long *nzw = (unsigned long long *)(wcount + 2);      // bit w % 64 of nzw[w / 64]: keep word w is not 0
     const int nW = N / 32;
-    if (tid == 0) *wcount = 0;
+    if (tid == 0) *wcount = nTailSlots;
     for (int w0 = 0; w0 < nW; w0 += WG) {
         const int w = w0 + tid;
         const unsigned long long bm = __ballot(w < nW && kw[w] != 0u);
         if ((tid & 63) == 0 && w < nW) nzw[w >> 6] = bm;
     }
     __syncthreads();
+    if (GEN && tid < 4 * c.C) {
+        // the tail behind the last kept coefficient of unit (ch, j): the start index the sums assume, five chains if it is long enough
+        const int ch = tid >> 2, j = tid & 3;
+        int dd, off, S;
+        const bool have = unit_geom(wc, j, c.BS, dd, off, S);
+        int start = 0, n = 0;
+        if (have) {
+            const int us = ch * c.BS + off, ue = us + S, usw = us >> 5;
+            int last = us - 1;
+            for (int q = (ue - 1) >> 11; q >= (usw >> 6); q--) {
+                unsigned long long mk = nzw[q];
+                if (q == ((ue - 1) >> 11) && ((ue >> 5) & 63)) mk &= (1ull << ((ue >> 5) & 63)) - 1ull;     // words below the unit's end
+                if (mk) { const int wp = q * 64 + 63 - __clzll(mk); if (wp >= usw) last = wp * 32 + 31 - __clz(kw[wp]); break; }
+            }
+            start = last + 1; n = ue - start;
+            c.tailSum[((size_t)(blk * c.C + ch) * 4 + j) * 8 + 5] = __int_as_float(start);
+        }
+        for (int chain = 0; chain < 5; chain++) {
+            const int slot = tid * 5 + chain;
+            wl[2 * slot] = (have && n >= 16) ? (0x80000000u | ((uint32_t)tid << 4) | (uint32_t)chain) : 0xFFFFFFFFu;
+            wl[2 * slot + 1] = (uint32_t)start;
+        }
+    }
     for (int w = tid; w < nW; w += WG) {
         const uint32_t m = kw[w];
         if (m == 0u) continue;
@@ -2069,7 +2129,44 @@ __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
     if (ULCX_DBG(c) & 0x20000) return;                     // (ablation build: loads + gap list)
     int nw = *wcount; if (nw > gapCap) nw = gapCap;
     for (int t = tid; t < nw; t += WG) {
-        int i = (int)wl[2 * t], start = (int)wl[2 * t + 1];
+        const uint32_t it = wl[2 * t];
+        if (GEN && (it & 0x80000000u)) {
+            if (it == 0xFFFFFFFFu || (ULCX_DBG(c) & 0x40000)) continue;      // (ablation build: no tail chains)
+            // one of the five ordered f32 sums of a unit's tail (NoiseFill.c:41-62), as tailsums_lane
+            const int chain = it & 7, u = (it >> 4) & 0xFFFF, ch = u >> 2, j = u & 3;
+            const int start = (int)wl[2 * t + 1];
+            int dd, off, S;
+            unit_geom(wc, j, c.BS, dd, off, S);
+            const int n = ch * c.BS + off + S - start;
+            const float2 *d = (const float2 *)(pairs + (start / 2) * 2);
+            const int np = (n + (start & 1) + 1) / 2;
+            const bool useY = (chain == 2) || (chain == 3);
+            const bool hasX1 = (chain <= 2), hasX2 = (chain == 1);
+            float acc = 0.0f;
+            int q = 0;
+            for (; q + 8 <= np; q += 8) {
+                float2 pv[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) pv[e] = d[q + e];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float x = (q + e) * 2.0f;
+                    float base = useY ? pv[e].y : pv[e].x;
+                    float m1 = hasX1 ? x : 1.0f, m2 = hasX2 ? x : 1.0f;
+                    acc += (base * m1) * m2;
+                }
+            }
+            for (; q < np; q++) {
+                float2 pv = d[q];
+                float x = q * 2.0f;
+                float base = useY ? pv.y : pv.x;
+                float m1 = hasX1 ? x : 1.0f, m2 = hasX2 ? x : 1.0f;
+                acc += (base * m1) * m2;
+            }
+            c.tailSum[((size_t)(blk * c.C + ch) * 4 + j) * 8 + chain] = acc;
+            continue;
+        }
+        int i = (int)it, start = (int)wl[2 * t + 1];
         int zr = i - start;
         int v = zr - 16; if (v > 0x1FF) v = 0x1FF;
         int n = v + 16;
@@ -2089,11 +2186,12 @@ __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
         gs[i] = make_float2((sum == 0.0f) ? -1.0f : ulcx_expf(sum / sumw), 0.0f);
     }
 }
+template <bool GEN>
 __global__ __launch_bounds__(WG) void k_gapsums(UlcxEncCtx c, int finalPass) {
     if (probes_over(c, finalPass)) return;
-    if (c.fbMode != 2) { gapsums_block(c, finalPass, blockIdx.x); return; }
+    if (c.fbMode != 2) { gapsums_block<GEN>(c, finalPass, blockIdx.x); return; }
     int n = fb_count(c);
-    for (int v = blockIdx.x; v < n; v += gridDim.x) { gapsums_block(c, finalPass, c.fbList[c.fbLo + v]); __syncthreads(); }
+    for (int v = blockIdx.x; v < n; v += gridDim.x) { gapsums_block<GEN>(c, finalPass, c.fbList[c.fbLo + v]); __syncthreads(); }
 }
 
 // Tail HF-extension sums (NoiseFill.c:41-62) for the tail after each unit's last kept
@@ -3148,13 +3246,15 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         CK(hipFuncSetAttribute((const void *)k_bark_uniform<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)barkLds));
         CK(hipFuncSetAttribute((const void *)k_bark_uniform<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)barkLds));
     }
+    const bool fusedNoise = aux.fusedNoise && c.useGapSums && c.useWave;
     auto launch_noise = [&](hipStream_t s2, bool ev0) -> int {
         if (c.barkRing) {
             hipLaunchKernelGGL(k_bark_uniform<true>, dim3((NB * c.C + 63) / 64), dim3(256), barkLds, s2, c);
             hipLaunchKernelGGL(k_bark_levels<true>, dim3((unsigned)(((size_t)NB * c.C * 32 + WG - 1) / WG)), dim3(WG), 0, s2, c);
         }
         hipLaunchKernelGGL(k_nbark, dim3((nUnits + 63) / 64), dim3(64), 0, s2, c, c.barkRing ? 1 : 0);    if (ev0) MARK();
-        hipLaunchKernelGGL(k_nline, dim3(NB), dim3(WG), 0, s2, c);                                   if (ev0) MARK();
+        if (!fusedNoise) hipLaunchKernelGGL(k_nline, dim3(NB), dim3(WG), 0, s2, c);                 // (fused: k_gapsums<true> forms the pairs)
+        if (ev0) MARK();
         return ULCX_OK;
     };
     // The noise log-spectrum (k_nbark: lane-serial ordered sums, latency-bound; k_nline) depends on the
@@ -3257,9 +3357,14 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     auto launch_encode = [&](UlcxEncCtx cc, hipStream_t s2, int fin, bool ev0, bool bigFirst) -> int {
         const bool fb2 = (cc.fbMode == 2);                 // exact path: small grids that walk the list of owned blocks
         const int fbW = NB < 128 ? NB : 128;
-        if (cc.useGapSums) {
+        if (cc.useGapSums && fusedNoise) {
+            const size_t glds = (size_t)N * 4 + N / 8 + 8 * (E_GAPCAP(N) + 20 * cc.C) + 16 + 8 * ((N / 32 + 63) / 64) + (size_t)cc.C * 4 * ULCX_NBARK * 4;
+            if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+            hipLaunchKernelGGL(k_gapsums<true>, dim3(fb2 ? fbW : NB), dim3(WG), glds, s2, cc, fin);
+            if (ev0 && ev) { CK(hipEventRecord(ev[stage++], s2)); CK(hipEventRecord(ev[stage++], s2)); }
+        } else if (cc.useGapSums) {
             size_t glds = (size_t)N * 4 + N / 8 + 8 * E_GAPCAP(N) + 16 + 8 * ((N / 32 + 63) / 64);
-            if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+            if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
             // the two speculative-sum kernels are independent and both latency-bound: on the main path k_tailsums
             // runs on a side stream beside k_gapsums
             const bool tailAside = !fb2 && side2 != nullptr && s2 == st;
@@ -3269,7 +3374,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                 hipLaunchKernelGGL(k_tailsums, dim3((nUnits * 8 + 63) / 64), dim3(64), 0, side2, cc, fin);
                 CK(hipEventRecord(evTail1, side2));
             }
-            hipLaunchKernelGGL(k_gapsums, dim3(fb2 ? fbW : NB), dim3(WG), glds, s2, cc, fin);
+            hipLaunchKernelGGL(k_gapsums<false>, dim3(fb2 ? fbW : NB), dim3(WG), glds, s2, cc, fin);
             if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
             if (tailAside) CK(hipStreamWaitEvent(s2, evTail1, 0));
             else hipLaunchKernelGGL(k_tailsums, dim3(fb2 ? fbW : (nUnits * 8 + 63) / 64), dim3(64), 0, s2, cc, fin);

@@ -177,6 +177,7 @@ struct UlcxEncAux {
     hipEvent_t *evXf;                    // [2*ULCX_XF_MAXCH] timing pairs around each transform chunk (used when ev != NULL)
     int wcPipe;                          // chunks of blocks pipelined between window control and transform; 1 = off
     int wcSteps;                         // fine steps of the window-control kernels per call (ULCX_WC_STEPS)
+    int fusedNoise;                      // k_gapsums forms the noise pairs and takes the tail sums: no k_nline / k_tailsums (ULCX_FUSED_NOISE)
     int cplxEarly, wcFuse, barkUniP;     // ULCX_CPLX_EARLY / ULCX_WC_FUSE / ULCX_BARK_UNIFORM_P, read once when the encoder is created
     int xfRun;                           // ULCX_XF_RUN: consecutive blocks of a stream one k_xf_fast workgroup takes (0: no separate kernel)
     int noiseEarly;                      // ULCX_NOISE_EARLY: noise log-spectrum chain starts behind the transform, not behind the masking sums
