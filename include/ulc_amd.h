@@ -94,6 +94,12 @@ int  ULC_DecodeBlock(struct ULC_DecoderState_t *State, float *DstData, const voi
  * returns at most maxBytes.  Host code, no GPU involved: ULC_DecodeBlock stages exactly this many bytes, and a
  * container reader can use it to index a .ulc payload (blocks carry no length, tools/ulcDecodeTool.c:153-165). */
 int  ulcx_block_extent_bytes(const void *SrcBuffer, int nChan, int BlockSize, int maxBytes);
+/* Round 3: the slot-form decoder cuts a call's (stream, block) pairs evenly over the synthesis workgroups when one workgroup
+ * per stream would leave the device idle (few long streams).  This is the cut's arithmetic, exported for inspection and the
+ * tests: the number of workgroups for nBlocks blocks of nStreams streams on a device that holds residentWG workgroups of the
+ * synthesis kernel (1536 on an MI355X for stereo BlockSize 2048), or 0 = one workgroup per stream.  No reference counterpart
+ * (the reference decodes one block per call, ulcDecoder.c:200-302). */
+int  ulcx_dec_split_plan(int nStreams, int nBlocks, int residentWG);
 
 /* ------------------------------------------------------------------------- */
 /* 2. Batched layer                                                           */

@@ -135,6 +135,24 @@ def test_batched_front_end_is_built_and_prints_usage():
     assert "ulcx_encode_host" in und and "orc_" not in und
 
 
+def test_decoder_split_plan_arithmetic(lib):
+    """ulcx_dec_split_plan (host arithmetic, round 3): when the synthesis cuts a call's (stream, block) pairs evenly over its
+    workgroups instead of giving every stream one.  1536 = resident workgroups of the stereo BlockSize-2048 kernel on an MI355X."""
+    f = lib.ulcx_dec_split_plan
+    f.argtypes = [C.c_int, C.c_int, C.c_int]; f.restype = C.c_int
+    assert f(4096, 32, 1536) == 0 and f(4096, 16, 1536) == 0        # the bench batch: 3 rounds of whole streams against 86 + 1 blocks: not 1.5 x
+    assert f(1, 1, 1536) == 0 and f(6, 1, 1536) == 0                  # the drop-in's shape: nothing to cut
+    g = f(64, 256, 1536)                                             # few long streams: 16384 pairs, 11 per workgroup
+    assert g == 16384 // 11 and g <= 1536
+    g = f(16, 512, 1536)
+    assert g == 8192 // 8                                            # never fewer than 8 blocks per workgroup (one more is run for the state)
+    assert f(3, 40, 1536) == 120 // 8
+    for (b, k, r) in [(5, 7, 64), (1000, 9, 100), (2, 3, 8), (1 << 20, 2, 1536)]:
+        g = f(b, k, r)
+        assert g == 0 or (1 <= g <= r and g != b)
+    assert f(0, 4, 16) == 0 and f(4, 0, 16) == 0 and f(4, 4, 0) == 0
+
+
 def test_block_extent_walk_matches_the_decoder_and_never_overreads(lib):
     """ulcx_block_extent_bytes (host code, what ULC_DecodeBlock stages): the byte count equals what the oracle decoder
     consumed, on hand-assembled streams with every code of the syntax and on encoder output - with every block placed

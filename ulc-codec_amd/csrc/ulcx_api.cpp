@@ -524,18 +524,26 @@ static UlcxDecAux dec_aux(ulcx_decoder *e) {
 // One decode launch.  When the batch does not fill the machine in whole rounds of one workgroup per stream - 4096 streams on
 // 1536 resident workgroups, or a few long streams - the synthesis takes an even cut of the (stream, block) pairs instead: a
 // workgroup then runs one extra block (the one in front of its range, for the lapping state), so the cut must pay for that.
+// The cut itself (host arithmetic, exported for the tests): workgroups of the synthesis for a call of nBlocks blocks of
+// nStreams streams on a device that holds residentWG workgroups of the kernel; 0 = one workgroup per stream.  Cost in block
+// times: ceil(streams / resident) rounds of nBlocks blocks against blocks-per-workgroup + 1 (the block in front of the range);
+// the cut has to win by 1.5 x - an even cut of uneven streams ends with its slowest workgroup (measured on the bench batch).
+extern "C" int ulcx_dec_split_plan(int nStreams, int nBlocks, int residentWG) {
+    if (nStreams < 1 || nBlocks < 1 || residentWG < 1) return 0;
+    const long long T = (long long)nStreams * nBlocks;
+    long long per = (T + residentWG - 1) / residentWG; if (per < 8) per = 8;
+    const long long grid = T / per;
+    const long long costStream = (((long long)nStreams + residentWG - 1) / residentWG) * nBlocks;
+    return (grid >= 1 && grid != nStreams && (per + 1) * 3 < costStream * 2) ? (int)grid : 0;
+}
 static int dec_launch(ulcx_decoder *e, UlcxDecCtx &c, hipStream_t st) {
     UlcxDecAux a = dec_aux(e);
     a.synGrid = 0;
     c.lapO = c.lap; c.lastSubO = c.lastSub; c.seedO = c.seed; c.deadO = c.dead;
     if (e->splitOK && a.nChunks <= 1 && e->synSlots > 0) {
-        const long long T = (long long)e->B * c.K;
-        long long per = (T + e->synSlots - 1) / e->synSlots; if (per < 8) per = 8;
-        const long long grid = T / per;
-        const long long costStream = (((long long)e->B + e->synSlots - 1) / e->synSlots) * c.K;     // block times, one workgroup per stream
-        if (grid >= 1 && grid != e->B && (per + 1) * 3 < costStream * 2) {       // (1.5 x: an even cut of uneven streams ends with its slowest workgroup, measured on the bench batch)
-            a.synGrid = (int)grid;
-            if (getenv("ULCX_DEBUG_PRINT")) fprintf(stderr, "[ulcx] synthesis: %lld (stream, block) pairs over %lld workgroups (%d resident), %lld + 1 blocks each\n", T, grid, e->synSlots, per);
+        a.synGrid = ulcx_dec_split_plan(e->B, c.K, e->synSlots);
+        if (a.synGrid) {
+            if (getenv("ULCX_DEBUG_PRINT")) fprintf(stderr, "[ulcx] synthesis: %lld (stream, block) pairs over %d workgroups (%d resident)\n", (long long)e->B * c.K, a.synGrid, e->synSlots);
             c.lapO = e->lap2; c.lastSubO = e->lastSub2; c.seedO = e->seed2; c.deadO = e->dead2;
         }
     }
