@@ -425,6 +425,7 @@ def test_pcm16_ingest_and_output_match_the_wav_io_conversions(bs, ch, rate, call
     {"ULCX_GAPSUMS": "0"},                         # no speculative noise sums
     {"ULCX_CPLX_EARLY": "0"},                      # complexity sums in one launch behind the transform (default: per transform chunk)
     {"ULCX_FUSED_NOISE": "1"},                     # k_gapsums forms the noise pairs and takes the tail sums (no k_nline / k_tailsums): measured slower, off
+    {"ULCX_ENC_GRAPH": "1"},                       # a repeated batched call replays a captured HIP graph
     {"ULCX_DIRECT_PACK": "0"},                     # every block packed by k_pack (default: the wave writer packs stereo un-decimated blocks itself)
     {"ULCX_BARK_UNIFORM": "0"},                    # noise Bark sums of every block on the lane-per-subblock kernel
     {"ULCX_BARK_UNIFORM_P": "0"},                  # the masking Bark sums of every block on the lane-per-subblock kernel
