@@ -1444,13 +1444,14 @@ __global__ __launch_bounds__(256) void k_bark_uniform(UlcxEncCtx c) {
     __syncthreads();                                             // tile 0 is in place
     for (int t = 0; t < nT; t++) {
         const float4 *mineRow = (const float4 *)(tiles + (t & 1) * BK_TILE_FLOATS + lane * BK_RS);
-        for (int hh = 0; hh < BK_TL / 32; hh++) {                // 32 lines at a time: sixteen 16-byte reads in registers
-            float4 q[16];
+        constexpr int LW = BK_TL < 32 ? BK_TL : 32;              // lines per straight-line stretch
+        for (int hh = 0; hh < BK_TL / LW; hh++) {                // 32 lines at a time: sixteen 16-byte reads in registers
+            float4 q[LW / 2];
 #pragma unroll
-            for (int j = 0; j < 16; j++) q[j] = mineRow[hh * 16 + j];
+            for (int j = 0; j < LW / 2; j++) q[j] = mineRow[hh * (LW / 2) + j];
 #pragma unroll
-            for (int i = 0; i < 32; i++) {
-                edges_at(t * BK_TL + hh * 32 + i);
+            for (int i = 0; i < LW; i++) {
+                edges_at(t * BK_TL + hh * LW + i);
                 const float4 qq = q[i >> 1];
                 add_line((i & 1) ? qq.z : qq.x, (i & 1) ? qq.w : qq.y);
             }
