@@ -20,7 +20,9 @@
 #define WG 128
 #define FFT_PACKED
 #include "ulcx_fft.h"
-#define DPS 4        // FFT array padding (ulcx_fft.h): one complex after every 16
+#ifndef DPS
+#define DPS 4        // FFT array padding (ulcx_fft.h): one complex after every 16 (3: after every 8 - conflict-free passes, 1 KB more LDS)
+#endif
 
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float expand_quantizer(int q) {        // ulcDecoder.c:96-98
@@ -371,7 +373,7 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 // float index inside a padded FFT array (two floats of padding after every 32): complex n sits at FFT_PADS(n, DPS)
-__device__ __forceinline__ int padf(int f) { return f + ((f >> 5) << 1); }
+__device__ __forceinline__ int padf(int f) { return f + ((f >> (DPS + 1)) << 1); }      // float index into a padded array of complex
 
 // Noise runs found while decoding a unit, 8 bytes each:
 //   x = first coefficient | count << 16 (count - 1 for a tail, which may span the whole unit) | tail << 31
@@ -478,13 +480,15 @@ __device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &
                 float mag = (float)(lvl * lvl) * quant * (rtail ? (1.0f / 16) : (1.0f / 4));      // ulcDecoder.c:146-150, :166-170
                 if (rtail && off > 0) mag = tailMag[chunk];                                         // the tail's chain at coefficient 32*chunk (k_dscan)
                 const float rr = rtail ? tailRR : 1.0f;
-                float *dst = sw.A + padf(plo);                                                      // a piece never crosses a padding gap
+                float *dst = sw.A + padf(plo);                                                      // (DPS 4: a piece never crosses a padding gap; DPS 3: up to two)
+                constexpr int GAPF = 2 << DPS;                                                      // floats between two padding gaps
+                const int g1 = GAPF - (plo & (GAPF - 1));                                           // piece elements in front of the first gap
                 SSTAMP(sw, 9);
 #pragma unroll
                 for (int i = 0; i < 32; i++) {
                     // ulcDecoder.c:156-160 / :181-184: flip on the draw's top bit (cumulative), store, decay (r = 1 for runs)
                     const float v = __uint_as_float(__float_as_uint(mag) | ((win << (31 - i)) & 0x80000000u));
-                    if (i < n) dst[i] = v;
+                    if (i < n) dst[GAPF >= 32 ? i : i + (i >= g1 ? 2 : 0) + (i >= g1 + GAPF ? 2 : 0)] = v;
                     mag *= rr;
                 }
             }
@@ -516,7 +520,7 @@ __device__ __forceinline__ void synth_unit(const UlcxDecCtx &c, const SynWave &s
             const int pos = rec.x & 0x7FFF, qi = (rec.x >> 15) & 31, m = (rec.x >> 20) & 7;
             const float quant = expand_quantizer(qi);
             float *dst = sw.A + padf(pos);
-            const int gap = 32 - (pos & 31);                         // coefficients before the next padding gap
+            const int gap = (2 << DPS) - (pos & ((2 << DPS) - 1));   // coefficients before the next padding gap (a run of <= 7 crosses at most one)
 #pragma unroll
             for (int i = 0; i < 7; i++) {
                 int sv = (int)((rec.y >> (4 * i)) & 0xF);
