@@ -1253,7 +1253,9 @@ __global__ __launch_bounds__(64) void k_nbark(UlcxEncCtx c, int useList) {
 #define NLINE_CH 2
 __global__ __launch_bounds__(WG) void k_nline(UlcxEncCtx c) {
     __shared__ float sbark[NLINE_CH * 4 * ULCX_NBARK];
+    __shared__ unsigned long long sexp[32];                  // expf's 2^(i/32) table: an LDS read instead of a global one in the middle of every evaluation
     const int blk = blockIdx.x, tid = threadIdx.x;
+    if (tid < 32) sexp[tid] = ulcx_exp2f_tab[tid];
     const int half = c.BS / 2;
     const int s = blk / c.K, k = blk % c.K;
     const int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
@@ -1282,7 +1284,7 @@ __global__ __launch_bounds__(WG) void k_nline(UlcxEncCtx c) {
                     float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
                     float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
                     float noise = L * (1.0f - fr) + R * fr;
-                    float w = ulcx_expf(0.5f * noise);
+                    float w = ulcx_expf_t(0.5f * noise, (const unsigned long long *)sexp);
                     o[2 * q] = w; o[2 * q + 1] = w * (noise + 0x1.62E430p-1f);
                 }
                 float2 *dst = (float2 *)(c.npair + (size_t)blk * (c.C * c.BS) + (size_t)(ch0 + cc) * c.BS);

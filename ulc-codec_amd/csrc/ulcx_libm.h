@@ -30,7 +30,38 @@ ULCX_DEV uint64_t ulcx_d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; 
 ULCX_DEV double ulcx_u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
 ULCX_DEV double ulcx_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-// glibc 2.35 sysdeps/ieee754/flt-32/e_expf.c (EXP2F_TABLE_BITS = 5)
+// glibc 2.35 sysdeps/ieee754/flt-32/e_expf.c (EXP2F_TABLE_BITS = 5); TAB: where the 32-entry 2^(i/32) table is read from (a kernel
+// that evaluates many of these may keep a copy in LDS: the look-up sits in the middle of the dependent chain)
+template <typename TAB>
+ULCX_DEV float ulcx_expf_t(float x, TAB tab) {
+    uint32_t ix = ulcx_f2u(x);
+    uint32_t abstop = (ix >> 20) & 0x7ff;
+    if (abstop >= 0x42b) {                       // |x| >= 88 or NaN
+        if (ix == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8) return x + x;
+        if (x > 0x1.62e42ep6f) return ulcx_u2f(0x7f800000u);      // overflow
+        if (x < -0x1.9fe368p6f) return 0.0f;                      // underflow
+        if (x < -0x1.9d1d9ep6f) return 0x1p-149f;                 // __math_may_uflowf
+    }
+    const double SHIFT = ulcx_u2d(ulcx_expf_consts[0]);
+    const double InvLn2N = ulcx_u2d(ulcx_expf_consts[1]);
+    const double C0 = ulcx_u2d(ulcx_expf_consts[2]);
+    const double C1 = ulcx_u2d(ulcx_expf_consts[3]);
+    const double C2 = ulcx_u2d(ulcx_expf_consts[4]);
+    double xd = (double)x;
+    double zs = ulcx_fma(InvLn2N, xd, SHIFT);
+    uint64_t ki = ulcx_d2u(zs);
+    double kd = zs - SHIFT;
+    double r = ulcx_fma(InvLn2N, xd, -kd);
+    uint64_t t = tab[ki & 31] + (ki << 47);
+    double s = ulcx_u2d(t);
+    double z = ulcx_fma(r, C0, C1);
+    double r2 = r * r;
+    double y = ulcx_fma(r, C2, 1.0);
+    y = ulcx_fma(z, r2, y);
+    y = y * s;
+    return (float)y;
+}
 ULCX_DEV float ulcx_expf(float x) {
     uint32_t ix = ulcx_f2u(x);
     uint32_t abstop = (ix >> 20) & 0x7ff;
