@@ -82,7 +82,7 @@ def cpu_baseline(sample_pcm, n_blocks, cfg, legs, target_seconds=4.0):
     S = sample_pcm.shape[0]
     bs, rate = cfg["bs"], cfg["rate"]
     slot = 2 * CH * bs + 16
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # the cores this process may run on
     threads = max(1, min(cores, 64))
     enc_fn = lib.orc_encode_stream_vbr if cfg["mode"] == "vbr" else lib.orc_encode_stream_cbr
 
@@ -100,6 +100,11 @@ def cpu_baseline(sample_pcm, n_blocks, cfg, legs, target_seconds=4.0):
         outs.append(o)
     d0 = np.zeros(n_blocks * bs * CH, np.float32); b0 = np.zeros(n_blocks, np.int32)
     t0 = time.perf_counter(); one(flat[0], outs[0].copy(), b0, d0); t1 = time.perf_counter() - t0
+    # one thread alone (what a single core does, the figure the many-thread rate should be read against): a few passes
+    n1 = max(1, min(S, int(1.5 / max(t1, 1e-4))))
+    t0 = time.perf_counter()
+    for i in range(n1): one(flat[i % S], outs[i % S].copy(), b0, d0)
+    one_thread = n1 * n_blocks * bs * CH / (time.perf_counter() - t0) / 1e6
     reps = max(1, int(target_seconds / max(t1, 1e-4)))
     done = [0] * threads
 
@@ -118,7 +123,8 @@ def cpu_baseline(sample_pcm, n_blocks, cfg, legs, target_seconds=4.0):
     el = time.perf_counter() - t0
     streams = sum(done)
     samples = streams * n_blocks * bs * CH
-    return {"value": samples / el / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+    return {"value": samples / el / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port", "one_thread": one_thread,
+            "os_cpu_count": os.cpu_count(),
             "sample": f"{streams} stream-{'+'.join(legs)}s of {n_blocks} blocks ({S} distinct seeded streams of the bench batch) in {el:.1f} s, "
                       f"one oracle instance per thread; scalar C port of the reference built gcc -O2 -ffp-contract=off as the reference's "
                       f"Makefile builds libulc - the reference's own SIMD lives in libfourier, which is absent from the tree, so no AVX2/FMA "
@@ -177,7 +183,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=0, help="consecutive blocks per stream per step (default: the config's: 32 for vbr50, 16 otherwise)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pmc-summary", default="", help="tools/pmc_summary.py output of a rocprofv3 --pmc run of THIS command: fills roofline.traffic "
-                    "(default: the committed profiles/r03_pmc_summary.json when it was taken on this very configuration; else null)")
+                    "(default: null - a traffic figure is never taken from another run)")
     ap.add_argument("--pcm16", action="store_true", help="separate configuration (SURVEY.md 8f rank 4): PCM16 ingest and PCM16 output "
                     "fused into the first/last kernel instead of the C API's f32; NOT the headline line")
     args = ap.parse_args()
@@ -332,17 +338,14 @@ def main():
     # the window-control pipeline) has kms = sum of its n launches, each timed by its own hipEvent pair on its stream.
     launches = float(enc.xf_launches()) if kname == "k_xf" else 1.0      # from the library: chunks of the last call
     # HBM bytes per launch of the roofline kernel: from the two PMC passes of THIS command (FETCH_SIZE / WRITE_SIZE cannot
-    # be collected inside a timed run) - handed in with --pmc-summary, or the summary committed under profiles/ when its
-    # recorded configuration is the one running (its git revision goes into the line)
+    # be collected inside a timed run) - handed in with --pmc-summary (tools/gpu_r04.sh does the three runs on one box); null otherwise
     traffic, traffic_src = None, None
-    pmc_path = args.pmc_summary or os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
-    if os.path.exists(pmc_path):
+    pmc_path = args.pmc_summary                              # only a summary of THIS command's own PMC passes, handed in explicitly
+    if pmc_path and os.path.exists(pmc_path):
         try:
             js = json.load(open(pmc_path))
             meta = js.get("_meta", {})
-            same = bool(args.pmc_summary) or (meta.get("config") == args.config and meta.get("blocks") == K and meta.get("streams") == B
-                                              and meta.get("mode") == args.mode and not args.pcm16)
-            ent = js.get(kname, {}) if same else {}
+            ent = js.get(kname, {})
             traffic = ent.get("hbm_bytes_per_launch")
             if traffic is not None:
                 traffic = traffic / launches
@@ -370,7 +373,7 @@ def main():
               f"step = {' then '.join(legs)}" + (f"; {cfg['total']} streams in total over {world} GPU(s)" if strong else "")
               + (" -- PCM16 ingest/output variant (int16 samples in HBM, not the C API's f32)" if args.pcm16 else ""))
         line = {
-            "metric": f"{what} Msamples/s at BlockSize={bs} stereo (channel-samples through {what}, {rc})",
+            "metric": f"{what} Msamples/s at BlockSize={bs} stereo (channel-samples through {what}, {rc}, {K} blocks per stream per call)",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" + (" (TEST RUN: ranks share one GPU, gloo control plane - not a result)" if share else ""),

@@ -171,6 +171,10 @@ int  ulcx_encoder_debug_fetch(ulcx_encoder *enc, int nBlocks, float *h_coef, flo
 /* Number of blocks of the last call (final pass) whose threshold tie group straddled the
  * cut and went through the exact heapsort emulation (BlockTransform.c:20-77).  Test hook. */
 int  ulcx_encoder_last_fallbacks(ulcx_encoder *enc);
+/* Test hook: from the next call on every `every`-th block of a call (block index % every == 0) is handed to the exact
+ * heapsort path whether or not its threshold tie group straddles the cut (0 = off, the default).  The results must not
+ * change: the full ranking decides the same kept set.  Exercises that path at a scale natural ties never reach. */
+int  ulcx_encoder_debug_force_exact(ulcx_encoder *enc, int every);
 
 int  ulcx_decoder_create(ulcx_decoder **dec, int device, int nStreams, int nChan, int BlockSize, int maxBlocksPerCall);
 void ulcx_decoder_destroy(ulcx_decoder *dec);

@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ulc-codec_amd"))
-from ulc_testlib import oracle_encode_debug
+from ulc_testlib import oracle_encode_debug, oracle_decode_stream
 
 pytestmark = pytest.mark.gpu
 
@@ -100,6 +100,12 @@ def test_config3_decode_65536_blocks_properties():
     # linearity of the decoder's transform stage is not observable through the API; determinism is:
     b = _run(B, K, bs, ch, rate, 0, 50.0, seed=3)
     assert torch.equal(a["dpcm"], b["dpcm"])
+    # ... and a seeded sample of the decoded streams against the oracle's decoder, sample for sample as bit patterns
+    out_h = a["out"].cpu().numpy(); dp_h = a["dpcm"].cpu().numpy(); db_h = a["dbits"].cpu().numpy()
+    for s in np.random.default_rng(2).choice(B, 6, replace=False):
+        rc, ref_pcm, ref_bits = oracle_decode_stream(out_h[s], ch, bs)
+        assert rc == 0 and np.array_equal(db_h[s], ref_bits), s
+        assert np.array_equal(dp_h[s].view(np.uint32), ref_pcm.view(np.uint32)), f"stream {s}: decoded PCM differs from the oracle's"
 
 
 def test_config4_cbr64_48k_never_over_budget():

@@ -103,6 +103,26 @@ def test_encode_tie_straddle_uses_exact_heapsort_order(mode, p0):
     enc.close()
 
 
+@pytest.mark.parametrize("mode,p0,every", [(0, 50.0, 2), (0, 50.0, 1), (1, 64.0, 2)])
+def test_exact_path_at_scale_in_stereo(mode, p0, every):
+    """ADVICE r3: the exact (heapsort-rank) path walks its list with a fixed grid of 128 workgroups = 256 blocks per trip;
+    natural ties put ~50 blocks of the bench batch there, so nothing ever made a second trip.  The test hook hands every
+    `every`-th block of a stereo BlockSize-2048 call to that path (640 blocks per call: 320 or 640 of them, several trips
+    per wave; the wave writer's direct packing is a one-trip protocol and must stand back) - same bytes as the oracle."""
+    amd = _amd()
+    bs, ch, rate, B, K = 2048, 2, 44100, 40, 16
+    pcm = _streams(B, K, bs, ch, rate, True, seed=515)
+    enc = amd.BatchEncoder(B, ch, bs, rate, K)
+    enc.force_exact(every)
+    res = enc.encode(pcm, mode, p0)
+    nfb = enc.last_fallbacks()
+    assert nfb > 256, f"only {nfb} blocks on the exact path: no wave made a second trip"        # (a stream's first block is silent: nothing to select)
+    for s in range(B):
+        ref = oracle_encode_debug(pcm[s], bs, rate, mode, p0, slot=enc.slot)
+        _compare_encode(res, ref, s, 0, K, None, f"forced exact path every={every}")
+    enc.close()
+
+
 def test_encode_many_blocks_bit_exact():
     """A few thousand blocks of the bench shape, every byte compared with the oracle."""
     amd = _amd()

@@ -30,10 +30,10 @@ struct ulcx_encoder {
     // single-block path (ulcx_encode_block1): own stream, pinned staging, the captured launch sequence
     struct Block1Meta { int32_t bits, wc; float cplx; int32_t pad; UlcxWcState wcs; };
     hipStream_t b1Stream; hipGraph_t b1Graph; hipGraphExec_t b1Exec; bool b1Init, b1Graphed, b1NoGraph;
-    int b1Mode; float b1P0, b1P1;
+    int b1Mode; float b1P0, b1P1; int b1Rekeys;
     float *pinIn; uint8_t *pinOut; Block1Meta *pinMeta;
     // batched calls that repeat (same buffers, same parameters - a caller that streams through fixed device buffers): the call's
-    // launch sequence captured once into a HIP graph and replayed (round 3; ULCX_ENC_GRAPH=0: off).  The key is every argument
+    // launch sequence captured once into a HIP graph and replayed (round 3; off unless ULCX_ENC_GRAPH=1).  The key is every argument
     // the captured kernels hold; a call with another key is enqueued directly, its first repetition captures.
     struct CallKey { int mode, nBlocks; float p0, p1; const void *pcm, *pcm16, *out, *bits, *wc, *cplx; };
     CallKey gKey, gLast; bool gOn, gValid, gHaveLast; int gFails;
@@ -107,13 +107,11 @@ static void cleanup(ulcx_encoder *e) {
     for (void *p : e->allocs) hipFree(p);
     if (e->tables) hipFree(e->tables);
     if (e->evOk) for (auto &v : e->ev) hipEventDestroy(v);
-    if (e->b1Init) {
-        if (e->b1Graphed) { hipGraphExecDestroy(e->b1Exec); hipGraphDestroy(e->b1Graph); }
-        hipStreamDestroy(e->b1Stream);
-        if (e->pinIn) hipHostFree(e->pinIn);
-        if (e->pinOut) hipHostFree(e->pinOut);
-        if (e->pinMeta) hipHostFree(e->pinMeta);
-    }
+    if (e->b1Graphed) { hipGraphExecDestroy(e->b1Exec); hipGraphDestroy(e->b1Graph); }
+    if (e->b1Stream) hipStreamDestroy(e->b1Stream);
+    if (e->pinIn) hipHostFree(e->pinIn);
+    if (e->pinOut) hipHostFree(e->pinOut);
+    if (e->pinMeta) hipHostFree(e->pinMeta);
     if (e->gValid) { hipGraphExecDestroy(e->gExec); hipGraphDestroy(e->gGraph); }
     if (e->gStream) hipStreamDestroy(e->gStream);
     if (e->sideOk) { hipStreamDestroy(e->side); hipEventDestroy(e->evFork); hipEventDestroy(e->evJoin); hipEventDestroy(e->evFork2); for (auto &v : e->evWC) hipEventDestroy(v); for (auto &v : e->evXf) hipEventDestroy(v); hipStreamDestroy(e->side2); hipStreamDestroy(e->side3); hipStreamDestroy(e->side4); for (auto &v : e->evE) hipEventDestroy(v); }
@@ -147,7 +145,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     e->device = device; e->B = nStreams; e->C = nChan; e->BS = BlockSize; e->rate = RateHz; e->maxK = maxBlocksPerCall;
     e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->timing = true; e->lastK = 0; e->sideOk = false; e->side = nullptr; e->keysFinal = false;
     e->d_pcm = nullptr; e->d_out = nullptr; e->d_bits = nullptr; e->d_wc = nullptr; e->d_cplx = nullptr;
-    e->b1Init = e->b1Graphed = e->b1NoGraph = false; e->pinIn = nullptr; e->pinOut = nullptr; e->pinMeta = nullptr;
+    e->b1Init = e->b1Graphed = e->b1NoGraph = false; e->b1Stream = nullptr; e->b1Rekeys = 0; e->pinIn = nullptr; e->pinOut = nullptr; e->pinMeta = nullptr;
     // (ULCX_ENC_GRAPH=1 switches it on: measured 11.26 ms per step either way - the replay enqueues the same barrier and
     //  dispatch packets, the 20-45 us between a kernel and its successor on another stream stay - so it only saves host time)
     e->gOn = false; e->gValid = false; e->gHaveLast = false; e->gFails = 0; e->gStream = nullptr;
@@ -396,11 +394,13 @@ extern "C" int ulcx_encode_block1(ulcx_encoder *e, int mode, float p0, float p1,
             if ((rc = dalloc(e->allocs, &e->d_wc, 1, false))) return rc;
             if ((rc = dalloc(e->allocs, &e->d_cplx, 1, false))) return rc;
         }
-        CKR(hipStreamCreateWithFlags(&e->b1Stream, hipStreamNonBlocking));
+        // (b1Init only once everything exists: a failed allocation leaves the call to be retried from scratch, never a
+        //  later call copying into a null staging buffer)
+        if (!e->b1Stream) CKR(hipStreamCreateWithFlags(&e->b1Stream, hipStreamNonBlocking));
+        if (!e->pinIn) CKR(hipHostMalloc((void **)&e->pinIn, sizeof(float) * cb, hipHostMallocDefault));
+        if (!e->pinOut) CKR(hipHostMalloc((void **)&e->pinOut, slot, hipHostMallocDefault));
+        if (!e->pinMeta) CKR(hipHostMalloc((void **)&e->pinMeta, sizeof(*e->pinMeta), hipHostMallocDefault));
         e->b1Init = true;
-        CKR(hipHostMalloc((void **)&e->pinIn, sizeof(float) * cb, hipHostMallocDefault));
-        CKR(hipHostMalloc((void **)&e->pinOut, slot, hipHostMallocDefault));
-        CKR(hipHostMalloc((void **)&e->pinMeta, sizeof(*e->pinMeta), hipHostMallocDefault));
         e->timing = false;                                 // (per-kernel events cannot be captured, and nobody reads them here)
     }
     auto enqueue = [&]() -> int {
@@ -417,6 +417,9 @@ extern "C" int ulcx_encode_block1(ulcx_encoder *e, int mode, float p0, float p1,
     memcpy(e->pinIn, h_pcm, sizeof(float) * cb);
     if (e->b1Graphed && (e->b1Mode != mode || e->b1P0 != p0 || e->b1P1 != p1)) {          // the parameters are part of the captured kernels' arguments
         hipGraphExecDestroy(e->b1Exec); hipGraphDestroy(e->b1Graph); e->b1Graphed = false;
+        // a caller whose parameters change from block to block (ULC_EncodeBlock_ABR: the reference's tool updates
+        // AvgComplexity every block) would pay a capture + instantiate per call: after the second change, direct launches
+        if (++e->b1Rekeys >= 2) e->b1NoGraph = true;
     }
     if (!e->b1Graphed && !e->b1NoGraph) {
         bool ok = hipStreamBeginCapture(e->b1Stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
@@ -468,6 +471,11 @@ extern "C" int ulcx_encoder_debug_fetch(ulcx_encoder *e, int nBlocks, float *h_c
     return ULCX_OK;
 }
 
+extern "C" int ulcx_encoder_debug_force_exact(ulcx_encoder *e, int every) {
+    if (!e || every < 0) return ULCX_ERR_ARG;
+    e->ctx.forceFb = every;
+    return ULCX_OK;
+}
 extern "C" int ulcx_encoder_last_fallbacks(ulcx_encoder *e) {
     if (!e) return ULCX_ERR_ARG;
     CKR(hipSetDevice(e->device));
@@ -513,13 +521,11 @@ static void cleanup(ulcx_decoder *e) {
     if (e->tables) hipFree(e->tables);
     if (e->evOk) for (auto &v : e->ev) hipEventDestroy(v);
     if (e->sideOk) { hipStreamDestroy(e->side); hipEventDestroy(e->evFork); for (auto &v : e->evScan) hipEventDestroy(v); }
-    if (e->b1Init) {
-        if (e->b1Graphed) { hipGraphExecDestroy(e->b1Exec); hipGraphDestroy(e->b1Graph); }
-        hipStreamDestroy(e->b1Stream);
-        if (e->pinIn) hipHostFree(e->pinIn);
-        if (e->pinPcm) hipHostFree(e->pinPcm);
-        if (e->pinMeta) hipHostFree(e->pinMeta);
-    }
+    if (e->b1Graphed) { hipGraphExecDestroy(e->b1Exec); hipGraphDestroy(e->b1Graph); }
+    if (e->b1Stream) hipStreamDestroy(e->b1Stream);
+    if (e->pinIn) hipHostFree(e->pinIn);
+    if (e->pinPcm) hipHostFree(e->pinPcm);
+    if (e->pinMeta) hipHostFree(e->pinMeta);
     delete e;
 }
 static int dec_reset_state(ulcx_decoder *e) {
@@ -613,7 +619,7 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     e->lap2 = nullptr; e->lastSub2 = nullptr; e->seed2 = nullptr; e->dead2 = nullptr; e->synSlots = 0; e->splitOK = false;
     e->scanLpw = 64; if (const char *pv = getenv("ULCX_DSCAN_LPW")) { int n = atoi(pv); if (n == 16 || n == 32 || n == 64) e->scanLpw = n; }
     e->ldsPad = 0; if (const char *pv = getenv("ULCX_DSYN_PAD")) { int n = atoi(pv); if (n > 0 && n < 120 * 1024) e->ldsPad = n & ~15; }
-    e->b1Init = e->b1Graphed = e->b1NoGraph = false; e->pinIn = nullptr; e->pinPcm = nullptr; e->pinMeta = nullptr; e->b1Slot = 0;
+    e->b1Init = e->b1Graphed = e->b1NoGraph = false; e->b1Stream = nullptr; e->pinIn = nullptr; e->pinPcm = nullptr; e->pinMeta = nullptr; e->b1Slot = 0;
     UlcxDecCtx &c = e->ctx;
     memset(&c, 0, sizeof(c));
     c.B = nStreams; c.C = nChan; c.BS = BlockSize; c.lgBS = ilog2i(BlockSize); c.maxK = maxBlocksPerCall;
@@ -754,11 +760,11 @@ extern "C" int ulcx_decode_block1(ulcx_decoder *e, const uint8_t *h_in, int nByt
         int rc;
         if (!e->d_in || e->d_in_bytes < (size_t)slot + 16) { if ((rc = dalloc(e->allocs, &e->d_in, (size_t)slot + 16, true))) return rc; e->d_in_bytes = (size_t)slot + 16; }
         if (!e->d_pcm) { if ((rc = dalloc(e->allocs, &e->d_pcm, cb, false))) return rc; if ((rc = dalloc(e->allocs, &e->d_bits, 1, false))) return rc; }
-        CKR(hipStreamCreateWithFlags(&e->b1Stream, hipStreamNonBlocking));
+        if (!e->b1Stream) CKR(hipStreamCreateWithFlags(&e->b1Stream, hipStreamNonBlocking));
+        if (!e->pinIn) CKR(hipHostMalloc((void **)&e->pinIn, (size_t)slot, hipHostMallocDefault));
+        if (!e->pinPcm) CKR(hipHostMalloc((void **)&e->pinPcm, sizeof(float) * cb, hipHostMallocDefault));
+        if (!e->pinMeta) CKR(hipHostMalloc((void **)&e->pinMeta, 2 * sizeof(int32_t), hipHostMallocDefault));
         e->b1Init = true; e->b1Slot = slot;
-        CKR(hipHostMalloc((void **)&e->pinIn, (size_t)slot, hipHostMallocDefault));
-        CKR(hipHostMalloc((void **)&e->pinPcm, sizeof(float) * cb, hipHostMallocDefault));
-        CKR(hipHostMalloc((void **)&e->pinMeta, 2 * sizeof(int32_t), hipHostMallocDefault));
         e->timing = false;
     }
     auto enqueue = [&]() -> int {

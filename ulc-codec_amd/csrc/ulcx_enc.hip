@@ -1661,7 +1661,7 @@ __global__ __launch_bounds__(WG) void k_select(UlcxEncCtx c, int finalPass) {
     }
     // prefix = ordered bits of threshold T; need = r (how many of the T-ties are kept); e = hist count
     int e = hist[prefix & 255];
-    bool straddle = (need < e);
+    bool straddle = (need < e) || (c.forceFb > 0 && blk % c.forceFb == 0);
     for (int i = tid; i < N; i += WG) {
         uint32_t u = key_ord(load_final_key(c, blk, i));
         bool kp = (u >= prefix);          // tie group fully in when not straddling
@@ -1814,7 +1814,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
         }
     }
     // the tie group at T straddles the cut iff more than kSel keys are >= T (kSel - #(u > T) < #(u == T))
-    const bool straddle = kSel < cntT;
+    const bool straddle = kSel < cntT || (c.forceFb > 0 && blk % c.forceFb == 0);
     // keep bitmap: the ballot of register r is the pair of words 2r, 2r+1 - gathered into lane r (R <= 64) or lanes r, r - 64
     // and stored once per lane instead of twice per register
     if constexpr (R <= 64) {
@@ -2946,7 +2946,9 @@ __global__ __launch_bounds__(256) void k_encode_wave(UlcxEncCtx c, int finalPass
     int nBlk = (phase == 1) ? c.slow[NBq + which] : (c.fbMode == 2) ? fb_count(c) : NBq;
     // direct packing: waves 2p, 2p+1 of the workgroup are the two channels of one block
     unsigned long long *xchAll = (unsigned long long *)((char *)e2all + 4 * (size_t)ldsPerWave);
-    const bool directOK = finalPass && c.C == 2 && phase != 1 && c.directPack;
+    // (only when every wave of the launch makes ONE trip: the pair's LDS word carries one hand-over, a channel-0 wave a trip
+    //  ahead of its partner would overwrite it - exact-path launches of more blocks than the grid covers go through k_pack)
+    const bool directOK = finalPass && c.C == 2 && phase != 1 && c.directPack && (long long)gridDim.x * 4 >= (long long)nBlk * c.C;
     if (directOK) { if (threadIdx.x < 2) xchAll[threadIdx.x] = 0; __syncthreads(); }
     int seq = 0;
     for (int u = blockIdx.x * 4 + wv; u < nBlk * c.C; u += gridDim.x * 4) {      // (block, channel) index; one trip for the full-batch launch

@@ -96,6 +96,7 @@ struct UlcxEncCtx {
     int    *ownSlot;                     // [NB] its slot in fbList
     int    *rankBuf;                     // [rankSlots][C*BS] full heapsort ranking of exact-path blocks
     int     dbgSkip;
+    int     forceFb;                     // test hook (ulcx_encoder_debug_force_exact): every forceFb-th block takes the exact path whatever its ties
     int     rankSlots, fbLo, fbHi;       // resident rank slots; slot window of the current exact-path launch
     int     fbMode;                      // 0 = all blocks, 1 = skip isFb blocks, 2 = only isFb blocks
     int     useWave;                     // wave-per-unit encode pass (k_encode_wave); serial kernel only for overflow blocks

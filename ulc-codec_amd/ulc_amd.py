@@ -20,7 +20,7 @@ EXPORTS = [
     "ulcx_last_error", "ulcx_device_count", "ulcx_encoder_create", "ulcx_encoder_destroy", "ulcx_encoder_reset",
     "ulcx_encoder_slot_bytes", "ulcx_encode_dev", "ulcx_encode_dev_pcm16", "ulcx_encode_host", "ulcx_encoder_debug_fetch",
     "ulcx_decoder_create", "ulcx_decoder_destroy", "ulcx_decoder_reset", "ulcx_decode_dev", "ulcx_decode_dev_pcm16", "ulcx_decode_host",
-    "ulcx_encoder_last_fallbacks", "ulcx_ulc_header_pack", "ulcx_ulc_header_parse", "ulcx_ulc_rate_kbps",
+    "ulcx_encoder_last_fallbacks", "ulcx_encoder_debug_force_exact", "ulcx_ulc_header_pack", "ulcx_ulc_header_parse", "ulcx_ulc_rate_kbps",
     "ulcx_pack_streams_dev", "ulcx_decode_packed_dev", "ulcx_decode_packed_host", "ulcx_decoder_upload_payload", "ulcx_decode_resident_host", "ulcx_encoder_stage_ms", "ulcx_encoder_stage_name", "ulcx_encoder_last_xf_launches", "ulcx_decoder_stage_ms", "ulcx_decoder_stage_name", "ulcx_block_extent_bytes", "ulcx_encoder_set_timing", "ulcx_decoder_set_timing", "ulcx_encode_block1", "ulcx_decode_block1", "ulcx_dec_split_plan",
 ]
 
@@ -58,6 +58,7 @@ def lib():
         l.ulcx_decode_dev_pcm16.argtypes = l.ulcx_decode_dev.argtypes
         l.ulcx_decode_host.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, _f32p, _i32p]
         l.ulcx_encoder_last_fallbacks.argtypes = [C.c_void_p]
+        l.ulcx_encoder_debug_force_exact.argtypes = [C.c_void_p, C.c_int]
         l.ulcx_decode_packed_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         l.ulcx_decode_packed_host.argtypes = [C.c_void_p, _u8p, C.c_longlong, _i32p, C.c_int, _f32p, _i32p]
         l.ulcx_encoder_set_timing.argtypes = [C.c_void_p, C.c_int]
@@ -157,6 +158,9 @@ class BatchEncoder:
 
     def last_fallbacks(self):
         return lib().ulcx_encoder_last_fallbacks(self.h)
+
+    def force_exact(self, every):
+        _check(lib().ulcx_encoder_debug_force_exact(self.h, int(every)), "ulcx_encoder_debug_force_exact")
 
     def xf_launches(self):
         return int(lib().ulcx_encoder_last_xf_launches(self.h))
