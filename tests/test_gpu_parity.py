@@ -438,17 +438,13 @@ def test_pcm16_ingest_and_output_match_the_wav_io_conversions(bs, ch, rate, call
     {"ULCX_ASYNC_FB": "0"},                        # no side streams at all (the mode the per-kernel profiles use)
     {"ULCX_WC_PIPE": "1"},                         # window control not pipelined with the transform
     {"ULCX_WC_PIPE": "3"}, {"ULCX_WC_PIPE": "8"},
-    {"ULCX_WC_STEPS": "4"}, {"ULCX_WC_ESTREAM": "1"},
+    {"ULCX_WC_STEPS": "4"},
     {"ULCX_WC_FUSE": "0"},                         # envelope and forward recurrence as two kernels (what non-stereo streams always use)
     {"ULCX_WC_FUSE": "0", "ULCX_WC_PIPE": "1"},
     {"ULCX_WAVE": "0"},                            # serial lane-per-unit writer as the main path
     {"ULCX_GAPSUMS": "0"},                         # no speculative noise sums
-    {"ULCX_CPLX_EARLY": "0"},                      # complexity sums in one launch behind the transform (default: per transform chunk)
-    {"ULCX_FUSED_NOISE": "1"},                     # k_gapsums forms the noise pairs and takes the tail sums (no k_nline / k_tailsums): measured slower, off
-    {"ULCX_ENC_GRAPH": "1"},                       # a repeated batched call replays a captured HIP graph
     {"ULCX_DIRECT_PACK": "0"},                     # every block packed by k_pack (default: the wave writer packs stereo un-decimated blocks itself)
-    {"ULCX_BARK_UNIFORM": "0"},                    # noise Bark sums of every block on the lane-per-subblock kernel
-    {"ULCX_BARK_UNIFORM_P": "0"},                  # the masking Bark sums of every block on the lane-per-subblock kernel
+    {"ULCX_BARK_UNIFORM": "0"},                    # Bark sums of every block on the lane-per-subblock kernels
     {"ULCX_ASYNC_FB": "0", "ULCX_WC_PIPE": "1", "ULCX_WAVE": "0", "ULCX_GAPSUMS": "0"},
 ])
 def test_runtime_switches_keep_parity(env):
@@ -457,8 +453,7 @@ def test_runtime_switches_keep_parity(env):
     window-control pipeline), encode vs the oracle and decode of the result vs the oracle decoder."""
     amd = _amd()
     bs, ch, rate, B, K = 1024, 2, 44100, 5, 16
-    graph = "ULCX_ENC_GRAPH" in env                          # (the replay starts with a call's second repetition and needs the per-kernel events off)
-    calls = 4 if graph else 2
+    calls = 2
     pcm = _streams(B, calls * K, bs, ch, rate, True, seed=808)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
@@ -466,7 +461,6 @@ def test_runtime_switches_keep_parity(env):
         for mode, p0 in ((amd.MODE_VBR, 45.0), (amd.MODE_CBR, 96.0)):
             enc = amd.BatchEncoder(B, ch, bs, rate, K)
             dec = amd.BatchDecoder(B, ch, bs, K)
-            if graph: enc.set_timing(False)
             refs = [oracle_encode_debug(pcm[s], bs, rate, 0 if mode == amd.MODE_VBR else 1, p0, slot=enc.slot) for s in range(B)]
             outs = []
             for call in range(calls):
@@ -489,20 +483,16 @@ def test_runtime_switches_keep_parity(env):
                 os.environ[k] = v
 
 @pytest.mark.parametrize("env,B,K", [
-    ({"ULCX_XF_RUN": "3"}, 6, 16),                 # steady-state blocks on k_xf_fast, runs of 3 with the half-frame carry
-    ({"ULCX_XF_RUN": "16", "ULCX_WC_PIPE": "1"}, 6, 16),
-    ({"ULCX_WC_LADDER": "1,2,5,8"}, 6, 16),        # explicit window-control / transform ladder
-    ({"ULCX_WC_LADDER": "1,1,2,2,2,2,2,2,2", "ULCX_XF_LADDER": "1,3,4,4,4"}, 6, 16),
-    ({"ULCX_NOISE_EARLY": "0"}, 6, 16),            # noise chain behind the masking sums (the round-2 order)
-    ({"ULCX_DEC_PIPE": "2"}, 130, 4),              # syntax walk of the next chunk of streams beside the synthesis
-    ({"ULCX_DSYN_LAPG": "0"}, 6, 16),              # synthesis with lapping state + twiddles in LDS (rounds 1-2; default: twiddles only)
-    ({"ULCX_DSYN_LAPG": "1"}, 6, 16),              # ... both in global memory
-    ({"ULCX_DSYN_PAD": "8192"}, 6, 16),
-    ({"ULCX_DEC_HALVES": "1"}, 260, 16),           # the walk of the second half of the blocks beside the synthesis of the first (>= 4096 blocks per call)
+    ({}, 6, 16),                                   # the default: every block transformed at once as if in the steady state, the rest repaired
+    ({"ULCX_XF_SPEC": "0"}, 6, 16),                # the transform in chunks behind the window decisions (what every other geometry does)
+    ({"ULCX_WC_STEPS": "8"}, 6, 16),
+    ({"ULCX_WC_PIPE": "1"}, 6, 16),
+    ({}, 300, 8),                                  # more (stream, block) pairs than the speculative transform has workgroups
+    ({"ULCX_DSYN_SPLIT": "0"}, 6, 16),
 ])
-def test_round3_switches_keep_parity(env, B, K):
-    """The switches round 3 added, on the headline geometry - stereo, BlockSize 2048, where the transform's
-    steady-state path and its run kernel exist: encode vs the oracle over two calls (state carry), decode vs the oracle."""
+def test_headline_geometry_schedules_keep_parity(env, B, K):
+    """The launch structures of the headline geometry - stereo, BlockSize 2048, where the speculative transform and its
+    repair launch exist: encode vs the oracle over two calls (state carry, window switching), decode vs the oracle."""
     amd = _amd()
     bs, ch, rate = 2048, 2, 44100
     pcm = _streams(B, 2 * K, bs, ch, rate, True, seed=4242)
@@ -511,7 +501,7 @@ def test_round3_switches_keep_parity(env, B, K):
     try:
         enc = amd.BatchEncoder(B, ch, bs, rate, K)
         dec = amd.BatchDecoder(B, ch, bs, K)
-        check = range(B) if B <= 8 else (0, 63, 64, 65, B - 1)
+        check = range(B) if B <= 8 else (0, 1, 63, 64, 65, 150, B - 2, B - 1)
         refs = {s: oracle_encode_debug(pcm[s], bs, rate, 0, 50.0, slot=enc.slot) for s in check}
         outs = []
         for call in range(2):

@@ -21,10 +21,9 @@ struct ulcx_encoder {
     bool evOk, evRecorded;
     int lastK;
     hipStream_t side; hipEvent_t evFork, evJoin, evFork2; bool sideOk; bool timing;
-    hipEvent_t evWC[7 + 3 * ULCX_WC_MAXCH + ULCX_XF_MAXCH + 1]; int wcPipe; hipStream_t side2, side3, side4; hipEvent_t evE[ULCX_WC_MAXCH]; hipEvent_t evXf[2 * ULCX_XF_MAXCH]; int nXf;      // window-control / transform chunk pipeline (ULCX_WC_PIPE chunks, default 4)
+    hipEvent_t evWC[7 + 3 * ULCX_WC_MAXCH + ULCX_XF_MAXCH + 1]; int wcPipe; hipStream_t side2, side3; hipEvent_t evXf[2 * ULCX_XF_MAXCH]; int nXf;      // window-control / transform pipeline (ULCX_WC_PIPE chunks, default 4)
     bool keysFinal;
-    int wcSteps, cplxEarly, wcFuse, barkUniP, noiseEarly, xfRun, fusedNoise; bool wcEStream;      // environment switches, read once at create
-    int nWcLad, nXfLad, wcLad[ULCX_WC_MAXCH], xfLad[ULCX_XF_MAXCH];   // ULCX_WC_LADDER / ULCX_XF_LADDER: step sizes in blocks
+    int wcSteps, wcFuse, xfSpec, xfSlots;      // environment switches, read once at create; resident workgroups of the transform kernels
     // staging for the host-pointer API
     float *d_pcm; uint8_t *d_out; int32_t *d_bits, *d_wc; float *d_cplx;
     // single-block path (ulcx_encode_block1): own stream, pinned staging, the captured launch sequence
@@ -32,17 +31,7 @@ struct ulcx_encoder {
     hipStream_t b1Stream; hipGraph_t b1Graph; hipGraphExec_t b1Exec; bool b1Init, b1Graphed, b1NoGraph;
     int b1Mode; float b1P0, b1P1; int b1Rekeys;
     float *pinIn; uint8_t *pinOut; Block1Meta *pinMeta;
-    // batched calls that repeat (same buffers, same parameters - a caller that streams through fixed device buffers): the call's
-    // launch sequence captured once into a HIP graph and replayed (round 3; off unless ULCX_ENC_GRAPH=1).  The key is every argument
-    // the captured kernels hold; a call with another key is enqueued directly, its first repetition captures.
-    struct CallKey { int mode, nBlocks; float p0, p1; const void *pcm, *pcm16, *out, *bits, *wc, *cplx; };
-    CallKey gKey, gLast; bool gOn, gValid, gHaveLast; int gFails;
-    hipStream_t gStream; hipGraph_t gGraph; hipGraphExec_t gExec;
 };
-static bool same_key(const ulcx_encoder::CallKey &a, const ulcx_encoder::CallKey &b) {
-    return a.mode == b.mode && a.nBlocks == b.nBlocks && a.p0 == b.p0 && a.p1 == b.p1 && a.pcm == b.pcm && a.pcm16 == b.pcm16 &&
-           a.out == b.out && a.bits == b.bits && a.wc == b.wc && a.cplx == b.cplx;
-}
 struct ulcx_decoder {
     int device, B, C, BS, maxK;
     UlcxDecCtx ctx;
@@ -52,8 +41,7 @@ struct ulcx_decoder {
     bool evOk, evRecorded, timing;
     uint8_t *d_in; size_t d_in_bytes; float *d_pcm; int32_t *d_bits;
     uint8_t *d_pay; int32_t *d_payBytes; long long payStride;     // resident packed payloads (ulcx_decoder_upload_payload)
-    hipStream_t side; hipEvent_t evFork, evScan[ULCX_DEC_MAXCH]; bool sideOk; int nChunks; int ldsPad, scanLpw, kHalves;   // walk / synthesis pipeline (ULCX_DEC_PIPE chunks)
-    // k_dsyn over an even cut of the call's (stream, block) pairs (DESIGN.md §4): the second set of state arrays, the resident
+    // k_dsyn over an even cut of the call's (stream, block) pairs (DESIGN.md): the second set of state arrays, the resident
     // workgroups of the kernel on this device, ULCX_DSYN_SPLIT=0 switches it off
     float *lap2; int *lastSub2; uint32_t *seed2; int *dead2; int synSlots; bool splitOK;
     // single-block path (ulcx_decode_block1)
@@ -112,9 +100,7 @@ static void cleanup(ulcx_encoder *e) {
     if (e->pinIn) hipHostFree(e->pinIn);
     if (e->pinOut) hipHostFree(e->pinOut);
     if (e->pinMeta) hipHostFree(e->pinMeta);
-    if (e->gValid) { hipGraphExecDestroy(e->gExec); hipGraphDestroy(e->gGraph); }
-    if (e->gStream) hipStreamDestroy(e->gStream);
-    if (e->sideOk) { hipStreamDestroy(e->side); hipEventDestroy(e->evFork); hipEventDestroy(e->evJoin); hipEventDestroy(e->evFork2); for (auto &v : e->evWC) hipEventDestroy(v); for (auto &v : e->evXf) hipEventDestroy(v); hipStreamDestroy(e->side2); hipStreamDestroy(e->side3); hipStreamDestroy(e->side4); for (auto &v : e->evE) hipEventDestroy(v); }
+    if (e->sideOk) { hipStreamDestroy(e->side); hipEventDestroy(e->evFork); hipEventDestroy(e->evJoin); hipEventDestroy(e->evFork2); for (auto &v : e->evWC) hipEventDestroy(v); for (auto &v : e->evXf) hipEventDestroy(v); hipStreamDestroy(e->side2); hipStreamDestroy(e->side3); }
     delete e;
 }
 
@@ -146,10 +132,6 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->timing = true; e->lastK = 0; e->sideOk = false; e->side = nullptr; e->keysFinal = false;
     e->d_pcm = nullptr; e->d_out = nullptr; e->d_bits = nullptr; e->d_wc = nullptr; e->d_cplx = nullptr;
     e->b1Init = e->b1Graphed = e->b1NoGraph = false; e->b1Stream = nullptr; e->b1Rekeys = 0; e->pinIn = nullptr; e->pinOut = nullptr; e->pinMeta = nullptr;
-    // (ULCX_ENC_GRAPH=1 switches it on: measured 11.26 ms per step either way - the replay enqueues the same barrier and
-    //  dispatch packets, the 20-45 us between a kernel and its successor on another stream stay - so it only saves host time)
-    e->gOn = false; e->gValid = false; e->gHaveLast = false; e->gFails = 0; e->gStream = nullptr;
-    if (const char *gv = getenv("ULCX_ENC_GRAPH")) e->gOn = gv[0] == '1';
     UlcxEncCtx &c = e->ctx;
     memset(&c, 0, sizeof(c));
     c.B = nStreams; c.C = nChan; c.BS = BlockSize; c.lgBS = ilog2i(BlockSize); c.maxK = maxBlocksPerCall; c.K = 0;
@@ -202,6 +184,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.barkN, NB * nChan * 4 * ULCX_NBARK, true);
     DA(c.barkP, NB * 4 * ULCX_NBARK, true);
     if (c.barkRing) { DA(c.barkRawN, NB * nChan * ULCX_NBARK * 3, false); DA(c.barkRawP, NB * ULCX_NBARK * 3, false); DA(c.decList, NB, false); DA(c.decCount, 1, true); }
+    DA(c.xfList, NB, false); DA(c.xfCount, 1, true);
     DA(c.nnz, NB, true);
     DA(c.cplx, NB, true);
     DA(c.nout, NB, true);
@@ -239,8 +222,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
                 hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&e->evFork2, hipEventDisableTiming) == hipSuccess) {
-                bool ok = hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&e->side3, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&e->side4, hipStreamNonBlocking) == hipSuccess;
-                for (auto &v : e->evE) ok = ok && hipEventCreateWithFlags(&v, hipEventDisableTiming) == hipSuccess;
+                bool ok = hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&e->side3, hipStreamNonBlocking) == hipSuccess;
                 for (auto &v : e->evWC) ok = ok && hipEventCreateWithFlags(&v, hipEventDisableTiming) == hipSuccess;
                 for (auto &v : e->evXf) ok = ok && hipEventCreate(&v) == hipSuccess;
                 e->sideOk = ok;
@@ -248,17 +230,13 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
         }
         e->wcPipe = e->sideOk ? 4 : 1;                         // transform chunks per call: 1 block, then thirds (4 vs 5 chunks: 9.50 vs 9.56 ms per bench step)
         if (const char *pv = getenv("ULCX_WC_PIPE")) { int n = atoi(pv); if (n >= 1 && n <= ULCX_XF_MAXCH && n != 2 && (n == 1 || e->sideOk)) e->wcPipe = n; }
-        { const char *v = getenv("ULCX_FUSED_NOISE"); e->fusedNoise = (v && v[0] == '1') ? 1 : 0; }
         e->wcSteps = -1; if (const char *sv = getenv("ULCX_WC_STEPS")) e->wcSteps = atoi(sv);      // -1: default; 0: the transform's chunks
-        e->wcEStream = getenv("ULCX_WC_ESTREAM") != nullptr;
-        { const char *v = getenv("ULCX_CPLX_EARLY"); e->cplxEarly = (v && v[0] == '0') ? 0 : 1; }      // (round 3: on - the last transform chunk runs alone and leaves room beside it)
         { const char *v = getenv("ULCX_WC_FUSE"); e->wcFuse = (v && v[0] == '0') ? 0 : 1; }
-        { const char *v = getenv("ULCX_BARK_UNIFORM_P"); e->barkUniP = (v && v[0] == '0') ? 0 : 1; }     // masking sums of un-decimated blocks on the uniform kernel too (round 3; =0: k_pbark for every block)
-        auto parse_ladder = [](const char *v, int *dst, int cap) { int n = 0; while (v && *v && n < cap) { int x = atoi(v); if (x < 1) return 0; dst[n++] = x; while (*v && *v != ',') v++; if (*v == ',') v++; } return n; };
-        { const char *v = getenv("ULCX_NOISE_EARLY"); e->noiseEarly = (v && v[0] == '0') ? 0 : 1; }     // default on (round 3: 10.35 vs 10.41 ms per encode of 131072 blocks)
-        e->xfRun = 0; if (const char *v = getenv("ULCX_XF_RUN")) { int n = atoi(v); if (n >= 0 && n <= 64) e->xfRun = n; }
-        e->nWcLad = parse_ladder(getenv("ULCX_WC_LADDER"), e->wcLad, ULCX_WC_MAXCH);
-        e->nXfLad = parse_ladder(getenv("ULCX_XF_LADDER"), e->xfLad, ULCX_XF_MAXCH);
+        // stereo BlockSize 2048: every block transformed at once as if in the steady state, beside window control, the rest
+        // repaired behind it (k_xf_spec / k_xf_fix); ULCX_XF_SPEC=0: the transform in chunks behind the window decisions
+        { const char *v = getenv("ULCX_XF_SPEC"); e->xfSpec = (v && v[0] == '0') ? 0 : 1; }
+        e->xfSlots = 0;
+        { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) e->xfSlots = 4 * cus; else (void)hipGetLastError(); }
     }
     DA(c.isFb, NB, true);
     DA(c.ownSlot, NB, true);
@@ -290,51 +268,12 @@ static int encode_dev_any(ulcx_encoder *e, int mode, float p0, float p1, const f
     c.vbrTarget = (mode == ULCX_MODE_VBR) ? 0x1.E4EFB7p3f * logf(100.0f / p0) : 0.0f;     // ulcEncoder.c:144 (host libm, data independent)
     c.pcm = d_pcm; c.pcm16 = d_pcm16; c.out = d_out; c.bits = d_bits; c.wcOut = d_wc; c.cplxOut = d_cplx;
     UlcxEncAux aux;
-    aux.side = e->sideOk ? e->side : nullptr; aux.side2 = e->sideOk ? e->side2 : nullptr; aux.side3 = e->sideOk ? e->side3 : nullptr; aux.side4 = (e->sideOk && e->wcEStream) ? e->side4 : nullptr; aux.evE = e->evE;
+    aux.side = e->sideOk ? e->side : nullptr; aux.side2 = e->sideOk ? e->side2 : nullptr; aux.side3 = e->sideOk ? e->side3 : nullptr;
     aux.evFork = e->evFork; aux.evJoin = e->evJoin; aux.evFork2 = e->evFork2; aux.evWC = e->evWC; aux.evXf = e->evXf;
     aux.wcPipe = (nBlocks >= 2 * e->wcPipe) ? e->wcPipe : (nBlocks >= 6 && e->wcPipe > 1 ? 3 : 1); aux.nXf = &e->nXf;
-    aux.wcSteps = e->wcSteps; aux.fusedNoise = e->fusedNoise; aux.cplxEarly = e->cplxEarly; aux.wcFuse = e->wcFuse; aux.barkUniP = e->barkUniP; aux.noiseEarly = e->noiseEarly; aux.xfRun = e->xfRun;
-    aux.nWcCut = aux.nXfCut = 0;
-    if (aux.wcPipe > 1) {
-        // schedules as cumulative block counts; a ladder applies when it sums to this call's block count and every transform
-        // chunk ends where a window-control step ends
-        auto cum = [&](const int *lad, int n, int *dst) { int t = 0; dst[0] = 0; for (int i = 0; i < n; i++) { t += lad[i]; dst[i + 1] = t; } return (n > 0 && t == nBlocks) ? n : 0; };
-        aux.nWcCut = cum(e->wcLad, e->nWcLad, aux.wcCut);
-        aux.nXfCut = e->nXfLad ? cum(e->xfLad, e->nXfLad, aux.xfCut) : (aux.nWcCut <= ULCX_XF_MAXCH ? cum(e->wcLad, e->nWcLad, aux.xfCut) : 0);
-        for (int j = 1; j <= aux.nXfCut && aux.nWcCut; j++) { bool hit = false; for (int w = 1; w <= aux.nWcCut; w++) hit = hit || aux.wcCut[w] == aux.xfCut[j]; if (!hit) aux.nWcCut = 0; }
-        if (!aux.nWcCut || !aux.nXfCut) aux.nWcCut = aux.nXfCut = 0;
-    }
-    int rc = ULCX_OK;
-    bool done = false;
-    // graph replay: no per-kernel events (they cannot be read back from a replay), side streams present (the fork / join
-    // structure is what the graph removes the packets of), not the single-block path (it captures its own sequence)
-    if (e->gOn && !e->timing && e->sideOk && e->gFails < 3 && !(e->B == 1 && e->maxK == 1)) {
-        const ulcx_encoder::CallKey key = { mode, nBlocks, p0, p1, d_pcm, d_pcm16, d_out, d_bits, d_wc, d_cplx };
-        if (e->gValid && !same_key(key, e->gKey)) { hipGraphExecDestroy(e->gExec); hipGraphDestroy(e->gGraph); e->gValid = false; }
-        if (!e->gValid && e->gHaveLast && same_key(key, e->gLast)) {
-            // second call in a row with these arguments: capture (on a stream of the encoder's own: the caller's may be the
-            // null stream, which cannot be captured; the graph is launched into the caller's stream)
-            bool ok = e->gStream || hipStreamCreateWithFlags(&e->gStream, hipStreamNonBlocking) == hipSuccess;
-            if (ok) ok = hipStreamBeginCapture(e->gStream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            if (ok) {
-                const int rcc = ulcx_enc_launch(c, e->gStream, nullptr, aux);
-                hipGraph_t g = nullptr;
-                const hipError_t ee = hipStreamEndCapture(e->gStream, &g);
-                ok = (rcc == ULCX_OK) && ee == hipSuccess && g != nullptr;
-                if (ok) ok = hipGraphInstantiate(&e->gExec, g, nullptr, nullptr, 0) == hipSuccess;
-                if (ok) { e->gGraph = g; e->gKey = key; e->gValid = true; }
-                else if (g) hipGraphDestroy(g);
-            }
-            if (!ok) { (void)hipGetLastError(); e->gFails++; }
-        }
-        e->gLast = key; e->gHaveLast = true;
-        if (e->gValid) {
-            if (hipGraphLaunch(e->gExec, (hipStream_t)hipStream) == hipSuccess) done = true;
-            else { (void)hipGetLastError(); hipGraphExecDestroy(e->gExec); hipGraphDestroy(e->gGraph); e->gValid = false; e->gFails = 3; }
-        }
-    }
-    if (!done) rc = ulcx_enc_launch(c, (hipStream_t)hipStream, e->timing ? e->ev : nullptr, aux);
-    e->evRecorded = (rc == ULCX_OK) && e->timing && !done;
+    aux.wcSteps = e->wcSteps; aux.wcFuse = e->wcFuse; aux.xfSpec = e->xfSpec; aux.xfSlots = e->xfSlots;
+    const int rc = ulcx_enc_launch(c, (hipStream_t)hipStream, e->timing ? e->ev : nullptr, aux);
+    e->evRecorded = (rc == ULCX_OK) && e->timing;
     e->lastK = nBlocks;
     e->keysFinal = false;
     return rc;
@@ -493,22 +432,25 @@ extern "C" int ulcx_encoder_stage_ms(ulcx_encoder *e, float *ms, int maxStages) 
         if (hipEventElapsedTime(&t, e->ev[i], e->ev[i + 1]) != hipSuccess) break;
         ms[n++] = t;
     }
-    // Pipelined window control: the k_xf interval spans start-up + waits + the transform chunk launches.
-    // Report the launches themselves as k_xf (what a kernel trace shows) and the rest as "wc_pipeline_exposed".
-    if (n == ULCX_ENC_STAGES && n < maxStages) {
+    // Pipelined window control: the k_xf interval spans start-up + waits + the transform's launches.  Report the launches
+    // themselves as k_xf (what a kernel trace shows: the chunks, or the one speculative launch over every block), the repair
+    // launch of the speculative transform as "k_xf_fix", and the rest of the interval as "wc_pipeline_exposed".
+    if (n == ULCX_ENC_STAGES && n + 1 < maxStages) {
         const int IX_XF = 5;
-        float exposed = 0.0f;
-        if (e->nXf > 0) {
+        float exposed = 0.0f, fix = 0.0f;
+        const int pairs = e->nXf == -2 ? 2 : e->nXf;
+        if (pairs > 0) {
             float sum = 0.0f; bool ok = true;
-            for (int j = 0; j < e->nXf; j++) { float t = 0; if (hipEventElapsedTime(&t, e->evXf[2 * j], e->evXf[2 * j + 1]) != hipSuccess) { ok = false; break; } sum += t; }
-            if (ok) { exposed = ms[IX_XF] - sum; ms[IX_XF] = sum; }
+            for (int j = 0; j < pairs; j++) { float t = 0; if (hipEventElapsedTime(&t, e->evXf[2 * j], e->evXf[2 * j + 1]) != hipSuccess) { ok = false; break; } sum += t; if (e->nXf == -2 && j == 1) fix = t; }
+            if (ok) { exposed = ms[IX_XF] - sum; ms[IX_XF] = sum - fix; }
         }
         ms[n++] = exposed;
+        ms[n++] = fix;
     }
     return n;
 }
 
-extern "C" int ulcx_encoder_last_xf_launches(ulcx_encoder *e) { return (e && e->evRecorded) ? (e->nXf > 0 ? e->nXf : 1) : 0; }
+extern "C" int ulcx_encoder_last_xf_launches(ulcx_encoder *e) { return (e && e->evRecorded) ? (e->nXf > 0 ? e->nXf : 1) : 0; }     // (the speculative transform: one launch over every block)
 
 // ---------------------------------------------------------------------------
 // decoder
@@ -520,7 +462,6 @@ static void cleanup(ulcx_decoder *e) {
     if (e->d_payBytes) hipFree(e->d_payBytes);
     if (e->tables) hipFree(e->tables);
     if (e->evOk) for (auto &v : e->ev) hipEventDestroy(v);
-    if (e->sideOk) { hipStreamDestroy(e->side); hipEventDestroy(e->evFork); for (auto &v : e->evScan) hipEventDestroy(v); }
     if (e->b1Graphed) { hipGraphExecDestroy(e->b1Exec); hipGraphDestroy(e->b1Graph); }
     if (e->b1Stream) hipStreamDestroy(e->b1Stream);
     if (e->pinIn) hipHostFree(e->pinIn);
@@ -566,12 +507,6 @@ static void build_rng_tables(std::vector<uint32_t> &jumpT) {
     }
 }
 
-static UlcxDecAux dec_aux(ulcx_decoder *e) {
-    UlcxDecAux a; a.side = e->sideOk ? e->side : nullptr; a.evFork = e->evFork; a.evScan = e->evScan; a.nChunks = e->nChunks;
-    a.ldsPad = e->ldsPad; a.scanLpw = e->scanLpw; a.synGrid = 0; a.kHalves = e->kHalves;
-    return a;
-}
-
 // One decode launch.  When the batch does not fill the machine in whole rounds of one workgroup per stream - 4096 streams on
 // 1536 resident workgroups, or a few long streams - the synthesis takes an even cut of the (stream, block) pairs instead: a
 // workgroup then runs one extra block (the one in front of its range, for the lapping state), so the cut must pay for that.
@@ -588,10 +523,10 @@ extern "C" int ulcx_dec_split_plan(int nStreams, int nBlocks, int residentWG) {
     return (grid >= 1 && grid != nStreams && (per + 1) * 3 < costStream * 2) ? (int)grid : 0;
 }
 static int dec_launch(ulcx_decoder *e, UlcxDecCtx &c, hipStream_t st) {
-    UlcxDecAux a = dec_aux(e);
+    UlcxDecAux a;
     a.synGrid = 0;
     c.lapO = c.lap; c.lastSubO = c.lastSub; c.seedO = c.seed; c.deadO = c.dead;
-    if (e->splitOK && a.nChunks <= 1 && e->synSlots > 0) {
+    if (e->splitOK && e->synSlots > 0) {
         a.synGrid = ulcx_dec_split_plan(e->B, c.K, e->synSlots);
         if (a.synGrid) {
             if (getenv("ULCX_DEBUG_PRINT")) fprintf(stderr, "[ulcx] synthesis: %lld (stream, block) pairs over %d workgroups (%d resident)\n", (long long)e->B * c.K, a.synGrid, e->synSlots);
@@ -615,10 +550,7 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     e->device = device; e->B = nStreams; e->C = nChan; e->BS = BlockSize; e->maxK = maxBlocksPerCall;
     e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->timing = true;
     e->d_in = nullptr; e->d_in_bytes = 0; e->d_pcm = nullptr; e->d_bits = nullptr; e->d_pay = nullptr; e->d_payBytes = nullptr; e->payStride = 0;
-    e->sideOk = false; e->side = nullptr; e->nChunks = 1; e->kHalves = 0;
     e->lap2 = nullptr; e->lastSub2 = nullptr; e->seed2 = nullptr; e->dead2 = nullptr; e->synSlots = 0; e->splitOK = false;
-    e->scanLpw = 64; if (const char *pv = getenv("ULCX_DSCAN_LPW")) { int n = atoi(pv); if (n == 16 || n == 32 || n == 64) e->scanLpw = n; }
-    e->ldsPad = 0; if (const char *pv = getenv("ULCX_DSYN_PAD")) { int n = atoi(pv); if (n > 0 && n < 120 * 1024) e->ldsPad = n & ~15; }
     e->b1Init = e->b1Graphed = e->b1NoGraph = false; e->b1Stream = nullptr; e->pinIn = nullptr; e->pinPcm = nullptr; e->pinMeta = nullptr; e->b1Slot = 0;
     UlcxDecCtx &c = e->ctx;
     memset(&c, 0, sizeof(c));
@@ -630,10 +562,8 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     // per channel (k_dsyn); everything else takes the general kernel (k_dgen: one array, state in HBM)
     c.fastOK = (nChan == 2 && BlockSize <= 4096) ? 1 : 0;
     if (const char *ev = getenv("ULCX_DEC_FAST")) c.fastOK = c.fastOK && (ev[0] != '0');
-    // stereo, BlockSize <= 2048: twiddles in LDS, lapping state in global memory (mode 2: six synthesis workgroups per CU;
-    // round 3: 1.00 -> 0.92 ms per 65536 blocks); ULCX_DSYN_LAPG=0 both in LDS (rounds 1-2), =1 both in global memory
-    c.twInLds = c.fastOK ? ((BlockSize <= 2048) ? 2 : 1) : 0;
-    if (const char *ev = getenv("ULCX_DSYN_LAPG")) { if (c.fastOK && BlockSize <= 2048) c.twInLds = ev[0] == '0' ? 1 : ev[0] == '1' ? 0 : 2; }
+    // stereo synthesis kernel: lapping state in global memory; BlockSize <= 2048: FFT twiddles in LDS (mode 2), above: from the tables
+    c.twInLds = c.fastOK ? ((BlockSize <= 2048) ? 2 : 0) : 0;
     rc = ulcx_tables_build(&c.T, &e->tables, BlockSize, 44100, false);
     if (rc) { cleanup(e); return rc; }
     size_t B = nStreams, NB = B * maxBlocksPerCall;
@@ -642,7 +572,7 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     DA(c.seed, B, true);
     DA(c.dead, B, true);
     c.lapO = c.lap; c.lastSubO = c.lastSub; c.seedO = c.seed; c.deadO = c.dead; c.lapScratch = nullptr; c.k0 = 0; c.k1 = 0;
-    if (c.fastOK && (BlockSize > 2048 || c.twInLds != 1)) {               // the kernels that keep the lapping state in global memory
+    if (c.fastOK) {                                                       // the kernel keeps the lapping state in global memory: any grid
         bool want = true;
         if (const char *ev = getenv("ULCX_DSYN_SPLIT")) want = ev[0] != '0';
         e->synSlots = want ? ulcx_dec_syn_slots(c) : 0;
@@ -677,27 +607,6 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
         DA(dj, jt.size(), false);
         if (hipMemcpy(dj, jt.data(), sizeof(uint32_t) * jt.size(), hipMemcpyHostToDevice) != hipSuccess) { ulcx_set_error("hipMemcpy(rng tables)"); cleanup(e); return ULCX_ERR_HIP; }
         c.jumpT = dj;
-    }
-    {   // side stream of the walk / synthesis pipeline; ULCX_DEC_PIPE=n chunks (default 1 = off), ULCX_ASYNC_FB=0: no side streams at all
-        const char *fb = getenv("ULCX_ASYNC_FB");
-        const char *pv = getenv("ULCX_DEC_PIPE");
-        int n = pv ? atoi(pv) : 1;                             // default off: measured 1.31 / 1.45 / 1.54 / 2.6 ms per decode for 1 / 2 / 4 / 8 chunks
-        if (n < 1) n = 1;
-        if (n > ULCX_DEC_MAXCH) n = ULCX_DEC_MAXCH;
-        // ULCX_DEC_HALVES=1: the walk of the second half of every stream's blocks beside the synthesis of the first (batches of
-        // >= 4096 blocks).  Off: measured 2.55 vs 2.50 ms per 131072 blocks, 1.28 vs 1.20 per 65536 - the synthesis slows down
-        // by more than the walk it hides, and two launches end in two partly filled rounds
-        const char *hv = getenv("ULCX_DEC_HALVES");
-        e->kHalves = (c.fastOK && hv && hv[0] == '1' && (long long)nStreams * maxBlocksPerCall >= 4096) ? 1 : 0;
-        if (!(fb && fb[0] == '0') && (n > 1 || e->kHalves)) {
-            bool ok = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess;
-            if (ok) {
-                ok = hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming) == hipSuccess;
-                for (auto &v : e->evScan) ok = ok && hipEventCreateWithFlags(&v, hipEventDisableTiming) == hipSuccess;
-                e->sideOk = ok;
-                if (ok) e->nChunks = n;
-            }
-        }
     }
     for (auto &v : e->ev) { if (hipEventCreate(&v) != hipSuccess) { ulcx_set_error("hipEventCreate failed"); cleanup(e); return ULCX_ERR_HIP; } }
     e->evOk = true;

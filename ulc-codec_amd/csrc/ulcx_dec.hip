@@ -305,9 +305,8 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
 }
 
 // Pass 1 - one lane per block.
-__global__ __launch_bounds__(64) void k_dscan(UlcxDecCtx c, int lpw) {
-    if ((int)threadIdx.x >= lpw) return;                           // (lpw < 64: half- or quarter-filled waves, more of them per SIMD)
-    const int id = blockIdx.x * lpw + threadIdx.x, Kc = c.k1 - c.k0;       // streams [s0, s1), blocks [k0, k1) of each (ulcx_dec_launch pipelines pieces of the batch)
+__global__ __launch_bounds__(64) void k_dscan(UlcxDecCtx c) {
+    const int id = blockIdx.x * 64 + threadIdx.x, Kc = c.k1 - c.k0;       // streams [s0, s1), blocks [k0, k1) of each
     if (id >= (c.s1 - c.s0) * Kc) return;
     const int blk = (c.s0 + id / Kc) * c.K + c.k0 + id % Kc;
     scan_block(c, blk, c.in + (size_t)blk * c.slot, c.slot * 8, c.slot, c.in, c.in + c.inBytes);
@@ -663,20 +662,18 @@ __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int 
 // ---------------------------------------------------------------------------
 // Stereo streams (BlockSize <= 4096): one workgroup = one stream, one wave per channel up to the end of the FFTs.
 // ---------------------------------------------------------------------------
-#ifndef DSYN_LAPG_WAVES
-#define DSYN_LAPG_WAVES 3
-#endif
-// LAPG: lapping state in global memory; TWL: twiddles in LDS; SPLIT: the grid is an even cut of the (stream, block) pairs
-// (else one workgroup per stream: the index arithmetic and the choice of the lapping rows below fold away)
-template <typename OUT, int DEC_MAXT, bool LAPG, bool TWL = !LAPG, bool SPLIT = false>
-__global__ __launch_bounds__(WG, (LAPG && DEC_MAXT == 16) ? DSYN_LAPG_WAVES : 3) void k_dsyn(UlcxDecCtx c) {
-    static_assert(LAPG || !SPLIT, "an even cut needs the lapping state in global memory");
+// The lapping state lives in global memory (L2-hot: every element is re-read by the thread that wrote it one block earlier);
+// TWL: FFT twiddles in LDS (BlockSize <= 2048); SPLIT: the grid is an even cut of the (stream, block) pairs (else one
+// workgroup per stream: the index arithmetic and the choice of the lapping rows below fold away)
+template <typename OUT, int DEC_MAXT, bool TWL, bool SPLIT = false>
+__global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
+    constexpr bool LAPG = true;
     extern __shared__ float lds[];
     const int BS = c.BS, H2 = BS / 2;
     constexpr int C = 2;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const DsynLds L = dsyn_lds(BS, C, 1, LAPG ? (TWL ? 2 : 0) : 1);
+    const DsynLds L = dsyn_lds(BS, C, 1, TWL ? 2 : 0);
     float2 *z    = (float2 *)lds;
     // lapping state: in LDS for the stream's blocks of this launch, or (LAPG) in global memory: the arrays a stream's state
     // is read from / written to at its first / last block of the launch, the workgroup's own scratch rows in between.
@@ -1107,16 +1104,12 @@ size_t ulcx_dec_lds_bytes(int BS, int C, int fast, int twInLds) {
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ulcx_set_error("%s: %s", #x, hipGetErrorString(e_)); return ULCX_ERR_HIP; } } while (0)
 
-// The syntax walk (k_dscan: one wave per 64 blocks, a chain of dependent instructions - it leaves most of the machine idle)
-// and the synthesis (k_dsyn: instruction-issue bound) are pipelined over chunks of streams: the walk of chunk i+1 runs on a
-// side stream beside the synthesis of chunk i.  aux.side == NULL (or a small batch): one chunk, everything on the caller's stream.
 // resident workgroups of the stereo synthesis kernel this context runs (float output; the PCM16 instantiation has the same
 // resources): what an even cut of the batch is sized for
 int ulcx_dec_syn_slots(const UlcxDecCtx &c) {
     if (!c.fastOK) return 0;
     const bool small = c.BS <= 2048;
-    const int mode = small ? c.twInLds : 0;
-    const void *fn = !small ? (const void *)k_dsyn<float, 32, true> : mode == 2 ? (const void *)k_dsyn<float, 16, true, true> : mode == 0 ? (const void *)k_dsyn<float, 16, true> : (const void *)k_dsyn<float, 16, false>;
+    const void *fn = small ? (const void *)k_dsyn<float, 16, true> : (const void *)k_dsyn<float, 32, false>;
     const size_t lds = ulcx_dec_lds_bytes(c.BS, c.C, c.fastOK, c.twInLds);
     if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
     int dev = 0, cus = 0, per = 0;
@@ -1125,89 +1118,43 @@ int ulcx_dec_syn_slots(const UlcxDecCtx &c) {
     return cus * per;
 }
 
+// Two kernels on the caller's stream: the syntax walk, then the synthesis.  (Measured and dropped, profiles/NOTES_r01-r04.md:
+// the walk of a chunk of streams / of the second half of the blocks beside the synthesis of the previous one - the
+// synthesis slows down by more than the walk it hides.)
+template <typename OUT>
+static void launch_syn(const UlcxDecCtx &cc, unsigned g, size_t lds, hipStream_t s2, bool split) {
+    const bool small = cc.BS <= 2048;
+    if (!cc.fastOK) hipLaunchKernelGGL(k_dgen<OUT>, dim3(g), dim3(WG), lds, s2, cc);
+    else if (small) { if (split) hipLaunchKernelGGL((k_dsyn<OUT, 16, true, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<OUT, 16, true, false>), dim3(g), dim3(WG), lds, s2, cc); }
+    else { if (split) hipLaunchKernelGGL((k_dsyn<OUT, 32, false, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<OUT, 32, false, false>), dim3(g), dim3(WG), lds, s2, cc); }
+}
 int ulcx_dec_launch(const UlcxDecCtx &cIn, hipStream_t st, hipEvent_t *ev, const UlcxDecAux &aux) {
     int stage = 0;
     if (ev) CK(hipEventRecord(ev[stage++], st));
     UlcxDecCtx c = cIn;
-    size_t lds = ulcx_dec_lds_bytes(c.BS, c.C, c.fastOK, c.twInLds) + (size_t)aux.ldsPad;     // (ldsPad: experiment, fewer workgroups per CU)
-    const bool small = c.BS <= 2048;                      // register slots of the decimated-block path (dec_time_wave)
-    // stereo, BlockSize <= 2048: where the lapping state and the FFT twiddles live (c.twInLds: 1 both in LDS - rounds 1-2 -,
-    // 2 twiddles in LDS and the lapping state in global memory: 23 KB, six workgroups per CU instead of five - round 3, the
-    // default -, 0 both in global memory)
-    const int mode = small ? c.twInLds : 0;
-    const void *fn = !c.fastOK ? (c.pcm16 ? (const void *)k_dgen<int16_t> : (const void *)k_dgen<float>)
-                   : !small ? (c.pcm16 ? (const void *)k_dsyn<int16_t, 32, true> : (const void *)k_dsyn<float, 32, true>)
-                   : c.pcm16 ? (mode == 2 ? (const void *)k_dsyn<int16_t, 16, true, true> : mode == 0 ? (const void *)k_dsyn<int16_t, 16, true> : (const void *)k_dsyn<int16_t, 16, false>)
-                             : (mode == 2 ? (const void *)k_dsyn<float, 16, true, true> : mode == 0 ? (const void *)k_dsyn<float, 16, true> : (const void *)k_dsyn<float, 16, false>);
-    if (lds > 48 * 1024) CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    auto scan = [&](hipStream_t s2, int s0, int s1, int k0 = 0, int k1 = -1) {
-        UlcxDecCtx cc = c; cc.s0 = s0; cc.s1 = s1; cc.k0 = k0; cc.k1 = k1 < 0 ? c.K : k1;
-        if (c.packed) hipLaunchKernelGGL(k_dscan_packed, dim3((s1 - s0 + 63) / 64), dim3(64), 0, s2, cc);
-        else { const int lpw = aux.scanLpw > 0 ? aux.scanLpw : 64; hipLaunchKernelGGL(k_dscan, dim3(((s1 - s0) * (cc.k1 - cc.k0) + lpw - 1) / lpw), dim3(64), 0, s2, cc, lpw); }
-    };
-    auto syn = [&](hipStream_t s2, int s0, int s1, int k0 = 0, int k1 = -1) {
-        UlcxDecCtx cc = c; cc.s0 = s0; cc.s1 = s1; cc.k0 = k0; cc.k1 = k1 < 0 ? c.K : k1;
-        const bool lapg = c.fastOK && (!small || mode != 1);       // kernels with the lapping state in global memory: any grid
-        const bool split = lapg && aux.synGrid > 0 && s0 == 0 && s1 == c.B;
-        const unsigned g = split ? (unsigned)aux.synGrid : (unsigned)(s1 - s0);
-        if (ULCX_DBG(c) & 8) {}
-        else if (!c.fastOK) { if (c.pcm16) hipLaunchKernelGGL(k_dgen<int16_t>, dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL(k_dgen<float>, dim3(g), dim3(WG), lds, s2, cc); }
-        else if (!small) {
-            if (c.pcm16) { if (split) hipLaunchKernelGGL((k_dsyn<int16_t, 32, true, false, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<int16_t, 32, true>), dim3(g), dim3(WG), lds, s2, cc); }
-            else { if (split) hipLaunchKernelGGL((k_dsyn<float, 32, true, false, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<float, 32, true>), dim3(g), dim3(WG), lds, s2, cc); }
+    c.s0 = 0; c.s1 = c.B; c.k0 = 0; c.k1 = c.K;
+    const size_t lds = ulcx_dec_lds_bytes(c.BS, c.C, c.fastOK, c.twInLds);
+    const bool small = c.BS <= 2048;
+    if (lds > 48 * 1024) {
+        const void *fn = !c.fastOK ? (c.pcm16 ? (const void *)k_dgen<int16_t> : (const void *)k_dgen<float>)
+                       : small ? (c.pcm16 ? (const void *)k_dsyn<int16_t, 16, true> : (const void *)k_dsyn<float, 16, true>)
+                               : (c.pcm16 ? (const void *)k_dsyn<int16_t, 32, false> : (const void *)k_dsyn<float, 32, false>);
+        CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (c.fastOK && aux.synGrid > 0) {
+            const void *fs = small ? (c.pcm16 ? (const void *)k_dsyn<int16_t, 16, true, true> : (const void *)k_dsyn<float, 16, true, true>)
+                                   : (c.pcm16 ? (const void *)k_dsyn<int16_t, 32, false, true> : (const void *)k_dsyn<float, 32, false, true>);
+            CK(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
-        else if (c.pcm16) {
-            if (mode == 2) { if (split) hipLaunchKernelGGL((k_dsyn<int16_t, 16, true, true, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<int16_t, 16, true, true>), dim3(g), dim3(WG), lds, s2, cc); }
-            else if (mode == 0) { if (split) hipLaunchKernelGGL((k_dsyn<int16_t, 16, true, false, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<int16_t, 16, true>), dim3(g), dim3(WG), lds, s2, cc); }
-            else hipLaunchKernelGGL((k_dsyn<int16_t, 16, false>), dim3(g), dim3(WG), lds, s2, cc);
-        } else {
-            if (mode == 2) { if (split) hipLaunchKernelGGL((k_dsyn<float, 16, true, true, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<float, 16, true, true>), dim3(g), dim3(WG), lds, s2, cc); }
-            else if (mode == 0) { if (split) hipLaunchKernelGGL((k_dsyn<float, 16, true, false, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<float, 16, true>), dim3(g), dim3(WG), lds, s2, cc); }
-            else hipLaunchKernelGGL((k_dsyn<float, 16, false>), dim3(g), dim3(WG), lds, s2, cc);
-        }
-    };
-    int nCh = (aux.side && aux.nChunks > 1) ? aux.nChunks : 1;
-    if (nCh > ULCX_DEC_MAXCH) nCh = ULCX_DEC_MAXCH;
-    if (c.B < 64 * nCh) nCh = 1;                          // (a chunk is at least a wave of the walk)
-    // The walk of the second half of every stream's blocks beside the synthesis of the first (round 3): the walk is one
-    // wave per SIMD of dependent instructions, the synthesis leaves it its issue slots; a stream's state goes from the first
-    // synthesis launch to the second through the state arrays like from one call to the next.  (Timing: the "k_dscan"
-    // interval is the first half's walk - the exposed one.)
-    const bool halves = nCh == 1 && aux.side && aux.kHalves && c.fastOK && !c.packed && aux.synGrid <= 0 && c.K >= 8 && (long long)c.B * c.K >= 4096;
-    if (halves) {
-        const int kh = c.K / 2;
-        scan(st, 0, c.B, 0, kh);
-        if (ev) CK(hipEventRecord(ev[stage++], st));
-        CK(hipEventRecord(aux.evFork, st));
-        CK(hipStreamWaitEvent(aux.side, aux.evFork, 0));
-        scan(aux.side, 0, c.B, kh, c.K);
-        CK(hipEventRecord(aux.evScan[1], aux.side));
-        syn(st, 0, c.B, 0, kh);
-        CK(hipStreamWaitEvent(st, aux.evScan[1], 0));
-        syn(st, 0, c.B, kh, c.K);
-        if (ev) CK(hipEventRecord(ev[stage++], st));
-    } else if (nCh == 1) {
-        scan(st, 0, c.B);
-        if (ev) CK(hipEventRecord(ev[stage++], st));
-        syn(st, 0, c.B);
-        if (ev) CK(hipEventRecord(ev[stage++], st));
-    } else {
-        // chunk boundaries on multiples of 64 streams.  Timing (ev): the "k_dscan" interval is the first chunk's walk (the
-        // exposed one), the "k_dsyn" interval everything behind it.
-        int cut[ULCX_DEC_MAXCH + 1];
-        for (int i = 0; i <= nCh; i++) cut[i] = (int)(((long long)c.B * i / nCh + 63) / 64 * 64);
-        cut[nCh] = c.B;
-        scan(st, cut[0], cut[1]);
-        if (ev) CK(hipEventRecord(ev[stage++], st));
-        CK(hipEventRecord(aux.evFork, st));
-        CK(hipStreamWaitEvent(aux.side, aux.evFork, 0));
-        for (int i = 1; i < nCh; i++) { scan(aux.side, cut[i], cut[i + 1]); CK(hipEventRecord(aux.evScan[i], aux.side)); }
-        for (int i = 0; i < nCh; i++) {
-            if (i > 0) CK(hipStreamWaitEvent(st, aux.evScan[i], 0));
-            syn(st, cut[i], cut[i + 1]);
-        }
-        if (ev) CK(hipEventRecord(ev[stage++], st));
     }
+    if (c.packed) hipLaunchKernelGGL(k_dscan_packed, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
+    else hipLaunchKernelGGL(k_dscan, dim3((c.B * c.K + 63) / 64), dim3(64), 0, st, c);
+    if (ev) CK(hipEventRecord(ev[stage++], st));
+    if (!(ULCX_DBG(c) & 8)) {
+        const bool split = c.fastOK && aux.synGrid > 0;
+        const unsigned g = split ? (unsigned)aux.synGrid : (unsigned)c.B;
+        if (c.pcm16) launch_syn<int16_t>(c, g, lds, st, split); else launch_syn<float>(c, g, lds, st, split);
+    }
+    if (ev) CK(hipEventRecord(ev[stage++], st));
     CK(hipGetLastError());
     return ULCX_OK;
 }

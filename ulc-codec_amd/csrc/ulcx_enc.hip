@@ -528,13 +528,11 @@ __device__ __forceinline__ float win_apply(float x, int i, int S, int aL, int ov
 // block between two full-overlap neighbours (PCM16 ingest: from the call's third block on).  Same arithmetic, same
 // order as the general body of k_xf below (which documents it) - only the index arithmetic, the loop bounds and the window
 // selects fold away, and the four 1024-point transforms run the compile-time passes (fft_wave_dif_ct).
-// XfCarry: what a workgroup that transforms CONSECUTIVE blocks of one stream keeps in registers from one block to the next.
-// Block k's frame is input blocks k-2 and k-1, block k+1's is k-1 and k: the samples a thread folds in the second half of
-// one frame (positions S + 2jj, 2S - 2 - 2jj and their neighbours) are the ones it folds in the first half of the next
-// (positions 2jj, S - 2 - 2jj) - after the M/S step, before the window.  Two fold trips x four positions x (M, S).
-struct XfCarry { float2 raw[2][4]; bool valid; };
-template <typename IN, bool CARRY>
-__device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int s, int k, int blk, int tid, XfCarry &cy) {
+// LOOP: the call sits inside a loop over blocks (k_xf_spec): the table loads and every index that depends on the thread only
+// do not depend on the block, and hoisted out of the loop they cost more registers than the 128-register cap of four
+// workgroups per CU has - opaque copies keep them where they are used; the full-size twiddles stay in LDS (haveTw).
+template <typename IN, bool LOOP>
+__device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int s, int k, int blk, int tid, bool haveTw, const uint32_t *touch = nullptr) {
     constexpr int BS = 2048, S = 2048, M = 1024, PS = 4, Mp = FFT_PADDEDS(M, PS);
     static_assert(WG == 256, "two fold / epilogue trips per thread");
     float2 *z = (float2 *)lds;
@@ -542,11 +540,9 @@ __device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int
     float2 *zc0 = z, *zs0 = z + Mp, *zc1 = z + 2 * Mp, *zs1 = z + 3 * Mp;
     const float2 *pre = c.T.pre[0];
     const float *rise = c.T.winRise + S, *fall = c.T.winFall + S;
-    if (CARRY) {
-        // (inside a loop over the run's blocks: the table loads below do not depend on the block, and hoisted out of the
-        //  loop they cost more registers than the 128-register cap has - opaque pointers keep them where they are)
+    if (LOOP) {
         asm volatile("" : "+s"(pre), "+s"(rise), "+s"(fall));
-        asm volatile("" : "+v"(tid));                          // (likewise every index that only depends on the thread)
+        asm volatile("" : "+v"(tid));
     }
     // frame = [(k-2) BS, k BS): its first half (positions < S) is block k-2, its second half block k-1 of the stream's
     // timeline; blocks -2 and -1 are the two the encoder keeps from the previous call (c.hist, always float)
@@ -557,28 +553,21 @@ __device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int
         if (k < 2) frameLo = histS + (size_t)k * BS * 2;                      // block k-2 = history block k
         if (k < 1) frameHi = histS;                                            // block k-1 = history block 1: (hist + BS*2) - S*2
     }
-    const bool reuse = CARRY && cy.valid;                      // (workgroup-uniform: the previous block of this workgroup's run took this path)
-    if (!reuse) {                                              // (otherwise the full-size twiddles are still in LDS)
+    if (!haveTw) {
 #pragma unroll
         for (int i = tid; i < M / 2; i += WG) twl[i] = c.T.tw[0][i];
     }
 #pragma unroll
     for (int jj0 = 0; jj0 < M / 2; jj0 += WG) {
         const int jj = jj0 + tid;
-        const int trip = jj0 / WG;
         const int iA = 2 * jj, iB = S - 2 - 2 * jj, iC = S + 2 * jj, iD = 2 * S - 2 - 2 * jj;
         const int ip[4] = { iA, iB, iC, iD };
         float2 xs[8];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            float2 m0, m1;                                     // the two positions ip[r], ip[r] + 1 after M/S
-            if (CARRY && r < 2 && reuse) { m0 = cy.raw[trip][2 * r]; m1 = cy.raw[trip][2 * r + 1]; }
-            else {
-                const float4 v = ld4((r < 2 ? frameLo : frameHi) + (size_t)ip[r] * 2);
-                m0 = make_float2((v.x + v.y) * 0.5f, (v.x - v.y) * 0.5f);
-                m1 = make_float2((v.z + v.w) * 0.5f, (v.z - v.w) * 0.5f);
-            }
-            if (CARRY && r >= 2) { cy.raw[trip][2 * (r - 2)] = m0; cy.raw[trip][2 * (r - 2) + 1] = m1; }     // the next block's first half
+            const float4 v = ld4((r < 2 ? frameLo : frameHi) + (size_t)ip[r] * 2);
+            const float2 m0 = make_float2((v.x + v.y) * 0.5f, (v.x - v.y) * 0.5f);     // the two positions ip[r], ip[r] + 1 after M/S
+            const float2 m1 = make_float2((v.z + v.w) * 0.5f, (v.z - v.w) * 0.5f);
             const float2 fw = (r < 2) ? *(const float2 *)(rise + ip[r]) : *(const float2 *)(fall + ip[r] - S);     // (even positions: 8-byte aligned)
             xs[2 * r]     = make_float2(m0.x * fw.x, m0.y * fw.x);
             xs[2 * r + 1] = make_float2(m1.x * fw.y, m1.y * fw.y);
@@ -603,6 +592,11 @@ __device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int
         }
     }
     __syncthreads();
+    // (LOOP) one 4-byte load per 128-byte line of the half frame the workgroup's NEXT block adds: issued behind this block's
+    // own loads - the wave's memory counter is in order, a touch in front of them would make the fold wait for it - and
+    // with the whole transform to arrive in; nothing looks at the value before the end of the block
+    uint32_t touched = 0;
+    if (LOOP && touch) touched = *touch;
     fft_wave_dif_ct<M, PS>(z + __builtin_amdgcn_readfirstlane(tid >> 6) * Mp, twl, tid & 63);
     __syncthreads();
     float *coefO = c.coef + (size_t)blk * (2 * BS);
@@ -660,7 +654,7 @@ __device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int
         *(float2 *)(ampO + j1) = make_float2(am[0][0], am[0][1]);
         *(float2 *)(ampO + j2) = make_float2(am[1][0], am[1][1]);
     }
-    if (CARRY) cy.valid = true;
+    if (LOOP) asm volatile("" :: "v"(touched));
     return nnz;
 }
 
@@ -682,55 +676,13 @@ __device__ __forceinline__ bool xf_is_fast(const UlcxEncCtx &c, int s, int k) {
     if (ovFirst > lastS) ovFirst = lastS;
     return ovFirst == BS && first_overlap(wcNext, BS) >= BS;
 }
-// The steady-state blocks as a kernel of their own (round 3): a workgroup takes a RUN of consecutive blocks of one stream
-// and keeps the half frame two neighbours share in registers (XfCarry: half the input loads, half the M/S arithmetic);
-// blocks of the run that do not qualify are left to k_xf (launched behind it with skipFast = 1).  In one kernel with the
-// general body the carry's 16 registers spill (128-register cap of four workgroups per CU: 2x slower); alone this path
-// has room.  Workgroups are dealt round-robin over the 8 XCDs: runs of one stream follow each other on one XCD.
-template <typename IN>
-__global__ __launch_bounds__(WG, 4) void k_xf_fast(UlcxEncCtx c, int k0, int k1, int run) {
-    extern __shared__ float lds[];
-    const int kc = k1 - k0;
-    const int nr = (kc + run - 1) / run;
-    const int units = c.B * nr;
-    const int per = (units + 7) / 8;
-    const int vu = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
-    if (vu >= units) return;
-    const int s = vu / nr;
-    const int kA = k0 + (vu % nr) * run, kB = (kA + run < k1) ? kA + run : k1;
-    const int tid = threadIdx.x;
-    int &s_nnz = *(int *)(lds + 4 * FFT_PADDEDS(2048, 4) + 2048 / 2);
-    XfCarry cy; cy.valid = false;
-    for (int k = kA; k < kB; k++) {
-        if (!xf_is_fast<IN>(c, s, k)) { cy.valid = false; continue; }
-        const int blk = s * c.K + k;
-        if (tid == 0) s_nnz = 0;
-        __syncthreads();
-        int nnz = xf_fast_2048<IN, true>(c, lds, s, k, blk, tid, cy);
-        for (int o = 32; o > 0; o >>= 1) nnz += __shfl_down(nnz, o);
-        if ((tid & 63) == 0) atomicAdd(&s_nnz, nnz);
-        __syncthreads();
-        if (tid == 0) c.nnz[blk] = s_nnz;
-        __syncthreads();
-    }
-}
-
+// One block (s, k) of the call by one workgroup: any window, any channel count up to BlockSize 8192.
 // ST: stereo instantiation (C = 2 as a compile-time constant: one channel pair, no per-pair branches)
-template <bool ST, typename IN>
-__global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1, int skipFast) {
-    extern __shared__ float lds[];
+// FAST: the block may be in the steady state of the headline geometry (then it takes xf_fast_2048); k_xf_fix's blocks never are
+template <bool ST, typename IN, bool FAST = true>
+__device__ __forceinline__ void xf_block(const UlcxEncCtx &c, float *lds, int s, int k, const int tid) {
     const int BS = c.BS, C = ST ? 2 : c.C;
-    // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its own L2).
-    // Consecutive blocks of a stream read overlapping input (each frame spans two blocks), so give an
-    // XCD a contiguous run of blocks: block = (b % 8) * ceil(NB/8) + b / 8.  Speed only, never correctness.
-    const int kc = k1 - k0;
-    int NBk = c.B * kc;
-    int per = (NBk + 7) / 8;
-    int vb = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
-    if (vb >= NBk) return;
-    int s = vb / kc, k = k0 + vb % kc;
-    int blk = s * c.K + k;
-    int tid = threadIdx.x;
+    const int blk = s * c.K + k;
     const int ps = ulcx_xf_pad_shift(BS, C);          // FFT array padding (ulcx_fft.h)
     float2 *z    = (float2 *)lds;                     // 4 arrays of up to BS/2 complex: {MDCT, MDST} x {ch, ch+1}
     float2 *twl  = (float2 *)(lds + 4 * FFT_PADDEDS(BS, ps));    // BS/4 complex: this subblock's FFT twiddles (no global-memory latency inside the FFT passes)
@@ -761,9 +713,8 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1, int 
     __syncthreads();
 
     // the steady state of the headline geometry takes the all-constants path (xf_fast_2048)
-    const bool fastBlk = ST && BS == 2048 && xf_is_fast<IN>(c, s, k);
-    XfCarry noCarry;
-    if (fastBlk) { if (skipFast) return; nnz = xf_fast_2048<IN, false>(c, lds, s, k, blk, tid, noCarry); }     // (skipFast: k_xf_fast has transformed it)
+    const bool fastBlk = FAST && ST && BS == 2048 && xf_is_fast<IN>(c, s, k);
+    if (FAST && fastBlk) nnz = xf_fast_2048<IN, false>(c, lds, s, k, blk, tid, false);
     else
     for (int ch0 = 0; ch0 < C; ch0 += 2) {             // one M/S pair (or a trailing single channel) at a time
         const int nch = ST ? 2 : ((ch0 + 1 < C) ? 2 : 1);
@@ -938,6 +889,90 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1, int 
     if (ampLds) for (int i = tid; i < BS / 2; i += WG) ampO[i] = amp2[i];
     __syncthreads();
     if (tid == 0) c.nnz[blk] = s_nnz;
+}
+
+// Blocks [k0, k1) of every stream, one workgroup each (the chunks of the window-control pipeline: every geometry but the
+// headline one, and small calls).  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its
+// own L2); consecutive blocks of a stream read overlapping input (a frame spans two blocks), so an XCD gets a contiguous
+// run of blocks: block = (b % 8) * ceil(NB/8) + b / 8.  Speed only, never correctness.
+template <bool ST, typename IN>
+__global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
+    extern __shared__ float lds[];
+    const int kc = k1 - k0;
+    const int NBk = c.B * kc;
+    const int per = (NBk + 7) / 8;
+    const int vb = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+    if (vb >= NBk) return;
+    xf_block<ST, IN>(c, lds, vb / kc, k0 + vb % kc, threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// The headline geometry (stereo, BlockSize 2048) does not wait for window control (round 4).  Nine blocks in ten are in
+// the steady state - an un-decimated block between two full-overlap neighbours - and which ones is only known once the
+// stream-serial transient chain has decided them, 1.8 ms into a 32-block call.  So:
+//   k_xf_spec  transforms EVERY block as if it were in the steady state, from the call's first microsecond, beside the
+//              window-control chain.  Persistent workgroups over an even cut of the (stream, block) pairs in stream-major
+//              order: consecutive blocks of a stream share half their frame (the second read hits L2), the twiddles are
+//              copied to LDS once per workgroup, and while block k is in the transform one lane per 128-byte line touches
+//              the new half frame of block k+1, so that its fold finds the samples in L2 instead of waiting for HBM.
+//   k_xf_list  once the call's windows are decided: the blocks whose window (or a neighbour's) is not the steady state.
+//   k_xf_fix   transforms exactly those again, with their real windows (the general body), over what k_xf_spec wrote.
+// The results are those of transforming every block once with its real window; the price is the listed blocks twice.
+// ---------------------------------------------------------------------------
+template <typename IN>
+__global__ __launch_bounds__(WG, 4) void k_xf_spec(UlcxEncCtx c) {
+    extern __shared__ float lds[];
+    constexpr int BS = 2048;
+    const long long T = (long long)c.B * c.K;
+    const int f0 = (int)(T * blockIdx.x / gridDim.x), f1 = (int)(T * (blockIdx.x + 1) / gridDim.x);
+    int &s_nnz = *(int *)(lds + 4 * FFT_PADDEDS(BS, 4) + BS / 2);
+    const int tidOuter = threadIdx.x;
+    bool haveTw = false;
+    for (int vb = f0; vb < f1; vb++) {
+        int tid = tidOuter;
+        asm volatile("" : "+v"(tid));
+        const int s = vb / c.K, k = vb - s * c.K;
+        // PCM16 ingest: the first two blocks of a call read their history halves as float - left to k_xf_fix (xf_is_fast)
+        if (!std::is_same<IN, float>::value && k < 2) continue;
+        if (tid == 0) s_nnz = 0;
+        // the half frame the NEXT block adds (input block k of this stream: 128 or 64 lines of 128 bytes), one lane per line
+        const uint32_t *touch = nullptr;
+        if (vb + 1 < f1 && k + 1 < c.K && tid < (int)(BS * 2 * sizeof(IN) / 128))
+            touch = (const uint32_t *)(pcm_base<IN>(c) + ((size_t)s * c.K + k) * BS * 2) + tid * 32;
+        __syncthreads();
+        int nnz = xf_fast_2048<IN, true>(c, lds, s, k, vb, tid, haveTw, touch);
+        haveTw = true;
+        for (int o = 32; o > 0; o >>= 1) nnz += __shfl_down(nnz, o);
+        if ((tid & 63) == 0) atomicAdd(&s_nnz, nnz);
+        __syncthreads();
+        if (tid == 0) c.nnz[vb] = s_nnz;
+    }
+}
+template <typename IN>
+__global__ __launch_bounds__(64) void k_xf_list(UlcxEncCtx c) {
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    const bool in = gid < c.B * c.K;
+    const int s = in ? gid / c.K : 0, k = in ? gid % c.K : 0;
+    const bool slow = in && !xf_is_fast<IN>(c, s, k);
+    const unsigned long long m = __ballot(slow);
+    if (!m) return;
+    int base = 0;
+    if (threadIdx.x == 0) base = atomicAdd(c.xfCount, __popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (slow) c.xfList[base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = gid;
+}
+template <typename IN>
+__global__ __launch_bounds__(WG, 4) void k_xf_fix(UlcxEncCtx c) {
+    extern __shared__ float lds[];
+    const int n = *c.xfCount;
+    const int tidOuter = threadIdx.x;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        int tid = tidOuter;
+        asm volatile("" : "+v"(tid));                          // (nothing that depends on the thread only is hoisted out of the loop and held in registers)
+        const int blk = c.xfList[i];
+        xf_block<true, IN, false>(c, lds, blk / c.K, blk % c.K, tid);
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2006,10 +2041,6 @@ __global__ __launch_bounds__(WG) void k_keep_ranks(UlcxEncCtx c, int finalPass) 
 #else
 #define E_GAPCAP(N) ((N) / 16)      // gaps >= 16 per block: at most N/17 of them (round 3: was a fixed 1024 - 8 KB of LDS, six workgroups per CU instead of eight)
 #endif
-// GEN (round 3, ULCX_FUSED_NOISE=1): the workgroup forms the block's {w, w*log} pairs itself from the Bark levels (what
-// k_nline does: Psyopt.c:236-248), leaves them in HBM for the writer's rare fall-backs, and takes the units' five tail sums
-// as further work items (what k_tailsums does: NoiseFill.c:41-62) - two kernels and two reads of the pair array less.
-template <bool GEN>
 __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
     extern __shared__ uint32_t gsm[];
     int tid = threadIdx.x;
@@ -2021,42 +2052,9 @@ __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     const uint32_t *keepB = c.keep + (size_t)blk * (N / 32);
     for (int i = tid; i < N / 32; i += WG) kw[i] = keepB[i];
-    const int nTailSlots = GEN ? 5 * 4 * c.C : 0;          // work-list slots in front of the gaps: (unit, chain) of the tail sums
-    if (!GEN) {
+    {
         const float4 *pg = (const float4 *)(c.npair + (size_t)blk * N);
         for (int i = tid; i < N / 4; i += WG) ((float4 *)pairs)[i] = ldnt(pg + i);
-    } else {
-        float *sbark = (float *)(gsm + N + N / 32 + 2 * (E_GAPCAP(N) + nTailSlots) + 4 + 2 * ((N / 32 + 63) / 64));
-        const int nLev = c.C * 4 * ULCX_NBARK;
-        for (int i = tid; i < nLev; i += WG) sbark[i] = c.barkN[(size_t)blk * nLev + i];
-        __syncthreads();
-        const int half = c.BS / 2;
-        float *gp = c.npair + (size_t)blk * N;
-        for (int jp = 2 * tid; jp < half; jp += 2 * WG) {      // two neighbouring line pairs per thread, every channel (as k_nline)
-            unsigned pat = ulcx_pattern(wc);
-            int off = 0, dd = 0, S = c.BS, j = 0;
-            for (;; j++) { dd = pat & 7; S = c.BS >> dd; if (2 * jp < off + S) break; off += S; pat >>= 4; }
-            const int line = jp - off / 2;
-            const int2 bi2 = *(const int2 *)(c.T.bandIdx[dd] + line);
-            const float2 fr2 = *(const float2 *)(c.T.bandFrac[dd] + line);
-            for (int ch = 0; ch < c.C; ch++) {
-                const float *bark = sbark + (ch * 4 + j) * ULCX_NBARK;
-                float o[4];
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    int bi = q ? bi2.y : bi2.x;
-                    float fr = q ? fr2.y : fr2.x;
-                    float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
-                    float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
-                    float noise = L * (1.0f - fr) + R * fr;
-                    float w = ulcx_expf(0.5f * noise);
-                    o[2 * q] = w; o[2 * q + 1] = w * (noise + 0x1.62E430p-1f);
-                }
-                const float4 v = make_float4(o[0], o[1], o[2], o[3]);
-                *(float4 *)(pairs + (size_t)ch * c.BS + 2 * jp) = v;
-                stnt((float4 *)(gp + (size_t)ch * c.BS + 2 * jp), v);
-            }
-        }
     }
     __syncthreads();
     if (ULCX_DBG(c) & 0x10000) return;                     // (ablation build: the loads alone)
@@ -2068,40 +2066,17 @@ __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
     // coefficient is the top bit of the last non-zero word, found in a bit mask of the non-zero words - or lies inside the
     // word between two set bits, and only one such run fits in 32 bits.
     uint32_t *wl = kw + N / 32;                            // work list: (kept coefficient, start of its gap) pairs
-    const int gapCap = E_GAPCAP(N) + nTailSlots;
+    const int gapCap = E_GAPCAP(N);
     int *wcount = (int *)(wl + 2 * gapCap);
     unsigned long long *nzw = (unsigned long long *)(wcount + 2);      // bit w % 64 of nzw[w / 64]: keep word w is not 0
     const int nW = N / 32;
-    if (tid == 0) *wcount = nTailSlots;
+    if (tid == 0) *wcount = 0;
     for (int w0 = 0; w0 < nW; w0 += WG) {
         const int w = w0 + tid;
         const unsigned long long bm = __ballot(w < nW && kw[w] != 0u);
         if ((tid & 63) == 0 && w < nW) nzw[w >> 6] = bm;
     }
     __syncthreads();
-    if (GEN && tid < 4 * c.C) {
-        // the tail behind the last kept coefficient of unit (ch, j): the start index the sums assume, five chains if it is long enough
-        const int ch = tid >> 2, j = tid & 3;
-        int dd, off, S;
-        const bool have = unit_geom(wc, j, c.BS, dd, off, S);
-        int start = 0, n = 0;
-        if (have) {
-            const int us = ch * c.BS + off, ue = us + S, usw = us >> 5;
-            int last = us - 1;
-            for (int q = (ue - 1) >> 11; q >= (usw >> 6); q--) {
-                unsigned long long mk = nzw[q];
-                if (q == ((ue - 1) >> 11) && ((ue >> 5) & 63)) mk &= (1ull << ((ue >> 5) & 63)) - 1ull;     // words below the unit's end
-                if (mk) { const int wp = q * 64 + 63 - __clzll(mk); if (wp >= usw) last = wp * 32 + 31 - __clz(kw[wp]); break; }
-            }
-            start = last + 1; n = ue - start;
-            c.tailSum[((size_t)(blk * c.C + ch) * 4 + j) * 8 + 5] = __int_as_float(start);
-        }
-        for (int chain = 0; chain < 5; chain++) {
-            const int slot = tid * 5 + chain;
-            wl[2 * slot] = (have && n >= 16) ? (0x80000000u | ((uint32_t)tid << 4) | (uint32_t)chain) : 0xFFFFFFFFu;
-            wl[2 * slot + 1] = (uint32_t)start;
-        }
-    }
     for (int w = tid; w < nW; w += WG) {
         const uint32_t m = kw[w];
         if (m == 0u) continue;
@@ -2140,42 +2115,6 @@ __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
     int nw = *wcount; if (nw > gapCap) nw = gapCap;
     for (int t = tid; t < nw; t += WG) {
         const uint32_t it = wl[2 * t];
-        if (GEN && (it & 0x80000000u)) {
-            if (it == 0xFFFFFFFFu || (ULCX_DBG(c) & 0x40000)) continue;      // (ablation build: no tail chains)
-            // one of the five ordered f32 sums of a unit's tail (NoiseFill.c:41-62), as tailsums_lane
-            const int chain = it & 7, u = (it >> 4) & 0xFFFF, ch = u >> 2, j = u & 3;
-            const int start = (int)wl[2 * t + 1];
-            int dd, off, S;
-            unit_geom(wc, j, c.BS, dd, off, S);
-            const int n = ch * c.BS + off + S - start;
-            const float2 *d = (const float2 *)(pairs + (start / 2) * 2);
-            const int np = (n + (start & 1) + 1) / 2;
-            const bool useY = (chain == 2) || (chain == 3);
-            const bool hasX1 = (chain <= 2), hasX2 = (chain == 1);
-            float acc = 0.0f;
-            int q = 0;
-            for (; q + 8 <= np; q += 8) {
-                float2 pv[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) pv[e] = d[q + e];
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    float x = (q + e) * 2.0f;
-                    float base = useY ? pv[e].y : pv[e].x;
-                    float m1 = hasX1 ? x : 1.0f, m2 = hasX2 ? x : 1.0f;
-                    acc += (base * m1) * m2;
-                }
-            }
-            for (; q < np; q++) {
-                float2 pv = d[q];
-                float x = q * 2.0f;
-                float base = useY ? pv.y : pv.x;
-                float m1 = hasX1 ? x : 1.0f, m2 = hasX2 ? x : 1.0f;
-                acc += (base * m1) * m2;
-            }
-            c.tailSum[((size_t)(blk * c.C + ch) * 4 + j) * 8 + chain] = acc;
-            continue;
-        }
         int i = (int)it, start = (int)wl[2 * t + 1];
         int zr = i - start;
         int v = zr - 16; if (v > 0x1FF) v = 0x1FF;
@@ -2196,12 +2135,11 @@ __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
         gs[i] = make_float2((sum == 0.0f) ? -1.0f : ulcx_expf(sum / sumw), 0.0f);
     }
 }
-template <bool GEN>
 __global__ __launch_bounds__(WG) void k_gapsums(UlcxEncCtx c, int finalPass) {
     if (probes_over(c, finalPass)) return;
-    if (c.fbMode != 2) { gapsums_block<GEN>(c, finalPass, blockIdx.x); return; }
+    if (c.fbMode != 2) { gapsums_block(c, finalPass, blockIdx.x); return; }
     int n = fb_count(c);
-    for (int v = blockIdx.x; v < n; v += gridDim.x) { gapsums_block<GEN>(c, finalPass, c.fbList[c.fbLo + v]); __syncthreads(); }
+    for (int v = blockIdx.x; v < n; v += gridDim.x) { gapsums_block(c, finalPass, c.fbList[c.fbLo + v]); __syncthreads(); }
 }
 
 // Tail HF-extension sums (NoiseFill.c:41-62) for the tail after each unit's last kept
@@ -3081,28 +3019,18 @@ static void launch_wc_ef(const UlcxEncCtx &c, hipStream_t st, int k0, int k1) {
     if (c.pcm16) hipLaunchKernelGGL((k_wc_ef<EF_NW, int16_t>), dim3((c.B + EF_SPW - 1) / EF_SPW), dim3(EF_NW * 64), EF_LDS_BYTES, st, c, k0, k1);
     else hipLaunchKernelGGL((k_wc_ef<EF_NW, float>), dim3((c.B + EF_SPW - 1) / EF_SPW), dim3(EF_NW * 64), EF_LDS_BYTES, st, c, k0, k1);
 }
-static void launch_xf(const UlcxEncCtx &c, unsigned grid, size_t lds, hipStream_t st, int k0, int k1, int run = 0) {
+static void launch_xf(const UlcxEncCtx &c, unsigned grid, size_t lds, hipStream_t st, int k0, int k1) {
     if (c.BS > 8192) {                                      // one array at a time (k_xf_big)
         if (c.pcm16) hipLaunchKernelGGL(k_xf_big<int16_t>, dim3(grid), dim3(WG), lds, st, c, k0, k1);
         else hipLaunchKernelGGL(k_xf_big<float>, dim3(grid), dim3(WG), lds, st, c, k0, k1);
         return;
     }
-    // run > 0: the steady-state blocks on k_xf_fast in runs of `run` consecutive blocks per workgroup, the rest behind it
-    int skipFast = 0;
-    if (run > 0 && c.C == 2 && c.BS == 2048 && k1 - k0 >= 2) {
-        if (run > k1 - k0) run = k1 - k0;
-        const int units = c.B * ((k1 - k0 + run - 1) / run);
-        const unsigned g2 = (unsigned)(((units + 7) / 8) * 8);
-        if (c.pcm16) hipLaunchKernelGGL(k_xf_fast<int16_t>, dim3(g2), dim3(WG), lds, st, c, k0, k1, run);
-        else hipLaunchKernelGGL(k_xf_fast<float>, dim3(g2), dim3(WG), lds, st, c, k0, k1, run);
-        skipFast = 1;
-    }
     if (c.pcm16) {
-        if (c.C == 2) hipLaunchKernelGGL((k_xf<true, int16_t>), dim3(grid), dim3(WG), lds, st, c, k0, k1, skipFast);
-        else hipLaunchKernelGGL((k_xf<false, int16_t>), dim3(grid), dim3(WG), lds, st, c, k0, k1, skipFast);
+        if (c.C == 2) hipLaunchKernelGGL((k_xf<true, int16_t>), dim3(grid), dim3(WG), lds, st, c, k0, k1);
+        else hipLaunchKernelGGL((k_xf<false, int16_t>), dim3(grid), dim3(WG), lds, st, c, k0, k1);
     } else {
-        if (c.C == 2) hipLaunchKernelGGL((k_xf<true, float>), dim3(grid), dim3(WG), lds, st, c, k0, k1, skipFast);
-        else hipLaunchKernelGGL((k_xf<false, float>), dim3(grid), dim3(WG), lds, st, c, k0, k1, skipFast);
+        if (c.C == 2) hipLaunchKernelGGL((k_xf<true, float>), dim3(grid), dim3(WG), lds, st, c, k0, k1);
+        else hipLaunchKernelGGL((k_xf<false, float>), dim3(grid), dim3(WG), lds, st, c, k0, k1);
     }
 }
 static void launch_state_update(const UlcxEncCtx &c, hipStream_t st) {
@@ -3117,24 +3045,27 @@ static void launch_state_update(const UlcxEncCtx &c, hipStream_t st) {
 const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES_REPORTED] = {
     "k_wc_energy", "k_wc_forward", "k_wc_backward", "k_wc_integrate", "k_wc_decide",
     "k_xf", "k_cplx", "k_pbark", "k_mask",
-    "k_select", "k_nbark", "k_nline", "k_heapsel", "k_gapsums", "k_tailsums", "k_encode_wave", "k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update", "wc_pipeline_exposed",
+    "k_select", "k_nbark", "k_nline", "k_heapsel", "k_gapsums", "k_tailsums", "k_encode_wave", "k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update", "wc_pipeline_exposed", "k_xf_fix",
 };
 
 int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const UlcxEncAux &aux) {
     UlcxEncCtx c = cIn;                                        // (keyFinal is set below for geometries without a wave selection kernel)
-    hipStream_t side = aux.side, side2 = aux.side2, side3 = aux.side3, side4 = aux.side4;
+    hipStream_t side = aux.side, side2 = aux.side2, side3 = aux.side3;
     hipEvent_t evFork = aux.evFork, evJoin = aux.evJoin, evFork2 = aux.evFork2, *evWC = aux.evWC;
     const int wcPipe = (side && side2 && side3) ? aux.wcPipe : 1;
     if (aux.nXf) *aux.nXf = 0;
     if (c.mode != ULCX_MODE_VBR) CK(hipMemsetAsync(c.cbrLive, 0, sizeof(int), st));
     if (c.barkRing) CK(hipMemsetAsync(c.decCount, 0, sizeof(int), st));           // k_xf lists this call's decimated blocks
+    CK(hipMemsetAsync(c.xfCount, 0, sizeof(int), st));                             // k_xf_list: blocks the speculative transform got wrong
     int NB = c.B * c.K;
     int stage = 0;
 #define MARK() do { if (ev) CK(hipEventRecord(ev[stage++], st)); } while (0)
     MARK();
-    // --- window control
+    // --- window control + transform
     hipEvent_t *evX = evWC + 7 + 3 * ULCX_WC_MAXCH;            // [ULCX_XF_MAXCH] transform chunk done, [ULCX_XF_MAXCH]: all early k_cplx launches done
-    const bool cplxEarly = wcPipe > 1 && side && side2 && side3 && aux.cplxEarly;
+    // the headline geometry transforms every block at once as if in the steady state and repairs the rest (k_xf_spec)
+    const bool spec = wcPipe > 1 && aux.xfSpec && c.C == 2 && c.BS == 2048 && aux.xfSlots > 0;
+    const bool cplxEarly = wcPipe > 1 && !spec;               // the ordered complexity sums per transform chunk, beside the next chunk
     {
         int SG = (c.B + 63) / 64;
         // Chunks of blocks: the window-control kernels of chunk j+1.. (two stream-long serial recurrences, a few
@@ -3165,53 +3096,47 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         };
         if (nCh <= 1) {
             int rc = launch_wc(st, 0, c.K, true); if (rc) return rc;
-            launch_xf(c, ((NB + 7) / 8) * 8, lds, st, 0, c.K, aux.xfRun);
+            launch_xf(c, ((NB + 7) / 8) * 8, lds, st, 0, c.K);
             MARK();
         } else {
             for (int i = 0; i < 5; i++) MARK();                    // (window-control stages: hidden in the k_xf interval in this mode)
-            // side: energy_j, forward_j (the sample-rate chain, back to back over the chunks);
-            // side2: backward_j behind forward_j;  side3: integrate_j, decide_j behind backward_j;
-            // main: xf_j behind decide_j.  The first chunk is a single block so the transform starts early.
-            hipEvent_t ev0 = evWC[0], *evF = evWC + 1, *evB = evWC + 1 + ULCX_WC_MAXCH, *evD = evWC + 1 + 2 * ULCX_WC_MAXCH, *evE = aux.evE;
+            // side: envelope + forward recurrence of step w (the sample-rate chain, back to back over the steps);
+            // side2: backward_w behind forward_w;  side3: integrate_w, decide_w behind backward_w;
+            // main: the transform - every block at once (spec), or chunk j behind the step that decides its last block.
+            hipEvent_t ev0 = evWC[0], *evF = evWC + 1, *evB = evWC + 1 + ULCX_WC_MAXCH, *evD = evWC + 1 + 2 * ULCX_WC_MAXCH;
             // The window-control kernels advance in uniform steps of a few blocks (ULCX_WC_STEPS; 0 = in the same chunks as
-            // the transform: first chunk one block, then thirds), and a transform chunk is launched as soon as the step
-            // holding its last block is decided.  Measured on the bench shape with the fused envelope/forward kernel:
-            // 4 steps 8.65-8.70 ms per step, 8 steps 8.73-8.81, 16 steps 8.9-9.0 (every launch of a chain kernel costs its
-            // fixed latency, and a step that has to be dispatched beside a transform chunk waits for its workgroup slots).
+            // the transform: first chunk one block, then thirds).  Measured with the chunked transform: 4 steps 8.65-8.70 ms
+            // per step of 65536 blocks, 8 steps 8.73-8.81, 16 steps 8.9-9.0 (every launch of a chain kernel costs its fixed
+            // latency, and a step that has to be dispatched beside a transform chunk waits for its workgroup slots).
             int nW = aux.wcSteps;
             if (nW < 0) nW = (c.K >= 8) ? 4 : 0;                               // default: 4 uniform steps (of >= 2 blocks)
             if (nW > ULCX_WC_MAXCH) nW = ULCX_WC_MAXCH;
             if (nW > c.K) nW = c.K;
-            bool sameCuts = nW < 1;
+            const bool sameCuts = nW < 1;
             if (sameCuts) nW = nCh;
             int cut[ULCX_XF_MAXCH + 1];
             cut[0] = 0; cut[1] = 1;
             for (int j = 2; j <= nCh; j++) cut[j] = 1 + (c.K - 1) * (j - 1) / (nCh - 1);
-            // explicit schedules (the encoder's ladder for this K, or ULCX_WC_LADDER / ULCX_XF_LADDER): window-control steps
-            // wcs[] and transform chunks cut[] as cumulative block counts
             int wcs[ULCX_WC_MAXCH + 1];
-            const bool ladder = aux.nWcCut > 0 && aux.nXfCut > 0 && aux.wcCut[aux.nWcCut] == c.K && aux.xfCut[aux.nXfCut] == c.K;
-            if (ladder) {
-                nW = aux.nWcCut; for (int j = 0; j <= nW; j++) wcs[j] = aux.wcCut[j];
-                for (int j = 0; j <= aux.nXfCut; j++) cut[j] = aux.xfCut[j];
-                sameCuts = false;
-            } else for (int w = 0; w <= nW; w++) wcs[w] = sameCuts ? cut[w] : (int)((long long)c.K * w / nW);
-            const int nChX = ladder ? aux.nXfCut : nCh;
+            for (int w = 0; w <= nW; w++) wcs[w] = sameCuts ? cut[w] : (int)((long long)c.K * w / nW);
             CK(hipEventRecord(ev0, st));
             CK(hipStreamWaitEvent(side, ev0, 0));
-            if (side4) CK(hipStreamWaitEvent(side4, ev0, 0));
+            if (spec) {
+                if (ev) CK(hipEventRecord(aux.evXf[0], st));
+                if (!(ULCX_DBG(c) & 0x2000)) {
+                    const unsigned g = (unsigned)(NB < aux.xfSlots ? NB : aux.xfSlots);
+                    if (c.pcm16) hipLaunchKernelGGL(k_xf_spec<int16_t>, dim3(g), dim3(WG), lds, st, c);
+                    else hipLaunchKernelGGL(k_xf_spec<float>, dim3(g), dim3(WG), lds, st, c);
+                }
+                if (ev) CK(hipEventRecord(aux.evXf[1], st));
+            }
             int jx = 0;                                        // next transform chunk to enqueue
             for (int w = 0; w < nW; w++) {
                 const int k0 = wcs[w], k1 = wcs[w + 1], kc = k1 - k0;
-                // (optionally the envelope kernel gets its own stream, ULCX_WC_ESTREAM=1; measured slower: beside it the
-                //  chain kernels slow down by more than the time it takes between two links of the chain)
-                hipStream_t es = side4 ? side4 : side;
-                if (side4 && w >= 2) CK(hipStreamWaitEvent(side4, evF[w - 2], 0));      // run ahead of the chain by one step only
-                if (wcFuse && !side4) launch_wc_ef(c, side, k0, k1);
+                if (wcFuse) launch_wc_ef(c, side, k0, k1);
                 else {
-                launch_wc_energy(c, (unsigned)(SG * ((kc * c.BS) / 64)), es, k0, k1);
-                if (side4) { CK(hipEventRecord(evE[w], side4)); CK(hipStreamWaitEvent(side, evE[w], 0)); }
-                hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, side, c, k0, k1);
+                    launch_wc_energy(c, (unsigned)(SG * ((kc * c.BS) / 64)), side, k0, k1);
+                    hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, side, c, k0, k1);
                 }
                 CK(hipEventRecord(evF[w], side));
                 CK(hipStreamWaitEvent(side2, evF[w], 0));
@@ -3222,25 +3147,35 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                 hipLaunchKernelGGL(k_wc_decide, dim3((c.B * kc + 63) / 64), dim3(64), 0, side3, c, k0, k1);
                 CK(hipEventRecord(evD[w], side3));
                 // transform chunks whose last block is now decided
-                while (jx < nChX && cut[jx + 1] <= k1) {
+                while (!spec && jx < nCh && cut[jx + 1] <= k1) {
                     int x0 = cut[jx], x1 = cut[jx + 1];
                     int nbk = c.B * (x1 - x0);
                     CK(hipStreamWaitEvent(st, evD[w], 0));
                     if (ev) CK(hipEventRecord(aux.evXf[2 * jx], st));
                     if (!(ULCX_DBG(c) & 0x2000))               // (ablation build: window control alone)
-                    launch_xf(c, ((nbk + 7) / 8) * 8, lds, st, x0, x1, aux.xfRun);
+                    launch_xf(c, ((nbk + 7) / 8) * 8, lds, st, x0, x1);
                     if (ev) CK(hipEventRecord(aux.evXf[2 * jx + 1], st));
                     if (cplxEarly) CK(hipEventRecord(evX[jx], st));
                     jx++;
                 }
             }
-            if (aux.nXf) *aux.nXf = nChX;
+            if (spec) {
+                // every window of the call is decided: list the blocks that are not in the steady state and transform them again
+                CK(hipStreamWaitEvent(st, evD[nW - 1], 0));
+                if (ev) CK(hipEventRecord(aux.evXf[2], st));
+                if (!(ULCX_DBG(c) & 0x2000)) {
+                    const unsigned g = (unsigned)(NB < aux.xfSlots ? NB : aux.xfSlots);
+                    if (c.pcm16) { hipLaunchKernelGGL(k_xf_list<int16_t>, dim3((NB + 63) / 64), dim3(64), 0, st, c); hipLaunchKernelGGL(k_xf_fix<int16_t>, dim3(g), dim3(WG), lds, st, c); }
+                    else { hipLaunchKernelGGL(k_xf_list<float>, dim3((NB + 63) / 64), dim3(64), 0, st, c); hipLaunchKernelGGL(k_xf_fix<float>, dim3(g), dim3(WG), lds, st, c); }
+                }
+                if (ev) CK(hipEventRecord(aux.evXf[3], st));
+            }
+            if (aux.nXf) *aux.nXf = spec ? -2 : nCh;               // (-2: a speculative launch and its repair, two event pairs)
             MARK();
-            // ULCX_CPLX_EARLY=1: the ordered complexity sums (k_cplx: lane-serial, HBM-bound) per transform chunk, on the envelope
-            // kernels' stream (all of those are enqueued by now): only the last chunk's are left beside k_pbark (0.40 -> 0.28 ms
-            // there) - but the transform's launches get 0.06..0.1 ms longer; 0.04 ms per encode at best, within the noise: off
+            // the ordered complexity sums (k_cplx: lane-serial, HBM-bound) per transform chunk, on the envelope kernels' stream
+            // (all of those are enqueued by now): only the last chunk's are left beside the masking sums
             if (cplxEarly) {
-                for (int j = 0; j < nChX; j++) {
+                for (int j = 0; j < nCh; j++) {
                     CK(hipStreamWaitEvent(side, evX[j], 0));
                     const int kc2 = cut[j + 1] - cut[j];
                     hipLaunchKernelGGL(k_cplx, dim3((c.B * kc2 + 63) / 64), dim3(64), 0, side, c, cut[j], cut[j + 1]);
@@ -3258,14 +3193,13 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         CK(hipFuncSetAttribute((const void *)k_bark_uniform<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)barkLds));
         CK(hipFuncSetAttribute((const void *)k_bark_uniform<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)barkLds));
     }
-    const bool fusedNoise = aux.fusedNoise && c.useGapSums && c.useWave;
     auto launch_noise = [&](hipStream_t s2, bool ev0) -> int {
         if (c.barkRing) {
             hipLaunchKernelGGL(k_bark_uniform<true>, dim3((NB * c.C + 63) / 64), dim3(256), barkLds, s2, c);
             hipLaunchKernelGGL(k_bark_levels<true>, dim3((unsigned)(((size_t)NB * c.C * 32 + WG - 1) / WG)), dim3(WG), 0, s2, c);
         }
         hipLaunchKernelGGL(k_nbark, dim3((nUnits + 63) / 64), dim3(64), 0, s2, c, c.barkRing ? 1 : 0);    if (ev0) MARK();
-        if (!fusedNoise) hipLaunchKernelGGL(k_nline, dim3(NB), dim3(WG), 0, s2, c);                 // (fused: k_gapsums<true> forms the pairs)
+        hipLaunchKernelGGL(k_nline, dim3(NB), dim3(WG), 0, s2, c);
         if (ev0) MARK();
         return ULCX_OK;
     };
@@ -3288,14 +3222,14 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         launch_state_update(c, side3);
         CK(hipEventRecord(evState, side3));
     } else { hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c, 0, c.K);                 MARK(); }
-    const bool noiseEarly = noiseAside && aux.noiseEarly;      // the noise chain right behind the transform (it only needs nsum), beside the masking sums
+    const bool noiseEarly = noiseAside;                        // the noise chain right behind the transform (it only needs nsum), beside the masking sums
     if (noiseEarly) {
         CK(hipStreamWaitEvent(side2, evN0, 0));
         int rcn = launch_noise(side2, false); if (rcn) return rcn;
         CK(hipEventRecord(evNoise, side2));
     }
     {
-        const bool uniP = c.barkRing && aux.barkUniP;       // (psycho sums: one wave per SIMD either way, no gain measured)
+        const bool uniP = c.barkRing != 0;                  // masking sums of the un-decimated blocks on the geometry-uniform kernel too
         if (uniP) {
             hipLaunchKernelGGL(k_bark_uniform<false>, dim3((NB + 63) / 64), dim3(256), barkLds, st, c);
             hipLaunchKernelGGL(k_bark_levels<false>, dim3((unsigned)(((size_t)NB * 32 + WG - 1) / WG)), dim3(WG), 0, st, c);
@@ -3369,14 +3303,9 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     auto launch_encode = [&](UlcxEncCtx cc, hipStream_t s2, int fin, bool ev0, bool bigFirst) -> int {
         const bool fb2 = (cc.fbMode == 2);                 // exact path: small grids that walk the list of owned blocks
         const int fbW = NB < 128 ? NB : 128;
-        if (cc.useGapSums && fusedNoise) {
-            const size_t glds = (size_t)N * 4 + N / 8 + 8 * (E_GAPCAP(N) + 20 * cc.C) + 16 + 8 * ((N / 32 + 63) / 64) + (size_t)cc.C * 4 * ULCX_NBARK * 4;
-            if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
-            hipLaunchKernelGGL(k_gapsums<true>, dim3(fb2 ? fbW : NB), dim3(WG), glds, s2, cc, fin);
-            if (ev0 && ev) { CK(hipEventRecord(ev[stage++], s2)); CK(hipEventRecord(ev[stage++], s2)); }
-        } else if (cc.useGapSums) {
+        if (cc.useGapSums) {
             size_t glds = (size_t)N * 4 + N / 8 + 8 * E_GAPCAP(N) + 16 + 8 * ((N / 32 + 63) / 64);
-            if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+            if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
             // the two speculative-sum kernels are independent and both latency-bound: on the main path k_tailsums
             // runs on a side stream beside k_gapsums
             const bool tailAside = !fb2 && side2 != nullptr && s2 == st;
@@ -3386,7 +3315,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                 hipLaunchKernelGGL(k_tailsums, dim3((nUnits * 8 + 63) / 64), dim3(64), 0, side2, cc, fin);
                 CK(hipEventRecord(evTail1, side2));
             }
-            hipLaunchKernelGGL(k_gapsums<false>, dim3(fb2 ? fbW : NB), dim3(WG), glds, s2, cc, fin);
+            hipLaunchKernelGGL(k_gapsums, dim3(fb2 ? fbW : NB), dim3(WG), glds, s2, cc, fin);
             if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
             if (tailAside) CK(hipStreamWaitEvent(s2, evTail1, 0));
             else hipLaunchKernelGGL(k_tailsums, dim3(fb2 ? fbW : (nUnits * 8 + 63) / 64), dim3(64), 0, s2, cc, fin);

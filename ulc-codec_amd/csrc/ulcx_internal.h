@@ -48,7 +48,8 @@ struct UlcxEncCtx {
     // geometry
     int B, K, C, BS, lgBS;               // streams, blocks this call, channels, block size
     int barkRing;                        // k_bark_uniform: snapshots a lane keeps of open Bark bands (power of two; 0 = k_nbark / k_pbark for every block)
-    int *decList, *decCount;             // blocks of this call with a decimated window (k_bark_classify): they take k_nbark / k_pbark
+    int *decList, *decCount;             // blocks of this call with a decimated window (listed by the transform): they take k_nbark / k_pbark
+    int *xfList, *xfCount;               // blocks of this call that are not in the steady state (k_xf_list): k_xf_fix transforms them again
     int maxK;                            // allocation stride for per-call arrays
     int slot;                            // bytes per output slot
     int unitCap;                         // bytes per (chan,subblock) nybble staging row = 2*BS+32 per channel
@@ -106,7 +107,7 @@ struct UlcxEncCtx {
 
 struct UlcxDecCtx {
     int B, K, C, BS, lgBS, maxK;
-    int s0, s1;                          // streams [s0, s1) this launch works on (ulcx_dec_launch pipelines chunks of the batch)
+    int s0, s1;                          // streams [s0, s1) this launch works on
     int slot;
     int dbgSkip;                         // timing experiments only (ULCX_DBG_SKIP)
     UlcxTables T;
@@ -162,7 +163,7 @@ void ulcx_set_error(const char *fmt, ...);
 
 // launchers (ulcx_enc.hip / ulcx_dec.hip)
 #define ULCX_ENC_STAGES 20
-#define ULCX_ENC_STAGES_REPORTED (ULCX_ENC_STAGES + 1)   // + "wc_pipeline_exposed" (computed, not an event interval)
+#define ULCX_ENC_STAGES_REPORTED (ULCX_ENC_STAGES + 2)   // + "wc_pipeline_exposed", "k_xf_fix" (computed from the transform's own event pairs)
 extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES_REPORTED];
 #define ULCX_DEC_STAGES 2
 #define ULCX_WC_MAXCH 32    // fine steps of the window-control pipeline per call
@@ -171,30 +172,17 @@ extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES_REPORTED];
 // streams and events the encoder launch uses beside the caller's stream
 struct UlcxEncAux {
     hipStream_t side, side2, side3;      // NULL: everything on the caller's stream
-    hipStream_t side4;                   // envelope kernel of the window-control pipeline (NULL: shares `side`)
-    hipEvent_t *evE;                     // [ULCX_WC_MAXCH]
     hipEvent_t evFork, evJoin, evFork2;  // exact-path fork/join
     hipEvent_t *evWC;                    // [7 + 3*ULCX_WC_MAXCH] window-control pipeline; then noise-spectrum fork/join, k_cplx join, k_tailsums fork/join, k_state_update join
-    hipEvent_t *evXf;                    // [2*ULCX_XF_MAXCH] timing pairs around each transform chunk (used when ev != NULL)
+    hipEvent_t *evXf;                    // [2*ULCX_XF_MAXCH] timing pairs around each transform launch (used when ev != NULL)
     int wcPipe;                          // chunks of blocks pipelined between window control and transform; 1 = off
     int wcSteps;                         // fine steps of the window-control kernels per call (ULCX_WC_STEPS)
-    int fusedNoise;                      // k_gapsums forms the noise pairs and takes the tail sums: no k_nline / k_tailsums (ULCX_FUSED_NOISE)
-    int cplxEarly, wcFuse, barkUniP;     // ULCX_CPLX_EARLY / ULCX_WC_FUSE / ULCX_BARK_UNIFORM_P, read once when the encoder is created
-    int xfRun;                           // ULCX_XF_RUN: consecutive blocks of a stream one k_xf_fast workgroup takes (0: no separate kernel)
-    int noiseEarly;                      // ULCX_NOISE_EARLY: noise log-spectrum chain starts behind the transform, not behind the masking sums
-    int nWcCut, nXfCut;                  // explicit schedules (0 = derive from wcSteps / wcPipe): cumulative block counts, last = K
-    int wcCut[ULCX_WC_MAXCH + 1], xfCut[ULCX_XF_MAXCH + 1];
-    int *nXf;                            // out: transform chunk launches this call
+    int wcFuse;                          // ULCX_WC_FUSE, read once when the encoder is created
+    int xfSpec, xfSlots;                 // the headline geometry's speculative transform (k_xf_spec; ULCX_XF_SPEC=0: chunks); workgroups of it the device holds
+    int *nXf;                            // out: transform launches this call (-2: the speculative launch + its repair)
 };
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, const UlcxEncAux &aux);
-#define ULCX_DEC_MAXCH 8
 struct UlcxDecAux {
-    hipStream_t side;                    // NULL: no pipelining
-    hipEvent_t evFork, *evScan;          // [ULCX_DEC_MAXCH]
-    int nChunks;
-    int ldsPad;                          // ULCX_DSYN_PAD: extra dynamic LDS bytes per synthesis workgroup (occupancy experiments)
-    int scanLpw;                         // blocks (= live lanes) per wave of the syntax walk: 64, 32 or 16
-    int kHalves;                         // the walk of the second half of the blocks beside the synthesis of the first (ULCX_DEC_HALVES=0: off)
     int synGrid;                         // > 0: workgroups of the synthesis over an even cut of the (stream, block) pairs; 0: one per stream
 };
 int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev, const UlcxDecAux &aux);
