@@ -23,7 +23,7 @@ struct ulcx_encoder {
     hipStream_t side; hipEvent_t evFork, evJoin, evFork2; bool sideOk; bool timing;
     hipEvent_t evWC[7 + 3 * ULCX_WC_MAXCH + ULCX_XF_MAXCH + 1]; int wcPipe; hipStream_t side2, side3; hipEvent_t evXf[2 * ULCX_XF_MAXCH]; int nXf;      // window-control / transform pipeline (ULCX_WC_PIPE chunks, default 4)
     bool keysFinal;
-    int wcSteps, wcFuse, xfSpec, xfSlots;      // environment switches, read once at create; resident workgroups of the transform kernels
+    int wcSteps, wcFuse, xfSpec, xfSlots, xfRun;      // environment switches, read once at create; resident workgroups of the transform kernels
     // staging for the host-pointer API
     float *d_pcm; uint8_t *d_out; int32_t *d_bits, *d_wc; float *d_cplx;
     // single-block path (ulcx_encode_block1): own stream, pinned staging, the captured launch sequence
@@ -184,7 +184,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.barkN, NB * nChan * 4 * ULCX_NBARK, true);
     DA(c.barkP, NB * 4 * ULCX_NBARK, true);
     if (c.barkRing) { DA(c.barkRawN, NB * nChan * ULCX_NBARK * 3, false); DA(c.barkRawP, NB * ULCX_NBARK * 3, false); DA(c.decList, NB, false); DA(c.decCount, 1, true); }
-    DA(c.xfList, NB, false); DA(c.xfCount, 1, true);
+    DA(c.xfList, NB, false); DA(c.xfCount, ULCX_WC_MAXCH, true);
     DA(c.nnz, NB, true);
     DA(c.cplx, NB, true);
     DA(c.nout, NB, true);
@@ -235,7 +235,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
         // stereo BlockSize 2048: every block transformed at once as if in the steady state, beside window control, the rest
         // repaired behind it (k_xf_spec / k_xf_fix); ULCX_XF_SPEC=0: the transform in chunks behind the window decisions
         { const char *v = getenv("ULCX_XF_SPEC"); e->xfSpec = (v && v[0] == '0') ? 0 : 1; }
-        e->xfSlots = 0;
+        e->xfSlots = 0; e->xfRun = 8; if (const char *v = getenv("ULCX_XF_RUN")) { int n = atoi(v); if (n >= 1 && n <= 4096) e->xfRun = n; }
         { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) e->xfSlots = 4 * cus; else (void)hipGetLastError(); }
     }
     DA(c.isFb, NB, true);
@@ -271,7 +271,7 @@ static int encode_dev_any(ulcx_encoder *e, int mode, float p0, float p1, const f
     aux.side = e->sideOk ? e->side : nullptr; aux.side2 = e->sideOk ? e->side2 : nullptr; aux.side3 = e->sideOk ? e->side3 : nullptr;
     aux.evFork = e->evFork; aux.evJoin = e->evJoin; aux.evFork2 = e->evFork2; aux.evWC = e->evWC; aux.evXf = e->evXf;
     aux.wcPipe = (nBlocks >= 2 * e->wcPipe) ? e->wcPipe : (nBlocks >= 6 && e->wcPipe > 1 ? 3 : 1); aux.nXf = &e->nXf;
-    aux.wcSteps = e->wcSteps; aux.wcFuse = e->wcFuse; aux.xfSpec = e->xfSpec; aux.xfSlots = e->xfSlots;
+    aux.wcSteps = e->wcSteps; aux.wcFuse = e->wcFuse; aux.xfSpec = e->xfSpec; aux.xfSlots = e->xfSlots; aux.xfRun = e->xfRun;
     const int rc = ulcx_enc_launch(c, (hipStream_t)hipStream, e->timing ? e->ev : nullptr, aux);
     e->evRecorded = (rc == ULCX_OK) && e->timing;
     e->lastK = nBlocks;

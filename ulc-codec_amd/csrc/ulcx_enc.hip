@@ -920,11 +920,14 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
 // The results are those of transforming every block once with its real window; the price is the listed blocks twice.
 // ---------------------------------------------------------------------------
 template <typename IN>
-__global__ __launch_bounds__(WG, 4) void k_xf_spec(UlcxEncCtx c) {
+__global__ __launch_bounds__(WG, 4) void k_xf_spec(UlcxEncCtx c, int run) {
     extern __shared__ float lds[];
     constexpr int BS = 2048;
-    const long long T = (long long)c.B * c.K;
-    const int f0 = (int)(T * blockIdx.x / gridDim.x), f1 = (int)(T * (blockIdx.x + 1) / gridDim.x);
+    // a workgroup = a run of consecutive (stream, block) pairs: long enough to pay for the twiddle copy and to find every
+    // first half frame but the run's first in L2, short enough that workgroups keep retiring (a grid of persistent
+    // workgroups holds every CU's LDS until the end: kernels launched beside it wait for a place)
+    const int NB = c.B * c.K;
+    const int f0 = blockIdx.x * run, f1 = min(f0 + run, NB);
     int &s_nnz = *(int *)(lds + 4 * FFT_PADDEDS(BS, 4) + BS / 2);
     const int tidOuter = threadIdx.x;
     bool haveTw = false;
@@ -948,28 +951,31 @@ __global__ __launch_bounds__(WG, 4) void k_xf_spec(UlcxEncCtx c) {
         if (tid == 0) c.nnz[vb] = s_nnz;
     }
 }
+// blocks [k0, k1) of every stream (a window-control step: their windows and their neighbours' are decided): the ones that
+// are not in the steady state, into the step's own segment of the list (it starts at B * k0; counter w)
 template <typename IN>
-__global__ __launch_bounds__(64) void k_xf_list(UlcxEncCtx c) {
-    const int gid = blockIdx.x * 64 + threadIdx.x;
-    const bool in = gid < c.B * c.K;
-    const int s = in ? gid / c.K : 0, k = in ? gid % c.K : 0;
+__global__ __launch_bounds__(64) void k_xf_list(UlcxEncCtx c, int k0, int k1, int w) {
+    const int gid = blockIdx.x * 64 + threadIdx.x, kc = k1 - k0;
+    const bool in = gid < c.B * kc;
+    const int s = in ? gid / kc : 0, k = in ? k0 + gid % kc : k0;
     const bool slow = in && !xf_is_fast<IN>(c, s, k);
     const unsigned long long m = __ballot(slow);
     if (!m) return;
     int base = 0;
-    if (threadIdx.x == 0) base = atomicAdd(c.xfCount, __popcll(m));
+    if (threadIdx.x == 0) base = atomicAdd(c.xfCount + w, __popcll(m));
     base = __builtin_amdgcn_readfirstlane(base);
-    if (slow) c.xfList[base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = gid;
+    if (slow) c.xfList[(size_t)c.B * k0 + base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = s * c.K + k;
 }
 template <typename IN>
-__global__ __launch_bounds__(WG, 4) void k_xf_fix(UlcxEncCtx c) {
+__global__ __launch_bounds__(WG, 4) void k_xf_fix(UlcxEncCtx c, int k0, int w) {
     extern __shared__ float lds[];
-    const int n = *c.xfCount;
+    const int n = c.xfCount[w];
+    const int *list = c.xfList + (size_t)c.B * k0;
     const int tidOuter = threadIdx.x;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         int tid = tidOuter;
         asm volatile("" : "+v"(tid));                          // (nothing that depends on the thread only is hoisted out of the loop and held in registers)
-        const int blk = c.xfList[i];
+        const int blk = list[i];
         xf_block<true, IN, false>(c, lds, blk / c.K, blk % c.K, tid);
         __syncthreads();
     }
@@ -3056,7 +3062,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     if (aux.nXf) *aux.nXf = 0;
     if (c.mode != ULCX_MODE_VBR) CK(hipMemsetAsync(c.cbrLive, 0, sizeof(int), st));
     if (c.barkRing) CK(hipMemsetAsync(c.decCount, 0, sizeof(int), st));           // k_xf lists this call's decimated blocks
-    CK(hipMemsetAsync(c.xfCount, 0, sizeof(int), st));                             // k_xf_list: blocks the speculative transform got wrong
+    CK(hipMemsetAsync(c.xfCount, 0, sizeof(int) * ULCX_WC_MAXCH, st));             // k_xf_list: blocks the speculative transform got wrong, per window-control step
     int NB = c.B * c.K;
     int stage = 0;
 #define MARK() do { if (ev) CK(hipEventRecord(ev[stage++], st)); } while (0)
@@ -3121,15 +3127,18 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             for (int w = 0; w <= nW; w++) wcs[w] = sameCuts ? cut[w] : (int)((long long)c.K * w / nW);
             CK(hipEventRecord(ev0, st));
             CK(hipStreamWaitEvent(side, ev0, 0));
-            if (spec) {
+            auto launch_spec = [&]() -> int {
                 if (ev) CK(hipEventRecord(aux.evXf[0], st));
                 if (!(ULCX_DBG(c) & 0x2000)) {
-                    const unsigned g = (unsigned)(NB < aux.xfSlots ? NB : aux.xfSlots);
-                    if (c.pcm16) hipLaunchKernelGGL(k_xf_spec<int16_t>, dim3(g), dim3(WG), lds, st, c);
-                    else hipLaunchKernelGGL(k_xf_spec<float>, dim3(g), dim3(WG), lds, st, c);
+                    const int run = aux.xfRun > 0 ? aux.xfRun : 8;
+                    const unsigned g = (unsigned)((NB + run - 1) / run);
+                    if (c.pcm16) hipLaunchKernelGGL(k_xf_spec<int16_t>, dim3(g), dim3(WG), lds, st, c, run);
+                    else hipLaunchKernelGGL(k_xf_spec<float>, dim3(g), dim3(WG), lds, st, c, run);
                 }
                 if (ev) CK(hipEventRecord(aux.evXf[1], st));
-            }
+                if (ev) CK(hipEventRecord(aux.evXf[2], st));      // (the repair launches: their own pair, the waits between them included)
+                return ULCX_OK;
+            };
             int jx = 0;                                        // next transform chunk to enqueue
             for (int w = 0; w < nW; w++) {
                 const int k0 = wcs[w], k1 = wcs[w + 1], kc = k1 - k0;
@@ -3139,6 +3148,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                     hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, side, c, k0, k1);
                 }
                 CK(hipEventRecord(evF[w], side));
+                if (spec && w == 0) { int rcs = launch_spec(); if (rcs) return rcs; }      // (behind the chain's first kernel: that one finds its slots free)
                 CK(hipStreamWaitEvent(side2, evF[w], 0));
                 hipLaunchKernelGGL(k_wc_backward, dim3(SG * kc), dim3(64), 0, side2, c, k0, k1);
                 CK(hipEventRecord(evB[w], side2));
@@ -3146,6 +3156,15 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                 hipLaunchKernelGGL(k_wc_integrate, dim3((c.B + 63) / 64), dim3(64), 0, side3, c, k0, k1);
                 hipLaunchKernelGGL(k_wc_decide, dim3((c.B * kc + 63) / 64), dim3(64), 0, side3, c, k0, k1);
                 CK(hipEventRecord(evD[w], side3));
+                if (spec && !(ULCX_DBG(c) & 0x2000)) {
+                    // the step's windows (and their neighbours') are decided: list its blocks that are not in the steady
+                    // state and transform them again, behind the speculative launch on the caller's stream
+                    CK(hipStreamWaitEvent(st, evD[w], 0));
+                    const int nbk = c.B * kc;
+                    const unsigned g = (unsigned)(nbk < aux.xfSlots ? nbk : aux.xfSlots);
+                    if (c.pcm16) { hipLaunchKernelGGL(k_xf_list<int16_t>, dim3((nbk + 63) / 64), dim3(64), 0, st, c, k0, k1, w); hipLaunchKernelGGL(k_xf_fix<int16_t>, dim3(g), dim3(WG), lds, st, c, k0, w); }
+                    else { hipLaunchKernelGGL(k_xf_list<float>, dim3((nbk + 63) / 64), dim3(64), 0, st, c, k0, k1, w); hipLaunchKernelGGL(k_xf_fix<float>, dim3(g), dim3(WG), lds, st, c, k0, w); }
+                }
                 // transform chunks whose last block is now decided
                 while (!spec && jx < nCh && cut[jx + 1] <= k1) {
                     int x0 = cut[jx], x1 = cut[jx + 1];
@@ -3159,17 +3178,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                     jx++;
                 }
             }
-            if (spec) {
-                // every window of the call is decided: list the blocks that are not in the steady state and transform them again
-                CK(hipStreamWaitEvent(st, evD[nW - 1], 0));
-                if (ev) CK(hipEventRecord(aux.evXf[2], st));
-                if (!(ULCX_DBG(c) & 0x2000)) {
-                    const unsigned g = (unsigned)(NB < aux.xfSlots ? NB : aux.xfSlots);
-                    if (c.pcm16) { hipLaunchKernelGGL(k_xf_list<int16_t>, dim3((NB + 63) / 64), dim3(64), 0, st, c); hipLaunchKernelGGL(k_xf_fix<int16_t>, dim3(g), dim3(WG), lds, st, c); }
-                    else { hipLaunchKernelGGL(k_xf_list<float>, dim3((NB + 63) / 64), dim3(64), 0, st, c); hipLaunchKernelGGL(k_xf_fix<float>, dim3(g), dim3(WG), lds, st, c); }
-                }
-                if (ev) CK(hipEventRecord(aux.evXf[3], st));
-            }
+            if (spec && ev) CK(hipEventRecord(aux.evXf[3], st));
             if (aux.nXf) *aux.nXf = spec ? -2 : nCh;               // (-2: a speculative launch and its repair, two event pairs)
             MARK();
             // the ordered complexity sums (k_cplx: lane-serial, HBM-bound) per transform chunk, on the envelope kernels' stream

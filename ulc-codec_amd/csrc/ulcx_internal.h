@@ -178,7 +178,7 @@ struct UlcxEncAux {
     int wcPipe;                          // chunks of blocks pipelined between window control and transform; 1 = off
     int wcSteps;                         // fine steps of the window-control kernels per call (ULCX_WC_STEPS)
     int wcFuse;                          // ULCX_WC_FUSE, read once when the encoder is created
-    int xfSpec, xfSlots;                 // the headline geometry's speculative transform (k_xf_spec; ULCX_XF_SPEC=0: chunks); workgroups of it the device holds
+    int xfSpec, xfSlots, xfRun;          // the headline geometry's speculative transform (k_xf_spec; ULCX_XF_SPEC=0: chunks); workgroups of it the device holds; blocks per workgroup
     int *nXf;                            // out: transform launches this call (-2: the speculative launch + its repair)
 };
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, const UlcxEncAux &aux);
