@@ -483,16 +483,15 @@ def test_runtime_switches_keep_parity(env):
                 os.environ[k] = v
 
 @pytest.mark.parametrize("env,B,K", [
-    ({}, 6, 16),                                   # the default: every block transformed at once as if in the steady state, the rest repaired
-    ({"ULCX_XF_SPEC": "0"}, 6, 16),                # the transform in chunks behind the window decisions (what every other geometry does)
+    ({}, 6, 16),
     ({"ULCX_WC_STEPS": "8"}, 6, 16),
     ({"ULCX_WC_PIPE": "1"}, 6, 16),
-    ({}, 300, 8),                                  # more (stream, block) pairs than the speculative transform has workgroups
+    ({}, 300, 8),
     ({"ULCX_DSYN_SPLIT": "0"}, 6, 16),
 ])
 def test_headline_geometry_schedules_keep_parity(env, B, K):
-    """The launch structures of the headline geometry - stereo, BlockSize 2048, where the speculative transform and its
-    repair launch exist: encode vs the oracle over two calls (state carry, window switching), decode vs the oracle."""
+    """The launch structures of the headline geometry - stereo, BlockSize 2048, where the transform's steady-state path
+    exists: encode vs the oracle over two calls (state carry, window switching), decode vs the oracle."""
     amd = _amd()
     bs, ch, rate = 2048, 2, 44100
     pcm = _streams(B, 2 * K, bs, ch, rate, True, seed=4242)

@@ -23,7 +23,7 @@ struct ulcx_encoder {
     hipStream_t side; hipEvent_t evFork, evJoin, evFork2; bool sideOk; bool timing;
     hipEvent_t evWC[7 + 3 * ULCX_WC_MAXCH + ULCX_XF_MAXCH + 1]; int wcPipe; hipStream_t side2, side3; hipEvent_t evXf[2 * ULCX_XF_MAXCH]; int nXf;      // window-control / transform pipeline (ULCX_WC_PIPE chunks, default 4)
     bool keysFinal;
-    int wcSteps, wcFuse, xfSpec, xfSlots, xfRun;      // environment switches, read once at create; resident workgroups of the transform kernels
+    int wcSteps, wcFuse;      // environment switches, read once at create
     // staging for the host-pointer API
     float *d_pcm; uint8_t *d_out; int32_t *d_bits, *d_wc; float *d_cplx;
     // single-block path (ulcx_encode_block1): own stream, pinned staging, the captured launch sequence
@@ -184,7 +184,6 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.barkN, NB * nChan * 4 * ULCX_NBARK, true);
     DA(c.barkP, NB * 4 * ULCX_NBARK, true);
     if (c.barkRing) { DA(c.barkRawN, NB * nChan * ULCX_NBARK * 3, false); DA(c.barkRawP, NB * ULCX_NBARK * 3, false); DA(c.decList, NB, false); DA(c.decCount, 1, true); }
-    DA(c.xfList, NB, false); DA(c.xfCount, ULCX_WC_MAXCH, true);
     DA(c.nnz, NB, true);
     DA(c.cplx, NB, true);
     DA(c.nout, NB, true);
@@ -232,11 +231,6 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
         if (const char *pv = getenv("ULCX_WC_PIPE")) { int n = atoi(pv); if (n >= 1 && n <= ULCX_XF_MAXCH && n != 2 && (n == 1 || e->sideOk)) e->wcPipe = n; }
         e->wcSteps = -1; if (const char *sv = getenv("ULCX_WC_STEPS")) e->wcSteps = atoi(sv);      // -1: default; 0: the transform's chunks
         { const char *v = getenv("ULCX_WC_FUSE"); e->wcFuse = (v && v[0] == '0') ? 0 : 1; }
-        // stereo BlockSize 2048: every block transformed at once as if in the steady state, beside window control, the rest
-        // repaired behind it (k_xf_spec / k_xf_fix); ULCX_XF_SPEC=0: the transform in chunks behind the window decisions
-        { const char *v = getenv("ULCX_XF_SPEC"); e->xfSpec = (v && v[0] == '0') ? 0 : 1; }
-        e->xfSlots = 0; e->xfRun = 8; if (const char *v = getenv("ULCX_XF_RUN")) { int n = atoi(v); if (n >= 1 && n <= 4096) e->xfRun = n; }
-        { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) e->xfSlots = 4 * cus; else (void)hipGetLastError(); }
     }
     DA(c.isFb, NB, true);
     DA(c.ownSlot, NB, true);
@@ -271,7 +265,7 @@ static int encode_dev_any(ulcx_encoder *e, int mode, float p0, float p1, const f
     aux.side = e->sideOk ? e->side : nullptr; aux.side2 = e->sideOk ? e->side2 : nullptr; aux.side3 = e->sideOk ? e->side3 : nullptr;
     aux.evFork = e->evFork; aux.evJoin = e->evJoin; aux.evFork2 = e->evFork2; aux.evWC = e->evWC; aux.evXf = e->evXf;
     aux.wcPipe = (nBlocks >= 2 * e->wcPipe) ? e->wcPipe : (nBlocks >= 6 && e->wcPipe > 1 ? 3 : 1); aux.nXf = &e->nXf;
-    aux.wcSteps = e->wcSteps; aux.wcFuse = e->wcFuse; aux.xfSpec = e->xfSpec; aux.xfSlots = e->xfSlots; aux.xfRun = e->xfRun;
+    aux.wcSteps = e->wcSteps; aux.wcFuse = e->wcFuse;
     const int rc = ulcx_enc_launch(c, (hipStream_t)hipStream, e->timing ? e->ev : nullptr, aux);
     e->evRecorded = (rc == ULCX_OK) && e->timing;
     e->lastK = nBlocks;
@@ -432,25 +426,22 @@ extern "C" int ulcx_encoder_stage_ms(ulcx_encoder *e, float *ms, int maxStages) 
         if (hipEventElapsedTime(&t, e->ev[i], e->ev[i + 1]) != hipSuccess) break;
         ms[n++] = t;
     }
-    // Pipelined window control: the k_xf interval spans start-up + waits + the transform's launches.  Report the launches
-    // themselves as k_xf (what a kernel trace shows: the chunks, or the one speculative launch over every block), the repair
-    // launch of the speculative transform as "k_xf_fix", and the rest of the interval as "wc_pipeline_exposed".
-    if (n == ULCX_ENC_STAGES && n + 1 < maxStages) {
+    // Pipelined window control: the k_xf interval spans start-up + waits + the transform chunk launches.
+    // Report the launches themselves as k_xf (what a kernel trace shows) and the rest as "wc_pipeline_exposed".
+    if (n == ULCX_ENC_STAGES && n < maxStages) {
         const int IX_XF = 5;
-        float exposed = 0.0f, fix = 0.0f;
-        const int pairs = e->nXf == -2 ? 2 : e->nXf;
-        if (pairs > 0) {
+        float exposed = 0.0f;
+        if (e->nXf > 0) {
             float sum = 0.0f; bool ok = true;
-            for (int j = 0; j < pairs; j++) { float t = 0; if (hipEventElapsedTime(&t, e->evXf[2 * j], e->evXf[2 * j + 1]) != hipSuccess) { ok = false; break; } sum += t; if (e->nXf == -2 && j == 1) fix = t; }
-            if (ok) { exposed = ms[IX_XF] - sum; ms[IX_XF] = sum - fix; }
+            for (int j = 0; j < e->nXf; j++) { float t = 0; if (hipEventElapsedTime(&t, e->evXf[2 * j], e->evXf[2 * j + 1]) != hipSuccess) { ok = false; break; } sum += t; }
+            if (ok) { exposed = ms[IX_XF] - sum; ms[IX_XF] = sum; }
         }
         ms[n++] = exposed;
-        ms[n++] = fix;
     }
     return n;
 }
 
-extern "C" int ulcx_encoder_last_xf_launches(ulcx_encoder *e) { return (e && e->evRecorded) ? (e->nXf > 0 ? e->nXf : 1) : 0; }     // (the speculative transform: one launch over every block)
+extern "C" int ulcx_encoder_last_xf_launches(ulcx_encoder *e) { return (e && e->evRecorded) ? (e->nXf > 0 ? e->nXf : 1) : 0; }
 
 // ---------------------------------------------------------------------------
 // decoder

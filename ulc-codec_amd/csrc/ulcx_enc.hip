@@ -528,11 +528,8 @@ __device__ __forceinline__ float win_apply(float x, int i, int S, int aL, int ov
 // block between two full-overlap neighbours (PCM16 ingest: from the call's third block on).  Same arithmetic, same
 // order as the general body of k_xf below (which documents it) - only the index arithmetic, the loop bounds and the window
 // selects fold away, and the four 1024-point transforms run the compile-time passes (fft_wave_dif_ct).
-// LOOP: the call sits inside a loop over blocks (k_xf_spec): the table loads and every index that depends on the thread only
-// do not depend on the block, and hoisted out of the loop they cost more registers than the 128-register cap of four
-// workgroups per CU has - opaque copies keep them where they are used; the full-size twiddles stay in LDS (haveTw).
-template <typename IN, bool LOOP>
-__device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int s, int k, int blk, int tid, bool haveTw, const uint32_t *touch = nullptr) {
+template <typename IN>
+__device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int s, int k, int blk, int tid) {
     constexpr int BS = 2048, S = 2048, M = 1024, PS = 4, Mp = FFT_PADDEDS(M, PS);
     static_assert(WG == 256, "two fold / epilogue trips per thread");
     float2 *z = (float2 *)lds;
@@ -540,10 +537,6 @@ __device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int
     float2 *zc0 = z, *zs0 = z + Mp, *zc1 = z + 2 * Mp, *zs1 = z + 3 * Mp;
     const float2 *pre = c.T.pre[0];
     const float *rise = c.T.winRise + S, *fall = c.T.winFall + S;
-    if (LOOP) {
-        asm volatile("" : "+s"(pre), "+s"(rise), "+s"(fall));
-        asm volatile("" : "+v"(tid));
-    }
     // frame = [(k-2) BS, k BS): its first half (positions < S) is block k-2, its second half block k-1 of the stream's
     // timeline; blocks -2 and -1 are the two the encoder keeps from the previous call (c.hist, always float)
     const IN *pcmS = pcm_base<IN>(c) + (size_t)s * c.K * BS * 2;
@@ -553,10 +546,8 @@ __device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int
         if (k < 2) frameLo = histS + (size_t)k * BS * 2;                      // block k-2 = history block k
         if (k < 1) frameHi = histS;                                            // block k-1 = history block 1: (hist + BS*2) - S*2
     }
-    if (!haveTw) {
 #pragma unroll
-        for (int i = tid; i < M / 2; i += WG) twl[i] = c.T.tw[0][i];
-    }
+    for (int i = tid; i < M / 2; i += WG) twl[i] = c.T.tw[0][i];
 #pragma unroll
     for (int jj0 = 0; jj0 < M / 2; jj0 += WG) {
         const int jj = jj0 + tid;
@@ -592,11 +583,6 @@ __device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int
         }
     }
     __syncthreads();
-    // (LOOP) one 4-byte load per 128-byte line of the half frame the workgroup's NEXT block adds: issued behind this block's
-    // own loads - the wave's memory counter is in order, a touch in front of them would make the fold wait for it - and
-    // with the whole transform to arrive in; nothing looks at the value before the end of the block
-    uint32_t touched = 0;
-    if (LOOP && touch) touched = *touch;
     fft_wave_dif_ct<M, PS>(z + __builtin_amdgcn_readfirstlane(tid >> 6) * Mp, twl, tid & 63);
     __syncthreads();
     float *coefO = c.coef + (size_t)blk * (2 * BS);
@@ -654,7 +640,6 @@ __device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int
         *(float2 *)(ampO + j1) = make_float2(am[0][0], am[0][1]);
         *(float2 *)(ampO + j2) = make_float2(am[1][0], am[1][1]);
     }
-    if (LOOP) asm volatile("" :: "v"(touched));
     return nnz;
 }
 
@@ -678,8 +663,7 @@ __device__ __forceinline__ bool xf_is_fast(const UlcxEncCtx &c, int s, int k) {
 }
 // One block (s, k) of the call by one workgroup: any window, any channel count up to BlockSize 8192.
 // ST: stereo instantiation (C = 2 as a compile-time constant: one channel pair, no per-pair branches)
-// FAST: the block may be in the steady state of the headline geometry (then it takes xf_fast_2048); k_xf_fix's blocks never are
-template <bool ST, typename IN, bool FAST = true>
+template <bool ST, typename IN>
 __device__ __forceinline__ void xf_block(const UlcxEncCtx &c, float *lds, int s, int k, const int tid) {
     const int BS = c.BS, C = ST ? 2 : c.C;
     const int blk = s * c.K + k;
@@ -713,8 +697,8 @@ __device__ __forceinline__ void xf_block(const UlcxEncCtx &c, float *lds, int s,
     __syncthreads();
 
     // the steady state of the headline geometry takes the all-constants path (xf_fast_2048)
-    const bool fastBlk = FAST && ST && BS == 2048 && xf_is_fast<IN>(c, s, k);
-    if (FAST && fastBlk) nnz = xf_fast_2048<IN, false>(c, lds, s, k, blk, tid, false);
+    const bool fastBlk = ST && BS == 2048 && xf_is_fast<IN>(c, s, k);
+    if (fastBlk) nnz = xf_fast_2048<IN>(c, lds, s, k, blk, tid);
     else
     for (int ch0 = 0; ch0 < C; ch0 += 2) {             // one M/S pair (or a trailing single channel) at a time
         const int nch = ST ? 2 : ((ch0 + 1 < C) ? 2 : 1);
@@ -904,81 +888,6 @@ __global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1) {
     const int vb = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
     if (vb >= NBk) return;
     xf_block<ST, IN>(c, lds, vb / kc, k0 + vb % kc, threadIdx.x);
-}
-
-// ---------------------------------------------------------------------------
-// The headline geometry (stereo, BlockSize 2048) does not wait for window control (round 4).  Nine blocks in ten are in
-// the steady state - an un-decimated block between two full-overlap neighbours - and which ones is only known once the
-// stream-serial transient chain has decided them, 1.8 ms into a 32-block call.  So:
-//   k_xf_spec  transforms EVERY block as if it were in the steady state, from the call's first microsecond, beside the
-//              window-control chain.  Persistent workgroups over an even cut of the (stream, block) pairs in stream-major
-//              order: consecutive blocks of a stream share half their frame (the second read hits L2), the twiddles are
-//              copied to LDS once per workgroup, and while block k is in the transform one lane per 128-byte line touches
-//              the new half frame of block k+1, so that its fold finds the samples in L2 instead of waiting for HBM.
-//   k_xf_list  once the call's windows are decided: the blocks whose window (or a neighbour's) is not the steady state.
-//   k_xf_fix   transforms exactly those again, with their real windows (the general body), over what k_xf_spec wrote.
-// The results are those of transforming every block once with its real window; the price is the listed blocks twice.
-// ---------------------------------------------------------------------------
-template <typename IN>
-__global__ __launch_bounds__(WG, 4) void k_xf_spec(UlcxEncCtx c, int run) {
-    extern __shared__ float lds[];
-    constexpr int BS = 2048;
-    // a workgroup = a run of consecutive (stream, block) pairs: long enough to pay for the twiddle copy and to find every
-    // first half frame but the run's first in L2, short enough that workgroups keep retiring (a grid of persistent
-    // workgroups holds every CU's LDS until the end: kernels launched beside it wait for a place)
-    const int NB = c.B * c.K;
-    const int f0 = blockIdx.x * run, f1 = min(f0 + run, NB);
-    int &s_nnz = *(int *)(lds + 4 * FFT_PADDEDS(BS, 4) + BS / 2);
-    const int tidOuter = threadIdx.x;
-    bool haveTw = false;
-    for (int vb = f0; vb < f1; vb++) {
-        int tid = tidOuter;
-        asm volatile("" : "+v"(tid));
-        const int s = vb / c.K, k = vb - s * c.K;
-        // PCM16 ingest: the first two blocks of a call read their history halves as float - left to k_xf_fix (xf_is_fast)
-        if (!std::is_same<IN, float>::value && k < 2) continue;
-        if (tid == 0) s_nnz = 0;
-        // the half frame the NEXT block adds (input block k of this stream: 128 or 64 lines of 128 bytes), one lane per line
-        const uint32_t *touch = nullptr;
-        if (vb + 1 < f1 && k + 1 < c.K && tid < (int)(BS * 2 * sizeof(IN) / 128))
-            touch = (const uint32_t *)(pcm_base<IN>(c) + ((size_t)s * c.K + k) * BS * 2) + tid * 32;
-        __syncthreads();
-        int nnz = xf_fast_2048<IN, true>(c, lds, s, k, vb, tid, haveTw, touch);
-        haveTw = true;
-        for (int o = 32; o > 0; o >>= 1) nnz += __shfl_down(nnz, o);
-        if ((tid & 63) == 0) atomicAdd(&s_nnz, nnz);
-        __syncthreads();
-        if (tid == 0) c.nnz[vb] = s_nnz;
-    }
-}
-// blocks [k0, k1) of every stream (a window-control step: their windows and their neighbours' are decided): the ones that
-// are not in the steady state, into the step's own segment of the list (it starts at B * k0; counter w)
-template <typename IN>
-__global__ __launch_bounds__(64) void k_xf_list(UlcxEncCtx c, int k0, int k1, int w) {
-    const int gid = blockIdx.x * 64 + threadIdx.x, kc = k1 - k0;
-    const bool in = gid < c.B * kc;
-    const int s = in ? gid / kc : 0, k = in ? k0 + gid % kc : k0;
-    const bool slow = in && !xf_is_fast<IN>(c, s, k);
-    const unsigned long long m = __ballot(slow);
-    if (!m) return;
-    int base = 0;
-    if (threadIdx.x == 0) base = atomicAdd(c.xfCount + w, __popcll(m));
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (slow) c.xfList[(size_t)c.B * k0 + base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = s * c.K + k;
-}
-template <typename IN>
-__global__ __launch_bounds__(WG, 4) void k_xf_fix(UlcxEncCtx c, int k0, int w) {
-    extern __shared__ float lds[];
-    const int n = c.xfCount[w];
-    const int *list = c.xfList + (size_t)c.B * k0;
-    const int tidOuter = threadIdx.x;
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        int tid = tidOuter;
-        asm volatile("" : "+v"(tid));                          // (nothing that depends on the thread only is hoisted out of the loop and held in registers)
-        const int blk = list[i];
-        xf_block<true, IN, false>(c, lds, blk / c.K, blk % c.K, tid);
-        __syncthreads();
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -3051,7 +2960,7 @@ static void launch_state_update(const UlcxEncCtx &c, hipStream_t st) {
 const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES_REPORTED] = {
     "k_wc_energy", "k_wc_forward", "k_wc_backward", "k_wc_integrate", "k_wc_decide",
     "k_xf", "k_cplx", "k_pbark", "k_mask",
-    "k_select", "k_nbark", "k_nline", "k_heapsel", "k_gapsums", "k_tailsums", "k_encode_wave", "k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update", "wc_pipeline_exposed", "k_xf_fix",
+    "k_select", "k_nbark", "k_nline", "k_heapsel", "k_gapsums", "k_tailsums", "k_encode_wave", "k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update", "wc_pipeline_exposed",
 };
 
 int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const UlcxEncAux &aux) {
@@ -3062,16 +2971,13 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     if (aux.nXf) *aux.nXf = 0;
     if (c.mode != ULCX_MODE_VBR) CK(hipMemsetAsync(c.cbrLive, 0, sizeof(int), st));
     if (c.barkRing) CK(hipMemsetAsync(c.decCount, 0, sizeof(int), st));           // k_xf lists this call's decimated blocks
-    CK(hipMemsetAsync(c.xfCount, 0, sizeof(int) * ULCX_WC_MAXCH, st));             // k_xf_list: blocks the speculative transform got wrong, per window-control step
     int NB = c.B * c.K;
     int stage = 0;
 #define MARK() do { if (ev) CK(hipEventRecord(ev[stage++], st)); } while (0)
     MARK();
     // --- window control + transform
     hipEvent_t *evX = evWC + 7 + 3 * ULCX_WC_MAXCH;            // [ULCX_XF_MAXCH] transform chunk done, [ULCX_XF_MAXCH]: all early k_cplx launches done
-    // the headline geometry transforms every block at once as if in the steady state and repairs the rest (k_xf_spec)
-    const bool spec = wcPipe > 1 && aux.xfSpec && c.C == 2 && c.BS == 2048 && aux.xfSlots > 0;
-    const bool cplxEarly = wcPipe > 1 && !spec;               // the ordered complexity sums per transform chunk, beside the next chunk
+    const bool cplxEarly = wcPipe > 1;                        // the ordered complexity sums per transform chunk, beside the next chunk
     {
         int SG = (c.B + 63) / 64;
         // Chunks of blocks: the window-control kernels of chunk j+1.. (two stream-long serial recurrences, a few
@@ -3108,7 +3014,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             for (int i = 0; i < 5; i++) MARK();                    // (window-control stages: hidden in the k_xf interval in this mode)
             // side: envelope + forward recurrence of step w (the sample-rate chain, back to back over the steps);
             // side2: backward_w behind forward_w;  side3: integrate_w, decide_w behind backward_w;
-            // main: the transform - every block at once (spec), or chunk j behind the step that decides its last block.
+            // main: transform chunk j behind the step that decides its last block.  The first chunk is a single block so the transform starts early.
             hipEvent_t ev0 = evWC[0], *evF = evWC + 1, *evB = evWC + 1 + ULCX_WC_MAXCH, *evD = evWC + 1 + 2 * ULCX_WC_MAXCH;
             // The window-control kernels advance in uniform steps of a few blocks (ULCX_WC_STEPS; 0 = in the same chunks as
             // the transform: first chunk one block, then thirds).  Measured with the chunked transform: 4 steps 8.65-8.70 ms
@@ -3127,18 +3033,6 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             for (int w = 0; w <= nW; w++) wcs[w] = sameCuts ? cut[w] : (int)((long long)c.K * w / nW);
             CK(hipEventRecord(ev0, st));
             CK(hipStreamWaitEvent(side, ev0, 0));
-            auto launch_spec = [&]() -> int {
-                if (ev) CK(hipEventRecord(aux.evXf[0], st));
-                if (!(ULCX_DBG(c) & 0x2000)) {
-                    const int run = aux.xfRun > 0 ? aux.xfRun : 8;
-                    const unsigned g = (unsigned)((NB + run - 1) / run);
-                    if (c.pcm16) hipLaunchKernelGGL(k_xf_spec<int16_t>, dim3(g), dim3(WG), lds, st, c, run);
-                    else hipLaunchKernelGGL(k_xf_spec<float>, dim3(g), dim3(WG), lds, st, c, run);
-                }
-                if (ev) CK(hipEventRecord(aux.evXf[1], st));
-                if (ev) CK(hipEventRecord(aux.evXf[2], st));      // (the repair launches: their own pair, the waits between them included)
-                return ULCX_OK;
-            };
             int jx = 0;                                        // next transform chunk to enqueue
             for (int w = 0; w < nW; w++) {
                 const int k0 = wcs[w], k1 = wcs[w + 1], kc = k1 - k0;
@@ -3148,7 +3042,6 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                     hipLaunchKernelGGL(k_wc_forward, dim3((c.B * 2 + 63) / 64), dim3(64), 0, side, c, k0, k1);
                 }
                 CK(hipEventRecord(evF[w], side));
-                if (spec && w == 0) { int rcs = launch_spec(); if (rcs) return rcs; }      // (behind the chain's first kernel: that one finds its slots free)
                 CK(hipStreamWaitEvent(side2, evF[w], 0));
                 hipLaunchKernelGGL(k_wc_backward, dim3(SG * kc), dim3(64), 0, side2, c, k0, k1);
                 CK(hipEventRecord(evB[w], side2));
@@ -3156,17 +3049,8 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                 hipLaunchKernelGGL(k_wc_integrate, dim3((c.B + 63) / 64), dim3(64), 0, side3, c, k0, k1);
                 hipLaunchKernelGGL(k_wc_decide, dim3((c.B * kc + 63) / 64), dim3(64), 0, side3, c, k0, k1);
                 CK(hipEventRecord(evD[w], side3));
-                if (spec && !(ULCX_DBG(c) & 0x2000)) {
-                    // the step's windows (and their neighbours') are decided: list its blocks that are not in the steady
-                    // state and transform them again, behind the speculative launch on the caller's stream
-                    CK(hipStreamWaitEvent(st, evD[w], 0));
-                    const int nbk = c.B * kc;
-                    const unsigned g = (unsigned)(nbk < aux.xfSlots ? nbk : aux.xfSlots);
-                    if (c.pcm16) { hipLaunchKernelGGL(k_xf_list<int16_t>, dim3((nbk + 63) / 64), dim3(64), 0, st, c, k0, k1, w); hipLaunchKernelGGL(k_xf_fix<int16_t>, dim3(g), dim3(WG), lds, st, c, k0, w); }
-                    else { hipLaunchKernelGGL(k_xf_list<float>, dim3((nbk + 63) / 64), dim3(64), 0, st, c, k0, k1, w); hipLaunchKernelGGL(k_xf_fix<float>, dim3(g), dim3(WG), lds, st, c, k0, w); }
-                }
                 // transform chunks whose last block is now decided
-                while (!spec && jx < nCh && cut[jx + 1] <= k1) {
+                while (jx < nCh && cut[jx + 1] <= k1) {
                     int x0 = cut[jx], x1 = cut[jx + 1];
                     int nbk = c.B * (x1 - x0);
                     CK(hipStreamWaitEvent(st, evD[w], 0));
@@ -3178,8 +3062,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                     jx++;
                 }
             }
-            if (spec && ev) CK(hipEventRecord(aux.evXf[3], st));
-            if (aux.nXf) *aux.nXf = spec ? -2 : nCh;               // (-2: a speculative launch and its repair, two event pairs)
+            if (aux.nXf) *aux.nXf = nCh;
             MARK();
             // the ordered complexity sums (k_cplx: lane-serial, HBM-bound) per transform chunk, on the envelope kernels' stream
             // (all of those are enqueued by now): only the last chunk's are left beside the masking sums

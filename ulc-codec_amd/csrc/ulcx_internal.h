@@ -49,7 +49,6 @@ struct UlcxEncCtx {
     int B, K, C, BS, lgBS;               // streams, blocks this call, channels, block size
     int barkRing;                        // k_bark_uniform: snapshots a lane keeps of open Bark bands (power of two; 0 = k_nbark / k_pbark for every block)
     int *decList, *decCount;             // blocks of this call with a decimated window (listed by the transform): they take k_nbark / k_pbark
-    int *xfList, *xfCount;               // blocks of this call that are not in the steady state (k_xf_list): k_xf_fix transforms them again
     int maxK;                            // allocation stride for per-call arrays
     int slot;                            // bytes per output slot
     int unitCap;                         // bytes per (chan,subblock) nybble staging row = 2*BS+32 per channel
@@ -163,7 +162,7 @@ void ulcx_set_error(const char *fmt, ...);
 
 // launchers (ulcx_enc.hip / ulcx_dec.hip)
 #define ULCX_ENC_STAGES 20
-#define ULCX_ENC_STAGES_REPORTED (ULCX_ENC_STAGES + 2)   // + "wc_pipeline_exposed", "k_xf_fix" (computed from the transform's own event pairs)
+#define ULCX_ENC_STAGES_REPORTED (ULCX_ENC_STAGES + 1)   // + "wc_pipeline_exposed" (computed, not an event interval)
 extern const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES_REPORTED];
 #define ULCX_DEC_STAGES 2
 #define ULCX_WC_MAXCH 32    // fine steps of the window-control pipeline per call
@@ -178,8 +177,7 @@ struct UlcxEncAux {
     int wcPipe;                          // chunks of blocks pipelined between window control and transform; 1 = off
     int wcSteps;                         // fine steps of the window-control kernels per call (ULCX_WC_STEPS)
     int wcFuse;                          // ULCX_WC_FUSE, read once when the encoder is created
-    int xfSpec, xfSlots, xfRun;          // the headline geometry's speculative transform (k_xf_spec; ULCX_XF_SPEC=0: chunks); workgroups of it the device holds; blocks per workgroup
-    int *nXf;                            // out: transform launches this call (-2: the speculative launch + its repair)
+    int *nXf;                            // out: transform launches this call
 };
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, const UlcxEncAux &aux);
 struct UlcxDecAux {
