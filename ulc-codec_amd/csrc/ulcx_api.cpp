@@ -24,6 +24,7 @@ struct ulcx_encoder {
     hipEvent_t evWC[7 + 3 * ULCX_WC_MAXCH + ULCX_XF_MAXCH + 1]; int wcPipe; hipStream_t side2, side3; hipEvent_t evXf[2 * ULCX_XF_MAXCH]; int nXf;      // window-control / transform pipeline (ULCX_WC_PIPE chunks, default 4)
     bool keysFinal;
     int wcSteps, wcFuse;      // environment switches, read once at create
+    int nsSlots;              // resident workgroups of k_nsums (its persistent grid)
     // staging for the host-pointer API
     float *d_pcm; uint8_t *d_out; int32_t *d_bits, *d_wc; float *d_cplx;
     // single-block path (ulcx_encode_block1): own stream, pinned staging, the captured launch sequence
@@ -179,7 +180,6 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.coef, NB * cb, false);
     DA(c.key, NB * cb, false);
     DA(c.nsum, NB * cb / 2, false);
-    DA(c.npair, NB * cb, false);
     DA(c.amp2, NB * BlockSize / 2, false);
     DA(c.barkN, NB * nChan * 4 * ULCX_NBARK, true);
     DA(c.barkP, NB * 4 * ULCX_NBARK, true);
@@ -189,7 +189,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.nout, NB, true);
     DA(c.slow, 3 * NB + 2, true);                      // flags [NB], retry-queue counters [2], retry queues [2][NB]
     c.useWave = 1;        // wave-per-unit encode pass fed by k_gapsums; ULCX_WAVE=0 selects the serial lane-per-unit kernel
-    c.useGapSums = ((size_t)cb * 4 + cb / 8 + 8192 + 16 <= 150 * 1024 && cb <= 16384) ? 1 : 0;
+    c.useGapSums = (cb <= 16384 && nChan <= 16) ? 1 : 0;          // (k_nsums: a block's pairs in LDS, two bits per channel in a word)
     if (const char *ev = getenv("ULCX_GAPSUMS")) c.useGapSums = (ev[0] != '0');
     DA(c.gapSum, NB * cb, false);
     DA(c.tailSum, NB * nChan * 4 * 8, true);
@@ -232,6 +232,8 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
         e->wcSteps = -1; if (const char *sv = getenv("ULCX_WC_STEPS")) e->wcSteps = atoi(sv);      // -1: default; 0: the transform's chunks
         { const char *v = getenv("ULCX_WC_FUSE"); e->wcFuse = (v && v[0] == '0') ? 0 : 1; }
     }
+    e->nsSlots = c.useGapSums ? ulcx_enc_nsums_slots(BlockSize, nChan) : 0;
+    if (e->nsSlots <= 0) e->nsSlots = 1024;
     DA(c.isFb, NB, true);
     DA(c.ownSlot, NB, true);
     {
@@ -265,7 +267,7 @@ static int encode_dev_any(ulcx_encoder *e, int mode, float p0, float p1, const f
     aux.side = e->sideOk ? e->side : nullptr; aux.side2 = e->sideOk ? e->side2 : nullptr; aux.side3 = e->sideOk ? e->side3 : nullptr;
     aux.evFork = e->evFork; aux.evJoin = e->evJoin; aux.evFork2 = e->evFork2; aux.evWC = e->evWC; aux.evXf = e->evXf;
     aux.wcPipe = (nBlocks >= 2 * e->wcPipe) ? e->wcPipe : (nBlocks >= 6 && e->wcPipe > 1 ? 3 : 1); aux.nXf = &e->nXf;
-    aux.wcSteps = e->wcSteps; aux.wcFuse = e->wcFuse;
+    aux.wcSteps = e->wcSteps; aux.wcFuse = e->wcFuse; aux.nsSlots = e->nsSlots;
     const int rc = ulcx_enc_launch(c, (hipStream_t)hipStream, e->timing ? e->ev : nullptr, aux);
     e->evRecorded = (rc == ULCX_OK) && e->timing;
     e->lastK = nBlocks;
@@ -385,7 +387,14 @@ extern "C" int ulcx_encoder_debug_fetch(ulcx_encoder *e, int nBlocks, float *h_c
     CKR(hipDeviceSynchronize());
     size_t NB = (size_t)e->B * nBlocks, cb = (size_t)e->C * e->BS;
     if (h_coef)  CKR(hipMemcpy(h_coef, e->ctx.coef, sizeof(float) * NB * cb, hipMemcpyDeviceToHost));
-    if (h_noise) CKR(hipMemcpy(h_noise, e->ctx.npair, sizeof(float) * NB * cb, hipMemcpyDeviceToHost));
+    if (h_noise) {
+        // the {w, w*log} pairs (the reference's TransformNoise) are not an array of the pipeline any more: formed here, for the tap
+        if (!e->ctx.npair) { int rc = dalloc(e->allocs, &e->ctx.npair, (size_t)e->B * e->maxK * cb, false); if (rc) return rc; }
+        UlcxEncCtx c2 = e->ctx; c2.K = nBlocks;
+        ulcx_enc_materialise_noise(c2, nullptr);
+        CKR(hipDeviceSynchronize());
+        CKR(hipMemcpy(h_noise, e->ctx.npair, sizeof(float) * NB * cb, hipMemcpyDeviceToHost));
+    }
     if (h_keys) {
         if (!e->keysFinal) {                       // the pipeline never writes final keys back; materialise them for the tap
             UlcxEncCtx c2 = e->ctx; c2.K = nBlocks; c2.keyFinal = 0;

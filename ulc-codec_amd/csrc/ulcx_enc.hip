@@ -1196,52 +1196,47 @@ __global__ __launch_bounds__(64) void k_nbark(UlcxEncCtx c, int useList) {
     (void)N;
 }
 
-// Psyopt.c:236-248: per-line interpolation + {w, w*(log+ln2)} pairs.
-// One workgroup per block, NLINE_CH channels at a time: their Bark levels sit in LDS, every thread takes two neighbouring
-// line pairs per trip and, for them, the geometry and the two table entries ONCE for all channels (round 3: a workgroup per
-// (block, channel) was capped by the eight waves a SIMD holds - 5 us of latency per 8 KB written).
-#define NLINE_CH 2
+// Psyopt.c:236-248: per-line interpolation + {w, w*(log+ln2)} pair of line pair jp (0 <= jp < BS/2) of one channel of a
+// block: a function of that channel's [4][25] Bark levels alone.  Round 4: the pairs are no array in HBM any more (16 KB a
+// block written by one kernel and read back by three: 15 % of the step's traffic) - k_nsums forms a block's pairs into LDS
+// for the sums it takes, the bitstream writer's rare fall-backs form the few they need on the spot (SumSrc), and the parity
+// tap materialises the array on request (k_nline).  SEXP: expf's 2^(i/32) table from an LDS copy (it sits in the middle of
+// every evaluation's dependent chain).
+template <bool SEXP>
+__device__ __forceinline__ float2 noise_pair(const UlcxEncCtx &c, const float *bark4, int wc, int jp, const unsigned long long *sexp) {
+    unsigned pat = ulcx_pattern(wc);
+    int off = 0, d = 0, S = c.BS, j = 0;
+    for (;; j++) { d = pat & 7; S = c.BS >> d; if (2 * jp < off + S) break; off += S; pat >>= 4; }
+    const int line = jp - off / 2;
+    const int bi = c.T.bandIdx[d][line];
+    const float fr = c.T.bandFrac[d][line];
+    const float *bark = bark4 + j * ULCX_NBARK;
+    const float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
+    const float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
+    const float noise = L * (1.0f - fr) + R * fr;
+    const float w = SEXP ? ulcx_expf_t(0.5f * noise, sexp) : ulcx_expf(0.5f * noise);
+    return make_float2(w, w * (noise + 0x1.62E430p-1f));
+}
+// the pair at float2 index p of the block's flattened [C][BS/2] pair array, from the Bark levels in global memory
+struct SumSrc { const UlcxEncCtx *c; const float *bark; int wc; };      // bark: the block's [C][4][25] levels
+__device__ __forceinline__ SumSrc sum_src(const UlcxEncCtx &c, int blk) {
+    SumSrc g; g.c = &c; g.bark = c.barkN + (size_t)blk * c.C * 4 * ULCX_NBARK;
+    g.wc = c.wcArr[(size_t)(blk / c.K) * (c.maxK + 2) + (blk % c.K) + 1];
+    return g;
+}
+__device__ __forceinline__ float2 pair_demand(const SumSrc &g, int p) {
+    const int half = g.c->BS >> 1, ch = p / half;
+    return noise_pair<false>(*g.c, g.bark + ch * 4 * ULCX_NBARK, g.wc, p - ch * half, nullptr);
+}
+// parity tap only (ulcx_encoder_debug_fetch): the whole array, as the reference leaves it in TransformNoise
 __global__ __launch_bounds__(WG) void k_nline(UlcxEncCtx c) {
-    __shared__ float sbark[NLINE_CH * 4 * ULCX_NBARK];
-    __shared__ unsigned long long sexp[32];                  // expf's 2^(i/32) table: an LDS read instead of a global one in the middle of every evaluation
-    const int blk = blockIdx.x, tid = threadIdx.x;
-    if (tid < 32) sexp[tid] = ulcx_exp2f_tab[tid];
-    const int half = c.BS / 2;
-    const int s = blk / c.K, k = blk % c.K;
-    const int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
-    for (int ch0 = 0; ch0 < c.C; ch0 += NLINE_CH) {
-        const int nch = (c.C - ch0 < NLINE_CH) ? c.C - ch0 : NLINE_CH;
-        if (ch0) __syncthreads();
-        for (int i = tid; i < nch * 4 * ULCX_NBARK; i += WG) sbark[i] = c.barkN[(size_t)(blk * c.C + ch0) * 4 * ULCX_NBARK + i];
-        __syncthreads();
-        // two neighbouring line pairs per thread: one 16-byte store (subblocks are multiples of 32 lines: both are in the same one)
-        for (int jp = 2 * tid; jp < half; jp += 2 * WG) {
-            unsigned pat = ulcx_pattern(wc);
-            int off = 0, d = 0, S = c.BS, j = 0;
-            for (;; j++) { d = pat & 7; S = c.BS >> d; if (2 * jp < off + S) break; off += S; pat >>= 4; }
-            const int line = jp - off / 2;
-            const int2 bi2 = *(const int2 *)(c.T.bandIdx[d] + line);
-            const float2 fr2 = *(const float2 *)(c.T.bandFrac[d] + line);
-#pragma unroll
-            for (int cc = 0; cc < NLINE_CH; cc++) {
-                if (cc >= nch) break;
-                const float *bark = sbark + (cc * 4 + j) * ULCX_NBARK;
-                float o[4];
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    int bi = q ? bi2.y : bi2.x;
-                    float fr = q ? fr2.y : fr2.x;
-                    float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
-                    float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
-                    float noise = L * (1.0f - fr) + R * fr;
-                    float w = ulcx_expf_t(0.5f * noise, (const unsigned long long *)sexp);
-                    o[2 * q] = w; o[2 * q + 1] = w * (noise + 0x1.62E430p-1f);
-                }
-                float2 *dst = (float2 *)(c.npair + (size_t)blk * (c.C * c.BS) + (size_t)(ch0 + cc) * c.BS);
-                stnt((float4 *)(dst + jp), make_float4(o[0], o[1], o[2], o[3]));
-            }
-        }
-    }
+    const int blk = blockIdx.x, half = c.BS / 2;
+    const SumSrc g = sum_src(c, blk);
+    float2 *dst = (float2 *)(c.npair + (size_t)blk * (c.C * c.BS));
+    for (int p = threadIdx.x; p < c.C * half; p += WG) dst[p] = pair_demand(g, p);
+}
+void ulcx_enc_materialise_noise(const UlcxEncCtx &c, hipStream_t st) {
+    hipLaunchKernelGGL(k_nline, dim3(c.B * c.K), dim3(WG), 0, st, c);
 }
 
 // Psyopt.c:86-137 on the channel-summed energies
@@ -1950,48 +1945,111 @@ __global__ __launch_bounds__(WG) void k_keep_ranks(UlcxEncCtx c, int finalPass) 
 // coefficient.  Same loops, same order as get_noise_q/get_hfext, so the values are the ones
 // the serial kernel would compute; it checks the assumption and recomputes if it is off
 // (a kept coefficient collapsed, a noise run fell back to a zero run, ...).
+// Round 4: no 16 KB-per-block pair array in HBM between them any more (was k_nline -> k_gapsums, k_tailsums).  k_nsums: a
+// workgroup forms its block's {w, w*log} pairs from the 100 Bark levels per channel straight into LDS (noise_pair), lists
+// the gaps and sums them.  k_tails: the units' tail chains, eight units per wave, the pairs of a step formed by the wave's
+// 64 lanes together (a workgroup of k_nsums that also ran its block's two 700-step chains lived 18 us for them).  A gap
+// longer than one noise run (16 + 511 coefficients) gets its SECOND run speculated too - where that one starts follows from
+// the gap's length alone as long as the first run is coded as noise: on the bench batch 0.30 runs per block, against 0.02
+// that need a third or sit elsewhere; those the writer sums itself, forming the pairs it needs (pair_demand).
 // ---------------------------------------------------------------------------
-#ifdef GAPCAP_OLD
-#define E_GAPCAP(N) 1024
-#else
-#define E_GAPCAP(N) ((N) / 16)      // gaps >= 16 per block: at most N/17 of them (round 3: was a fixed 1024 - 8 KB of LDS, six workgroups per CU instead of eight)
+#define E_GAPCAP(N) ((N) / 16)      // gaps >= 16 per block: at most N/17 of them
+#define WAVE_SYNC_E() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#ifndef NSUMS_LB
+#define NSUMS_LB 8                                         // 64 registers: 63 used, no spill; 7 workgroups per CU by LDS
 #endif
-__device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
-    extern __shared__ uint32_t gsm[];
-    int tid = threadIdx.x;
-    if (skip_block(c, blk, finalPass)) return;
-    const int N = c.C * c.BS;
-    float *pairs = (float *)gsm;                           // N floats: the block's {w, w*log} pairs
-    uint32_t *kw = gsm + N;                                // keep words of the block
-    int s = blk / c.K, k = blk % c.K;
-    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
-    const uint32_t *keepB = c.keep + (size_t)blk * (N / 32);
-    for (int i = tid; i < N / 32; i += WG) kw[i] = keepB[i];
-    {
-        const float4 *pg = (const float4 *)(c.npair + (size_t)blk * N);
-        for (int i = tid; i < N / 4; i += WG) ((float4 *)pairs)[i] = ldnt(pg + i);
+__host__ __device__ static inline size_t nsums_lds_bytes(int N, int C) {
+    return (size_t)N * 4 + N / 8 + 8 * (size_t)E_GAPCAP(N) + 16 + 8 * (size_t)((N / 32 + 63) / 64) + (size_t)C * 4 * ULCX_NBARK * 4 + 32 * 8 + N / 16;
+}
+// ordered {Sum, SumW} of the pairs that cover coefficients [start, start + n) (NoiseFill.c:24-28), finished to the
+// amplitude the writer quantises (:29-30; -1: "Sum == 0")
+__device__ __forceinline__ float run_amplitude(const float *pairs, int start, int n) {
+    const float2 *d = (const float2 *)(pairs + (start / 2) * 2);
+    const int np = (n + (start & 1) + 1) / 2;
+    float sum = 0.0f, sumw = 0.0f;
+    int q = 0;
+    for (; q + 8 <= np; q += 8) {
+        float2 p[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) p[u] = d[q + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { sum += p[u].y; sumw += p[u].x; }
     }
-    __syncthreads();
-    if (ULCX_DBG(c) & 0x10000) return;                     // (ablation build: the loads alone)
-    float2 *gs = c.gapSum + (size_t)blk * N;
-    // gaps in front of kept coefficients.  Pass 1 lists the kept coefficients whose gap is long enough for a noise run,
-    // pass 2 takes one listed gap per thread (a wave's time is its longest gap once).  Pass 1 is per keep WORD, not per
-    // kept coefficient (round 3: a loop over the set bits, a walk back to the previous kept coefficient for each, was
-    // 0.44 of the kernel's 0.96 ms): a gap of >= 16 zeros either ends at the word's first set bit - the previous kept
-    // coefficient is the top bit of the last non-zero word, found in a bit mask of the non-zero words - or lies inside the
-    // word between two set bits, and only one such run fits in 32 bits.
-    uint32_t *wl = kw + N / 32;                            // work list: (kept coefficient, start of its gap) pairs
+    for (; q < np; q++) { float2 p = d[q]; sum += p.y; sumw += p.x; }
+    return (sum == 0.0f) ? -1.0f : ulcx_expf(sum / sumw);
+}
+// what a workgroup fetches for its NEXT block while it works on the current one (a block's first instructions used to be
+// three dependent trips to HBM - window code, keep words, Bark levels - with 6 workgroups a CU to hide them behind: the
+// list phase alone took 0.86 ms of the kernel's 1.35)
+#define NS_KW 2                                            // keep words per thread: N / 32 <= 512
+#define NS_BK 7                                            // Bark levels per thread: C * 100 <= 1600
+struct NsPre { uint32_t kw[NS_KW]; float bk[NS_BK]; int wc; };
+__device__ __forceinline__ void nsums_fetch(const UlcxEncCtx &c, int blk, NsPre &p) {
+    const int tid = threadIdx.x, nW = c.C * c.BS / 32, nLev = c.C * 4 * ULCX_NBARK;
+    const uint32_t *keepB = c.keep + (size_t)blk * nW;
+    const float *bg = c.barkN + (size_t)blk * nLev;
+#pragma unroll
+    for (int i = 0; i < NS_KW; i++) p.kw[i] = (tid + i * WG < nW) ? keepB[tid + i * WG] : 0u;
+#pragma unroll
+    for (int i = 0; i < NS_BK; i++) p.bk[i] = (tid + i * WG < nLev) ? bg[tid + i * WG] : 0.0f;
+    p.wc = c.wcArr[(size_t)(blk / c.K) * (c.maxK + 2) + (blk % c.K) + 1];
+}
+__device__ void nsums_block(const UlcxEncCtx &c, int blk, const NsPre &pre) {
+    extern __shared__ uint32_t gsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int N = c.C * c.BS, nW = N / 32, half = c.BS / 2;
+    float *pairs = (float *)gsm;                           // N floats: the block's {w, w*log} pairs (the ones a run covers)
+    uint32_t *kw = gsm + N;                                // keep words of the block
+    uint32_t *wl = kw + nW;                                // work list: one entry per noise run: (kept coefficient | run << 16, start of the run)
     const int gapCap = E_GAPCAP(N);
     int *wcount = (int *)(wl + 2 * gapCap);
-    unsigned long long *nzw = (unsigned long long *)(wcount + 2);      // bit w % 64 of nzw[w / 64]: keep word w is not 0
-    const int nW = N / 32;
+    unsigned long long *nzw = (unsigned long long *)(wcount + 4);      // bit w % 64 of nzw[w / 64]: keep word w is not 0
+    float *sbark = (float *)(nzw + (nW + 63) / 64);        // the block's [C][4][25] Bark levels
+    unsigned long long *sexp = (unsigned long long *)(sbark + c.C * 4 * ULCX_NBARK);
+    uint32_t *need = (uint32_t *)(sexp + 32);              // bit p: pair p of the block is inside a listed run
+    const int wc = pre.wc;
+    const int nLev = c.C * 4 * ULCX_NBARK;
+#pragma unroll
+    for (int i = 0; i < NS_KW; i++) if (tid + i * WG < nW) kw[tid + i * WG] = pre.kw[i];
+#pragma unroll
+    for (int i = 0; i < NS_BK; i++) if (tid + i * WG < nLev) sbark[tid + i * WG] = pre.bk[i];
+    if (tid < 32) sexp[tid] = ulcx_exp2f_tab[tid];
+    for (int i = tid; i < N / 64; i += WG) need[i] = 0u;
     if (tid == 0) *wcount = 0;
+    __syncthreads();
+    // gaps in front of kept coefficients.  Pass 1 lists the noise runs of every gap that is long enough for one, pass 2
+    // forms the pairs those runs cover, pass 3 takes one listed run per thread (a wave's time is its longest run once).
+    // Pass 1 is per keep WORD, not per kept coefficient: a gap of >= 16 zeros either ends at the word's first set bit - the
+    // previous kept coefficient is the top bit of the last non-zero word, found in a bit mask of the non-zero words - or
+    // lies inside the word between two set bits, and only one such run fits in 32 bits.
     for (int w0 = 0; w0 < nW; w0 += WG) {
         const int w = w0 + tid;
         const unsigned long long bm = __ballot(w < nW && kw[w] != 0u);
-        if ((tid & 63) == 0 && w < nW) nzw[w >> 6] = bm;
+        if (lane == 0 && w < nW) nzw[w >> 6] = bm;
     }
     __syncthreads();
+    // a gap of zr zeros in front of kept coefficient `it`, starting at `st`: its noise runs - 16 + min(rest - 16, 511)
+    // coefficients each while the rest is >= 16 (Encode.c:149-160: where a run starts follows from the gap's length alone
+    // as long as every run before it was coded as noise) - one work item each, and their pairs marked as needed
+    auto list_gap = [&](int it, int st) {
+        int rem = it - st, nr = 0;
+        for (int r2 = rem; r2 >= 16; nr++) { int v = r2 - 16; if (v > 0x1FF) v = 0x1FF; r2 -= v + 16; }
+        int slot = atomicAdd(wcount, nr);
+        int start = st;
+        for (int r = 0; r < nr; r++, slot++) {
+            int v = rem - 16; if (v > 0x1FF) v = 0x1FF;
+            const int n = v + 16;
+            if (slot < gapCap) { wl[2 * slot] = (uint32_t)it | ((uint32_t)r << 16); wl[2 * slot + 1] = (uint32_t)start; }
+            const int p0 = start >> 1, p1 = p0 + (n + (start & 1) + 1) / 2 - 1;       // the pairs run_amplitude reads
+            for (int pw = p0 >> 5; pw <= (p1 >> 5); pw++) {
+                uint32_t m = 0xFFFFFFFFu;
+                if (pw == (p0 >> 5)) m &= 0xFFFFFFFFu << (p0 & 31);
+                if (pw == (p1 >> 5)) m &= 0xFFFFFFFFu >> (31 - (p1 & 31));
+                atomicOr(&need[pw], m);
+            }
+            start += n; rem -= n;
+        }
+    };
     for (int w = tid; w < nW; w += WG) {
         const uint32_t m = kw[w];
         if (m == 0u) continue;
@@ -2009,118 +2067,180 @@ __device__ void gapsums_block(const UlcxEncCtx &c, int finalPass, int blk) {
             if (mk) { const int wp = q * 64 + 63 - __clzll(mk); if (wp >= usw) prev = wp * 32 + 31 - __clz(kw[wp]); break; }
         }
         const int f = __ffs(m) - 1;
-        int nIt = 0, it0 = 0, st0 = 0, it1 = 0, st1 = 0;
-        if (i0 + f - (prev + 1) >= 16) { it0 = i0 + f; st0 = prev + 1; nIt = 1; }
+        if (i0 + f - (prev + 1) >= 16) list_gap(i0 + f, prev + 1);
         uint32_t z = ~m, rr = z & (z >> 1); rr &= rr >> 2; rr &= rr >> 4; rr &= rr >> 8;      // bit k: bits k..k+15 of the word are 0
         rr &= ~((2u << f) - 1u);                           // runs above the first set bit only
         if (rr) {
-            const int k = __ffs(rr) - 1;                   // the run starts behind a set bit
-            const uint32_t up = m >> k;
-            if (up) { it1 = i0 + k + __ffs(up) - 1; st1 = i0 + k; nIt |= 2; }
-        }
-        if (nIt) {
-            const int n = (nIt & 1) + (nIt >> 1);
-            const int slot = atomicAdd(wcount, n);
-            if (nIt & 1) { wl[2 * slot] = (uint32_t)it0; wl[2 * slot + 1] = (uint32_t)st0; }
-            if (nIt & 2) { const int s2 = slot + (nIt & 1); wl[2 * s2] = (uint32_t)it1; wl[2 * s2 + 1] = (uint32_t)st1; }
+            const int kk = __ffs(rr) - 1;                  // the run starts behind a set bit
+            const uint32_t up = m >> kk;
+            if (up) list_gap(i0 + kk + __ffs(up) - 1, i0 + kk);
         }
     }
     __syncthreads();
-    if (ULCX_DBG(c) & 0x20000) return;                     // (ablation build: loads + gap list)
+    if (ULCX_DBG(c) & 0x10000) return;                     // (ablation build: the list alone)
+    // the pairs the listed runs cover (on the bench batch a third of the block's: the dense low end has no gap of 16, the
+    // tails behind the last kept coefficients are k_tails' business): two neighbouring line pairs per thread and trip,
+    // geometry and table entries once for every channel
+    for (int jp = 2 * tid; jp < half; jp += 2 * WG) {
+        uint32_t want = 0;
+        for (int ch = 0; ch < c.C; ch++) want |= ((need[(ch * half + jp) >> 5] >> (jp & 31)) & 3u) << (2 * ch);
+        if (!want) continue;
+        unsigned pat = ulcx_pattern(wc);
+        int off = 0, dd = 0, S = c.BS, j = 0;
+        for (;; j++) { dd = pat & 7; S = c.BS >> dd; if (2 * jp < off + S) break; off += S; pat >>= 4; }
+        const int line = jp - off / 2;                     // (subblocks are multiples of 32 lines: both pairs lie in the same one)
+        const int2 bi2 = *(const int2 *)(c.T.bandIdx[dd] + line);
+        const float2 fr2 = *(const float2 *)(c.T.bandFrac[dd] + line);
+        for (int ch = 0; ch < c.C; ch++) {
+            if (!((want >> (2 * ch)) & 3u)) continue;
+            const float *bark = sbark + (ch * 4 + j) * ULCX_NBARK;
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int bi = q ? bi2.y : bi2.x;
+                const float fr = q ? fr2.y : fr2.x;
+                const float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
+                const float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
+                const float noise = L * (1.0f - fr) + R * fr;
+                const float w = ulcx_expf_t(0.5f * noise, sexp);
+                o[2 * q] = w; o[2 * q + 1] = w * (noise + 0x1.62E430p-1f);
+            }
+            *(float4 *)(pairs + (size_t)ch * c.BS + 2 * jp) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    __syncthreads();
+    if (ULCX_DBG(c) & 0x20000) return;                     // (ablation build: list + pairs)
+    // ---- one listed run per thread: run r of the gap in front of kept coefficient i leaves its amplitude in component
+    //      r & 1 of gapSum[i - (r >> 1)] (positions i - 1, i - 2 .. lie inside a gap that has a third, fifth .. run: not kept)
+    float *gs = (float *)(c.gapSum + (size_t)blk * N);
     int nw = *wcount; if (nw > gapCap) nw = gapCap;
     for (int t = tid; t < nw; t += WG) {
         const uint32_t it = wl[2 * t];
-        int i = (int)it, start = (int)wl[2 * t + 1];
-        int zr = i - start;
-        int v = zr - 16; if (v > 0x1FF) v = 0x1FF;
-        int n = v + 16;
-        const float2 *d = (const float2 *)(pairs + (start / 2) * 2);
-        int np = (n + (start & 1) + 1) / 2;
-        float sum = 0.0f, sumw = 0.0f;
-        int q = 0;
-        for (; q + 8 <= np; q += 8) {
-            float2 p[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) p[u] = d[q + u];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { sum += p[u].y; sumw += p[u].x; }
-        }
-        for (; q < np; q++) { float2 p = d[q]; sum += p.y; sumw += p.x; }
-        // NoiseFill.c:29-30: the amplitude does not depend on the quantizer, so finish it here
-        gs[i] = make_float2((sum == 0.0f) ? -1.0f : ulcx_expf(sum / sumw), 0.0f);
+        const int i = (int)(it & 0xFFFFu), r = (int)(it >> 16), start = (int)wl[2 * t + 1];
+        int v = i - start - 16; if (v > 0x1FF) v = 0x1FF;
+        gs[2 * (i - (r >> 1)) + (r & 1)] = run_amplitude(pairs, start, v + 16);
     }
 }
-__global__ __launch_bounds__(WG) void k_gapsums(UlcxEncCtx c, int finalPass) {
+// Persistent workgroups: block v, v + grid, .. of the launch's blocks (all of them, or the exact path's resident list);
+// the next block's keep words, Bark levels and window code travel in registers while the current one is worked on.
+__global__ __launch_bounds__(WG, NSUMS_LB) void k_nsums(UlcxEncCtx c, int finalPass) {
     if (probes_over(c, finalPass)) return;
-    if (c.fbMode != 2) { gapsums_block(c, finalPass, blockIdx.x); return; }
-    int n = fb_count(c);
-    for (int v = blockIdx.x; v < n; v += gridDim.x) { gapsums_block(c, finalPass, c.fbList[c.fbLo + v]); __syncthreads(); }
+    const int n = (c.fbMode == 2) ? fb_count(c) : c.B * c.K;
+    auto blk_of = [&](int v) { return (c.fbMode == 2) ? c.fbList[c.fbLo + v] : v; };
+    auto next_live = [&](int v) { while (v < n && skip_block(c, blk_of(v), finalPass)) v += gridDim.x; return v; };
+    int v = next_live(blockIdx.x);
+    if (v >= n) return;
+    NsPre cur, nxt;
+    nsums_fetch(c, blk_of(v), cur);
+    while (v < n) {
+        const int vn = next_live(v + gridDim.x);
+        if (vn < n) nsums_fetch(c, blk_of(vn), nxt);
+        nsums_block(c, blk_of(v), cur);
+        __syncthreads();
+        cur = nxt;
+        v = vn;
+    }
 }
 
-// Tail HF-extension sums (NoiseFill.c:41-62) for the tail after each unit's last kept
-// coefficient: 8 lanes per unit, lanes 0..4 carry one ordered f32 chain each, lane 5 records
-// the start index the sums assume.  Pairs are read straight from HBM/L2 in batches of 8: the
-// chains are latency-bound, so they get their own launch with every unit of the batch in flight.
-__device__ void tailsums_lane(const UlcxEncCtx &c, int finalPass, int tid0, int nBlk) {
-    int chain = tid0 & 7;
-    int ui = tid0 >> 3;
-    int nBC = nBlk * c.C;
-    if (ui >= nBC * 4) return;
-    int j = ui / nBC, rem = ui - j * nBC, blk = rem / c.C, ch = rem - blk * c.C;     // subblock index slowest
-    if (c.fbMode == 2) blk = c.fbList[c.fbLo + blk];
-    if (skip_block(c, blk, finalPass)) return;
-    int s = blk / c.K, k = blk % c.K;
-    int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
-    int d0, off, S;
-    if (!unit_geom(wc, j, c.BS, d0, off, S)) return;
+// Tail HF-extension sums (NoiseFill.c:41-62) for the tail after each unit's last kept coefficient.  A wave = eight units,
+// eight lanes each: lanes 0..4 of a unit carry one ordered f32 chain each, lane 5 records the start index the sums assume.
+// The pairs are formed by the wave itself, eight per unit and step (lane e of a unit forms pair 8 T + e of its tail), into a
+// double-buffered LDS tile the unit's chain lanes then walk: forming step T + 1 and summing step T are one instruction
+// stream, the former fills the latter's dependent adds.
+#define TAILS_UPW 8                                         // units per wave
+__device__ __forceinline__ void tails_wave(const UlcxEncCtx &c, int finalPass, int unit0, int nBlk, float *tile /* [2][8][8] float2 */,
+                                           float *sbark /* [8][25] */, const unsigned long long *sexp, int lane) {
+    const int us = lane >> 3, e = lane & 7;                 // unit slot of the wave, role inside the unit
+    const int ui = unit0 + us;
+    const int nBC = nBlk * c.C;
+    bool on = ui < nBC * 4;
+    int j = 0, blk = 0, ch = 0;
+    if (on) { j = ui / nBC; const int rem = ui - j * nBC; blk = rem / c.C; ch = rem - blk * c.C; }     // subblock index slowest
+    if (on && c.fbMode == 2) blk = c.fbList[c.fbLo + blk];
+    if (on && skip_block(c, blk, finalPass)) on = false;
+    int wc = 0x10, dd = 0, off = 0, S = c.BS;
+    if (on) { wc = c.wcArr[(size_t)(blk / c.K) * (c.maxK + 2) + (blk % c.K) + 1]; on = unit_geom(wc, j, c.BS, dd, off, S); }
+    if (!__ballot(on)) return;
     const int N = c.C * c.BS;
-    const uint32_t *kw = c.keep + (size_t)blk * (N / 32);
-    const float *pairs = c.npair + (size_t)blk * N;
-    float *ts = c.tailSum + ((size_t)(blk * c.C + ch) * 4 + j) * 8;
-    int us = ch * c.BS + off, ue = us + S;
-    int last = us - 1;                                       // last kept index in [us, ue) (unit bounds are multiples of 32)
-    for (int w = (ue - 1) >> 5; (w << 5) >= us; w--) {
-        uint32_t m = kw[w];
-        if (m) { last = (w << 5) + 31 - __clz(m); break; }
-        if (w == 0) break;
+    int start = 0, n = 0;
+    if (on) {
+        const uint32_t *kw = c.keep + (size_t)blk * (N / 32);
+        const int ub = ch * c.BS + off, ue = ub + S;
+        int last = ub - 1;                                   // last kept index in [ub, ue) (unit bounds are multiples of 32)
+        for (int w = (ue - 1) >> 5; (w << 5) >= ub; w--) {
+            const uint32_t m = kw[w];
+            if (m) { last = (w << 5) + 31 - __clz(m); break; }
+            if (w == 0) break;
+        }
+        start = last + 1; n = ue - start;
+        float *ts = c.tailSum + ((size_t)(blk * c.C + ch) * 4 + j) * 8;
+        if (e == 5) ts[5] = __int_as_float(start);
+        // the unit's 25 Bark levels: lanes 0..7 of the unit copy them (4 each, the last one 1)
+        const float *bg = c.barkN + ((size_t)(blk * c.C + ch) * 4 + j) * ULCX_NBARK;
+        for (int i = e; i < ULCX_NBARK; i += 8) sbark[us * ULCX_NBARK + i] = bg[i];
     }
-    int start = last + 1, n = ue - start;
-    if (chain == 5) ts[5] = __int_as_float(start);
-    if (n < 16 || chain >= 5) return;
-    const float2 *d = (const float2 *)(pairs + (start / 2) * 2);
-    int np = (n + (start & 1) + 1) / 2;
+    const bool chainOn = on && n >= 16;
+    const int np = chainOn ? (n + (start & 1) + 1) / 2 : 0;      // pairs of the unit's tail
+    const int line0 = ((start - (ch * c.BS + off)) >> 1);        // line pair of the tail's first pair inside the unit
+    int npMax = np;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(npMax, o); npMax = v > npMax ? v : npMax; }
+    if (npMax == 0) return;
+    WAVE_SYNC_E();
+    const int *bandIdx = c.T.bandIdx[dd];
+    const float *bandFrac = c.T.bandFrac[dd];
+    const float *bark = sbark + us * ULCX_NBARK;
+    auto form = [&](int T) {                                 // pair 8 T + e of this unit's tail into tile buffer T & 1
+        const int q = 8 * T + e;
+        float2 pr = make_float2(0.0f, 0.0f);
+        if (q < np) {
+            const int line = line0 + q;
+            const int bi = bandIdx[line];
+            const float fr = bandFrac[line];
+            const float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
+            const float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
+            const float noise = L * (1.0f - fr) + R * fr;
+            const float w = ulcx_expf_t(0.5f * noise, sexp);
+            pr = make_float2(w, w * (noise + 0x1.62E430p-1f));
+        }
+        ((float2 *)tile)[((T & 1) * TAILS_UPW + us) * 8 + e] = pr;
+    };
     // term = (base * m1) * m2 with exact multiplications by 1.0f where a factor is absent:
     //   SumX: w*x   SumX2: (w*x)*x   SumXY: x*wy   SumY: wy   SumW: w
-    bool useY = (chain == 2) || (chain == 3);
-    bool hasX1 = (chain <= 2), hasX2 = (chain == 1);
+    const bool useY = (e == 2) || (e == 3);
+    const bool hasX1 = (e <= 2), hasX2 = (e == 1);
     float acc = 0.0f;
-    int q = 0;
-    for (; q + 8 <= np; q += 8) {
-        float2 pv[8];
+    const int nT = (npMax + 7) >> 3;
+    form(0);
+    WAVE_SYNC_E();
+    for (int T = 0; T < nT; T++) {
+        if (T + 1 < nT) form(T + 1);
+        const float *row = tile + (((T & 1) * TAILS_UPW + us) * 8) * 2 + (useY ? 1 : 0);
 #pragma unroll
-        for (int e = 0; e < 8; e++) pv[e] = d[q + e];
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            float x = (q + e) * 2.0f;
-            float base = useY ? pv[e].y : pv[e].x;
-            float m1 = hasX1 ? x : 1.0f, m2 = hasX2 ? x : 1.0f;
-            acc += (base * m1) * m2;
+        for (int i = 0; i < 8; i++) {
+            const int q = 8 * T + i;
+            const float base = row[2 * i];
+            const float x = q * 2.0f;
+            const float m1 = hasX1 ? x : 1.0f, m2 = hasX2 ? x : 1.0f;
+            const float t = (base * m1) * m2;
+            acc = (q < np) ? acc + t : acc;
         }
+        WAVE_SYNC_E();
     }
-    for (; q < np; q++) {
-        float2 pv = d[q];
-        float x = q * 2.0f;
-        float base = useY ? pv.y : pv.x;
-        float m1 = hasX1 ? x : 1.0f, m2 = hasX2 ? x : 1.0f;
-        acc += (base * m1) * m2;
-    }
-    ts[chain] = acc;
+    if (chainOn && e < 5) c.tailSum[((size_t)(blk * c.C + ch) * 4 + j) * 8 + e] = acc;
 }
-__global__ __launch_bounds__(64) void k_tailsums(UlcxEncCtx c, int finalPass) {
+__global__ __launch_bounds__(WG) void k_tails(UlcxEncCtx c, int finalPass) {
     if (probes_over(c, finalPass)) return;
-    if (c.fbMode != 2) { tailsums_lane(c, finalPass, blockIdx.x * 64 + threadIdx.x, c.B * c.K); return; }
-    int n = fb_count(c), total = n * c.C * 32;
-    for (int t = blockIdx.x * 64; t < total; t += gridDim.x * 64) tailsums_lane(c, finalPass, t + threadIdx.x, n);
+    __shared__ float tiles[WG / 64][2 * TAILS_UPW * 8 * 2];
+    __shared__ float sbark[WG / 64][TAILS_UPW * ULCX_NBARK];
+    __shared__ unsigned long long sexp[32];
+    if (threadIdx.x < 32) sexp[threadIdx.x] = ulcx_exp2f_tab[threadIdx.x];
+    __syncthreads();
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nBlk = (c.fbMode == 2) ? fb_count(c) : c.B * c.K;
+    const int nUnits = nBlk * c.C * 4;
+    for (int u0 = (blockIdx.x * (WG / 64) + wv) * TAILS_UPW; u0 < nUnits; u0 += gridDim.x * (WG / 64) * TAILS_UPW)
+        tails_wave(c, finalPass, u0, nBlk, tiles[wv], sbark[wv], sexp, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -2160,31 +2280,24 @@ __device__ __forceinline__ int next_kept(const uint32_t *keep, int i, int end) {
     }
     return end;
 }
-// NoiseFill.c:15-36 (pairs is the block-level {w, w*log} array, Band a block-level index)
-__device__ __forceinline__ int get_noise_q(const float *pairs, int band, int n, float q) {
-    const float2 *d = (const float2 *)(pairs + (band / 2) * 2);
+// NoiseFill.c:15-36 (band = a block-level coefficient index; the pairs are formed as they are summed: SumSrc).  What the
+// speculative sums of k_nsums did not cover: about 0.02 runs per block on the bench batch.
+__device__ __forceinline__ int get_noise_q(const SumSrc &g, int band, int n, float q) {
+    const int p0 = band / 2;
     n = (n + (band & 1) + 1) / 2;
     float sum = 0.0f, sumw = 0.0f;
-    int i = 0;
-    for (; i + 8 <= n; i += 8) {                    // loads batched, adds in the reference's order
-        float2 p[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) p[j] = d[i + j];
-#pragma unroll
-        for (int j = 0; j < 8; j++) { sum += p[j].y; sumw += p[j].x; }
-    }
-    for (; i < n; i++) { float2 p = d[i]; sum += p.y; sumw += p.x; }
+    for (int i = 0; i < n; i++) { const float2 p = pair_demand(g, p0 + i); sum += p.y; sumw += p.x; }
     if (sum == 0.0f) return 0;
     float amp = ulcx_expf(sum / sumw);
     return quant_coef_u(amp * q, 8);
 }
-// get_noise_q with the sums already evaluated (k_gapsums)
+// get_noise_q with the sums already evaluated (k_nsums)
 __device__ __forceinline__ int noise_q_from_sums(float sum, float sumw, float q) {
     if (sum == 0.0f) return 0;
     float amp = ulcx_expf(sum / sumw);
     return quant_coef_u(amp * q, 8);
 }
-// get_hfext with the five sums already evaluated (k_gapsums)
+// get_hfext with the five sums already evaluated (k_nsums)
 __device__ __forceinline__ void hfext_from_sums(float sx, float sx2, float sxy, float sy, float sw, float q, int &noiseQ, int &noiseDecay) {
     float det = sw * sx2 - sx * sx;
     if (det == 0.0f) { noiseQ = noiseDecay = 0; return; }
@@ -2199,51 +2312,25 @@ __device__ __forceinline__ void hfext_from_sums(float sx, float sx2, float sxy, 
     noiseQ = nq; noiseDecay = nd;
 }
 // NoiseFill.c:41-94
-__device__ __forceinline__ void get_hfext(const float *pairs, int band, int n, float q, int &noiseQ, int &noiseDecay) {
-    const float2 *d = (const float2 *)(pairs + (band / 2) * 2);
+__device__ __forceinline__ void get_hfext(const SumSrc &g, int band, int n, float q, int &noiseQ, int &noiseDecay) {
+    const int p0 = band / 2;
     n = (n + (band & 1) + 1) / 2;
     float sx = 0.0f, sx2 = 0.0f, sxy = 0.0f, sy = 0.0f, sw = 0.0f;
-    int i = 0;
-    for (; i + 8 <= n; i += 8) {
-        float2 p[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) p[j] = d[i + j];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            float x = (i + j) * 2.0f;
-            float wx = p[j].x * x;
-            sx += wx;
-            sx2 += wx * x;
-            sxy += x * p[j].y;
-            sy += p[j].y;
-            sw += p[j].x;
-        }
-    }
-    for (; i < n; i++) {
-        float x = i * 2.0f;
-        float2 p = d[i];
-        float wx = p.x * x;
+    for (int i = 0; i < n; i++) {
+        const float x = i * 2.0f;
+        const float2 p = pair_demand(g, p0 + i);
+        const float wx = p.x * x;
         sx += wx;
         sx2 += wx * x;
         sxy += x * p.y;
         sy += p.y;
         sw += p.x;
     }
-    float det = sw * sx2 - sx * sx;
-    if (det == 0.0f) { noiseQ = noiseDecay = 0; return; }
-    float amp = (sx2 * sy - sx * sxy) / det;
-    float dec = (sw * sxy - sx * sy) / det;
-    amp = ulcx_expf(amp);
-    dec = (dec < 0.0f) ? ulcx_expf(dec) : 1.0f;
-    int nq = quant_coef_u(amp * q * 4.0f, 16);
-    int nd = quant_u((dec - 1.0f) * -0x1.0p19f);
-    if (!nd) return;
-    if (nd > 0xFF) nd = 0xFF;
-    noiseQ = nq; noiseDecay = nd;
+    hfext_from_sums(sx, sx2, sxy, sy, sw, q, noiseQ, noiseDecay);
 }
 
 // Encode.c:92-197
-__device__ __forceinline__ int write_zone(NybWriter &w, int cur, int end, float quant, const float *coef, const float *pairs,
+__device__ __forceinline__ int write_zone(NybWriter &w, int cur, int end, float quant, const float *coef, const SumSrc &pairs,
                           const uint32_t *keep, int nextCoded, const float2 *gapSum = nullptr, int *lastKept = nullptr) {
     for (;;) {
         cur = next_kept(keep, cur, end);
@@ -2253,7 +2340,8 @@ __device__ __forceinline__ int write_zone(NybWriter &w, int cur, int end, float 
         if (fabsf(coef[cur] * quant) < 2.5f) { cur++; continue; }
         int n = 0, v = 0;
         int zr = cur - nextCoded;
-        bool specOk = gapSum && (nextCoded == prevKept + 1);      // k_gapsums assumed exactly this gap
+        bool specOk = gapSum && (nextCoded == prevKept + 1);      // k_nsums assumed exactly this gap
+        int run = 0;                                               // noise runs attempted in this gap
         while (zr) {
             if (zr <= 2) {
                 int q1 = quant_coef(coef[nextCoded] * quant, 7);
@@ -2270,11 +2358,13 @@ __device__ __forceinline__ int write_zone(NybWriter &w, int cur, int end, float 
             if (zr >= 16) {
                 v = zr - 16; if (v > 0x1FF) v = 0x1FF;
                 n = v + 16;
-                float amp = specOk ? gapSum[cur].x : -2.0f;
+                float amp = -2.0f;
+                if (specOk) { const float2 a = gapSum[cur - (run >> 1)]; amp = (run & 1) ? a.y : a.x; }
                 if (amp > -1.5f) nq = (amp < 0.0f) ? 0 : quant_coef_u(amp * quant, 8);
                 else nq = get_noise_q(pairs, nextCoded, n, quant);
+                run++;
             }
-            specOk = false;                                        // only the first run of a gap was speculated
+            specOk = specOk && nq != 0;                            // (a zero run instead moves the start of whatever follows)
             if (nq) {
                 w.put(0x8); w.put((unsigned)(v >> 5)); w.put((unsigned)(v >> 1)); w.put((unsigned)((v & 1) | ((nq - 1) << 1)));
             } else if (zr < 33) {
@@ -2312,7 +2402,7 @@ __device__ void encode_units_lane(const UlcxEncCtx &c, int finalPass, int gid, i
     if (!unit_geom(wc, j, c.BS, d, off, S)) { c.unitNyb[gid] = 0; return; }
     int N = c.C * c.BS;
     const float *coef = c.coef + (size_t)blk * N;
-    const float *pairs = c.npair + (size_t)blk * N;
+    const SumSrc pairs = sum_src(c, blk);
     const uint32_t *keep = c.keep + (size_t)blk * (N / 32);
     NybWriter w;
     w.cap = 2 * S + 8;
@@ -2405,10 +2495,12 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
 }
 
 // run codes of one gap (Encode.c:118-188); nybbles appended LSB-first to (lo,hi), count in cnt.
-// amp0 >= -1: noise amplitude of the gap's FIRST run already evaluated by k_gapsums (-1 = "Sum == 0");
-// anything else (and every later run of the gap) is summed here from the pairs in HBM.
-__device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const float *coefU, const float *pairU, float amp0,
+// amp0 / amp1 >= -1: noise amplitude of the gap's first / second run already evaluated by k_nsums (-1 = "Sum == 0");
+// anything else is summed here, the pairs formed on the spot (get_noise_q).
+__device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const float *coefU, const SumSrc &src, int ubase, float amp0, float amp1,
+                                          const float2 *gapI /* gapSum entry of the coefficient behind the gap, or null */,
                                           unsigned long long &lo, unsigned long long &hi, int &cnt, bool dbgNoSum = false) {
+    int run = 0;                                               // noise runs attempted in this gap
     // a trip's nybbles (at most four) are gathered in a 16-bit word and appended once: one 64-bit shift per trip
     // (nybbles past the 32nd are dropped but counted: the caller treats cnt > 32 as an overflow)
     // (selects between VALUES, both words updated every time: written as if / else on lo and hi the compiler indexes
@@ -2439,9 +2531,15 @@ __device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const flo
             v = zr - 16; if (v > 0x1FF) v = 0x1FF;
             n = v + 16;
             if (amp0 > -1.5f) nq = (amp0 < 0.0f) ? 0 : quant_coef_u(amp0 * quant, 8);
-            else nq = dbgNoSum ? 0 : get_noise_q(pairU, nc, n, quant);
-        }
-        amp0 = -2.0f;
+            else nq = dbgNoSum ? 0 : get_noise_q(src, ubase + nc, n, quant);
+            // the next run was speculated behind runs that were all coded as noise: the second comes with the first, the
+            // third .. from the entries in front of the coefficient's (k_nsums)
+            run++;
+            const bool chain = nq != 0 && amp0 > -1.5f && gapI != nullptr;
+            float nxt = amp1;
+            if (chain && run >= 2 && zr - n >= 16) { const float2 a = gapI[-(run >> 1)]; nxt = (run & 1) ? a.y : a.x; }
+            amp0 = chain ? nxt : -2.0f; amp1 = -2.0f;
+        } else amp0 = -2.0f;
         if (nq) append(0x8u | (((unsigned)(v >> 5) & 0xF) << 4) | (((unsigned)(v >> 1) & 0xF) << 8) | ((((unsigned)(v & 1) | ((unsigned)(nq - 1) << 1)) & 0xF) << 12), 4);
         else if (zr < 33) { v = zr - 1; if (v > 0xF) v = 0xF; n = v + 1; append((unsigned)v << 4, 2); }
         else { v = zr - 33; if (v > 0xFF) v = 0xFF; n = v + 33; append(0x1u | (((unsigned)(v >> 4) & 0xF) << 4) | (((unsigned)v & 0xF) << 8), 3); }
@@ -2469,7 +2567,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
     const int N = c.C * c.BS;
     const int ubase = ch * c.BS + off;                       // unit offset inside the block arrays
     const float *coefU = c.coef + (size_t)blk * N + ubase;
-    const float *pairU = c.npair + (size_t)blk * N + ubase;
+    const SumSrc src = sum_src(c, blk);
     const float2 *gapU = c.gapSum + (size_t)blk * N + ubase;
     const uint32_t *keepU = c.keep + (size_t)blk * (N / 32) + (ubase >> 5);
 
@@ -2602,7 +2700,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
 
     // E. quantise kept items, drop the ones that collapse (Encode.c:114), compact in place.
     //    Bit 15 of the compacted index records "the kept item right before me was coded too",
-    //    i.e. the gap in front of me is exactly the one k_gapsums speculated on.
+    //    i.e. the gap in front of me is exactly the one k_nsums speculated on.
     int nC = 0;
     if (!overflow) {
         bool prevCodedCarry = true;                          // before the first kept item: gap starts at the unit start, as speculated
@@ -2643,9 +2741,9 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
                 qn = ((int *)kval)[m];
                 pre = zpre[z] - ((zp >= 0) ? zpre[zp] : 0);
                 int zr = idx - start;
-                float amp0 = -2.0f;
-                if (zr >= 16 && (raw & 0x8000) && c.useGapSums) amp0 = gapU[idx].x;
-                gap_codes(start, zr, (float)(1u << zqi[z]), coefU, pairU, amp0, lo, hi, cnt, (ULCX_DBG(c) & 0x40) != 0);
+                float amp0 = -2.0f, amp1 = -2.0f;
+                if (zr >= 16 && (raw & 0x8000) && c.useGapSums) { const float2 a = gapU[idx]; amp0 = a.x; amp1 = a.y; }
+                gap_codes(start, zr, (float)(1u << zqi[z]), coefU, src, ubase, amp0, amp1, amp0 > -1.5f ? gapU + idx : nullptr, lo, hi, cnt, (ULCX_DBG(c) & 0x40) != 0);
             }
             int mine = (m < nC) ? pre + cnt + 1 : 0;
             int tot, ex = wave_excl_scan(mine, lane, tot);
@@ -2685,12 +2783,12 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
                 sx = ts[0]; sx2 = ts[1]; sxy = ts[2]; sy = ts[3]; sw = ts[4];
             } else {
                 // NoiseFill.c:41-62: five ordered f32 sums, one per lane 0..4 (rare: the speculated tail start was off)
-                const float2 *dd = (const float2 *)(pairU + (nextCoded / 2) * 2);
+                const int p0 = (ubase + nextCoded) / 2;
                 int np = (n + (nextCoded & 1) + 1) / 2;
                 float acc = 0.0f;
                 if (lane < 5) {
                     for (int i = 0; i < np; i++) {
-                        float2 pv = dd[i];
+                        float2 pv = pair_demand(src, p0 + i);
                         float x = i * 2.0f;
                         float wx = pv.x * x;
                         float term = (lane == 0) ? wx : (lane == 1) ? wx * x : (lane == 2) ? x * pv.y : (lane == 3) ? pv.y : pv.x;
@@ -2924,6 +3022,14 @@ size_t ulcx_enc_xf_lds_bytes(int BS, int C) {
     return full <= ULCX_LDS_LIMIT ? full : z + (size_t)BS * 2 + 32;   // (C > 2 at BlockSize 8192: twiddles stay in global memory)
 }
 
+int ulcx_enc_nsums_slots(int BS, int C) {
+    const size_t lds = nsums_lds_bytes(C * BS, C);
+    if (lds > 48 * 1024 && hipFuncSetAttribute((const void *)k_nsums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int dev = 0, cus = 0, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void *)k_nsums, WG, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return cus * per;
+}
 // launch the input-reading kernels for the call's sample type (float | PCM16)
 static void launch_wc_energy(const UlcxEncCtx &c, unsigned grid, hipStream_t st, int k0, int k1) {
     if (c.pcm16) hipLaunchKernelGGL(k_wc_energy<int16_t>, dim3(grid), dim3(WG), 0, st, c, k0, k1);
@@ -2960,7 +3066,7 @@ static void launch_state_update(const UlcxEncCtx &c, hipStream_t st) {
 const char *const ulcx_enc_stage_names[ULCX_ENC_STAGES_REPORTED] = {
     "k_wc_energy", "k_wc_forward", "k_wc_backward", "k_wc_integrate", "k_wc_decide",
     "k_xf", "k_cplx", "k_pbark", "k_mask",
-    "k_select", "k_nbark", "k_nline", "k_heapsel", "k_gapsums", "k_tailsums", "k_encode_wave", "k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update", "wc_pipeline_exposed",
+    "k_select", "k_nbark", "(k_nline: gone)", "k_heapsel", "k_nsums", "k_tails", "k_encode_wave", "k_encode_units", "k_pack", "cbr_probe_passes", "k_state_update", "wc_pipeline_exposed",
 };
 
 int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const UlcxEncAux &aux) {
@@ -3091,7 +3197,6 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             hipLaunchKernelGGL(k_bark_levels<true>, dim3((unsigned)(((size_t)NB * c.C * 32 + WG - 1) / WG)), dim3(WG), 0, s2, c);
         }
         hipLaunchKernelGGL(k_nbark, dim3((nUnits + 63) / 64), dim3(64), 0, s2, c, c.barkRing ? 1 : 0);    if (ev0) MARK();
-        hipLaunchKernelGGL(k_nline, dim3(NB), dim3(WG), 0, s2, c);
         if (ev0) MARK();
         return ULCX_OK;
     };
@@ -3196,21 +3301,22 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         const bool fb2 = (cc.fbMode == 2);                 // exact path: small grids that walk the list of owned blocks
         const int fbW = NB < 128 ? NB : 128;
         if (cc.useGapSums) {
-            size_t glds = (size_t)N * 4 + N / 8 + 8 * E_GAPCAP(N) + 16 + 8 * ((N / 32 + 63) / 64);
-            if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_gapsums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
-            // the two speculative-sum kernels are independent and both latency-bound: on the main path k_tailsums
-            // runs on a side stream beside k_gapsums
+            const size_t glds = nsums_lds_bytes(N, cc.C);
+            if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_nsums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+            // the two speculative-sum kernels are independent: on the main path the tail chains run on a side stream beside the gaps
             const bool tailAside = !fb2 && side2 != nullptr && s2 == st;
+            const unsigned tg = (unsigned)((nUnits + 4 * TAILS_UPW - 1) / (4 * TAILS_UPW));
             if (tailAside) {
                 CK(hipEventRecord(evTail0, s2));
                 CK(hipStreamWaitEvent(side2, evTail0, 0));
-                hipLaunchKernelGGL(k_tailsums, dim3((nUnits * 8 + 63) / 64), dim3(64), 0, side2, cc, fin);
+                hipLaunchKernelGGL(k_tails, dim3(tg), dim3(WG), 0, side2, cc, fin);
                 CK(hipEventRecord(evTail1, side2));
             }
-            hipLaunchKernelGGL(k_gapsums, dim3(fb2 ? fbW : NB), dim3(WG), glds, s2, cc, fin);
+            const int nsGrid = NB < aux.nsSlots ? NB : aux.nsSlots;             // persistent: what the device holds at once
+            hipLaunchKernelGGL(k_nsums, dim3(fb2 ? fbW : nsGrid), dim3(WG), glds, s2, cc, fin);
             if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
             if (tailAside) CK(hipStreamWaitEvent(s2, evTail1, 0));
-            else hipLaunchKernelGGL(k_tailsums, dim3(fb2 ? fbW : (nUnits * 8 + 63) / 64), dim3(64), 0, s2, cc, fin);
+            else hipLaunchKernelGGL(k_tails, dim3(fb2 ? fbW : tg), dim3(WG), 0, s2, cc, fin);
             if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
         } else if (ev0 && ev) { CK(hipEventRecord(ev[stage++], s2)); CK(hipEventRecord(ev[stage++], s2)); }
         if (cc.useWave) {

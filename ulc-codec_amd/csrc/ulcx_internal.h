@@ -73,7 +73,7 @@ struct UlcxEncCtx {
     float  *coef;                        // [NB][C*BS]   normalised MDCT (TransformBuffer)
     float  *key;                         // [NB][C*BS]   key0 = FastLog(Re^2) | -inf; final keys are formed on the fly (final_key)
     float  *nsum;                        // [NB][C*BS/2] per-line |X|^2 (noise input)
-    float  *npair;                       // [NB][C*BS]   {w, w*log} pairs (TransformNoise)
+    float  *npair;                       // [NB][C*BS]   {w, w*log} pairs (TransformNoise): parity tap only, allocated on its first use
     float  *amp2;                        // [NB][BS/2]
     float  *barkN;                       // [NB][C*4][25]
     float  *barkP;                       // [NB][4][25]
@@ -177,6 +177,7 @@ struct UlcxEncAux {
     int wcPipe;                          // chunks of blocks pipelined between window control and transform; 1 = off
     int wcSteps;                         // fine steps of the window-control kernels per call (ULCX_WC_STEPS)
     int wcFuse;                          // ULCX_WC_FUSE, read once when the encoder is created
+    int nsSlots;                         // workgroups of k_nsums the device holds at once (its persistent grid)
     int *nXf;                            // out: transform launches this call
 };
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, const UlcxEncAux &aux);
@@ -189,6 +190,7 @@ int ulcx_dec_syn_slots(const UlcxDecCtx &c);      // resident workgroups of the 
 int ulcx_pack_launch(int nStreams, int nBlocks, int slotBytes, const uint8_t *d_slots, const int32_t *d_bits, uint8_t *d_payload,
                      long long stride, int32_t *d_payloadBytes, int32_t *d_maxBlock, hipStream_t st);
 size_t ulcx_enc_xf_lds_bytes(int BS, int C);
+int ulcx_enc_nsums_slots(int BS, int C);                 // resident workgroups of k_nsums on the current device
 // FFT array padding of k_xf (ulcx_fft.h).  One complex per 8 makes every pass conflict-free but costs 2 KB of LDS at
 // BlockSize 2048 and with it the 4th workgroup per CU: measured 2.13 ms vs 1.88 ms with one per 16.
 __host__ __device__ static inline int ulcx_xf_pad_shift(int BS, int C) { (void)BS; (void)C; return 4; }
@@ -200,3 +202,4 @@ __host__ __device__ static inline int ulcx_xf_pad_shift(int BS, int C) { (void)B
 #endif
 __host__ __device__ static inline int ulcx_sel_lds_words(int BS) { int a = BS / 2 + 4 * ULCX_NBARK, b = ULCX_SEL_CAP * 64; return a > b ? a : b; }
 void ulcx_enc_finalize_keys(const UlcxEncCtx &c, hipStream_t st);
+void ulcx_enc_materialise_noise(const UlcxEncCtx &c, hipStream_t st);     // parity tap: the {w, w*log} pairs of the last call into c.npair
