@@ -20,6 +20,9 @@
 #define WG 128
 #define FFT_PACKED
 #include "ulcx_fft.h"
+#ifndef DSYN_C2048
+#define DSYN_C2048 1
+#endif
 #ifndef DPS
 #define DPS 4        // FFT array padding (ulcx_fft.h): one complex after every 16 (3: after every 8 - conflict-free passes, 1 KB more LDS)
 #endif
@@ -665,11 +668,13 @@ __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int 
 // The lapping state lives in global memory (L2-hot: every element is re-read by the thread that wrote it one block earlier);
 // TWL: FFT twiddles in LDS (BlockSize <= 2048); SPLIT: the grid is an even cut of the (stream, block) pairs (else one
 // workgroup per stream: the index arithmetic and the choice of the lapping rows below fold away)
-template <typename OUT, int DEC_MAXT, bool TWL, bool SPLIT = false>
+// BSC: BlockSize as a compile-time constant (2048: the headline geometry - the loops of an un-decimated block unroll, the
+// table and lapping-state loads of a thread's trips can be issued together; 0: read from the context)
+template <typename OUT, int DEC_MAXT, bool TWL, bool SPLIT = false, int BSC = 0>
 __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
     constexpr bool LAPG = true;
     extern __shared__ float lds[];
-    const int BS = c.BS, H2 = BS / 2;
+    const int BS = BSC ? BSC : c.BS, H2 = BS / 2;
     constexpr int C = 2;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -828,6 +833,7 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                 // DCT-IV pre-twiddle in place: n and M-1-n together read and write the same two complex slots
                 const float2 *pre = c.T.pre[d];
                 if (!(ULCX_DBG(c) & 2)) {
+#pragma unroll
                 for (int n = lane; n < M / 2; n += 64) {
                     const int n2 = M - 1 - n;
                     const int pn = FFT_PADS(n, DPS), pn2 = FFT_PADS(n2, DPS);
@@ -861,6 +867,7 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                 const int bits = 31 - __clz(M);
                 const float *R0 = lapR, *R1 = lapR + H2;
                 float *L0 = lapW, *L1 = lapW + H2;
+#pragma unroll
                 for (int kk = tid; kk < M / 2; kk += WG) {
                     const int k1 = kk, k2 = M - 1 - kk;
                     int r1 = (int)(__brev((unsigned)k1) >> (32 - bits));
@@ -1125,6 +1132,7 @@ template <typename OUT>
 static void launch_syn(const UlcxDecCtx &cc, unsigned g, size_t lds, hipStream_t s2, bool split) {
     const bool small = cc.BS <= 2048;
     if (!cc.fastOK) hipLaunchKernelGGL(k_dgen<OUT>, dim3(g), dim3(WG), lds, s2, cc);
+    else if (cc.BS == 2048 && DSYN_C2048) { if (split) hipLaunchKernelGGL((k_dsyn<OUT, 16, true, true, 2048>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<OUT, 16, true, false, 2048>), dim3(g), dim3(WG), lds, s2, cc); }
     else if (small) { if (split) hipLaunchKernelGGL((k_dsyn<OUT, 16, true, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<OUT, 16, true, false>), dim3(g), dim3(WG), lds, s2, cc); }
     else { if (split) hipLaunchKernelGGL((k_dsyn<OUT, 32, false, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<OUT, 32, false, false>), dim3(g), dim3(WG), lds, s2, cc); }
 }
