@@ -120,6 +120,34 @@ def test_batched_front_end_matches_the_reference_tools_file_for_file(arg, fmt, t
         assert got[-nbytes:] == ref[-nbytes:], f"{u.name}: batched decode differs from ulcdecodetool"
 
 
+@pytest.mark.skipif(not os.path.exists(TOOL), reason="ulc-codec_amd/ulcx-tool not built")
+@pytest.mark.parametrize("ndev", [2, 3])
+def test_batched_front_end_devices_option_does_not_change_the_files(ndev, tmp_path):
+    """SURVEY.md §8(e) below bench.py: `ulcx-tool -devices:N` deals the inputs round-robin over N groups, each with its own
+    encoder / decoder and its own host thread (group g on device g % visible: on the 1-GPU box the groups share device 0).
+    Every file must be the one the single-group run writes."""
+    rate, ch = 44100, 2
+    ins = []
+    for i, sec in enumerate([0.9, 0.4, 1.3, 0.25, 0.7, 1.1, 0.5]):
+        pcm = synth_pcm(60 + i, int(sec * rate), ch, rate, transient=(i % 3) != 1, seed=13)
+        p = tmp_path / f"d{i}.wav"
+        _write_wav16(p, np.clip(np.rint(pcm * 32767.0), -32768, 32767).astype(np.int16), rate)
+        ins.append(p)
+    one, many = tmp_path / "one", tmp_path / "many"
+    one.mkdir(); many.mkdir()
+    _run([TOOL, "encode", str(one), "-45"] + [str(p) for p in ins])
+    _run([TOOL, "encode", str(many), "-45", f"-devices:{ndev}"] + [str(p) for p in ins])
+    for p in ins:
+        assert open(many / (p.stem + ".ulc"), "rb").read() == open(one / (p.stem + ".ulc"), "rb").read(), f"{p.name}: -devices:{ndev} changed the encoded file"
+    w1, wn = tmp_path / "w1", tmp_path / "wn"
+    w1.mkdir(); wn.mkdir()
+    ulcs = [str(one / (p.stem + ".ulc")) for p in ins]
+    _run([TOOL, "decode", str(w1)] + ulcs)
+    _run([TOOL, "decode", str(wn), f"-devices:{ndev}"] + ulcs)
+    for p in ins:
+        assert open(wn / (p.stem + ".wav"), "rb").read() == open(w1 / (p.stem + ".wav"), "rb").read(), f"{p.name}: -devices:{ndev} changed the decoded file"
+
+
 @needs_tools
 @pytest.mark.skipif(not os.path.exists(TOOL), reason="ulc-codec_amd/ulcx-tool not built")
 def test_abr_workflow_analyse_then_encode_matches_the_reference_tools(tmp_path):

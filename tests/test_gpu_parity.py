@@ -523,6 +523,49 @@ def test_headline_geometry_schedules_keep_parity(env, B, K):
 
 
 
+def test_two_host_threads_drive_two_encoders_and_two_decoders():
+    """"one host thread (or one HIP stream) per device".  Two host threads of ONE process, each with its
+    own encoder and decoder (both on device 0 of the 1-GPU box; on a multi-GPU node thread t takes device t), encode and
+    decode their own half of the streams at the same time, several calls each: every byte and every sample against the
+    oracle.  (ctypes releases the GIL for the duration of a library call: the calls do overlap.)"""
+    import threading
+    amd = _amd()
+    ndev = amd.lib().ulcx_device_count()
+    bs, ch, rate, B, K, calls = 2048, 2, 44100, 10, 6, 3
+    pcm = _streams(2 * B, calls * K, bs, ch, rate, True, seed=909)
+    slot = 2 * ch * bs + 16
+    res = [None, None]
+
+    def work(t):
+        try:
+            mine = pcm[t * B:(t + 1) * B]
+            enc = amd.BatchEncoder(B, ch, bs, rate, K, device=t % ndev)
+            dec = amd.BatchDecoder(B, ch, bs, K, device=t % ndev)
+            outs, pcms = [], []
+            for c in range(calls):
+                o = enc.encode(mine[:, c * K * bs:(c + 1) * K * bs], amd.MODE_VBR if t == 0 else amd.MODE_CBR, 50.0 if t == 0 else 72.0)
+                outs.append(o)
+                pcms.append(dec.decode(o[0]))
+            enc.close(); dec.close()
+            res[t] = (outs, pcms)
+        except Exception as e:                                   # (surfaces in the assert below)
+            res[t] = e
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in ths: th.start()
+    for th in ths: th.join()
+    for t in range(2):
+        assert not isinstance(res[t], Exception), f"thread {t}: {res[t]}"
+        outs, pcms = res[t]
+        for s in range(B):
+            ref = oracle_encode_debug(pcm[t * B + s], bs, rate, 0 if t == 0 else 1, 50.0 if t == 0 else 72.0, slot=slot)
+            for c in range(calls):
+                _compare_encode(outs[c], ref, s, c * K, K, None, f"thread {t}")
+            rc, ref_pcm, ref_bits = oracle_decode_stream(ref["out"], ch, bs)
+            got = np.concatenate([p[0][s] for p in pcms])
+            assert rc == 0 and np.array_equal(got.view(np.uint32), ref_pcm.view(np.uint32)), f"thread {t} stream {s}: decoded PCM differs"
+
+
 def test_timing_events_can_be_switched_off():
     """ulcx_encoder_set_timing / ulcx_decoder_set_timing: without the per-kernel events the results are the same and
     the stage tables are empty; switched on again they are filled."""

@@ -1,8 +1,8 @@
 /*
  * ulcx_tool.c — batched front-end over libulc_amd.so.
  *
- *   ulcx-tool encode OUTDIR RATE[,AvgComplexity] [-blocksize:N] IN1.wav IN2.wav ...
- *   ulcx-tool decode OUTDIR [-format:PCM16|FLOAT32]            IN1.ulc IN2.ulc ...
+ *   ulcx-tool encode OUTDIR RATE[,AvgComplexity] [-blocksize:N] [-devices:N] IN1.wav IN2.wav ...
+ *   ulcx-tool decode OUTDIR [-format:PCM16|FLOAT32] [-devices:N]             IN1.ulc IN2.ulc ...
  *
  * What tools/ulcEncodeTool.c / tools/ulcDecodeTool.c of the reference do for ONE file per
  * process, done for MANY files per call: every input is one stream of the batch, all streams
@@ -15,10 +15,16 @@
  * (decode); inputs may have different lengths (shorter ones are padded with silence and trimmed
  * to their own block count on output).
  *
+ * -devices:N (independent streams shard by plain batch split, one host thread per device, no collective): the
+ * inputs are dealt round-robin over N groups, every group gets its own encoder / decoder and its own host thread; group g
+ * runs on device g % (visible devices), so N may exceed the device count (two groups then share a GPU).  The files written
+ * do not depend on N.
+ *
  * WAV support is deliberately minimal: RIFF/WAVE, "fmt " PCM 16-bit or IEEE float 32-bit, one
  * "data" chunk.  Host code is plain C over the C ABI of include/ulc_amd.h.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -96,17 +102,14 @@ static void out_path(char *dst, size_t n, const char *dir, const char *in, const
 }
 #define DIE(...) do { fprintf(stderr, "ulcx-tool: " __VA_ARGS__); fprintf(stderr, "\n"); return 2; } while (0)
 
-static int do_encode(int argc, char **argv) {
-    if (argc < 5) DIE("usage: ulcx-tool encode OUTDIR RATE[,AvgComplexity] [-blocksize:N] IN.wav ...");
-    const char *outdir = argv[2];
-    float rate = 0.0f, avgc = 0.0f;
-    sscanf(argv[3], "%f,%f", &rate, &avgc);
-    if (rate == 0.0f || avgc < 0.0f) DIE("invalid coding rate '%s'", argv[3]);
-    int bs = 2048, a = 4;
-    if (a < argc && !strncmp(argv[a], "-blocksize:", 11)) { bs = atoi(argv[a] + 11); a++; }
-    if (bs < 256 || bs > 8192 || (bs & -bs) != bs) DIE("unsupported block size %d", bs);
-    int B = argc - a;
-    if (B < 1) DIE("no input files");
+/* one group of inputs = one batch on one device (the whole command line, or a -devices:N share of it on its own thread) */
+struct group { int decode, device, n; char **files; const char *outdir; float rate, avgc; int bs, isFloat; int rc; };
+
+static int encode_group(const struct group *g) {
+    const char *outdir = g->outdir;
+    const float rate = g->rate, avgc = g->avgc;
+    const int bs = g->bs, B = g->n, a = 0;
+    char **argv = g->files;
     struct wav *w = (struct wav *)calloc((size_t)B, sizeof(*w));
     uint32_t maxBlk = 0;
     for (int s = 0; s < B; s++) {
@@ -120,7 +123,7 @@ static int do_encode(int argc, char **argv) {
     int mode = rate < 0.0f ? ULCX_MODE_VBR : (avgc > 0.0f ? ULCX_MODE_ABR : ULCX_MODE_CBR);
     float p0 = rate < 0.0f ? -rate : rate;
     ulcx_encoder *enc = NULL;
-    if (ulcx_encoder_create(&enc, 0, B, C, bs, hz, KBLOCKS) != ULCX_OK) DIE("encoder: %s", ulcx_last_error());
+    if (ulcx_encoder_create(&enc, g->device, B, C, bs, hz, KBLOCKS) != ULCX_OK) DIE("encoder: %s", ulcx_last_error());
     const int slot = ulcx_encoder_slot_bytes(enc);
     size_t frame = (size_t)bs * C;
     float *pcm = (float *)malloc(sizeof(float) * (size_t)B * KBLOCKS * frame);
@@ -170,18 +173,10 @@ static int do_encode(int argc, char **argv) {
     return 0;
 }
 
-static int do_decode(int argc, char **argv) {
-    if (argc < 4) DIE("usage: ulcx-tool decode OUTDIR [-format:PCM16|FLOAT32] IN.ulc ...");
-    const char *outdir = argv[2];
-    int a = 3, isFloat = 0;
-    if (!strncmp(argv[a], "-format:", 8)) {
-        const char *f = argv[a] + 8;
-        if (!strcmp(f, "FLOAT32") || !strcmp(f, "float32")) isFloat = 1;
-        else if (strcmp(f, "PCM16") && strcmp(f, "pcm16")) DIE("unsupported output format '%s'", f);
-        a++;
-    }
-    int B = argc - a;
-    if (B < 1) DIE("no input files");
+static int decode_group(const struct group *g) {
+    const char *outdir = g->outdir;
+    const int isFloat = g->isFloat, B = g->n, a = 0;
+    char **argv = g->files;
     ulcx_file_header *h = (ulcx_file_header *)calloc((size_t)B, sizeof(*h));
     uint8_t **pay = (uint8_t **)calloc((size_t)B, sizeof(uint8_t *));
     int32_t *payBytes = (int32_t *)calloc((size_t)B, sizeof(int32_t));
@@ -216,7 +211,7 @@ static int do_decode(int argc, char **argv) {
     uint8_t *payload = (uint8_t *)calloc((size_t)B, (size_t)stride);
     for (int s = 0; s < B; s++) { memcpy(payload + (size_t)s * stride, pay[s] + h[s].StreamOffs, (size_t)payBytes[s]); free(pay[s]); }
     ulcx_decoder *dec = NULL;
-    if (ulcx_decoder_create(&dec, 0, B, C, bs, KBLOCKS) != ULCX_OK) DIE("decoder: %s", ulcx_last_error());
+    if (ulcx_decoder_create(&dec, g->device, B, C, bs, KBLOCKS) != ULCX_OK) DIE("decoder: %s", ulcx_last_error());
     size_t frame = (size_t)bs * C;
     float *pcm = (float *)malloc(sizeof(float) * (size_t)B * KBLOCKS * frame);
     int32_t *bits = (int32_t *)malloc(sizeof(int32_t) * (size_t)B * KBLOCKS);
@@ -255,13 +250,74 @@ static int do_decode(int argc, char **argv) {
     return rcAll;
 }
 
+static void *group_main(void *p) {
+    struct group *g = (struct group *)p;
+    g->rc = g->decode ? decode_group(g) : encode_group(g);
+    return NULL;
+}
+/* the command line's inputs as nDev groups (input i goes to group i % nDev), one host thread and one codec object each */
+static int run_groups(struct group *proto, int nFiles, char **files, int nDev) {
+    if (nFiles < 1) DIE("no input files");
+    if (nDev > nFiles) nDev = nFiles;
+    const int have = ulcx_device_count();
+    if (have < 1) DIE("no HIP device: %s", ulcx_last_error());
+    if (nDev <= 1) { proto->device = 0; proto->n = nFiles; proto->files = files; return proto->decode ? decode_group(proto) : encode_group(proto); }
+    struct group *gs = (struct group *)calloc((size_t)nDev, sizeof(*gs));
+    char **deal = (char **)calloc((size_t)nFiles, sizeof(char *));
+    pthread_t *th = (pthread_t *)calloc((size_t)nDev, sizeof(pthread_t));
+    int at = 0, rc = 0;
+    for (int g = 0; g < nDev; g++) {
+        gs[g] = *proto; gs[g].device = g % have; gs[g].files = deal + at; gs[g].n = 0; gs[g].rc = 0;
+        for (int i = g; i < nFiles; i += nDev) deal[at + gs[g].n++] = files[i];
+        at += gs[g].n;
+    }
+    for (int g = 0; g < nDev; g++) if (pthread_create(&th[g], NULL, group_main, &gs[g])) DIE("cannot start a host thread for group %d", g);
+    for (int g = 0; g < nDev; g++) { pthread_join(th[g], NULL); if (gs[g].rc > rc) rc = gs[g].rc; }
+    free(gs); free(deal); free(th);
+    return rc;
+}
+static int do_encode(int argc, char **argv) {
+    if (argc < 5) DIE("usage: ulcx-tool encode OUTDIR RATE[,AvgComplexity] [-blocksize:N] [-devices:N] IN.wav ...");
+    struct group g; memset(&g, 0, sizeof(g));
+    g.outdir = argv[2];
+    sscanf(argv[3], "%f,%f", &g.rate, &g.avgc);
+    if (g.rate == 0.0f || g.avgc < 0.0f) DIE("invalid coding rate '%s'", argv[3]);
+    int a = 4, nDev = 1;
+    g.bs = 2048;
+    for (; a < argc && argv[a][0] == '-'; a++) {
+        if (!strncmp(argv[a], "-blocksize:", 11)) g.bs = atoi(argv[a] + 11);
+        else if (!strncmp(argv[a], "-devices:", 9)) nDev = atoi(argv[a] + 9);
+        else DIE("unknown option '%s'", argv[a]);
+    }
+    if (g.bs < 256 || g.bs > 8192 || (g.bs & -g.bs) != g.bs) DIE("unsupported block size %d", g.bs);
+    if (nDev < 1 || nDev > 64) DIE("-devices:%d out of range", nDev);
+    return run_groups(&g, argc - a, argv + a, nDev);
+}
+static int do_decode(int argc, char **argv) {
+    if (argc < 4) DIE("usage: ulcx-tool decode OUTDIR [-format:PCM16|FLOAT32] [-devices:N] IN.ulc ...");
+    struct group g; memset(&g, 0, sizeof(g));
+    g.decode = 1; g.outdir = argv[2];
+    int a = 3, nDev = 1;
+    for (; a < argc && argv[a][0] == '-'; a++) {
+        if (!strncmp(argv[a], "-format:", 8)) {
+            const char *f = argv[a] + 8;
+            if (!strcmp(f, "FLOAT32") || !strcmp(f, "float32")) g.isFloat = 1;
+            else if (strcmp(f, "PCM16") && strcmp(f, "pcm16")) DIE("unsupported output format '%s'", f);
+        } else if (!strncmp(argv[a], "-devices:", 9)) nDev = atoi(argv[a] + 9);
+        else DIE("unknown option '%s'", argv[a]);
+    }
+    if (nDev < 1 || nDev > 64) DIE("-devices:%d out of range", nDev);
+    return run_groups(&g, argc - a, argv + a, nDev);
+}
+
 int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "encode")) return do_encode(argc, argv);
     if (argc >= 2 && !strcmp(argv[1], "decode")) return do_decode(argc, argv);
     fprintf(stderr,
             "ulcx-tool - batched ulc-codec front-end over libulc_amd.so (MI355X)\n"
-            "  ulcx-tool encode OUTDIR RATE[,AvgComplexity] [-blocksize:N] IN1.wav IN2.wav ...\n"
+            "  ulcx-tool encode OUTDIR RATE[,AvgComplexity] [-blocksize:N] [-devices:N] IN1.wav IN2.wav ...\n"
             "      RATE < 0: VBR quality; RATE > 0: CBR kbps; RATE,AvgComplexity: ABR  (as ulcencodetool)\n"
-            "  ulcx-tool decode OUTDIR [-format:PCM16|FLOAT32] IN1.ulc IN2.ulc ...\n");
+            "  ulcx-tool decode OUTDIR [-format:PCM16|FLOAT32] [-devices:N] IN1.ulc IN2.ulc ...\n"
+            "  -devices:N  inputs dealt round-robin over N groups, one host thread + one codec object each (device g %% visible)\n");
     return 1;
 }

@@ -179,8 +179,8 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.wcArr, B * (K + 2), true);
     DA(c.coef, NB * cb, false);
     DA(c.key, NB * cb, false);
-    DA(c.nsum, NB * cb / 2, false);
-    DA(c.amp2, NB * BlockSize / 2, false);
+    DA(c.nsum, ((NB * nChan + 63) / 64) * 64 * (size_t)(BlockSize / 2), false);      // rows in tiles of 64 (tile_idx)
+    DA(c.amp2, ((NB + 63) / 64) * 64 * (size_t)(BlockSize / 2), false);
     DA(c.barkN, NB * nChan * 4 * ULCX_NBARK, true);
     DA(c.barkP, NB * 4 * ULCX_NBARK, true);
     if (c.barkRing) { DA(c.barkRawN, NB * nChan * ULCX_NBARK * 3, false); DA(c.barkRawP, NB * ULCX_NBARK * 3, false); DA(c.decList, NB, false); DA(c.decCount, 1, true); }

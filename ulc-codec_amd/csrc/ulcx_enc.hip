@@ -87,6 +87,14 @@ __device__ __forceinline__ void stnt(float4 *p, float4 v) { f32x4 w = { v.x, v.y
 __device__ __forceinline__ void stnt(float2 *p, float2 v) { f32x2 w = { v.x, v.y }; __builtin_nontemporal_store(w, (f32x2 *)p); }
 __device__ __forceinline__ void stnt(float *p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ float ldnt(const float *p) { return __builtin_nontemporal_load(p); }
+// Line energies (nsum: rows = (block, channel); amp2: rows = block; a row = the BS/2 lines of the pseudo-DFT) are stored in
+// TILES of 64 rows x 32 lines, 8 KB contiguous each (round 4): the Bark kernel that takes 64 rows at a time (k_bark_uniform)
+// reads whole tiles - rows side by side 4 KB apart gave it 128-byte pieces, 2.5 TB/s.  Index of line l of row r:
+__device__ __forceinline__ size_t tile_idx(int half, int row, int l) {
+    return (((size_t)(row >> 6) * (half >> 5) + (l >> 5)) * 64 + (row & 63)) * 32 + (l & 31);
+}
+// ... and the offset of line l relative to a line at a multiple of 32 of the same row (lane-per-unit kernels walk a row)
+__device__ __forceinline__ int tile_off(int l) { return ((l >> 5) << 11) + (l & 31); }
 // the window-control scratch (envelope planes): hinted like the rest unless built with -DWC_NO_NT (experiment: does the
 // hand-over between the chain kernels stay in the Infinity Cache when the steps are small?)
 #ifdef WC_NO_NT
@@ -586,8 +594,6 @@ __device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int
     fft_wave_dif_ct<M, PS>(z + __builtin_amdgcn_readfirstlane(tid >> 6) * Mp, twl, tid & 63);
     __syncthreads();
     float *coefO = c.coef + (size_t)blk * (2 * BS);
-    float *nsumO = c.nsum + (size_t)blk * BS;
-    float *ampO = c.amp2 + (size_t)blk * (BS / 2);
     constexpr float norm = 2.0f / S;
     int nnz = 0;
     // A thread takes TWO neighbouring post-twiddle indices (kk = 2 tid, 2 tid + 1: M/2 = 2 WG of them), so that what it
@@ -634,11 +640,11 @@ __device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int
         for (int q = 0; q < 2; q++) {
             stnt((float4 *)(coefO + q * BS + 2 * j1), make_float4(re[q][0][0], re[q][0][1], re[q][0][2], re[q][0][3]));
             stnt((float4 *)(coefO + q * BS + 2 * j2), make_float4(re[q][1][0], re[q][1][1], re[q][1][2], re[q][1][3]));
-            stnt((float2 *)(nsumO + q * (BS / 2) + j1), make_float2(ns[q][0][0], ns[q][0][1]));
-            stnt((float2 *)(nsumO + q * (BS / 2) + j2), make_float2(ns[q][1][0], ns[q][1][1]));
+            stnt((float2 *)(c.nsum + tile_idx(BS / 2, blk * 2 + q, j1)), make_float2(ns[q][0][0], ns[q][0][1]));
+            stnt((float2 *)(c.nsum + tile_idx(BS / 2, blk * 2 + q, j2)), make_float2(ns[q][1][0], ns[q][1][1]));
         }
-        *(float2 *)(ampO + j1) = make_float2(am[0][0], am[0][1]);
-        *(float2 *)(ampO + j2) = make_float2(am[1][0], am[1][1]);
+        *(float2 *)(c.amp2 + tile_idx(BS / 2, blk, j1)) = make_float2(am[0][0], am[0][1]);
+        *(float2 *)(c.amp2 + tile_idx(BS / 2, blk, j2)) = make_float2(am[1][0], am[1][1]);
     }
     return nnz;
 }
@@ -674,7 +680,6 @@ __device__ __forceinline__ void xf_block(const UlcxEncCtx &c, float *lds, int s,
     const bool ampLds = (C > 2);                             // line energies accumulate across channel pairs: only then in LDS
     const bool twInLds = !(ampLds && (size_t)16 * (BS + (BS >> ps)) + (size_t)BS * 4 + 32 > ULCX_LDS_LIMIT);   // (BlockSize 8192 with C > 2: no room, twiddles from global memory)
     float  *amp2 = twInLds ? lds + 4 * FFT_PADDEDS(BS, ps) + BS / 2 + 4 : lds + 4 * FFT_PADDEDS(BS, ps);   // BS/2 (takes the twiddles' place when they are not resident)
-    float *ampO = c.amp2 + (size_t)blk * (BS / 2);
     if (tid == 0) s_nnz = 0;
     if (ampLds) for (int i = tid; i < BS / 2; i += WG) amp2[i] = 0.0f;
 
@@ -692,7 +697,6 @@ __device__ __forceinline__ void xf_block(const UlcxEncCtx &c, float *lds, int s,
     }
     size_t cb = (size_t)C * BS;
     float *coefO = c.coef + (size_t)blk * cb;
-    float *nsumO = c.nsum + (size_t)blk * (cb / 2);
     int nnz = 0;
     __syncthreads();
 
@@ -856,12 +860,12 @@ __device__ __forceinline__ void xf_block(const UlcxEncCtx &c, float *lds, int s,
                         int j = p ? k2 : k1;
                         size_t gi = (size_t)ch * BS + off + 2 * j;
                         stnt((float2 *)(coefO + gi), make_float2(re0, re1));
-                        stnt(nsumO + (size_t)ch * (BS / 2) + off / 2 + j, a0 + a1);       // (0 + a0) + a1
+                        stnt(c.nsum + tile_idx(BS / 2, blk * C + ch, off / 2 + j), a0 + a1);       // (0 + a0) + a1
                         if (p) { am2 += a0; am2 += a1; } else { am1 += a0; am1 += a1; } // channel order preserved
                     }
                 }
                 if (ampLds) { amp2[off / 2 + k1] = am1; amp2[off / 2 + k2] = am2; }
-                else { ampO[off / 2 + k1] = am1; ampO[off / 2 + k2] = am2; }
+                else { c.amp2[tile_idx(BS / 2, blk, off / 2 + k1)] = am1; c.amp2[tile_idx(BS / 2, blk, off / 2 + k2)] = am2; }
             }
             __syncthreads();
             off += S; ovL = ov;
@@ -870,7 +874,7 @@ __device__ __forceinline__ void xf_block(const UlcxEncCtx &c, float *lds, int s,
     // wave-reduce the non-zero count
     for (int o = 32; o > 0; o >>= 1) nnz += __shfl_down(nnz, o);
     if ((tid & 63) == 0) atomicAdd(&s_nnz, nnz);
-    if (ampLds) for (int i = tid; i < BS / 2; i += WG) ampO[i] = amp2[i];
+    if (ampLds) for (int i = tid; i < BS / 2; i += WG) c.amp2[tile_idx(BS / 2, blk, i)] = amp2[i];
     __syncthreads();
     if (tid == 0) c.nnz[blk] = s_nnz;
 }
@@ -925,8 +929,6 @@ __global__ __launch_bounds__(WG) void k_xf_big(UlcxEncCtx c, int k0, int k1) {
     }
     const size_t cb = (size_t)C * BS;
     float *coefO = c.coef + (size_t)blk * cb;
-    float *nsumO = c.nsum + (size_t)blk * (cb / 2);
-    float *ampO = c.amp2 + (size_t)blk * (BS / 2);
     int nnz = 0;
     __syncthreads();
     for (int ch = 0; ch < C; ch++) {
@@ -992,10 +994,11 @@ __global__ __launch_bounds__(WG) void k_xf_big(UlcxEncCtx c, int k0, int k1) {
                             const float2 re = *(const float2 *)(coefO + gi);
                             const float re0s = re.x * re.x, im0s = im0 * im0, re1s = re.y * re.y, im1s = im1 * im1;
                             const float a0 = re0s + im0s, a1 = re1s + im1s;
-                            nsumO[(size_t)ch * (BS / 2) + off / 2 + j] = a0 + a1;       // (0 + a0) + a1
-                            float am = (ch == 0) ? 0.0f : ampO[off / 2 + j];            // channel order preserved
+                            c.nsum[tile_idx(BS / 2, blk * C + ch, off / 2 + j)] = a0 + a1;       // (0 + a0) + a1
+                            float *ap = c.amp2 + tile_idx(BS / 2, blk, off / 2 + j);
+                            float am = (ch == 0) ? 0.0f : *ap;                           // channel order preserved
                             am += a0; am += a1;
-                            ampO[off / 2 + j] = am;
+                            *ap = am;
                         }
                     }
                 }
@@ -1110,7 +1113,8 @@ __device__ __forceinline__ void linesum_add(float vf, double &fl, double &pk, do
     pk += vl * v;
     pw += v;
 }
-// Advance the running prefix to `end`.  `src` is 16-byte aligned at line 0: the body goes in aligned groups of four
+// Advance the running prefix to `end`.  `src` points at the unit's line 0 inside the tiled array (tile_off: a unit starts at a
+// multiple of 32 lines) and is 16-byte aligned there: the body goes in aligned groups of four
 // lines per load (one lane per unit means every load instruction touches 64 different cache lines, so these kernels
 // are bound by the number of load instructions: 16 bytes per lane instead of 4 cuts them fourfold).  `prev` receives
 // the prefix one line before `end` (the lower edge of a later band is floor(x) where this upper edge is ceil(x)).
@@ -1118,20 +1122,20 @@ __device__ __forceinline__ void linesum_advance(const float *src, LineSum &ls, i
     double fl = ls.fl, pk = ls.pk, pw = ls.pw;
     int l = ls.end;
     const int stop = (prev && end > l) ? end - 1 : end;              // stop one line early to take the snapshot
-    while (l < stop && (l & 3)) { linesum_add(src[l], fl, pk, pw); l++; }
+    while (l < stop && (l & 3)) { linesum_add(src[tile_off(l)], fl, pk, pw); l++; }
     for (; l + 8 <= stop; l += 8) {                                   // two aligned 16-byte loads in flight; sums keep the reference's order
-        float4 a = *(const float4 *)(src + l), b = *(const float4 *)(src + l + 4);
+        float4 a = *(const float4 *)(src + tile_off(l)), b = *(const float4 *)(src + tile_off(l + 4));
         linesum_add(a.x, fl, pk, pw); linesum_add(a.y, fl, pk, pw); linesum_add(a.z, fl, pk, pw); linesum_add(a.w, fl, pk, pw);
         linesum_add(b.x, fl, pk, pw); linesum_add(b.y, fl, pk, pw); linesum_add(b.z, fl, pk, pw); linesum_add(b.w, fl, pk, pw);
     }
     for (; l + 4 <= stop; l += 4) {
-        float4 a = *(const float4 *)(src + l);
+        float4 a = *(const float4 *)(src + tile_off(l));
         linesum_add(a.x, fl, pk, pw); linesum_add(a.y, fl, pk, pw); linesum_add(a.z, fl, pk, pw); linesum_add(a.w, fl, pk, pw);
     }
-    for (; l < stop; l++) linesum_add(src[l], fl, pk, pw);
+    for (; l < stop; l++) linesum_add(src[tile_off(l)], fl, pk, pw);
     if (prev) {
         prev->end = l; prev->fl = fl; prev->pk = pk; prev->pw = pw;
-        if (l < end) { linesum_add(src[l], fl, pk, pw); l++; }
+        if (l < end) { linesum_add(src[tile_off(l)], fl, pk, pw); l++; }
     }
     ls.end = end; ls.fl = fl; ls.pk = pk; ls.pw = pw;
 }
@@ -1171,7 +1175,7 @@ __global__ __launch_bounds__(64) void k_nbark(UlcxEncCtx c, int useList) {
     int d, off, S;
     if (!unit_geom(wc, j, c.BS, d, off, S)) return;
     int N = S / 2;
-    const float *data = c.nsum + (size_t)blk * (c.C * c.BS / 2) + (size_t)ch * (c.BS / 2) + off / 2;
+    const float *data = c.nsum + tile_idx(c.BS / 2, blk * c.C + ch, off / 2);
     float *bark = c.barkN + (size_t)gid * ULCX_NBARK;
     float level = -100.0f;
     // lower edge of band b = floor(x), upper edge of band b-2 = ceil(x) of the same x: the lower cursor takes the upper
@@ -1251,7 +1255,7 @@ __global__ __launch_bounds__(64) void k_pbark(UlcxEncCtx c, int useList) {
     int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
     int d, off, S;
     if (!unit_geom(wc, j, c.BS, d, off, S)) return;
-    const float *data = c.amp2 + (size_t)blk * (c.BS / 2) + off / 2;
+    const float *data = c.amp2 + tile_idx(c.BS / 2, blk, off / 2);
     float *bark = c.barkP + (size_t)gid * ULCX_NBARK;
     float unmask = 0.0f;
     LineSum lo = {0, 0.0, 0.0, 0.0}, hi = {0, 0.0, 0.0, 0.0};             // (as k_nbark; here the lower edge of band b is the upper edge of band b-1)
@@ -1288,9 +1292,7 @@ __global__ __launch_bounds__(64) void k_pbark(UlcxEncCtx c, int useList) {
 // FastLog of every value and leave {v, log v} pairs in LDS; wave 0 only walks its rows through the finished tile - two
 // conversions, the product and the three ordered sums per line (7 instructions) - while the others prepare the next tile
 // in the second buffer.  One barrier per tile.  Same sums, same order.
-#ifndef BK_TL
-#define BK_TL 32                                           // lines per tile (32 or 64; BlockSize / 2 must be a multiple)
-#endif
+#define BK_TL 32                                           // lines per tile = the tile of the arrays (tile_idx)
 #define BK_PPR (BK_TL / 4)                                 // 16-byte pieces per row of a tile
 #define BK_PIECES (64 * BK_PPR)
 #define BK_NPC ((BK_PIECES + 191) / 192)                   // pieces per producer lane
@@ -1325,7 +1327,7 @@ __global__ __launch_bounds__(256) void k_bark_uniform(UlcxEncCtx c) {
 #pragma unroll
             for (int i = 0; i < BK_NPC; i++) {
                 const int pc = p0 + 192 * i;
-                if (pc < BK_PIECES) r[i] = *(const float4 *)(src + (size_t)min(row0 + pc / BK_PPR, nRows - 1) * half + t * BK_TL + (pc % BK_PPR) * 4);
+                if (pc < BK_PIECES) r[i] = *(const float4 *)(src + ((size_t)(row0 >> 6) * nT + t) * (64 * BK_TL) + pc * 4);      // (a tile of the array IS a tile of this kernel)
             }
         };
         auto put = [&](const float4 (&r)[BK_NPC], int t) {
