@@ -2,10 +2,10 @@
 # Round artefacts -> gpurun_out/$TAG (copy what is to be judged into profiles/): smoke, bench lines (headline, per mode,
 # K = 32, the other configurations), rocprofv3 kernel stats of the headline command, PMC traffic passes of the same
 # command (FETCH_SIZE / WRITE_SIZE in separate runs), SQ counter passes (single-stream mode: clean per-kernel numbers),
-# one step's kernel timeline, the drop-in's single-stream rate.   usage: GIT_REV=$(git rev-parse --short HEAD) gpurun ... tools/gpu_r03.sh [tag]
+# one step's kernel timeline, the drop-in's single-stream rate.   usage: GIT_REV=$(git rev-parse --short HEAD) gpurun ... tools/gpu_r04.sh [tag]
 # (the GPU box has no .git: the revision the numbers belong to is handed in)
 cd "$(dirname "$0")/.."
-TAG=${1:-r03}; O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
+TAG=${1:-r04}; O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?" >> $O/smoke.txt
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --mode encode --no-cpu > $O/bench_encode.json 2>> $O/bench.err

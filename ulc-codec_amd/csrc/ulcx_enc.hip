@@ -1949,8 +1949,8 @@ __global__ __launch_bounds__(WG) void k_keep_ranks(UlcxEncCtx c, int finalPass) 
 // (a kept coefficient collapsed, a noise run fell back to a zero run, ...).
 // Round 4: no 16 KB-per-block pair array in HBM between them any more (was k_nline -> k_gapsums, k_tailsums).  k_nsums: a
 // workgroup forms its block's {w, w*log} pairs from the 100 Bark levels per channel straight into LDS (noise_pair), lists
-// the gaps and sums them.  k_tails: the units' tail chains, eight units per wave, the pairs of a step formed by the wave's
-// 64 lanes together (a workgroup of k_nsums that also ran its block's two 700-step chains lived 18 us for them).  A gap
+// the gaps and sums them.  k_tails: the units' tail chains, 64 units per workgroup (a workgroup of k_nsums that also ran
+// its block's two 700-step chains lived 18 us for them).  A gap
 // longer than one noise run (16 + 511 coefficients) gets its SECOND run speculated too - where that one starts follows from
 // the gap's length alone as long as the first run is coded as noise: on the bench batch 0.30 runs per block, against 0.02
 // that need a third or sit elsewhere; those the writer sums itself, forming the pairs it needs (pair_demand).
@@ -2144,105 +2144,120 @@ __global__ __launch_bounds__(WG, NSUMS_LB) void k_nsums(UlcxEncCtx c, int finalP
     }
 }
 
-// Tail HF-extension sums (NoiseFill.c:41-62) for the tail after each unit's last kept coefficient.  A wave = eight units,
-// eight lanes each: lanes 0..4 of a unit carry one ordered f32 chain each, lane 5 records the start index the sums assume.
-// The pairs are formed by the wave itself, eight per unit and step (lane e of a unit forms pair 8 T + e of its tail), into a
-// double-buffered LDS tile the unit's chain lanes then walk: forming step T + 1 and summing step T are one instruction
-// stream, the former fills the latter's dependent adds.
-#define TAILS_UPW 8                                         // units per wave
-__device__ __forceinline__ void tails_wave(const UlcxEncCtx &c, int finalPass, int unit0, int nBlk, float *tile /* [2][8][8] float2 */,
-                                           float *sbark /* [8][25] */, const unsigned long long *sexp, int lane) {
-    const int us = lane >> 3, e = lane & 7;                 // unit slot of the wave, role inside the unit
-    const int ui = unit0 + us;
-    const int nBC = nBlk * c.C;
-    bool on = ui < nBC * 4;
-    int j = 0, blk = 0, ch = 0;
-    if (on) { j = ui / nBC; const int rem = ui - j * nBC; blk = rem / c.C; ch = rem - blk * c.C; }     // subblock index slowest
-    if (on && c.fbMode == 2) blk = c.fbList[c.fbLo + blk];
-    if (on && skip_block(c, blk, finalPass)) on = false;
-    int wc = 0x10, dd = 0, off = 0, S = c.BS;
-    if (on) { wc = c.wcArr[(size_t)(blk / c.K) * (c.maxK + 2) + (blk % c.K) + 1]; on = unit_geom(wc, j, c.BS, dd, off, S); }
-    if (!__ballot(on)) return;
-    const int N = c.C * c.BS;
-    int start = 0, n = 0;
-    if (on) {
-        const uint32_t *kw = c.keep + (size_t)blk * (N / 32);
-        const int ub = ch * c.BS + off, ue = ub + S;
-        int last = ub - 1;                                   // last kept index in [ub, ue) (unit bounds are multiples of 32)
-        for (int w = (ue - 1) >> 5; (w << 5) >= ub; w--) {
-            const uint32_t m = kw[w];
-            if (m) { last = (w << 5) + 31 - __clz(m); break; }
-            if (w == 0) break;
-        }
-        start = last + 1; n = ue - start;
-        float *ts = c.tailSum + ((size_t)(blk * c.C + ch) * 4 + j) * 8;
-        if (e == 5) ts[5] = __int_as_float(start);
-        // the unit's 25 Bark levels: lanes 0..7 of the unit copy them (4 each, the last one 1)
-        const float *bg = c.barkN + ((size_t)(blk * c.C + ch) * 4 + j) * ULCX_NBARK;
-        for (int i = e; i < ULCX_NBARK; i += 8) sbark[us * ULCX_NBARK + i] = bg[i];
-    }
-    const bool chainOn = on && n >= 16;
-    const int np = chainOn ? (n + (start & 1) + 1) / 2 : 0;      // pairs of the unit's tail
-    const int line0 = ((start - (ch * c.BS + off)) >> 1);        // line pair of the tail's first pair inside the unit
-    int npMax = np;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(npMax, o); npMax = v > npMax ? v : npMax; }
-    if (npMax == 0) return;
-    WAVE_SYNC_E();
-    const int *bandIdx = c.T.bandIdx[dd];
-    const float *bandFrac = c.T.bandFrac[dd];
-    const float *bark = sbark + us * ULCX_NBARK;
-    auto form = [&](int T) {                                 // pair 8 T + e of this unit's tail into tile buffer T & 1
-        const int q = 8 * T + e;
-        float2 pr = make_float2(0.0f, 0.0f);
-        if (q < np) {
-            const int line = line0 + q;
-            const int bi = bandIdx[line];
-            const float fr = bandFrac[line];
-            const float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
-            const float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
-            const float noise = L * (1.0f - fr) + R * fr;
-            const float w = ulcx_expf_t(0.5f * noise, sexp);
-            pr = make_float2(w, w * (noise + 0x1.62E430p-1f));
-        }
-        ((float2 *)tile)[((T & 1) * TAILS_UPW + us) * 8 + e] = pr;
-    };
-    // term = (base * m1) * m2 with exact multiplications by 1.0f where a factor is absent:
-    //   SumX: w*x   SumX2: (w*x)*x   SumXY: x*wy   SumY: wy   SumW: w
-    const bool useY = (e == 2) || (e == 3);
-    const bool hasX1 = (e <= 2), hasX2 = (e == 1);
-    float acc = 0.0f;
-    const int nT = (npMax + 7) >> 3;
-    form(0);
-    WAVE_SYNC_E();
-    for (int T = 0; T < nT; T++) {
-        if (T + 1 < nT) form(T + 1);
-        const float *row = tile + (((T & 1) * TAILS_UPW + us) * 8) * 2 + (useY ? 1 : 0);
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int q = 8 * T + i;
-            const float base = row[2 * i];
-            const float x = q * 2.0f;
-            const float m1 = hasX1 ? x : 1.0f, m2 = hasX2 ? x : 1.0f;
-            const float t = (base * m1) * m2;
-            acc = (q < np) ? acc + t : acc;
-        }
-        WAVE_SYNC_E();
-    }
-    if (chainOn && e < 5) c.tailSum[((size_t)(blk * c.C + ch) * 4 + j) * 8 + e] = acc;
-}
+// Tail HF-extension sums (NoiseFill.c:41-62) for the tail after each unit's last kept coefficient: five ordered f32 chains
+// per unit over the {w, wy} pairs from there to the unit's end (two thirds of a block's pairs on the bench batch).
+// A workgroup = 64 units.  All four waves form pairs - thread t: unit t & 63, pairs (t >> 6) and (t >> 6) + 4 of the
+// tile's eight - into a double-buffered LDS tile, stored by component ([pair][unit]: conflict-free); then a chain wave's
+// lane IS a unit and every lane of a wave runs the SAME chains - wave 0: SumX = sum w x and SumX2 = sum (w x) x, wave 1:
+// SumXY = sum x wy and SumY = sum wy, wave 2: SumW = sum w - so no lane selects a factor (lanes of one wave carrying
+// different chains cost two selects and two multiplications by 1.0 per pair: 1.9 wave-instructions per unit and pair, now
+// 1.0).  Forming tile T + 1 and summing tile T are one instruction stream between two barriers.  A pair behind a unit's
+// end is formed as {0, 0}: its terms add +0.
+#define TAILS_U 64                                          // units per workgroup
+#define TAILS_TP 8                                          // pairs per unit and tile
 __global__ __launch_bounds__(WG) void k_tails(UlcxEncCtx c, int finalPass) {
     if (probes_over(c, finalPass)) return;
-    __shared__ float tiles[WG / 64][2 * TAILS_UPW * 8 * 2];
-    __shared__ float sbark[WG / 64][TAILS_UPW * ULCX_NBARK];
+    __shared__ float tileW[2][TAILS_TP][TAILS_U], tileY[2][TAILS_TP][TAILS_U];
+    __shared__ float sbark[TAILS_U][ULCX_NBARK];
     __shared__ unsigned long long sexp[32];
-    if (threadIdx.x < 32) sexp[threadIdx.x] = ulcx_exp2f_tab[threadIdx.x];
-    __syncthreads();
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    __shared__ int uNp[TAILS_U], uLine0[TAILS_U], uD[TAILS_U], s_npMax;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nBlk = (c.fbMode == 2) ? fb_count(c) : c.B * c.K;
-    const int nUnits = nBlk * c.C * 4;
-    for (int u0 = (blockIdx.x * (WG / 64) + wv) * TAILS_UPW; u0 < nUnits; u0 += gridDim.x * (WG / 64) * TAILS_UPW)
-        tails_wave(c, finalPass, u0, nBlk, tiles[wv], sbark[wv], sexp, lane);
+    const int nBC = nBlk * c.C, nUnits = nBC * 4, N = c.C * c.BS;
+    if (tid < 32) sexp[tid] = ulcx_exp2f_tab[tid];
+    for (int u0 = blockIdx.x * TAILS_U; u0 < nUnits; u0 += gridDim.x * TAILS_U) {
+        __syncthreads();                                     // (the previous trip's tiles and unit tables are done with)
+        if (tid == 0) s_npMax = 0;
+        __syncthreads();
+        // ---- the units: thread u < 64 finds unit u0 + u's tail (subblock index slowest: un-decimated blocks leave the
+        //      workgroups of subblocks 1..3 empty at once)
+        int blk = 0, ch = 0, j = 0, start = 0, np = 0;
+        bool on = false;
+        if (tid < TAILS_U) {
+            const int ui = u0 + tid;
+            on = ui < nUnits;
+            if (on) { j = ui / nBC; const int rem = ui - j * nBC; blk = rem / c.C; ch = rem - blk * c.C; }
+            if (on && c.fbMode == 2) blk = c.fbList[c.fbLo + blk];
+            if (on && skip_block(c, blk, finalPass)) on = false;
+            int dd = 0, off = 0, S = c.BS;
+            if (on) { const int wc = c.wcArr[(size_t)(blk / c.K) * (c.maxK + 2) + (blk % c.K) + 1]; on = unit_geom(wc, j, c.BS, dd, off, S); }
+            if (on) {
+                const uint32_t *kw = c.keep + (size_t)blk * (N / 32);
+                const int ub = ch * c.BS + off, ue = ub + S;
+                int last = ub - 1;                               // last kept index in [ub, ue) (unit bounds are multiples of 32)
+                for (int w = (ue - 1) >> 5; (w << 5) >= ub; w--) {
+                    const uint32_t m = kw[w];
+                    if (m) { last = (w << 5) + 31 - __clz(m); break; }
+                    if (w == 0) break;
+                }
+                start = last + 1;
+                const int n = ue - start;
+                c.tailSum[((size_t)(blk * c.C + ch) * 4 + j) * 8 + 5] = __int_as_float(start);
+                np = n >= 16 ? (n + (start & 1) + 1) / 2 : 0;
+                uLine0[tid] = (start - ub) >> 1;
+                const float *bg = c.barkN + ((size_t)(blk * c.C + ch) * 4 + j) * ULCX_NBARK;
+                for (int i = 0; i < ULCX_NBARK; i++) sbark[tid][i] = bg[i];
+            }
+            uNp[tid] = np; uD[tid] = dd;
+            if (np > 0) atomicMax(&s_npMax, np);
+        }
+        __syncthreads();
+        const int npMax = s_npMax;
+        if (npMax == 0) continue;
+        // ---- forming: this thread's unit and its two pairs of every tile
+        const int fu = lane, fe = wv;                        // unit, first pair of the tile (the second: fe + 4)
+        const int fnp = uNp[fu], fline0 = uLine0[fu];
+        const int *bandIdx = c.T.bandIdx[uD[fu]];
+        const float *bandFrac = c.T.bandFrac[uD[fu]];
+        const float *bark = sbark[fu];
+        auto form = [&](int T) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int e = fe + 4 * h, q = TAILS_TP * T + e;
+                float w = 0.0f, wy = 0.0f;
+                if (q < fnp) {
+                    const int line = fline0 + q;
+                    const int bi = bandIdx[line];
+                    const float fr = bandFrac[line];
+                    const float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
+                    const float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
+                    const float noise = L * (1.0f - fr) + R * fr;
+                    w = ulcx_expf_t(0.5f * noise, sexp);
+                    wy = w * (noise + 0x1.62E430p-1f);
+                }
+                tileW[T & 1][e][fu] = w; tileY[T & 1][e][fu] = wy;
+            }
+        };
+        float acc0 = 0.0f, acc1 = 0.0f;                      // wave 0: SumX, SumX2; wave 1: SumXY, SumY; wave 2: SumW
+        const int nT = (npMax + TAILS_TP - 1) / TAILS_TP;
+        form(0);
+        __syncthreads();
+        for (int T = 0; T < nT; T++) {
+            if (T + 1 < nT) form(T + 1);
+            const int b = T & 1;
+            if (wv == 0) {
+#pragma unroll
+                for (int i = 0; i < TAILS_TP; i++) { const float x = (TAILS_TP * T + i) * 2.0f, wx = tileW[b][i][lane] * x; acc0 += wx; acc1 += wx * x; }
+            } else if (wv == 1) {
+#pragma unroll
+                for (int i = 0; i < TAILS_TP; i++) { const float x = (TAILS_TP * T + i) * 2.0f, y = tileY[b][i][lane]; acc0 += x * y; acc1 += y; }
+            } else if (wv == 2) {
+#pragma unroll
+                for (int i = 0; i < TAILS_TP; i++) acc0 += tileW[b][i][lane];
+            }
+            __syncthreads();
+        }
+        // ---- the sums of unit `lane`: thread lane < 64 of wave 0 knows where they go; the other chain waves look it up the same way
+        if (wv < 3 && uNp[lane] > 0) {
+            const int ui = u0 + lane;
+            int uj = ui / nBC; const int rem = ui - uj * nBC; int ublk = rem / c.C; const int uch = rem - ublk * c.C;
+            if (c.fbMode == 2) ublk = c.fbList[c.fbLo + ublk];
+            float *ts = c.tailSum + ((size_t)(ublk * c.C + uch) * 4 + uj) * 8;
+            if (wv == 0) { ts[0] = acc0; ts[1] = acc1; }
+            else if (wv == 1) { ts[2] = acc0; ts[3] = acc1; }
+            else ts[4] = acc0;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -3307,7 +3322,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             if (glds > 48 * 1024) CK(hipFuncSetAttribute((const void *)k_nsums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
             // the two speculative-sum kernels are independent: on the main path the tail chains run on a side stream beside the gaps
             const bool tailAside = !fb2 && side2 != nullptr && s2 == st;
-            const unsigned tg = (unsigned)((nUnits + 4 * TAILS_UPW - 1) / (4 * TAILS_UPW));
+            const unsigned tg = (unsigned)((nUnits + TAILS_U - 1) / TAILS_U);
             if (tailAside) {
                 CK(hipEventRecord(evTail0, s2));
                 CK(hipStreamWaitEvent(side2, evTail0, 0));
