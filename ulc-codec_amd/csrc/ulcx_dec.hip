@@ -176,6 +176,77 @@ struct NybWin {
     }
 };
 
+// The same view for a lane whose every look stays inside the caller's buffer (k_dscan checks that per wave: all but the
+// waves at the buffer's ends), without NybWin's stall: there the load sits in a branch and its result is copied into the
+// loop-carried registers right behind it, so the compiler waits for it on the spot (`s_waitcnt vmcnt(0)`, records stored
+// since included) - a memory round trip in almost every trip of a wave, some lane of 64 always being at a chunk's end.
+// Here every look issues ONE load into registers nothing touches before the next look (a trip of the walk is ~1500
+// cycles of dependent arithmetic: a chunk's latency): a lane that moved on to its next chunk fetches the chunk two
+// ahead, every other lane reads one common address (one line for all of them), and the next look takes the value over
+// with a select.  The shift to the next chunk is a select too.
+// Bytes behind readBytes are not masked: limit = 8 readBytes in every caller, a code that uses a nybble behind it ends
+// behind limit, and the walk calls that block corrupt whatever the nybble was.
+struct NybWinFast {
+    const uint4 *p16, *common; int a; int chunk; bool gNew;
+    uint32_t c0, c1, c2, c3, n0, n1, n2, n3, f0, f1, f2, f3, g0, g1, g2, g3;
+    __device__ __forceinline__ void init(const uint8_t *p, int, const uint8_t *, const uint8_t *) {
+        a = (int)((uintptr_t)p & 15); p16 = (const uint4 *)(p - a); chunk = 0; gNew = false;
+        common = (const uint4 *)(((uintptr_t)__builtin_amdgcn_readfirstlane((int)((uintptr_t)p16 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uintptr_t)p16));
+        const uint4 v0 = p16[0], v1 = p16[1], v2 = p16[2];
+        c0 = v0.x; c1 = v0.y; c2 = v0.z; c3 = v0.w; n0 = v1.x; n1 = v1.y; n2 = v1.z; n3 = v1.w; f0 = v2.x; f1 = v2.y; f2 = v2.z; f3 = v2.w;
+        g0 = g1 = g2 = g3 = 0;
+    }
+    __device__ __forceinline__ uint64_t at64(int pos) {
+        const int q = (pos >> 2) + 2 * a;
+        f0 = gNew ? g0 : f0; f1 = gNew ? g1 : f1; f2 = gNew ? g2 : f2; f3 = gNew ? g3 : f3;      // the last look's load
+        const bool adv = (q >> 5) > chunk;                   // (a trip moves at most 12 nybbles: one chunk at a time)
+        c0 = adv ? n0 : c0; c1 = adv ? n1 : c1; c2 = adv ? n2 : c2; c3 = adv ? n3 : c3;
+        n0 = adv ? f0 : n0; n1 = adv ? f1 : n1; n2 = adv ? f2 : n2; n3 = adv ? f3 : n3;
+        chunk += adv ? 1 : 0;
+        const uint4 v = *(adv ? p16 + (chunk + 2) : common);
+        g0 = v.x; g1 = v.y; g2 = v.z; g3 = v.w; gNew = adv;
+        const int di = (q >> 3) & 3, sh = (q & 7) * 4;
+        uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3, x4 = n0, x5 = n1;
+        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5));
+        const uint32_t d0 = di == 0 ? x0 : di == 1 ? x1 : di == 2 ? x2 : x3;
+        const uint32_t d1 = di == 0 ? x1 : di == 1 ? x2 : di == 2 ? x3 : x4;
+        const uint32_t d2 = di == 0 ? x2 : di == 1 ? x3 : di == 2 ? x4 : x5;
+        return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+    }
+    __device__ __forceinline__ uint32_t at(int pos) { return (uint32_t)at64(pos); }
+};
+
+// Where the walk's records go (k_dscan).  Every lane appends 8-byte records to the row of ITS block: stored one by one
+// that is up to 64 partial lines per store instruction and two such instructions per trip - more than half of the
+// kernel's time, and three times the records' bytes in HBM traffic (partly written lines evicted and fetched again).
+// Instead a lane parks its records in an LDS ring (row r of the ring holds the records number r mod R of every lane, rotated
+// by r so that one lane's consecutive records lie in different banks), and when some lane's ring is nearly full the
+// wave writes out all of them: two owners per trip, a half-wave per owner, the owner's pending records to consecutive
+// addresses of its row.
+#define DSCAN_RP 24              // plain-run records a lane may have pending (a trip adds at most two)
+#define DSCAN_RN 12              // noise records (at most one per trip)
+#define DSCAN_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+template <int R>
+__device__ __forceinline__ void ring_put(uint2 *ring, int lane, int slotR, uint2 rec) { ring[slotR * 64 + ((lane + slotR) & 63)] = rec; }
+// f .. n-1: this lane's pending records; rowIdx: its block; base + rowIdx * stride: the block's row (stride records)
+template <int R>
+__device__ __forceinline__ void ring_flush(uint2 *ring, int lane, int &f, int n, uint2 *base, int rowIdx, int stride) {
+    DSCAN_WAVE_SYNC();
+    const int cnt = n - f, half = lane >> 5, i = lane & 31;
+#pragma unroll 4
+    for (int it = 0; it < 32; it++) {
+        const int j = 2 * it + half;
+        const int cj = __builtin_amdgcn_ds_bpermute(j << 2, cnt);
+        const int fj = __builtin_amdgcn_ds_bpermute(j << 2, f);
+        const int rj = __builtin_amdgcn_ds_bpermute(j << 2, rowIdx);
+        const int idx = fj + i;
+        const int r = idx % R;
+        if (i < cj && idx < stride) base[(size_t)rj * stride + idx] = ring[r * 64 + ((j + r) & 63)];
+    }
+    f = n;
+    DSCAN_WAVE_SYNC();
+}
+
 // Syntax walk of one block starting at p (limit = bits that may be consumed, readBytes = bytes that may be
 // used).  The walk is the one thing that cannot be done in parallel; everything it learns on the way is left for the
 // synthesis in a form that can: per (channel, subblock) unit
@@ -186,9 +257,14 @@ struct NybWin {
 //   * the unit's draws-so-far, its decaying-noise tail's parameters and (after the walk) the tail's level chain;
 // and bits / WindowCtrl / draws of the block.  Returns bits consumed (0 = corrupt).  One flat loop, one code (or one
 // run of plain coefficients) per trip.
+// RING: the records through the wave's LDS rings (every lane of the wave is here, `live` or not, and stays to the end);
+// else stored one by one (lanes come and go as they please: k_dscan_packed).
+template <typename WIN = NybWin, bool RING = false>
 __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const uint8_t *p, int limit, int readBytes,
-                                          const uint8_t *bufBeg, const uint8_t *bufEnd) {
-    NybWin win; win.init(p, readBytes, bufBeg, bufEnd);
+                                          const uint8_t *bufBeg, const uint8_t *bufEnd, bool live = true, uint2 *ringP = nullptr, uint2 *ringN = nullptr) {
+    const int rlane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    int fP = 0, fN = 0, wP = 0, wN = 0;                             // RING: records written out so far, ring rows of the next records
+    WIN win; win.init(p, readBytes, bufBeg, bufEnd);
     int pos = 0;
     int wc;
     {
@@ -208,12 +284,21 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
     uint2 *prec = c.prec + (size_t)blk * c.precStride;
     uint2 *nrec = c.nrec + (size_t)blk * c.nrecStride;
     int nP = 0, nN = 0, uP0 = 0, uN0 = 0;                           // records written so far in the block / at the current unit's start
+    auto put_prec = [&](uint2 rec) {
+        if (RING) { ring_put<DSCAN_RP>(ringP, rlane, wP, rec); wP = (wP + 1 == DSCAN_RP) ? 0 : wP + 1; }
+        else if (nP < c.precStride) prec[nP] = rec;
+        nP++;
+    };
+    auto put_nrec = [&](uint2 rec) {
+        if (RING) { ring_put<DSCAN_RN>(ringN, rlane, wN, rec); wN = (wN + 1 == DSCAN_RN) ? 0 : wN + 1; }
+        else if (nN < c.nrecStride) nrec[nN] = rec;
+        nN++;
+    };
     int u = 0, draws = 0, uslot = 0, uDraw0 = 0, uj = 0, uch4 = 0;
-    udraw[0] = 0;
-    utail[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (live) { udraw[0] = 0; utail[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
     int S = c.BS >> (pat & 7), N = S;
     bool first = true;
-    bool fin = (limit < 16), bad = fin;
+    bool fin = (limit < 16) | !live, bad = fin;
     auto next_unit = [&]() {
         urec[uslot] = make_int4(uP0, nP - uP0, uN0, nN - uN0);
         u++;
@@ -233,7 +318,9 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
     int qidx = 30;                                                  // (index 30 expands to 0.0; every unit opens with a quantizer code)
     // One trip = a run of plain coefficient nybbles (possibly empty), then ONE other code: every lane does both parts every
     // trip, so lanes that alternate between the two kinds (the usual stream) do not wait for each other's other half.
-    while (!fin) {
+    for (;;) {
+        if (RING) { if (!__any(!fin)) break; } else if (fin) break;
+        if (!fin) {
         const uint64_t w64 = win.at64(pos);
         uint32_t w = (uint32_t)w64;
         // 1. plain coefficients (+-2..+-7), up to the seven the window holds.  Never across the unit end or the block's bits;
@@ -242,28 +329,23 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
         m = m < N ? m : N;
         m = (pos + 4 * m <= limit) ? m : 0;
         if (m > 0) {
-            if (nP < c.precStride) prec[nP] = make_uint2((uint32_t)(S - N) | ((uint32_t)qidx << 15) | ((uint32_t)m << 20), w & (0xFFFFFFFFu >> (32 - 4 * m)));
-            nP++;
+            put_prec(make_uint2((uint32_t)(S - N) | ((uint32_t)qidx << 15) | ((uint32_t)m << 20), w & (0xFFFFFFFFu >> (32 - 4 * m))));
             pos += 4 * m; N -= m;
             if (N == 0) next_unit();
             w = (uint32_t)(w64 >> (4 * m));
         }
-        if (fin) break;
+        if (!fin) {
         // 2. one code
         Code k = decode_code(w, first);
         const bool over = (k.zrun & (k.n > N)) | (k.n8 & (k.np > N));     // ulcDecoder.c:127,139,154
         const bool toEnd = k.stop | k.tail;
         const int used = over ? 0 : (toEnd ? N : k.n + k.np);
         qidx = (k.qnew >= 0) ? k.qnew : qidx;                              // ulcDecoder.c:89-98
-        if (k.plain) {                                                     // (a plain coefficient part 1 left: the block's bits end inside the run)
-            if (nP < c.precStride) prec[nP] = make_uint2((uint32_t)(S - N) | ((uint32_t)qidx << 15) | (1u << 20), w & 0xFu);
-            nP++;
-        }
+        if (k.plain) put_prec(make_uint2((uint32_t)(S - N) | ((uint32_t)qidx << 15) | (1u << 20), w & 0xFu));   // (a plain coefficient part 1 left: the block's bits end inside the run)
         if ((k.n8 | k.tail) & !over) {
             const int np = k.tail ? N : k.np;
-            if (nN < c.nrecStride) nrec[nN] = make_uint2((uint32_t)(S - N) | ((uint32_t)(np - (k.tail ? 1 : 0)) << 16) | (k.tail ? 0x80000000u : 0u),
-                                                         (uint32_t)(draws - uDraw0) | ((uint32_t)k.l << 16) | ((uint32_t)qidx << 21));
-            nN++;
+            put_nrec(make_uint2((uint32_t)(S - N) | ((uint32_t)(np - (k.tail ? 1 : 0)) << 16) | (k.tail ? 0x80000000u : 0u),
+                                (uint32_t)(draws - uDraw0) | ((uint32_t)k.l << 16) | ((uint32_t)qidx << 21)));
         }
         if (k.tail & !over) {
             // ulcDecoder.c:163-186: start amplitude, decay, first coefficient, count; the chain itself runs after the walk
@@ -278,6 +360,17 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
         first = false;
         if ((N == 0) | over) next_unit();
         if (pos > limit) { bad = true; fin = true; }               // ran off the readable bytes: corrupt
+        }
+        }
+        if (RING && __any((nP - fP > DSCAN_RP - 2) | (nN - fN > DSCAN_RN - 1))) {
+            ring_flush<DSCAN_RP>(ringP, rlane, fP, nP, c.prec, blk, c.precStride);
+            ring_flush<DSCAN_RN>(ringN, rlane, fN, nN, c.nrec, blk, c.nrecStride);
+        }
+    }
+    if (RING) {
+        ring_flush<DSCAN_RP>(ringP, rlane, fP, nP, c.prec, blk, c.precStride);
+        ring_flush<DSCAN_RN>(ringN, rlane, fN, nN, c.nrec, blk, c.nrecStride);
+        if (!live) return 0;
     }
     bool ok = !bad;
     c.bits[blk] = ok ? pos : 0;
@@ -309,10 +402,17 @@ __device__ __forceinline__ int scan_block(const UlcxDecCtx &c, int blk, const ui
 
 // Pass 1 - one lane per block.
 __global__ __launch_bounds__(64) void k_dscan(UlcxDecCtx c) {
-    const int id = blockIdx.x * 64 + threadIdx.x, Kc = c.k1 - c.k0;       // streams [s0, s1), blocks [k0, k1) of each
-    if (id >= (c.s1 - c.s0) * Kc) return;
+    __shared__ uint2 ringP[DSCAN_RP * 64], ringN[DSCAN_RN * 64];
+    const int id0 = blockIdx.x * 64 + threadIdx.x, Kc = c.k1 - c.k0;      // streams [s0, s1), blocks [k0, k1) of each
+    const bool live = id0 < (c.s1 - c.s0) * Kc;
+    const int id = live ? id0 : (c.s1 - c.s0) * Kc - 1;                   // (a lane without a block shadows the last one, and writes nothing)
     const int blk = (c.s0 + id / Kc) * c.K + c.k0 + id % Kc;
-    scan_block(c, blk, c.in + (size_t)blk * c.slot, c.slot * 8, c.slot, c.in, c.in + c.inBytes);
+    const uint8_t *p = c.in + (size_t)blk * c.slot, *bufEnd = c.in + c.inBytes;
+    // every look of every lane of the wave inside the buffer (a look reads up to three 16-byte chunks behind the one
+    // the position is in, and the position stops at the slot's end): the window without bounds checks
+    const bool inside = (size_t)(p - c.in) >= ((uintptr_t)p & 15) && (size_t)(bufEnd - p) >= (size_t)c.slot + 80;
+    if (__ballot(!inside) == 0ull) scan_block<NybWinFast, true>(c, blk, p, c.slot * 8, c.slot, c.in, bufEnd, live, ringP, ringN);
+    else scan_block<NybWin, true>(c, blk, p, c.slot * 8, c.slot, c.in, bufEnd, live, ringP, ringN);
 }
 
 // Pass 1, packed payloads - one lane per stream: a block's start is only known once the previous
@@ -650,6 +750,7 @@ template <> __device__ __forceinline__ int16_t *out_base<int16_t>(const UlcxDecC
 // LDS carve, in floats.  Stereo kernel (k_dsyn):  z [2 padded arrays of BS/2 complex] | lap [2][BS/2] | twl [BS/4 complex] |
 //   per wave: noise runs, prefix counts, seed table | 128 block / unit seeds.  General kernel (k_dgen): z [1 array] | per-wave lists.
 #define DSYN_PWORDS(BS) (((BS) / 32 > 64 ? (BS) / 32 : 64) + 2)
+#define DSYN_CHUNK 32            // blocks of a stream whose RNG states and headers the stereo kernel stages at once (<= 64)
 struct DsynLds { int zFloats, lapFloats, twFloats, listFloats; };
 __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int twInLds) {
     DsynLds l;
@@ -658,6 +759,7 @@ __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int 
     l.lapFloats = (fast && BS <= 2048 && twInLds == 1) ? 2 * (BS / 2) : 0;      // (above 2048 the stereo kernel keeps the lapping state in global memory: a third workgroup per CU)
     l.twFloats = (fast && BS <= 2048 && twInLds != 0) ? BS / 2 : 0;               // (likewise the FFT twiddles: read from the tables in global memory, L1/L2-hot, a fourth workgroup per CU)
     l.listFloats = 2 * (64 + DSYN_PWORDS(BS)) + 128;             // per wave: prefix counts, sign-parity stream; per workgroup: 128 block / channel RNG states
+    if (fast) l.listFloats += 2 * DSYN_CHUNK * 8;                // stereo kernel: the headers of a chunk of blocks, per channel
     (void)C;
     return l;
 }
@@ -692,6 +794,8 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
     sw.pre  = (int *)(lds + L.zFloats + L.lapFloats + L.twFloats) + wv * (64 + DSYN_PWORDS(BS));
     sw.seedTab = (uint32_t *)(sw.pre + 64);
     uint32_t *bseed = (uint32_t *)(lds + L.zFloats + L.lapFloats + L.twFloats + 2 * (64 + DSYN_PWORDS(BS)));   // [0,64): RNG state at each block's start, [64,128): at its second channel
+    // [wave][block of the chunk][8]: {window code, the first unit's four record fields, its draws (un-decimated block), its tail decay, -}
+    int *hdr = (int *)(bseed + 128) + wv * (DSYN_CHUNK * 8);
     sw.lane = lane;
     if (TWL) for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
     bool twFull = true;
@@ -762,26 +866,40 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
             }
             chunkK = -1;
         }
-        if (chunkK < 0 || k >= chunkK + 64) {
-            // The stream's one RNG chain (ulcDecoder.c:75-81) for the next 64 blocks at once: a block starts draws-of-its-
-            // predecessors after the chunk's first state - one lane per block, prefix sum, one jump each (wave 1: the
+        if (chunkK < 0 || k >= chunkK + DSYN_CHUNK) {
+            // The stream's one RNG chain (ulcDecoder.c:75-81) for the next DSYN_CHUNK blocks at once: a block starts draws-
+            // of-its-predecessors after the chunk's first state - one lane per block, prefix sum, one jump each (wave 1: the
             // state at each block's second channel).  A corrupt block ends the stream: it and its successors draw nothing.
+            // The same lanes leave what a block's first unit needs from the walk's per-block arrays in LDS: a block
+            // then starts from LDS instead of from a round trip to HBM.
             __syncthreads();
-            const int kk = k + lane, bk = s * c.K + (kk < c.k1 ? kk : k);
-            const bool on = kk < c.k1;
-            int dr = on ? c.draws[bk] : 0;
-            const unsigned long long badm = __ballot(on && c.wcScan[bk] == 0);
+            const int kk = k + lane, bk = s * c.K + (kk < c.k1 && lane < DSYN_CHUNK ? kk : k);
+            const bool on = kk < c.k1 && lane < DSYN_CHUNK;
+            const int wcl = c.wcScan[bk];
+            const int drb = c.draws[bk];
+            const int ud4 = c.unitDraws[(size_t)bk * C * 4 + 4];
+            const int4 url = c.unitRec[(size_t)bk * C * 4 + wv * 4];
+            const float rrl = c.unitTail[(size_t)bk * C * 4 + wv * 4].y;
+            int dr = on ? drb : 0;
+            const unsigned long long badm = __ballot(on && wcl == 0);
             if (badm && lane >= __builtin_ctzll(badm)) dr = 0;
             const uint32_t incl = wave_scan_add((uint32_t)dr);
-            const uint32_t before = incl - (uint32_t)dr + (wv ? (uint32_t)c.unitDraws[(size_t)bk * C * 4 + 4] : 0u);
+            const uint32_t before = incl - (uint32_t)dr + (wv ? (uint32_t)ud4 : 0u);
             bseed[wv * 64 + lane] = rng_jump(c.jumpT, seed, before);
+            if (lane < DSYN_CHUNK) {
+                int *h = hdr + lane * 8;
+                h[0] = wcl; h[1] = url.x; h[2] = url.y; h[3] = url.z; h[4] = url.w;
+                h[5] = wv ? drb - ud4 : ud4;                       // draws of the channel's one unit in an un-decimated block (unitDraws[0] = 0)
+                h[6] = __float_as_int(rrl);
+            }
             const uint32_t chunkDraws = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             __syncthreads();
             seed = rng_jump(c.jumpT, seed, chunkDraws);            // state after the chunk: the next chunk's start / the stream's state behind the launch
             chunkK = k;
         }
-        const int kb = k - chunkK;                                   // this block's slot in the chunk's seed table
-        const int wc = c.wcScan[blk];
+        const int kb = k - chunkK;                                   // this block's slot in the chunk's tables
+        const int *hb = hdr + kb * 8;
+        const int wc = hb[0];
         if (wc == 0) dead = 1;                                       // a corrupt block ends the stream (ulcDecodeTool.c:154-157)
         const bool lastOfStream = k == c.k1 - 1;
         OUT *outp = out_base<OUT>(c) + (size_t)blk * C * BS;
@@ -827,9 +945,14 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                 sw.A = (float *)zj;
                 const uint32_t unitSeed = (j == 0) ? bseed[wv * 64 + kb] : rng_jump(c.jumpT, bseed[kb], (uint32_t)udraw[wv * 4 + j]);
                 STAMP(1);
-                if (!(ULCX_DBG(c) & 1)) synth_unit(c, sw, S, prec, nrec, urec[wv * 4 + j], unitSeed, unit_draws(wv, j), utail[wv * 4 + j].y, tmag + (size_t)(wv * 4 + j) * c.tailStride, Mp);
+                const bool u0 = j == 0;
+                const int4 ur = u0 ? make_int4(hb[1], hb[2], hb[3], hb[4]) : urec[wv * 4 + j];
+                const int ud = (u0 && whole) ? hb[5] : unit_draws(wv, j);
+                const float urr = u0 ? __int_as_float(hb[6]) : utail[wv * 4 + j].y;
+                if (!(ULCX_DBG(c) & 1)) synth_unit(c, sw, S, prec, nrec, ur, unitSeed, ud, urr, tmag + (size_t)(wv * 4 + j) * c.tailStride, Mp);
                 else for (int i = lane; i < Mp; i += 64) zj[i] = make_float2(0.0f, 0.0f);
                 STAMP(2);
+
                 // DCT-IV pre-twiddle in place: n and M-1-n together read and write the same two complex slots
                 const float2 *pre = c.T.pre[d];
                 if (!(ULCX_DBG(c) & 2)) {
