@@ -609,7 +609,9 @@ __device__ __forceinline__ void synth_unit(const UlcxDecCtx &c, const SynWave &s
     // (hex digits 1 and 2 of 32*l), their loads in flight behind the coefficient scatter
     uint32_t sj = rng_jump_digit(c.jumpT, unitSeed, 1, (uint32_t)(lane & 7) << 1);
     const uint2 *pr = prec + ur.x;
-    const uint2 recFirst = (lane < ur.y) ? pr[lane] : make_uint2(0u, 0u);   // round 0 of the plain-run records: in flight behind the zero fill
+    // rounds 0..2 of the plain-run records: in flight behind the zero fill (one round trip to memory, not one per round)
+    const uint2 recFirst = (lane < ur.y) ? pr[lane] : make_uint2(0u, 0u);
+    const uint2 rec1 = (lane + 64 < ur.y) ? pr[lane + 64] : make_uint2(0u, 0u), rec2 = (lane + 128 < ur.y) ? pr[lane + 128] : make_uint2(0u, 0u);
     if (zeroFloat2) {                                            // (the caller's array: cleared here, behind the loads above)
         float2 *Az = (float2 *)sw.A;
         for (int i = lane; i < zeroFloat2; i += 64) Az[i] = make_float2(0.0f, 0.0f);
@@ -618,7 +620,7 @@ __device__ __forceinline__ void synth_unit(const UlcxDecCtx &c, const SynWave &s
     for (int r0 = 0; r0 < ur.y; r0 += 64) {
         const int r = r0 + lane;
         if (r < ur.y) {
-            const uint2 rec = (r0 == 0) ? recFirst : pr[r];
+            const uint2 rec = (r0 == 0) ? recFirst : (r0 == 64) ? rec1 : (r0 == 128) ? rec2 : pr[r];
             const int pos = rec.x & 0x7FFF, qi = (rec.x >> 15) & 31, m = (rec.x >> 20) & 7;
             const float quant = expand_quantizer(qi);
             float *dst = sw.A + padf(pos);
@@ -956,6 +958,26 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                 // DCT-IV pre-twiddle in place: n and M-1-n together read and write the same two complex slots
                 const float2 *pre = c.T.pre[d];
                 if (!(ULCX_DBG(c) & 2)) {
+                if (BSC == 2048 && whole) {
+                    // the headline geometry: eight trips per lane, four at a time with every load of the four in front of the
+                    // arithmetic (a trip is a chain load -> multiply -> store; in a loop the eight chains run one after the other)
+                    constexpr int MC = 1024;
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        float2 va[4], vb[4], p1[4], p2[4];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const int n = lane + 64 * (4 * h + t), n2 = MC - 1 - n;
+                            va[t] = zj[FFT_PADS(n, DPS)]; vb[t] = zj[FFT_PADS(n2, DPS)]; p1[t] = pre[n]; p2[t] = pre[n2];
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const int n = lane + 64 * (4 * h + t), n2 = MC - 1 - n;
+                            zj[FFT_PADS(n, DPS)]  = cmulc(make_float2(va[t].x, vb[t].y), p1[t]);
+                            zj[FFT_PADS(n2, DPS)] = cmulc(make_float2(vb[t].x, va[t].y), p2[t]);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int n = lane; n < M / 2; n += 64) {
                     const int n2 = M - 1 - n;
@@ -963,6 +985,7 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                     const float2 a = zj[pn], b = zj[pn2];            // (X[2n], X[2n+1]), (X[S-2-2n], X[S-1-2n])
                     zj[pn]  = cmulc(make_float2(a.x, b.y), pre[n]);
                     zj[pn2] = cmulc(make_float2(b.x, a.y), pre[n2]);
+                }
                 }
                 STAMP(11);
                 if constexpr (!TWL) { if (M == 1024) fft_wave_dif_ct<1024, DPS>(zj, c.T.tw[d], lane); else fft_wave_dif(zj, M, c.T.tw[d], lane, DPS); }
