@@ -201,6 +201,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     if (const char *ev = getenv("ULCX_DBG_SKIP")) c.dbgSkip = atoi(ev);   // timing experiments only (breaks results)
 #endif
     DA(c.cbrLo, NB, true); DA(c.cbrHi, NB, true); DA(c.cbrDone, NB, true); DA(c.cbrBudget, NB, true); DA(c.cbrLive, 1, true);
+    DA(c.selWin, NB, true); DA(c.selT, NB, true); c.selPass = 0;
     DA(c.keep, NB * cb / 32, true);
     DA(c.fbList, NB, true);
     DA(c.fbCount, 4, true);

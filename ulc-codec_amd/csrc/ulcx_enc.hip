@@ -1085,6 +1085,7 @@ __global__ __launch_bounds__(64) void k_cplx(UlcxEncCtx c, int k0, int k1) {
         }
         c.cbrLo[blk] = lo; c.cbrHi[blk] = hi;
         c.cbrDone[blk] = done;
+        c.selWin[blk] = make_uint4(0u, 0u, (uint32_t)(c.C * c.BS), 0u);      // the key window of the block's probes: everything
         if (!done) atomicAdd(c.cbrLive, 1);                // rate searches still open: the probe passes leave at once when it reaches 0
         c.nout[blk] = nOut;
         c.cbrBudget[blk] = budget;
@@ -1638,7 +1639,9 @@ __device__ __forceinline__ void sel_gather_keep(const uint32_t (&u)[R], uint32_t
 }
 // One WAVE per block, keys held in registers (R = N/64 per lane): no workgroup barriers,
 // the 256-bin histogram of each radix pass lives in a private 1 KB LDS slice.
-template <int R, int LGBS = 0>                           // LGBS: log2(BlockSize) as a compile-time constant (0: read from the context)
+// PASS: 0 = one-pass call (VBR); rate search: 1 = first probe (leaves the ordered keys in c.key), 2 = later probes and the
+// final pass (read them back, search the window the earlier probes left)
+template <int R, int LGBS = 0, int PASS = 0>             // LGBS: log2(BlockSize) as a compile-time constant (0: read from the context)
 __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass) {
     if (probes_over(c, finalPass)) return;
     int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1663,7 +1666,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
         // being read from an array another kernel wrote
         float *msk = sel_lds + wv * selStride;
         float *sbarkw = msk + c.BS / 2;
-        {
+        if constexpr (PASS != 2) {
             for (int i = lane; i < 4 * ULCX_NBARK; i += 64) sbarkw[i] = c.barkP[(size_t)blk * 4 * ULCX_NBARK + i];
             const int wcB = c.wcArr[(size_t)(blk / c.K) * (c.maxK + 2) + (blk % c.K) + 1];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1672,6 +1675,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
         }
         // batches of 8: the loads of one batch are in flight together, but the compiler may not hoist all R of them
         // above the arithmetic (that doubled the register count and halved the occupancy)
+        if constexpr (PASS != 2)
 #pragma unroll
         for (int r0 = 0; r0 < R; r0 += 8) {
             float cv[8], mv[8];
@@ -1679,8 +1683,19 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
             for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; cv[q] = ldnt(coef + i); mv[q] = msk[(i & (bsK - 1)) >> 1]; }
 #pragma unroll
             for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; u[r0 + q] = sel_key(cv[q], mv[q], i >> lgK); }
+            if constexpr (PASS == 1) {
+#pragma unroll
+                for (int q = 0; q < 8 && r0 + q < R; q++) ((uint32_t *)c.key + (size_t)blk * N)[(r0 + q) * 64 + lane] = u[r0 + q];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    // Rate search (CBR / ABR): the ordered keys of a block are the same in all its probes.  The first pass leaves them in
+    // c.key (unused otherwise while the keys are formed on the fly), the later ones read them back.
+    uint32_t *ukeys = (uint32_t *)c.key + (size_t)blk * N;
+    if constexpr (PASS == 2) {
+#pragma unroll
+        for (int r = 0; r < R; r++) u[r] = ukeys[r * 64 + lane];
     }
     // T = kSel-th largest ordered key = the largest t with count(u >= t) >= kSel, found bit by bit - but not every bit on
     // all R keys per lane (a histogram radix select serialises on LDS atomics here: log-domain keys share their top byte):
@@ -1692,35 +1707,65 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
     //     them, or a window that never gets small - ties, silence -, keeps the full probes) and the remaining bits are
     //     resolved on SEL_CAP compares per lane.
     // A probe that separates exactly kSel keys ends the search at once (the answer is the smallest key above it).
-    constexpr int SEL_CAP = ULCX_SEL_CAP, SEL_CAND = ULCX_SEL_CAND;
+    constexpr int SEL_CAP = ULCX_SEL_CAP, SEL_CAND = ULCX_SEL_CAND, SEL_WIN = ULCX_SEL_CAND + ULCX_SEL_CAND / 4;     // (two candidates per lane on average: more, and some lane of 64 has more than SEL_CAP)
     constexpr bool SEL_COMPACT = R > 2 * SEL_CAP;         // (few keys per lane: the full probes are as cheap)
     uint32_t T = 0;
     int cntT = N;                                         // keys >= T (the search keeps it: no counting pass at the end)
     {
-        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+        int cntLo = N, cntHi = 0;                         // keys >= T, keys >= T + 2^(bit+1)
+        bool compacted = false, tried = false;
+        uint32_t cd[SEL_CAP];
+        // Rate search: the earlier probes of this block have left a window [TL, TH) of keys with count(u >= TL) = cL and
+        // count(u >= TH) = cH known (pack_block), and every later threshold lies in it: when few keys are left in the
+        // window they go to the candidate registers at once and the search runs on them alone, above cH.
+        if constexpr (SEL_COMPACT && PASS == 2) {
+            const uint4 w = c.selWin[blk];
+            if ((int)w.z - (int)w.w <= SEL_WIN) {
+                uint32_t *cl = (uint32_t *)(sel_lds + wv * selStride);
+                const uint32_t span = w.y - w.x;          // (TH = 0: no upper bound yet; the subtraction wraps to 2^32 - TL)
+                int nL = 0;
 #pragma unroll
-        for (int r = 0; r < R; r++) { mn = u[r] < mn ? u[r] : mn; mx = u[r] > mx ? u[r] : mx; }
+                for (int r = 0; r < R; r++) {
+                    const bool act = (u[r] - w.x) < span;
+                    if (act && nL < SEL_CAP) cl[nL * 64 + lane] = u[r];
+                    nL += act ? 1 : 0;
+                }
+                if (!__any(nL > SEL_CAP)) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int j = 0; j < SEL_CAP; j++) cd[j] = (j < nL) ? cl[j * 64 + lane] : 0u;
+                    compacted = (int)w.z > (int)w.w; tried = compacted;          // (an empty window cannot happen; the full search is right whatever the window says)
+                    if (compacted) { cntLo = (int)w.z; cntHi = (int)w.w; }
+                }
+            }
+        }
+        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+        if (!compacted) {
+#pragma unroll
+            for (int r = 0; r < R; r++) { mn = u[r] < mn ? u[r] : mn; mx = u[r] > mx ? u[r] : mx; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SEL_CAP; j++) { const uint32_t v = cd[j] ? cd[j] : 0xFFFFFFFFu; mn = v < mn ? v : mn; mx = cd[j] > mx ? cd[j] : mx; }
+        }
         mn = wave_min_u32(mn); mx = wave_max_u32(mx);
         const uint32_t dif = mn ^ mx;
         if (ULCX_DBG(c) & 0x1000) T = mn;                  // (ablation build only: no search, everything is kept)
-        else if (dif == 0) T = mn;
+        else if (dif == 0) { T = mn; cntT = cntLo; }
         else {
             int bit = 31 - __clz(dif);
-            T = mx & ~((2u << bit) - 1u);                 // the common prefix (count(u >= T) = N >= kSel)
-            int cntLo = N, cntHi = 0;                     // keys >= T, keys >= T + 2^(bit+1)
-            bool compacted = false, tried = false;
-            uint32_t cd[SEL_CAP];
+            T = mx & ~((2u << bit) - 1u);                 // the common prefix (count(u >= T) = cntLo >= kSel)
             for (; bit >= 0; bit--) {
                 const uint32_t t = T | (1u << bit);
+                // (counted on the scalar side: a compare into a lane mask, s_bcnt1, s_add - one vector instruction per key
+                //  instead of two and a wait state, no reduction across the wave at the end)
                 int cnt = 0;
                 if (!compacted) {
 #pragma unroll
-                    for (int r = 0; r < R; r++) cnt += (u[r] >= t) ? 1 : 0;
-                    cnt = wave_sum_i32(cnt);
+                    for (int r = 0; r < R; r++) cnt += __popcll(__ballot(u[r] >= t));
                 } else {
 #pragma unroll
-                    for (int j = 0; j < SEL_CAP; j++) cnt += (cd[j] >= t) ? 1 : 0;
-                    cnt = cntHi + wave_sum_i32(cnt);
+                    for (int j = 0; j < SEL_CAP; j++) cnt += __popcll(__ballot(cd[j] >= t));
+                    cnt += cntHi;
                 }
                 if (cnt == kSel) {
                     // t falls between the kSel-th and the next key: the answer is the smallest key >= t, no need to
@@ -1760,6 +1805,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
             cntT = cntLo;
         }
     }
+    if constexpr (PASS != 0) c.selT[blk] = T;                       // (uniform store: the threshold of this probe, for the window update)
     // the tie group at T straddles the cut iff more than kSel keys are >= T (kSel - #(u > T) < #(u == T))
     const bool straddle = kSel < cntT || (c.forceFb > 0 && blk % c.forceFb == 0);
     // keep bitmap: the ballot of register r is the pair of words 2r, 2r+1 - gathered into lane r (R <= 64) or lanes r, r - 64
@@ -2964,6 +3010,18 @@ __device__ void pack_block(const UlcxEncCtx &c, int finalPass, int blk) {
             if (stop || !(lo < hi - 1)) { c.cbrDone[blk] = 1; c.nout[blk] = lo; if (c.fbMode != 2) atomicSub(c.cbrLive, 1); }   // final pass encodes at Lo (ulcEncoder.c:113-114)
             else c.nout[blk] = (int)((unsigned)(lo + hi) / 2u);
             c.cbrLo[blk] = lo; c.cbrHi[blk] = hi;
+            // The key window the later probes of this block search (k_select_wave): this probe kept the nOut keys >= T
+            // exactly (a block whose tie group straddles the cut has left for the exact path).  More coefficients from here
+            // on: their thresholds are <= T, and nOut - 1 keys lie above T.  Fewer: they are > T, nOut - 1 of them.
+            if (c.selPass && c.fbMode != 2 && nOut > 0) {
+                const uint32_t T = c.selT[blk];
+                uint4 w = c.selWin[blk];
+                if (T != 0xFFFFFFFFu) {
+                    if (bitsTot > budget) { w.x = T + 1; w.z = (uint32_t)(nOut - 1); }
+                    else { w.y = T + 1; w.w = (uint32_t)(nOut - 1); }
+                    c.selWin[blk] = w;
+                }
+            }
         }
         return;
     }
@@ -3283,23 +3341,28 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     }
     const size_t selLds = (size_t)4 * ulcx_sel_lds_words(c.BS) * sizeof(float);
     if (selLds > 48 * 1024 && selLds <= ULCX_LDS_LIMIT && (N / 64 == 128 || N / 64 == 64)) {   // (mono BlockSize 8192: 67 KB)
-        CK(hipFuncSetAttribute((const void *)k_select_wave<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)selLds));
-        CK(hipFuncSetAttribute((const void *)k_select_wave<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)selLds));
-        CK(hipFuncSetAttribute((const void *)k_select_wave<64, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)selLds));
+#define SELA(...) do { CK(hipFuncSetAttribute((const void *)k_select_wave<__VA_ARGS__, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)selLds)); \
+                       CK(hipFuncSetAttribute((const void *)k_select_wave<__VA_ARGS__, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)selLds)); \
+                       CK(hipFuncSetAttribute((const void *)k_select_wave<__VA_ARGS__, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)selLds)); } while (0)
+        SELA(128, 0); SELA(64, 0); SELA(64, 11);
+#undef SELA
     }
     auto launch_select = [&](int fin) {
         int R = N / 64;
+        const dim3 g((NB + 3) / 4), b(256);
+#define SELW(...) do { if (c.selPass == 1) hipLaunchKernelGGL((k_select_wave<__VA_ARGS__, 1>), g, b, selLds, st, c, fin); \
+                       else if (c.selPass == 2) hipLaunchKernelGGL((k_select_wave<__VA_ARGS__, 2>), g, b, selLds, st, c, fin); \
+                       else hipLaunchKernelGGL((k_select_wave<__VA_ARGS__, 0>), g, b, selLds, st, c, fin); } while (0)
         switch (R) {
-            case 128: hipLaunchKernelGGL(k_select_wave<128>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;   // (BlockSize 4096 stereo: ~200 VGPRs, one wave per SIMD)
-            case 64: if (c.lgBS == 11) hipLaunchKernelGGL((k_select_wave<64, 11>), dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin);     // (stereo BlockSize 2048)
-                     else hipLaunchKernelGGL(k_select_wave<64>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin);
-                     return true;
-            case 32: hipLaunchKernelGGL(k_select_wave<32>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;
-            case 16: hipLaunchKernelGGL(k_select_wave<16>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;
-            case 8:  hipLaunchKernelGGL(k_select_wave<8>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;
-            case 4:  hipLaunchKernelGGL(k_select_wave<4>, dim3((NB + 3) / 4), dim3(256), selLds, st, c, fin); return true;
+            case 128: SELW(128, 0); return true;             // (BlockSize 4096 stereo: ~200 VGPRs, one wave per SIMD)
+            case 64: if (c.lgBS == 11) SELW(64, 11); else SELW(64, 0); return true;      // (11: stereo BlockSize 2048)
+            case 32: SELW(32, 0); return true;
+            case 16: SELW(16, 0); return true;
+            case 8:  SELW(8, 0); return true;
+            case 4:  SELW(4, 0); return true;
             default: return false;
         }
+#undef SELW
     };
     // wave-kernel capacities: small (ordinary blocks, high occupancy) and full (any unit of this block size)
     WaveCaps capS = { WAVE_SK, WAVE_SZ, WAVE_SN };
@@ -3389,6 +3452,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         bool ev0 = (p == 0);
         const bool async_fb = canFork && fin;
         if (c.useWave && p > 0) CK(hipMemsetAsync(c.slow, 0, sizeof(int) * ((size_t)NB + 2), st));
+        c.selPass = (probes > 0 && !c.keyFinal) ? (p == 0 ? 1 : 2) : 0;
         if (!launch_select(fin)) {
             hipLaunchKernelGGL(k_select, dim3(NB), dim3(WG), 0, st, c, fin);
         }

@@ -87,6 +87,9 @@ struct UlcxEncCtx {
     uint8_t *unitBuf;                    // [NB][C][unitCap]
     int    *unitNyb;                     // [NB][C*4]
     int    *cbrBudget;                   // [NB] bit budget (ulcEncoder.c:96)
+    uint4  *selWin;                      // [NB] rate search: {TL, TH, count(key >= TL), count(key >= TH)} - the ordered-key window later probes search
+    uint32_t *selT;                      // [NB] the threshold key of the current probe
+    int     selPass;                     // k_select_wave in a rate search: 1 = first probe (stores the ordered keys in `key`), 2 = later ones (read them); 0 = one-pass call
     int    *cbrLive;                     // [1] rate searches of the lock-step path still open (probe passes leave at once at 0)
     int    *slow;                        // [NB] wave-encoder give-up bits (1: small caps, 2: full caps -> k_encode_units); then 2 queue counters, 2 retry queues [NB]
     float2 *gapSum;                      // [NB][C*BS] {Sum, SumW} of the noise run in front of each kept coefficient (speculative)
