@@ -3,7 +3,7 @@ cd /root/repo; export TMPDIR=/tmp
 ARGS=${1:---mode decode}; PAT=${2:-k_d}
 for f in ab/*.so; do
   n=$(basename $f .so); rm -rf /tmp/prof_$n
-  ULC_AMD_LIB=$PWD/$f timeout 240 rocprofv3 --kernel-trace --stats -d /tmp/prof_$n -o x --output-format csv -- python bench.py $ARGS --steps 10 --warmup 2 --no-cpu > /tmp/prof_$n.log 2>&1
+  ULC_AMD_LIB=$PWD/$f timeout 240 rocprofv3 --kernel-trace --stats -d /tmp/prof_$n -o x --output-format csv -- python bench.py $ARGS --steps ${AB_STEPS:-10} --warmup ${AB_WARM:-2} --no-cpu > /tmp/prof_$n.log 2>&1
   echo "== $n: $(grep -o '"ms_per_step": [0-9.]*' /tmp/prof_$n.log | head -1)"
   python - "$n" "$PAT" <<'PY'
 import csv,glob,sys,re

@@ -239,7 +239,9 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.ownSlot, NB, true);
     {
         size_t slots = NB;
-        size_t maxSlots = ((size_t)1 << 30) / (cb * 4);          // at most 1 GiB of resident rankings
+        // at most 8 GiB of resident rankings (a 288 GB device; 1 GiB until round 4: a rate-search call over 524 288 blocks
+        // then enqueued the exact path's fifteen passes for eight groups of slots, seven of them always empty)
+        size_t maxSlots = ((size_t)8 << 30) / (cb * 4);
         if (maxSlots < 1) maxSlots = 1;
         if (slots > maxSlots) slots = maxSlots;
         c.rankSlots = (int)slots;
