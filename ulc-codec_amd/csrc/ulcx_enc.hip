@@ -3208,6 +3208,8 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
             const bool sameCuts = nW < 1;
             if (sameCuts) nW = nCh;
             int cut[ULCX_XF_MAXCH + 1];
+            // (transform chunks cut where the window-control steps end - eight blocks behind the first step instead of one - :
+            //  the transform's interval +0.37 ms, the exposed window control -0.37 ms, the phase the same 4.0 ms)
             cut[0] = 0; cut[1] = 1;
             for (int j = 2; j <= nCh; j++) cut[j] = 1 + (c.K - 1) * (j - 1) / (nCh - 1);
             int wcs[ULCX_WC_MAXCH + 1];
