@@ -7,9 +7,10 @@ usage: bounds_table.py sq_pass1.csv sq_pass2.csv kernel_stats.csv pmc_summary.js
 For every kernel of the step, per bench step (launches of one step summed):
   ms            device time alone on the GPU (kernel stats of the single-stream run; as shipped several overlap)
   hbm_ms        measured HBM bytes / 6.3 TB/s (the copy rate MI355X_MICROARCH.md measures; the 8 TB/s spec is the roofline's peak)
-  valu_ms       vector instructions x 2 cycles (a wave64 instruction occupies its SIMD-32 for two) / (1024 SIMDs x 2.4 GHz):
-                the floor if every SIMD issued vector work every cycle; packed, binary64 and transcendental instructions
-                take 4-8, so this is a lower bound of the floor
+  valu_ms       cycles the vector units were occupied (SQ_ACTIVE_INST_VALU, quad-cycles x 4) / (1024 SIMDs x 2.4 GHz): the
+                floor if every SIMD issued vector work back to back.  On these kernels that is 4.0 cycles per vector
+                instruction (round 4: k_select_wave runs at 94 % of it, and no kernel here has ever run faster than it), not
+                the 2 a wave64 instruction needs on a SIMD-32 on paper
   chain_ms      wave lifetime: SQ_WAVE_CYCLES per wave (quad-cycles x 4) / 2.4 GHz x waves per SIMD slot in sequence
                 = what the kernel takes if it is bound by how long ONE wave lives (dependent chains, waits); for kernels with
                 at most one wave per SIMD this is the kernel's time
@@ -64,7 +65,7 @@ def main():
         hbm = traffic.get(k, {}).get("hbm_bytes_per_launch")
         hbm_ms = hbm / HBM_ACHIEVABLE * 1e3 if hbm else None
         valu = c.get("SQ_INSTS_VALU", 0.0)
-        valu_ms = valu * 2.0 / (SIMDS * CLK) * 1e3
+        valu_ms = (c.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 or valu * 4.0) / (SIMDS * CLK) * 1e3
         wave_cyc = c.get("SQ_WAVE_CYCLES", 0.0) * 4.0 / waves if waves else 0.0       # cycles one wave lives
         rounds = max(1.0, waves / calls * steps_stats / (SIMDS * 8.0)) if calls else 1.0   # wave slots: 8 per SIMD
         per_launch_chain = wave_cyc / CLK * 1e3 * rounds
