@@ -82,6 +82,25 @@ def test_encode_cbr_abr_bit_exact(bs, ch, rate, mode, p0, p1):
     enc.close()
 
 
+def test_rate_search_at_high_rates_over_several_calls():
+    """ABR at 229 kbps on a signal beyond full scale, three calls of ten blocks: what the randomised sweep found wrong in the
+    first form of the rate search's key window (round 4: equal keys at a probe's threshold; blocks whose search is over
+    before the first probe).  Sizes and bytes against the oracle."""
+    amd = _amd()
+    bs, ch, rate, B, K, calls = 2048, 2, 48000, 3, 10, 3
+    pcm = np.stack([synth_pcm(s, calls * K * bs, ch, rate, transient=True, seed=760153175) for s in range(B)]) * np.float32(8.0)
+    enc = amd.BatchEncoder(B, ch, bs, rate, K)
+    outs = [enc.encode(pcm[:, c * K * bs:(c + 1) * K * bs], 2, 228.95, 0.33) for c in range(calls)]
+    out = np.concatenate([o[0] for o in outs], axis=1); bits = np.concatenate([o[1] for o in outs], axis=1)
+    for s in range(B):
+        ref = oracle_encode_debug(pcm[s], bs, rate, 2, 228.95, 0.33, slot=enc.slot)
+        assert np.array_equal(bits[s], ref["bits"]), f"stream {s} sizes"
+        for k in range(calls * K):
+            nb = bits[s, k] // 8
+            assert np.array_equal(out[s, k, :nb], ref["out"][k, :nb]), f"stream {s} block {k} bytes"
+    enc.close()
+
+
 @pytest.mark.parametrize("mode,p0", [(0, 50.0), (1, 96.0)])
 def test_encode_tie_straddle_uses_exact_heapsort_order(mode, p0):
     """Key ties straddling the cut need the exact heapsort emulation (SURVEY.md §7 hard part 2).

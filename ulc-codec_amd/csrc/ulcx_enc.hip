@@ -1647,16 +1647,19 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
     int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int blk = blockIdx.x * 4 + wv;                        // 4 waves per workgroup, one block per wave
     if (blk >= c.B * c.K) return;
-    if (!finalPass && c.cbrDone[blk]) return;
+    // (the first probe of a rate search forms and stores the keys of EVERY block: one whose search is over before it starts,
+    //  or that keeps nothing in this probe, still needs them in a later pass)
+    const bool idle = !finalPass && c.cbrDone[blk];
+    if (PASS != 1 && idle) return;
     if (c.isFb[blk]) return;                              // already handed to the exact (heapsort-rank) path this call
     const int N = R * 64;
     int kSel = c.nout[blk];
     const float *coef = c.coef + (size_t)blk * N;
     uint32_t *keep = c.keep + (size_t)blk * (N / 32);
-    if (kSel <= 0) {
+    if (kSel <= 0 && !idle) {
         for (int i = lane; i < N / 32; i += 64) keep[i] = 0;
-        return;
     }
+    if (PASS != 1 && kSel <= 0) return;
     extern __shared__ float sel_lds[];                        // per wave: BS/2 masking levels + the block's 4 x 25 Bark levels; later the candidate lists
     const int selStride = ulcx_sel_lds_words(c.BS);
     uint32_t u[R];
@@ -1690,6 +1693,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if (PASS == 1 && (idle || kSel <= 0)) return;         // (keys stored above)
     // Rate search (CBR / ABR): the ordered keys of a block are the same in all its probes.  The first pass leaves them in
     // c.key (unused otherwise while the keys are formed on the fly), the later ones read them back.
     uint32_t *ukeys = (uint32_t *)c.key + (size_t)blk * N;
@@ -1716,11 +1720,14 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
         bool compacted = false, tried = false;
         uint32_t cd[SEL_CAP];
         // Rate search: the earlier probes of this block have left a window [TL, TH) of keys with count(u >= TL) = cL and
-        // count(u >= TH) = cH known (pack_block), and every later threshold lies in it: when few keys are left in the
-        // window they go to the candidate registers at once and the search runs on them alone, above cH.
+        // count(u >= TH) = cH known (pack_block), and every later threshold lies in it or is TH itself (the probe that set TH,
+        // once more: the final pass): when few keys are left in the window they go to the candidate registers at once and
+        // the search runs on them alone, above cH.
+        bool same = false;
         if constexpr (SEL_COMPACT && PASS == 2) {
             const uint4 w = c.selWin[blk];
-            if ((int)w.z - (int)w.w <= SEL_WIN) {
+            same = w.y != 0u && kSel == (int)w.w;
+            if (!same && (int)w.z - (int)w.w <= SEL_WIN) {
                 uint32_t *cl = (uint32_t *)(sel_lds + wv * selStride);
                 const uint32_t span = w.y - w.x;          // (TH = 0: no upper bound yet; the subtraction wraps to 2^32 - TL)
                 int nL = 0;
@@ -1750,6 +1757,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
         mn = wave_min_u32(mn); mx = wave_max_u32(mx);
         const uint32_t dif = mn ^ mx;
         if (ULCX_DBG(c) & 0x1000) T = mn;                  // (ablation build only: no search, everything is kept)
+        else if (same) { T = c.selWin[blk].y; cntT = kSel; }
         else if (dif == 0) { T = mn; cntT = cntLo; }
         else {
             int bit = 31 - __clz(dif);
@@ -3010,17 +3018,17 @@ __device__ void pack_block(const UlcxEncCtx &c, int finalPass, int blk) {
             if (stop || !(lo < hi - 1)) { c.cbrDone[blk] = 1; c.nout[blk] = lo; if (c.fbMode != 2) atomicSub(c.cbrLive, 1); }   // final pass encodes at Lo (ulcEncoder.c:113-114)
             else c.nout[blk] = (int)((unsigned)(lo + hi) / 2u);
             c.cbrLo[blk] = lo; c.cbrHi[blk] = hi;
-            // The key window the later probes of this block search (k_select_wave): this probe kept the nOut keys >= T
-            // exactly (a block whose tie group straddles the cut has left for the exact path).  More coefficients from here
-            // on: their thresholds are <= T, and nOut - 1 keys lie above T.  Fewer: they are > T, nOut - 1 of them.
+            // The key window the later probes of this block search (k_select_wave): this probe kept the nOut keys >= T, exactly
+            // those (a block whose tie group straddles the cut has left for the exact path).  Fewer coefficients from here on:
+            // the thresholds are >= T, inside the nOut keys from T up.  More (or the same once more, in the final pass): they
+            // are T itself or lie below it, under the nOut keys from T up.  (T may be one of several equal keys: the bounds are
+            // counts at T, never at its neighbour.)
             if (c.selPass && c.fbMode != 2 && nOut > 0) {
                 const uint32_t T = c.selT[blk];
                 uint4 w = c.selWin[blk];
-                if (T != 0xFFFFFFFFu) {
-                    if (bitsTot > budget) { w.x = T + 1; w.z = (uint32_t)(nOut - 1); }
-                    else { w.y = T + 1; w.w = (uint32_t)(nOut - 1); }
-                    c.selWin[blk] = w;
-                }
+                if (bitsTot > budget) { w.x = T; w.z = (uint32_t)nOut; }
+                else { w.y = T; w.w = (uint32_t)nOut; }
+                c.selWin[blk] = w;
             }
         }
         return;
