@@ -1086,7 +1086,13 @@ __global__ __launch_bounds__(64) void k_cplx(UlcxEncCtx c, int k0, int k1) {
         c.cbrLo[blk] = lo; c.cbrHi[blk] = hi;
         c.cbrDone[blk] = done;
         c.selWin[blk] = make_uint4(0u, 0u, (uint32_t)(c.C * c.BS), 0u);      // the key window of the block's probes: everything
-        if (!done) atomicAdd(c.cbrLive, 1);                // rate searches still open: the probe passes leave at once when it reaches 0
+        // rate searches still open (the probe passes leave at once when it reaches 0): one atomic per wave, not per block -
+        // half a million adds to one word are 3 ms
+        {
+            const unsigned long long open = __ballot(!done);
+            if (open && (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(open >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)open, 0u)) == 0 && !done)
+                atomicAdd(c.cbrLive, (int)__popcll(open));
+        }
         c.nout[blk] = nOut;
         c.cbrBudget[blk] = budget;
     }
@@ -3058,6 +3064,43 @@ __device__ void pack_block(const UlcxEncCtx &c, int finalPass, int blk) {
     }
     if (lane == 0) c.bits[blk] = bitsTot;
 }
+// A probe pass of the rate search on the lock-step path: only the size matters (ulcEncoder.c:100-110).  One LANE per block
+// (pack_block's probe branch is one wave per block, one lane of it working, and one atomic per finished search: at half a
+// million blocks the pass in which most searches end spent 3 ms on that counter).
+__global__ __launch_bounds__(256) void k_rate_step(UlcxEncCtx c) {
+    if (probes_over(c, 0)) return;
+    const int blk = blockIdx.x * 256 + threadIdx.x;
+    bool ended = false;
+    if (blk < c.B * c.K && !skip_block(c, blk, 0)) {
+        const int s = blk / c.K, k = blk % c.K;
+        const int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
+        const int nU = c.C * 4;
+        const int *un = c.unitNyb + (size_t)blk * nU;
+        int total = (wc & 8) ? 2 : 1;
+        for (int u = 0; u < nU; u++) total += un[u];
+        const int bitsTot = ((total * 4) + 7) & ~7;
+        const int budget = c.cbrBudget[blk];
+        int lo = c.cbrLo[blk], hi = c.cbrHi[blk];
+        const int nOut = c.nout[blk];
+        bool stop = false;
+        if (bitsTot < budget) lo = nOut;
+        else if (bitsTot > budget) hi = nOut - 1;
+        else { lo = nOut; stop = true; }
+        if (stop || !(lo < hi - 1)) { c.cbrDone[blk] = 1; c.nout[blk] = lo; ended = true; }      // final pass encodes at Lo (ulcEncoder.c:113-114)
+        else c.nout[blk] = (int)((unsigned)(lo + hi) / 2u);
+        c.cbrLo[blk] = lo; c.cbrHi[blk] = hi;
+        if (c.selPass && nOut > 0) {                              // the key window of the later probes: see pack_block
+            const uint32_t T = c.selT[blk];
+            uint4 w = c.selWin[blk];
+            if (bitsTot > budget) { w.x = T; w.z = (uint32_t)nOut; }
+            else { w.y = T; w.w = (uint32_t)nOut; }
+            c.selWin[blk] = w;
+        }
+    }
+    const unsigned long long e = __ballot(ended);
+    if (e && (threadIdx.x & 63) == 0) atomicSub(c.cbrLive, (int)__popcll(e));
+}
+
 // (four blocks per workgroup: since the wave writer packs most blocks itself this kernel is mostly waves that leave at
 //  once, and single-wave workgroups are bound by the dispatch rate)
 __global__ __launch_bounds__(256) void k_pack(UlcxEncCtx c, int finalPass) {
@@ -3427,7 +3470,8 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
         hipLaunchKernelGGL(k_encode_units, dim3(fb2 ? fbW : (nUnits + 63) / 64), dim3(64), 0, s2, cc, fin);
         if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
-        hipLaunchKernelGGL(k_pack, dim3(fb2 ? (fbW + 3) / 4 : (NB + 3) / 4), dim3(256), 0, s2, cc, fin);
+        if (!fin && !fb2) hipLaunchKernelGGL(k_rate_step, dim3((NB + 255) / 256), dim3(256), 0, s2, cc);
+        else hipLaunchKernelGGL(k_pack, dim3(fb2 ? (fbW + 3) / 4 : (NB + 3) / 4), dim3(256), 0, s2, cc, fin);
         if (ev0 && ev) CK(hipEventRecord(ev[stage++], s2));
         return ULCX_OK;
     };
