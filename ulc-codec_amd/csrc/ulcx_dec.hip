@@ -233,8 +233,10 @@ template <int R>
 __device__ __forceinline__ void ring_flush(uint2 *ring, int lane, int &f, int n, uint2 *base, int rowIdx, int stride) {
     DSCAN_WAVE_SYNC();
     const int cnt = n - f, half = lane >> 5, i = lane & 31;
+    const unsigned long long pend = __ballot(cnt > 0);       // (a wave with few live lanes - the drop-in's one block - skips the rest)
 #pragma unroll 4
     for (int it = 0; it < 32; it++) {
+        if (!((pend >> (2 * it)) & 3ull)) continue;
         const int j = 2 * it + half;
         const int cj = __builtin_amdgcn_ds_bpermute(j << 2, cnt);
         const int fj = __builtin_amdgcn_ds_bpermute(j << 2, f);
