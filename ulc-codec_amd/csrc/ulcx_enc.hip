@@ -1086,6 +1086,7 @@ __global__ __launch_bounds__(64) void k_cplx(UlcxEncCtx c, int k0, int k1) {
         c.cbrLo[blk] = lo; c.cbrHi[blk] = hi;
         c.cbrDone[blk] = done;
         c.selWin[blk] = make_uint4(0u, 0u, (uint32_t)(c.C * c.BS), 0u);      // the key window of the block's probes: everything
+        for (int u = 0; u < c.C * 4; u++) c.tailSum[((size_t)blk * c.C * 4 + u) * 8 + 6] = 0.0f;      // k_tails: no tail sums of this call yet
         // rate searches still open (the probe passes leave at once when it reaches 0): one atomic per wave, not per block -
         // half a million adds to one word are 3 ms
         {
@@ -2252,8 +2253,14 @@ __global__ __launch_bounds__(WG) void k_tails(UlcxEncCtx c, int finalPass) {
                 }
                 start = last + 1;
                 const int n = ue - start;
-                c.tailSum[((size_t)(blk * c.C + ch) * 4 + j) * 8 + 5] = __int_as_float(start);
-                np = n >= 16 ? (n + (start & 1) + 1) / 2 : 0;
+                float *tsu = c.tailSum + ((size_t)(blk * c.C + ch) * 4 + j) * 8;
+                // Rate search: the sums are a function of where the tail starts (and of the block's levels), and a later
+                // probe of the block often ends on the same last kept coefficient: the sums an earlier probe of THIS call
+                // left for the same start are taken as they are (slot 6: set here, cleared by k_cplx at the start of every
+                // rate-search call - not a call counter in the context: the drop-in replays ONE captured call).
+                const bool again = c.selPass == 2 && __float_as_int(tsu[6]) == 1 && __float_as_int(tsu[5]) == start;
+                tsu[5] = __int_as_float(start); tsu[6] = __int_as_float(1);
+                np = (n >= 16 && !again) ? (n + (start & 1) + 1) / 2 : 0;
                 uLine0[tid] = (start - ub) >> 1;
                 const float *bg = c.barkN + ((size_t)(blk * c.C + ch) * 4 + j) * ULCX_NBARK;
                 for (int i = 0; i < ULCX_NBARK; i++) sbark[tid][i] = bg[i];
