@@ -2670,6 +2670,12 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
     //    rounds a unit for ~100 kept coefficients: 0.50 of the kernel's 1.48 ms.)
     int nK = 0;
     const int nWords = S >> 5;
+    // (a pass's coefficients travel while the next pass finds its own: the store of pass p sits behind the search of pass
+    //  p + 1 - and in front of its loads, so that no copy of a register in flight is needed)
+    float pendV = 0.0f; int pendAt = -1;
+    // the unit's tail sums (k_tails), asked for now and used at the very end
+    const float4 tsA = *(const float4 *)(c.tailSum + (size_t)gid * 8);
+    const float2 tsB = *(const float2 *)(c.tailSum + (size_t)gid * 8 + 4);
     for (int wb = 0; wb < nWords; wb += 64) {
         const uint32_t kw = (wb + lane < nWords) ? keepU[wb + lane] : 0u;      // words past the unit read as "nothing kept"
         const int pc = __popc(kw);
@@ -2699,10 +2705,14 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
                 r = up ? r - cl : r; t = up ? t >> sh : t; pos = up ? pos + sh : pos;
             }
             const int idx = (wb + lo) * 32 + pos;
-            if (j < tot && nK + j < E2_KCAP) { kidx[nK + j] = (uint16_t)idx; kval[nK + j] = coefU[idx]; }
+            if (pendAt >= 0) kval[pendAt] = pendV;
+            const bool mine = j < tot && nK + j < E2_KCAP;
+            pendAt = mine ? nK + j : -1;
+            if (mine) { kidx[nK + j] = (uint16_t)idx; pendV = coefU[idx]; }
         }
         nK += tot;
     }
+    if (pendAt >= 0) kval[pendAt] = pendV;
     bool overflow = nK > E2_KCAP;
     WAVE_SYNC();
     if ((ULCX_DBG(c) >> 8) == 1) { if (lane == 0) c.unitNyb[gid] = 0; return; }
@@ -2814,9 +2824,21 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
     // F+H. gaps -> run codes; positions by prefix sum; emission
     int total = 0;
     if (!overflow) {
+        // the speculated amplitudes of a round's gaps (k_nsums) are asked for one round ahead: they arrive behind the run
+        // codes of the round in front
+        auto gap_amps = [&](int m) {
+            float2 a = make_float2(-2.0f, -2.0f);
+            if (m < nC) {
+                const int raw = kidx[m], idx = raw & 0x7FFF, start = (m > 0) ? (kidx[m - 1] & 0x7FFF) + 1 : 0;
+                if (idx - start >= 16 && (raw & 0x8000) && c.useGapSums) a = gapU[idx];
+            }
+            return a;
+        };
+        float2 ampR = gap_amps(lane);
         for (int base = 0; base < nC; base += 64) {
             int m = base + lane;
             unsigned long long lo = 0, hi = 0; int cnt = 0, pre = 0, z = 0, zp = -1, qn = 0;
+            const float2 ampN = gap_amps(m + 64);
             if (m < nC) {
                 int raw = kidx[m];
                 int idx = raw & 0x7FFF;
@@ -2825,8 +2847,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
                 qn = ((int *)kval)[m];
                 pre = zpre[z] - ((zp >= 0) ? zpre[zp] : 0);
                 int zr = idx - start;
-                float amp0 = -2.0f, amp1 = -2.0f;
-                if (zr >= 16 && (raw & 0x8000) && c.useGapSums) { const float2 a = gapU[idx]; amp0 = a.x; amp1 = a.y; }
+                const float amp0 = ampR.x, amp1 = ampR.y;
                 gap_codes(start, zr, (float)(1u << zqi[z]), coefU, src, ubase, amp0, amp1, amp0 > -1.5f ? gapU + idx : nullptr, lo, hi, cnt, (ULCX_DBG(c) & 0x40) != 0);
             }
             int mine = (m < nC) ? pre + cnt + 1 : 0;
@@ -2846,6 +2867,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
                 nyb[p++] = (uint8_t)(qn & 0xF);
             }
             total += tot;
+            ampR = ampN;
         }
         overflow = __any(overflow);
     }
@@ -2861,10 +2883,9 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
         int qtail = ((nZ > 0) ? zpre[nZ - 1] : 0) - ((zlast >= 0) ? zpre[zlast] : 0);
         int nq = 0, nd = 0;
         if (n > 4 && prevQ != -1 && n >= 16) {
-            const float *ts = c.tailSum + (size_t)gid * 8;
             float sx, sx2, sxy, sy, sw;
-            if (c.useGapSums && __float_as_int(ts[5]) == ubase + nextCoded) {
-                sx = ts[0]; sx2 = ts[1]; sxy = ts[2]; sy = ts[3]; sw = ts[4];
+            if (c.useGapSums && __float_as_int(tsB.y) == ubase + nextCoded) {
+                sx = tsA.x; sx2 = tsA.y; sxy = tsA.z; sy = tsA.w; sw = tsB.x;
             } else {
                 // NoiseFill.c:41-62: five ordered f32 sums, one per lane 0..4 (rare: the speculated tail start was off)
                 const int p0 = (ubase + nextCoded) / 2;
