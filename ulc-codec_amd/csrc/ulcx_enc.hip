@@ -275,6 +275,15 @@ __global__ __launch_bounds__(NW * 64) void k_wc_ef(UlcxEncCtx c, int k0, int k1)
 #define EF_AHEAD 3
 #endif
         float2 A[EF_AHEAD][NS][3];
+        // this lane's sample of step 0 of the call, per stream of the wave (the 64-bit stream offset once, not per tile:
+        // three quarter-rate multiplies a tile)
+        const IN *sbase[NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            const int s = s0 + p + NP * i;
+            const int sc = ((p + NP * i < EF_SPW) && (s < c.B)) ? s : 0;
+            sbase[i] = pcm_base<IN>(c) + (size_t)sc * c.K * c.BS * 2 + 2 * lane;
+        }
         auto issue = [&](float2 (&A)[NS][3], int j) {     // the three samples of this lane's time step of tile j, every stream of this wave
             const int t0 = (k0 * c.BS + j * 64) - c.BS / 2;                                                     // lane 0's centre sample (wave-uniform)
             const int t = t0 + lane;
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(NW * 64) void k_wc_ef(UlcxEncCtx c, int k0, int k1)
                     // the tile and its two neighbours lie in this call's input (all but the first BS/2 + 1 steps of a call): one
                     // wave-uniform base, three loads at constant offsets (round 3: the general form below - a history / input
                     // select and a 64-bit stream offset per load - was 54 of the 113 vector instructions a step costs here)
-                    const IN *q = pcm_base<IN>(c) + ((size_t)sc * c.K * c.BS + (size_t)t0) * 2 + 2 * lane;
+                    const IN *q = sbase[i] + 2 * (ptrdiff_t)t0;
                     A[i][0] = ld2(q - 2); A[i][1] = ld2(q); A[i][2] = ld2(q + 2);
                 } else { A[i][0] = smp_ld2<IN>(c, sc, t - 1); A[i][1] = smp_ld2<IN>(c, sc, t); A[i][2] = smp_ld2<IN>(c, sc, t + 1); }
             }
