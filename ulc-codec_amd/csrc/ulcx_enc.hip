@@ -443,11 +443,16 @@ __global__ __launch_bounds__(64) void k_wc_integrate(UlcxEncCtx c, int k0, int k
     const float cBlk = c.cBlk;
     float sum = 0.0f;
     int inBin = 0, gbin = k0 * 8;         // steps accumulated in the current bin; global bin index = k*8 + i
-    for (int i = 0; i < nq; i += D * U) {
+    // A trip = D groups of U quads.  The recurrence is three dependent instructions a step (25 cycles: tools/ubench/
+    // dep_chain.hip) and every other instruction the wave issues between them costs its 4 cycles on top: all but the last
+    // trip fetch ahead without asking whether there is more, and when a bin is a whole number of trips (BlockSize >= 512)
+    // the bin boundary is looked for once per trip, not once per group (38 -> 34 cycles a step).
+    auto trip = [&](int i, auto tailT, auto fineT) {
+        constexpr bool TAIL = decltype(tailT)::value, FINE = decltype(fineT)::value;
 #pragma unroll
         for (int g = 0; g < D; g++) {
-            const bool more = (i + (g + D - 1) * U) < nq;
-            const float4 *lp = more ? rp : v;
+            const float4 *lp = rp;
+            if (TAIL) { const bool more = (i + (g + D - 1) * U) < nq; lp = more ? rp : v; }
 #pragma unroll
             for (int j = 0; j < U; j++) x[(g + D - 1) % D][j] = wc_ld(lp + (size_t)j * QS);
             rp += U * QS;
@@ -460,13 +465,19 @@ __global__ __launch_bounds__(64) void k_wc_integrate(UlcxEncCtx c, int k0, int k
                 d = q.z - env; env += d * cBlk; sum += env;
                 d = q.w - env; env += d * cBlk; sum += env;
             }
-            inBin += 4 * U;
-            if (inBin == bin) {           // bin boundary (bins never straddle a group); the weight is the step count
-                if (live) { float *o = bins + (size_t)(gbin / 8 + 1) * 16; o[gbin & 7] = sum; o[8 + (gbin & 7)] = (float)bin; }
-                sum = 0.0f; inBin = 0; gbin++;
+            if (FINE || g == D - 1) {
+                inBin += FINE ? 4 * U : 4 * U * D;
+                if (inBin == bin) {       // bin boundary (bins never straddle a group); the weight is the step count
+                    if (live) { float *o = bins + (size_t)(gbin / 8 + 1) * 16; o[gbin & 7] = sum; o[8 + (gbin & 7)] = (float)bin; }
+                    sum = 0.0f; inBin = 0; gbin++;
+                }
             }
         }
-    }
+    };
+    const bool coarse = (bin % (4 * U * D)) == 0;
+    int i = 0;
+    if (coarse) { for (; i + 2 * D * U <= nq; i += D * U) trip(i, std::false_type{}, std::false_type{}); for (; i < nq; i += D * U) trip(i, std::true_type{}, std::false_type{}); }
+    else { for (; i + 2 * D * U <= nq; i += D * U) trip(i, std::false_type{}, std::true_type{}); for (; i < nq; i += D * U) trip(i, std::true_type{}, std::true_type{}); }
     if (live) c.wcs[s].tf[2] = env;       // only this kernel reads tf[2]
 }
 
