@@ -335,7 +335,14 @@ __global__ __launch_bounds__(NW * 64) void k_wc_ef(UlcxEncCtx c, int k0, int k1)
     float env = live ? c.wcs[s].tf[f] : 0.0f;
     const float cc = f ? c.cBP : c.cHP;
     constexpr int QS = 512 / 4;                           // float4s between consecutive quads of a stream
-    float4 *wp = (float4 *)((float *)c.env + envq_idx(c, live ? s : 0, k0 * c.BS / 4) + f * 256);
+    // Where the chain's results go.  A lane without a stream (s >= B, the batch's last group) stores like the others, into
+    // its own padded rows of the scratch: the recurrence is three dependent instructions a step (25 cycles: tools/ubench/
+    // dep_chain.hip) and every other instruction between them costs 4 more - a predicated store with a 64-bit vector
+    // address add was five of them per quad.
+    // (four pointers 8 KB apart, each the middle of four quads: every store's offset fits the instruction's immediate)
+    char *wq[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) wq[k] = (char *)((float *)c.env + envq_idx(c, s, k0 * c.BS / 4) + f * 256) + k * 8192 + 4096;
     for (int j = 0; j < nT; j++) {
         for (;;) {                                        // every producer wave has finished tile j
             int m = (lane < NP) ? __atomic_load_n(&flags[lane], __ATOMIC_ACQUIRE) : 0x7fffffff;
@@ -356,9 +363,10 @@ __global__ __launch_bounds__(NW * 64) void k_wc_ef(UlcxEncCtx c, int k0, int k1)
             d = v.y - env; env += d * cc; v.y = env;
             d = v.z - env; env += d * cc; v.z = env;
             d = v.w - env; env += d * cc; v.w = env;
-            if (live) wc_st(wp + (size_t)q * QS, v);
+            wc_st((float4 *)(wq[q >> 2] + ((q & 3) * 2048 - 4096)), v);
         }
-        wp += 16 * QS;
+#pragma unroll
+        for (int k = 0; k < 4; k++) wq[k] += 16 * QS * sizeof(float4);
     }
     if (live) c.wcs[s].tf[f] = env;                       // state for the next call
 }
