@@ -563,11 +563,14 @@ __device__ __forceinline__ float win_apply(float x, int i, int S, int aL, int ov
 // The steady state of the headline geometry, every size a compile-time constant: stereo, BlockSize 2048, an un-decimated
 // block between two full-overlap neighbours (PCM16 ingest: from the call's third block on).  Same arithmetic, same
 // order as the general body of k_xf below (which documents it) - only the index arithmetic, the loop bounds and the window
-// selects fold away, and the four 1024-point transforms run the compile-time passes (fft_wave_dif_ct).
-template <typename IN>
-__device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int s, int k, int blk, int tid) {
-    constexpr int BS = 2048, S = 2048, M = 1024, PS = 4, Mp = FFT_PADDEDS(M, PS);
-    static_assert(WG == 256, "two fold / epilogue trips per thread");
+// selects fold away, and the four transforms run the compile-time passes (fft_wave_dif_ct).
+// (BSC: 2048, the headline geometry; 4096 since round 4 - the window-switching configuration's un-decimated blocks)
+template <typename IN, int BSC>
+__device__ __forceinline__ int xf_fast(const UlcxEncCtx &c, float *lds, int s, int k, int blk, int tid) {
+    constexpr int BS = BSC, S = BSC, M = BSC / 2, PS = 4, Mp = FFT_PADDEDS(M, PS);
+    constexpr int LGM = BSC == 4096 ? 11 : 10;
+    static_assert(BSC == 2048 || BSC == 4096, "sizes with a compile-time transform");
+    static_assert(WG == 256 && (M / 2) % (2 * WG) == 0, "whole fold / epilogue trips per thread");
     float2 *z = (float2 *)lds;
     float2 *twl = (float2 *)(lds + 4 * FFT_PADDEDS(BS, PS));
     float2 *zc0 = z, *zs0 = z + Mp, *zc1 = z + 2 * Mp, *zs1 = z + 3 * Mp;
@@ -627,8 +630,9 @@ __device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int
     // A thread takes TWO neighbouring post-twiddle indices (kk = 2 tid, 2 tid + 1: M/2 = 2 WG of them), so that what it
     // writes is contiguous: coefficients 4 tid .. 4 tid + 3 and BS - 4 - 4 tid .. BS - 1 - 4 tid of each channel as 16-byte
     // stores, line energies as 8-byte stores (one index per thread gave 8- and 4-byte stores: twice the store instructions).
-    {
-        const int kA = 2 * tid, kB = 2 * tid + 1;                 // k1 of the two; their mirrors k2 = M-1-kA, M-1-kB = (M-1-kA) - 1
+#pragma unroll
+    for (int e0 = 0; e0 < M / 2; e0 += 2 * WG) {
+        const int kA = e0 + 2 * tid, kB = e0 + 2 * tid + 1;       // k1 of the two; their mirrors k2 = M-1-kA, M-1-kB = (M-1-kA) - 1
         const int kk2[2] = { kA, kB };
         float re[2][2][4];                                        // [channel][0: the k1 side, 1: the k2 side][4 consecutive coefficients]
         float ns[2][2][2];                                        // [channel][side][2 consecutive lines]
@@ -636,7 +640,7 @@ __device__ __forceinline__ int xf_fast_2048(const UlcxEncCtx &c, float *lds, int
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int k1 = kk2[u], k2 = M - 1 - k1;
-            const int r1 = (int)(__brev((unsigned)k1) >> 22), r2 = (int)(__brev((unsigned)k2) >> 22);
+            const int r1 = (int)(__brev((unsigned)k1) >> (32 - LGM)), r2 = (int)(__brev((unsigned)k2) >> (32 - LGM));
             const float2 P1 = pre[k1], P2 = pre[k2];
             const fft_v2f Pv1 = { P1.x, P1.y }, Pv2 = { P2.x, P2.y };
 #pragma unroll
@@ -728,9 +732,9 @@ __device__ __forceinline__ void xf_block(const UlcxEncCtx &c, float *lds, int s,
     int nnz = 0;
     __syncthreads();
 
-    // the steady state of the headline geometry takes the all-constants path (xf_fast_2048)
-    const bool fastBlk = ST && BS == 2048 && xf_is_fast<IN>(c, s, k);
-    if (fastBlk) nnz = xf_fast_2048<IN>(c, lds, s, k, blk, tid);
+    // the steady state of the headline geometry (and of BlockSize 4096) takes the all-constants path (xf_fast)
+    const bool fastBlk = ST && (BS == 2048 || BS == 4096) && xf_is_fast<IN>(c, s, k);
+    if (fastBlk) nnz = (BS == 2048) ? xf_fast<IN, 2048>(c, lds, s, k, blk, tid) : xf_fast<IN, 4096>(c, lds, s, k, blk, tid);
     else
     for (int ch0 = 0; ch0 < C; ch0 += 2) {             // one M/S pair (or a trailing single channel) at a time
         const int nch = ST ? 2 : ((ch0 + 1 < C) ? 2 : 1);
