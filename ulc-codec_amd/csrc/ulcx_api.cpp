@@ -202,6 +202,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
 #endif
     DA(c.cbrLo, NB, true); DA(c.cbrHi, NB, true); DA(c.cbrDone, NB, true); DA(c.cbrBudget, NB, true); DA(c.cbrLive, 1, true);
     DA(c.selWin, NB, true); DA(c.selT, NB, true); c.selPass = 0;
+    { const char *ev = getenv("ULCX_SEL_PAIR"); c.selPair = ev ? atoi(ev) : 1; }
     DA(c.keep, NB * cb / 32, true);
     DA(c.fbList, NB, true);
     DA(c.fbCount, 4, true);

@@ -1680,26 +1680,39 @@ __device__ __forceinline__ void sel_gather_keep(const uint32_t (&u)[R], uint32_t
 // the 256-bin histogram of each radix pass lives in a private 1 KB LDS slice.
 // PASS: 0 = one-pass call (VBR); rate search: 1 = first probe (leaves the ordered keys in c.key), 2 = later probes and the
 // final pass (read them back, search the window the earlier probes left)
-template <int R, int LGBS = 0, int PASS = 0>             // LGBS: log2(BlockSize) as a compile-time constant (0: read from the context)
-__global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass) {
-    if (probes_over(c, finalPass)) return;
-    int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    int blk = blockIdx.x * 4 + wv;                        // 4 waves per workgroup, one block per wave
-    if (blk >= c.B * c.K) return;
+// PAIR: TWO waves per block, one per channel of a stereo block (R = BlockSize/64 keys per lane each), one block per
+// workgroup: every count, minimum and decision of the search is formed over both waves through two words of LDS and a
+// workgroup barrier (the two waves take every branch together).  BlockSize 4096 stereo: 128 keys per lane in one wave are
+// 200 registers, two waves per SIMD.
+template <int R, int LGBS, int PASS, bool PAIR>          // LGBS: log2(BlockSize) as a compile-time constant (0: read from the context)
+__device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, int blk, int wv, int lane, int half, volatile uint32_t *xch, float *sel_lds) {
+    // sums / minima / maxima over the pair's two waves (wave-uniform values; the exchanges alternate between two slots, so
+    // one barrier per exchange is enough)
+    int xt = 0;
+    auto xchg = [&](uint32_t v) -> uint32_t {
+        if (lane == 0) xch[(xt & 1) * 2 + half] = v;
+        __syncthreads();
+        const uint32_t o = xch[(xt & 1) * 2 + (1 - half)];
+        xt++;
+        return o;
+    };
+    auto pair_sum = [&](int v) -> int { if (!PAIR) return v; return v + (int)xchg((uint32_t)v); };
+    auto pair_min = [&](uint32_t v) -> uint32_t { if (!PAIR) return v; const uint32_t o = xchg(v); return o < v ? o : v; };
+    auto pair_max = [&](uint32_t v) -> uint32_t { if (!PAIR) return v; const uint32_t o = xchg(v); return o > v ? o : v; };
     // (the first probe of a rate search forms and stores the keys of EVERY block: one whose search is over before it starts,
     //  or that keeps nothing in this probe, still needs them in a later pass)
     const bool idle = !finalPass && c.cbrDone[blk];
     if (PASS != 1 && idle) return;
     if (c.isFb[blk]) return;                              // already handed to the exact (heapsort-rank) path this call
-    const int N = R * 64;
+    constexpr int NW = R * 64, N = PAIR ? 2 * NW : NW;      // this wave's keys, the block's
     int kSel = c.nout[blk];
-    const float *coef = c.coef + (size_t)blk * N;
-    uint32_t *keep = c.keep + (size_t)blk * (N / 32);
+    const float *coef = c.coef + (size_t)blk * N + (size_t)half * NW;
+    uint32_t *keep = c.keep + (size_t)blk * (N / 32) + half * (NW / 32);
     if (kSel <= 0 && !idle) {
-        for (int i = lane; i < N / 32; i += 64) keep[i] = 0;
+        for (int i = lane; i < NW / 32; i += 64) keep[i] = 0;
     }
     if (PASS != 1 && kSel <= 0) return;
-    extern __shared__ float sel_lds[];                        // per wave: BS/2 masking levels + the block's 4 x 25 Bark levels; later the candidate lists
+    // sel_lds, per wave (PAIR: per block): BS/2 masking levels + the block's 4 x 25 Bark levels; later the candidate lists
     const int selStride = ulcx_sel_lds_words(c.BS);
     uint32_t u[R];
     const int lgK = LGBS ? LGBS : c.lgBS, bsK = LGBS ? (1 << LGBS) : c.BS;   // (constants: channel and LDS offsets of a key fold per register)
@@ -1712,8 +1725,10 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
             for (int i = lane; i < 4 * ULCX_NBARK; i += 64) sbarkw[i] = c.barkP[(size_t)blk * 4 * ULCX_NBARK + i];
             const int wcB = c.wcArr[(size_t)(blk / c.K) * (c.maxK + 2) + (blk % c.K) + 1];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int jp = lane; jp < c.BS / 2; jp += 64) msk[jp] = mask_level(c, sbarkw, wcB, jp);
+            if (PAIR) __syncthreads();                          // (both waves have stored the same Bark levels)
+            for (int jp = lane + (PAIR ? 64 * half : 0); jp < c.BS / 2; jp += (PAIR ? 128 : 64)) msk[jp] = mask_level(c, sbarkw, wcB, jp);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (PAIR) __syncthreads();
         }
         // batches of 8: the loads of one batch are in flight together, but the compiler may not hoist all R of them
         // above the arithmetic (that doubled the register count and halved the occupancy)
@@ -1724,10 +1739,10 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
 #pragma unroll
             for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; cv[q] = ldnt(coef + i); mv[q] = msk[(i & (bsK - 1)) >> 1]; }
 #pragma unroll
-            for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; u[r0 + q] = sel_key(cv[q], mv[q], i >> lgK); }
+            for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; u[r0 + q] = sel_key(cv[q], mv[q], PAIR ? half : (i >> lgK)); }
             if constexpr (PASS == 1) {
 #pragma unroll
-                for (int q = 0; q < 8 && r0 + q < R; q++) ((uint32_t *)c.key + (size_t)blk * N)[(r0 + q) * 64 + lane] = u[r0 + q];
+                for (int q = 0; q < 8 && r0 + q < R; q++) ((uint32_t *)c.key + (size_t)blk * N + (size_t)half * NW)[(r0 + q) * 64 + lane] = u[r0 + q];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1735,7 +1750,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
     if (PASS == 1 && (idle || kSel <= 0)) return;         // (keys stored above)
     // Rate search (CBR / ABR): the ordered keys of a block are the same in all its probes.  The first pass leaves them in
     // c.key (unused otherwise while the keys are formed on the fly), the later ones read them back.
-    uint32_t *ukeys = (uint32_t *)c.key + (size_t)blk * N;
+    uint32_t *ukeys = (uint32_t *)c.key + (size_t)blk * N + (size_t)half * NW;
     if constexpr (PASS == 2) {
 #pragma unroll
         for (int r = 0; r < R; r++) u[r] = ukeys[r * 64 + lane];
@@ -1767,7 +1782,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
             const uint4 w = c.selWin[blk];
             same = w.y != 0u && kSel == (int)w.w;
             if (!same && (int)w.z - (int)w.w <= SEL_WIN) {
-                uint32_t *cl = (uint32_t *)(sel_lds + wv * selStride);
+                uint32_t *cl = (uint32_t *)(sel_lds + wv * selStride) + half * (SEL_CAP * 64);
                 const uint32_t span = w.y - w.x;          // (TH = 0: no upper bound yet; the subtraction wraps to 2^32 - TL)
                 int nL = 0;
 #pragma unroll
@@ -1776,7 +1791,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
                     if (act && nL < SEL_CAP) cl[nL * 64 + lane] = u[r];
                     nL += act ? 1 : 0;
                 }
-                if (!__any(nL > SEL_CAP)) {
+                if (pair_sum(__any(nL > SEL_CAP) ? 1 : 0) == 0) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
                     for (int j = 0; j < SEL_CAP; j++) cd[j] = (j < nL) ? cl[j * 64 + lane] : 0u;
@@ -1793,7 +1808,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
 #pragma unroll
             for (int j = 0; j < SEL_CAP; j++) { const uint32_t v = cd[j] ? cd[j] : 0xFFFFFFFFu; mn = v < mn ? v : mn; mx = cd[j] > mx ? cd[j] : mx; }
         }
-        mn = wave_min_u32(mn); mx = wave_max_u32(mx);
+        mn = pair_min(wave_min_u32(mn)); mx = pair_max(wave_max_u32(mx));
         const uint32_t dif = mn ^ mx;
         if (ULCX_DBG(c) & 0x1000) T = mn;                  // (ablation build only: no search, everything is kept)
         else if (same) { T = c.selWin[blk].y; cntT = kSel; }
@@ -1809,10 +1824,11 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
                 if (!compacted) {
 #pragma unroll
                     for (int r = 0; r < R; r++) cnt += __popcll(__ballot(u[r] >= t));
+                    cnt = pair_sum(cnt);
                 } else {
 #pragma unroll
                     for (int j = 0; j < SEL_CAP; j++) cnt += __popcll(__ballot(cd[j] >= t));
-                    cnt += cntHi;
+                    cnt = pair_sum(cnt) + cntHi;
                 }
                 if (cnt == kSel) {
                     // t falls between the kSel-th and the next key: the answer is the smallest key >= t, no need to
@@ -1825,14 +1841,15 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
 #pragma unroll
                         for (int j = 0; j < SEL_CAP; j++) { uint32_t v = (cd[j] >= t) ? cd[j] : 0xFFFFFFFFu; m2 = v < m2 ? v : m2; }
                     }
-                    T = wave_min_u32(m2); cntLo = kSel;
+                    T = pair_min(wave_min_u32(m2)); cntLo = kSel;
                     break;
                 }
                 if (cnt > kSel) { T = t; cntLo = cnt; } else if (!compacted) cntHi = cnt;
                 if (SEL_COMPACT && !compacted && !tried && bit > 0 && cntLo - cntHi <= SEL_CAND) {
                     // candidates: T <= u < T + 2^bit (the window the next probe halves)
                     tried = true;
-                    uint32_t *cl = (uint32_t *)(sel_lds + wv * selStride);        // (the masking levels are used up)
+                    if (PAIR) __syncthreads();                                    // (the masking levels are used up - by both waves)
+                    uint32_t *cl = (uint32_t *)(sel_lds + wv * selStride) + half * (SEL_CAP * 64);
                     const uint32_t W = 1u << bit;
                     int nL = 0;
 #pragma unroll
@@ -1841,7 +1858,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
                         if (act && nL < SEL_CAP) cl[nL * 64 + lane] = u[r];
                         nL += act ? 1 : 0;
                     }
-                    if (!__any(nL > SEL_CAP)) {
+                    if (pair_sum(__any(nL > SEL_CAP) ? 1 : 0) == 0) {
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
                         for (int j = 0; j < SEL_CAP; j++) cd[j] = (j < nL) ? cl[j * 64 + lane] : 0u;       // (0 is below every probe)
@@ -1852,7 +1869,7 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
             cntT = cntLo;
         }
     }
-    if constexpr (PASS != 0) c.selT[blk] = T;                       // (uniform store: the threshold of this probe, for the window update)
+    if constexpr (PASS != 0) if (half == 0) c.selT[blk] = T;                       // (uniform store: the threshold of this probe, for the window update)
     // the tie group at T straddles the cut iff more than kSel keys are >= T (kSel - #(u > T) < #(u == T))
     const bool straddle = kSel < cntT || (c.forceFb > 0 && blk % c.forceFb == 0);
     // keep bitmap: the ballot of register r is the pair of words 2r, 2r+1 - gathered into lane r (R <= 64) or lanes r, r - 64
@@ -1869,13 +1886,39 @@ __global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass
             if (lane == 32) keep[2 * r + 1] = (uint32_t)(m >> 32);
         }
     }
-    if (straddle && lane == 0) {
+    if (straddle && lane == 0 && half == 0) {
         int slot = atomicAdd(c.fbCount, 1);
         c.fbList[slot] = blk;
         c.ownSlot[blk] = slot;
         c.isFb[blk] = 1;
         if (!finalPass) atomicSub(c.cbrLive, 1);              // (the exact path finishes its search on its own)
     }
+}
+
+
+// One WAVE per block, four blocks per workgroup
+template <int R, int LGBS = 0, int PASS = 0>
+__global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass) {
+    if (probes_over(c, finalPass)) return;
+    extern __shared__ float sel_lds[];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int blk = blockIdx.x * 4 + wv;                  // 4 waves per workgroup, one block per wave
+    if (blk >= c.B * c.K) return;
+    select_body<R, LGBS, PASS, false>(c, finalPass, blk, wv, lane, 0, nullptr, sel_lds);
+}
+// Two waves per block (stereo: a wave per channel), one block per workgroup
+template <int R, int LGBS = 0, int PASS = 0>
+__global__ __launch_bounds__(128) void k_select_pair(UlcxEncCtx c, int finalPass) {
+    extern __shared__ float sel_lds[];
+    __shared__ uint32_t xch[4];
+    __shared__ int over;
+    // (the count of open searches is read ONCE per workgroup: other blocks' waves count it down while this kernel runs, and
+    //  the two waves of a block must not disagree on whether to go on)
+    if (threadIdx.x == 0) over = probes_over(c, finalPass) ? 1 : 0;
+    __syncthreads();
+    if (over) return;
+    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    select_body<R, LGBS, PASS, true>(c, finalPass, blockIdx.x, 0, lane, half, xch, sel_lds);
 }
 
 // Exact emulation of the reference's min-heap heapsort for the (rare) blocks whose
@@ -3460,6 +3503,7 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         SELA(128, 0); SELA(64, 0); SELA(64, 11);
 #undef SELA
     }
+    const size_t selLdsPair = (size_t)ulcx_sel_lds_words(c.BS) * sizeof(float);      // one block per workgroup
     auto launch_select = [&](int fin) {
         int R = N / 64;
         const dim3 g((NB + 3) / 4), b(256);
@@ -3467,8 +3511,16 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
                        else if (c.selPass == 2) hipLaunchKernelGGL((k_select_wave<__VA_ARGS__, 2>), g, b, selLds, st, c, fin); \
                        else hipLaunchKernelGGL((k_select_wave<__VA_ARGS__, 0>), g, b, selLds, st, c, fin); } while (0)
         switch (R) {
-            case 128: SELW(128, 0); return true;             // (BlockSize 4096 stereo: ~200 VGPRs, one wave per SIMD)
-            case 64: if (c.lgBS == 11) SELW(64, 11); else SELW(64, 0); return true;      // (11: stereo BlockSize 2048)
+            case 128:                                        // (one wave: ~200 VGPRs, two waves per SIMD)
+                if (c.C == 2 && c.selPair) {                 // stereo BlockSize 4096: a wave per channel
+                    const dim3 gp(NB), bp(128);
+                    if (c.selPass == 1) hipLaunchKernelGGL((k_select_pair<64, 12, 1>), gp, bp, selLdsPair, st, c, fin);
+                    else if (c.selPass == 2) hipLaunchKernelGGL((k_select_pair<64, 12, 2>), gp, bp, selLdsPair, st, c, fin);
+                    else hipLaunchKernelGGL((k_select_pair<64, 12, 0>), gp, bp, selLdsPair, st, c, fin);
+                } else SELW(128, 0);
+                return true;
+            case 64: if (c.lgBS == 11) SELW(64, 11); else SELW(64, 0); return true;      // (11: stereo BlockSize 2048; with a wave per
+                                                                                         //  channel its selection is 1.08 -> 1.23 ms: barriers)
             case 32: SELW(32, 0); return true;
             case 16: SELW(16, 0); return true;
             case 8:  SELW(8, 0); return true;

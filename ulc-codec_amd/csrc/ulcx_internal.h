@@ -89,6 +89,7 @@ struct UlcxEncCtx {
     int    *cbrBudget;                   // [NB] bit budget (ulcEncoder.c:96)
     uint4  *selWin;                      // [NB] rate search: {TL, TH, count(key >= TL), count(key >= TH)} - the ordered-key window later probes search
     uint32_t *selT;                      // [NB] the threshold key of the current probe
+    int     selPair;                     // stereo BlockSize 4096: the selection with a wave per channel (k_select_pair); ULCX_SEL_PAIR=0: one wave per block
     int     selPass;                     // k_select_wave in a rate search: 1 = first probe (stores the ordered keys in `key`), 2 = later ones (read them); 0 = one-pass call
     int    *cbrLive;                     // [1] rate searches of the lock-step path still open (probe passes leave at once at 0)
     int    *slow;                        // [NB] wave-encoder give-up bits (1: small caps, 2: full caps -> k_encode_units); then 2 queue counters, 2 retry queues [NB]
