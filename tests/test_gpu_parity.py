@@ -501,6 +501,29 @@ def test_runtime_switches_keep_parity(env):
             else:
                 os.environ[k] = v
 
+@pytest.mark.parametrize("pair", ["1", "0"])
+def test_blocksize_4096_selection_with_one_or_two_waves_per_block(pair):
+    """Stereo BlockSize 4096 selects with a wave per channel (k_select_pair, round 4; ULCX_SEL_PAIR=0: one wave holding all
+    8192 keys): VBR and CBR, two calls, streams and sizes against the oracle."""
+    amd = _amd()
+    bs, ch, rate, B, K, calls = 4096, 2, 48000, 3, 5, 2
+    pcm = _streams(B, calls * K, bs, ch, rate, True, seed=4096)
+    old = os.environ.get("ULCX_SEL_PAIR")
+    os.environ["ULCX_SEL_PAIR"] = pair
+    try:
+        for mode, p0 in ((amd.MODE_VBR, 55.0), (amd.MODE_CBR, 80.0)):
+            enc = amd.BatchEncoder(B, ch, bs, rate, K)
+            refs = [oracle_encode_debug(pcm[s], bs, rate, 0 if mode == amd.MODE_VBR else 1, p0, slot=enc.slot) for s in range(B)]
+            for call in range(calls):
+                res = enc.encode(pcm[:, call * K * bs:(call + 1) * K * bs], mode, p0)
+                for s in range(B):
+                    _compare_encode(res, refs[s], s, call * K, K, None, f"pair={pair} mode={mode}")
+            enc.close()
+    finally:
+        if old is None: os.environ.pop("ULCX_SEL_PAIR", None)
+        else: os.environ["ULCX_SEL_PAIR"] = old
+
+
 @pytest.mark.parametrize("env,B,K", [
     ({}, 6, 16),
     ({"ULCX_WC_STEPS": "8"}, 6, 16),
