@@ -25,7 +25,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -74,62 +73,87 @@ def make_pcm(torch, B, n, device, seed, bursts_per_s=4.0, decades=2.0):
     return pcm.contiguous()          # [B][n][2] f32
 
 
-def cpu_baseline(sample_pcm, n_blocks, cfg, legs, target_seconds=4.0):
-    """Oracle (kind 'port') on the host cores: the legs of the step on a bounded sample.  sample_pcm: numpy [S][n][C]."""
+def host_cpu_budget():
+    """(threads to use, facts): the CPUs this process may run on = min(scheduler affinity, cgroup CPU quota)."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:                                                     # cgroup v2: "max 100000" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:                                                 # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            quota = None
+    model, phys = "unknown", set()
+    try:
+        pid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model == "unknown":
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                pid = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                phys.add((pid, ln.split(":", 1)[1].strip()))
+    except Exception:
+        pass
+    threads = aff if quota is None else max(1, min(aff, int(quota + 0.999)))
+    return threads, {"affinity_cpus": aff, "cgroup_cpu_quota": quota, "os_cpu_count": os.cpu_count(),
+                     "physical_cores_in_cpuinfo": len(phys) or None, "cpu_model": model}
+
+
+def cpu_baseline(sample_pcm, n_blocks, cfg, legs, target_seconds=8.0):
+    """Oracle (kind 'port') on the host cores: the legs of the step on a bounded sample.  sample_pcm: numpy [S][n][C].
+    The worker loop is C (oracle/orc_bench.c: one POSIX thread per CPU this process may use, each with its own oracle
+    encoder / decoder, time-boxed); Python only prepares the sample and reads the counts."""
+    import ctypes as C
     import numpy as np
     from ulc_testlib import oracle, ptr, f32p, u8p, i32p
     lib = oracle()
+    lib.orc_bench_threads.restype = C.c_int
+    lib.orc_bench_threads.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, u8p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                      C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     S = sample_pcm.shape[0]
     bs, rate = cfg["bs"], cfg["rate"]
     slot = 2 * CH * bs + 16
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # the cores this process may run on
-    threads = max(1, min(cores, 64))
-    enc_fn = lib.orc_encode_stream_vbr if cfg["mode"] == "vbr" else lib.orc_encode_stream_cbr
+    threads, facts = host_cpu_budget()
+    mode = 0 if cfg["mode"] == "vbr" else 1
+    enc_fn = lib.orc_encode_stream_vbr if mode == 0 else lib.orc_encode_stream_cbr
+    legbits = (1 if ("encode" in legs or "decode" not in legs) else 0) | (2 if "decode" in legs else 0)
+    flat = np.ascontiguousarray(sample_pcm.reshape(S, -1).astype(np.float32))
+    outs = np.zeros((S, n_blocks, slot), np.uint8)
+    for i in range(S):                                   # (a decode-only leg needs encoded input: made once, untimed)
+        b = np.zeros(n_blocks, np.int32)
+        enc_fn(rate, CH, bs, ptr(flat[i], f32p), n_blocks, cfg["p0"], ptr(outs[i], u8p), slot, ptr(b, i32p), None, None)
 
-    def one(pcm, out, bits, dec):
-        if "encode" in legs or "decode" not in legs:
-            enc_fn(rate, CH, bs, ptr(pcm, f32p), n_blocks, cfg["p0"], ptr(out, u8p), slot, ptr(bits, i32p), None, None)
-        if "decode" in legs:
-            lib.orc_decode_stream(CH, bs, ptr(out, u8p), slot, n_blocks, ptr(dec, f32p), None)
+    def run(nthr, seconds):
+        el, n = C.c_double(0.0), C.c_longlong(0)
+        rc = lib.orc_bench_threads(nthr, mode, legbits, rate, CH, bs, ptr(flat, f32p), ptr(outs, u8p), S, n_blocks, slot, cfg["p0"], seconds,
+                                   C.byref(el), C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"orc_bench_threads failed: {rc}")
+        return n.value, el.value
 
-    flat = [np.ascontiguousarray(sample_pcm[i].reshape(-1)) for i in range(S)]
-    outs = []
-    for i in range(S):                                   # (decode-only legs need encoded input: made once, untimed)
-        o = np.zeros((n_blocks, slot), np.uint8); b = np.zeros(n_blocks, np.int32)
-        enc_fn(rate, CH, bs, ptr(flat[i], f32p), n_blocks, cfg["p0"], ptr(o, u8p), slot, ptr(b, i32p), None, None)
-        outs.append(o)
-    d0 = np.zeros(n_blocks * bs * CH, np.float32); b0 = np.zeros(n_blocks, np.int32)
-    t0 = time.perf_counter(); one(flat[0], outs[0].copy(), b0, d0); t1 = time.perf_counter() - t0
-    # one thread alone (what a single core does, the figure the many-thread rate should be read against): a few passes
-    n1 = max(1, min(S, int(1.5 / max(t1, 1e-4))))
-    t0 = time.perf_counter()
-    for i in range(n1): one(flat[i % S], outs[i % S].copy(), b0, d0)
-    one_thread = n1 * n_blocks * bs * CH / (time.perf_counter() - t0) / 1e6
-    reps = max(1, int(target_seconds / max(t1, 1e-4)))
-    done = [0] * threads
-
-    def worker(i):
-        b = np.zeros(n_blocks, np.int32); d = np.zeros(n_blocks * bs * CH, np.float32)
-        mine = [o.copy() for o in outs]
-        for r in range(reps):
-            j = (i + r) % S
-            one(flat[j], mine[j], b, d)
-            done[i] += 1
-
-    ths = [threading.Thread(target=worker, args=(i,)) for i in range(threads)]
-    t0 = time.perf_counter()
-    for th in ths: th.start()
-    for th in ths: th.join()
-    el = time.perf_counter() - t0
-    streams = sum(done)
-    samples = streams * n_blocks * bs * CH
-    return {"value": samples / el / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port", "one_thread": one_thread,
-            "os_cpu_count": os.cpu_count(),
-            "sample": f"{streams} stream-{'+'.join(legs)}s of {n_blocks} blocks ({S} distinct seeded streams of the bench batch) in {el:.1f} s, "
-                      f"one oracle instance per thread; scalar C port of the reference built gcc -O2 -ffp-contract=off as the reference's "
-                      f"Makefile builds libulc - the reference's own SIMD lives in libfourier, which is absent from the tree, so no AVX2/FMA "
-                      f"reference path can be timed (an -mavx2 build of the port without contraction is bit-identical and within a few per "
-                      f"cent: DESIGN.md §8)"}
+    n1, el1 = run(1, 2.0)                                # one thread alone: what a single core does
+    one_thread = n1 * n_blocks * bs * CH / el1 / 1e6
+    streams, el = run(threads, target_seconds)
+    value = streams * n_blocks * bs * CH / el / 1e6
+    # if the full count scales badly, half of it tells SMT siblings / a quota from a harness limit (there is none: the loop is C)
+    half = None
+    if threads >= 4:
+        nh, elh = run(threads // 2, min(target_seconds, 4.0))
+        half = {"threads": threads // 2, "value": nh * n_blocks * bs * CH / elh / 1e6}
+    return {"value": value, "unit": "Msamples/s", "cores": threads, "kind": "port", "one_thread": one_thread,
+            "scaling_per_core": value / (one_thread * threads), "half_the_threads": half, **facts,
+            "sample": f"{streams} stream-{'+'.join(legs)}s of {n_blocks} blocks ({S} distinct seeded streams of the bench batch) in {el:.1f} s on "
+                      f"{threads} POSIX threads (C worker loop, oracle/orc_bench.c; one oracle encoder/decoder per thread); scalar C port of the "
+                      f"reference built gcc -O2 -ffp-contract=off as the reference's Makefile builds libulc - the reference's own SIMD lives in "
+                      f"libfourier, which is absent from the tree, so no AVX2/FMA reference path can be timed (an -mavx2 build of the port "
+                      f"without contraction is bit-identical and within a few per cent: DESIGN.md §8)"}
 
 
 def self_launch(n):
@@ -181,6 +205,8 @@ def main():
     ap.add_argument("--mode", choices=["both", "encode", "decode"], default="both")
     ap.add_argument("--streams", type=int, default=0, help="independent streams per GPU (default: the config's; fixed-total configs split their total over the GPUs)")
     ap.add_argument("--blocks", type=int, default=0, help="consecutive blocks per stream per step (default: the config's: 32 for vbr50, 16 otherwise)")
+    ap.add_argument("--total-streams", type=int, default=0, help="fixed-total (strong-scaling) configurations: the total split over the GPUs "
+                    "(default: the config's: 32768 / 16384); a reduced total is a test run, never a result line for BASELINE's configuration")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pmc-summary", default="", help="tools/pmc_summary.py output of a rocprofv3 --pmc run of THIS command: fills roofline.traffic "
                     "(default: null - a traffic figure is never taken from another run)")
@@ -230,8 +256,9 @@ def main():
     # independent streams shard across ranks by plain batch split (shard.py), no collective on the data path.
     # weak: every rank owns its own B streams; strong (fixed-total configs): rank r owns stream_range(total, r, world)
     strong = cfg["total"] is not None and not args.streams
+    total_streams = (args.total_streams or cfg["total"]) if strong else None
     if strong:
-        lo, hi = shard.stream_range(cfg["total"], rank, world)
+        lo, hi = shard.stream_range(total_streams, rank, world)
         B, first_id = hi - lo, lo
     else:
         B = args.streams or cfg["per_gpu"] or 4096
@@ -315,7 +342,7 @@ def main():
     assert ok, "decode of the encoded blocks failed: some block was rejected or consumed more bits than were written"
     units = B * K * bs * CH                                      # channel-samples through the step (each goes through every leg of it), this rank
     if strong:
-        total_units = cfg["total"] * K * bs * CH
+        total_units = total_streams * K * bs * CH
         value = total_units * args.steps / el / 1e6
     else:
         value = shard.whole_job_throughput(units * args.steps, world, el) / 1e6
@@ -370,13 +397,14 @@ def main():
         what = {"both": "encode+decode", "encode": "encode", "decode": "decode"}[args.mode]
         rc = "VBR -%g" % cfg["p0"] if cfg["mode"] == "vbr" else "CBR %g kbps" % cfg["p0"]
         wl = (f"{args.config} ({cfg['ref']}): Batch={B} independent {rate / 1000:g} kHz stereo streams/GPU x {K} blocks, BlockSize={bs}, {rc}; "
-              f"step = {' then '.join(legs)}" + (f"; {cfg['total']} streams in total over {world} GPU(s)" if strong else "")
+              f"step = {' then '.join(legs)}" + (f"; {total_streams} streams in total over {world} GPU(s)" if strong else "")
               + (" -- PCM16 ingest/output variant (int16 samples in HBM, not the C API's f32)" if args.pcm16 else ""))
         line = {
             "metric": f"{what} Msamples/s at BlockSize={bs} stereo (channel-samples through {what}, {rc}, {K} blocks per stream per call)",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic" + (" (TEST RUN: ranks share one GPU, gloo control plane - not a result)" if share else ""),
+            "dtype": "f32", "data": "synthetic" + (" (TEST RUN: ranks share one GPU, gloo control plane - not a result)" if share else "")
+                    + (f" (TEST RUN: {total_streams} streams in total instead of the configuration's {cfg['total']} - not a result)" if strong and total_streams != cfg["total"] else ""),
             "config": {"workload": wl, "config": args.config, "mode": args.mode,
                        "streams_per_gpu": B, "blocks_per_stream_per_step": K, "block_size": bs, "channels": CH, "rate_hz": rate,
                        "parallelism": f"batch split over {world} GPU(s), no collective on the data path",

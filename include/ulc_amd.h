@@ -203,6 +203,13 @@ int  ulcx_decode_host(ulcx_decoder *dec, const uint8_t *h_in, int slotBytes, int
 int  ulcx_encode_block1(ulcx_encoder *enc, int mode, float param0, float param1, const float *h_pcm,
                         uint8_t *h_out, int32_t *bits, float *cplx, int32_t stateOut[2], float transientFilter[3]);
 int  ulcx_decode_block1(ulcx_decoder *dec, const uint8_t *h_in, int nBytes, float *h_pcm, int32_t *bits, int32_t *lastSubBlockSize);
+/* As ulcx_decode_block1 with the noise generator's state handed in and out.  The reference keeps that state in a
+ * function-static word (libulc/ulcDecoder.c:75-81): one xorshift32 chain per PROCESS, shared by every decoder object, never
+ * re-seeded by ULC_DecoderState_Init.  The drop-in of section 1 owns such a word and passes it here, so a process that
+ * decodes several files one after the other draws the same noise as with the reference.  rngState NULL = the state stays
+ * with the decoder object (what the batched entries do per stream). */
+int  ulcx_decode_block1_rng(ulcx_decoder *dec, const uint8_t *h_in, int nBytes, float *h_pcm, int32_t *bits, int32_t *lastSubBlockSize,
+                            uint32_t *rngState);
 
 /* PCM16 output: as ulcx_decode_dev, writing d_pcm16 [nStreams][nBlocks][BlockSize][nChan]
  * int16, converted on store exactly as the reference's WAV writer does with ULC_DecodeBlock's output

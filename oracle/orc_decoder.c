@@ -8,6 +8,8 @@
  * a function-static shared by every decoder in the process (ulcDecoder.c:75-81).
  * The tools run one decoder per process, so "stream == fresh seed 1234567" is the
  * observable behaviour; here (and in the batched product) the seed is per state.
+ * orc_decode_stream_seeded hands the state in and out for the one case where the
+ * difference shows: several files decoded by one process through the drop-in ABI.
  */
 #include <math.h>
 #include <stdint.h>
@@ -207,6 +209,26 @@ int orc_decode_stream(int nChan, int BlockSize, const uint8_t *in, int slotBytes
         if (bitsRead) bitsRead[k] = b;
         if (!b) { rc = k + 1; break; }
     }
+    orc_decoder_destroy(&st);
+    return rc;
+}
+
+/* As orc_decode_stream with the noise generator's state handed in and out: the reference's generator is a function-static
+ * word (ulcDecoder.c:75-81), so a process that decodes a second file continues the first file's chain.  *seed = 1234567 for
+ * the first decoder of a "process", then whatever the previous call left. */
+int orc_decode_stream_seeded(int nChan, int BlockSize, const uint8_t *in, int slotBytes, int nBlocks, float *pcm, int32_t *bitsRead, uint32_t *seed) {
+    orc_decoder st; memset(&st, 0, sizeof(st));
+    st.nChan = nChan; st.BlockSize = BlockSize;
+    if (orc_decoder_init(&st) < 0) return -1;
+    st.Seed = *seed;
+    size_t blk = (size_t)nChan * BlockSize;
+    int rc = 0;
+    for (int k = 0; k < nBlocks; k++) {
+        int b = orc_decode_block(&st, pcm + k * blk, in + (size_t)k * slotBytes);
+        if (bitsRead) bitsRead[k] = b;
+        if (!b) { rc = k + 1; break; }
+    }
+    *seed = st.Seed;
     orc_decoder_destroy(&st);
     return rc;
 }

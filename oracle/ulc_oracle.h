@@ -122,7 +122,12 @@ int orc_encode_stream_debug(int mode, int RateHz, int nChan, int BlockSize, cons
                             float *coef, float *noise, float *keys, int32_t *ranks, int32_t *nout);
 /* Decodes nBlocks from per-block slots (fresh state, fresh RNG seed). Returns 0 on success, blockIndex+1 of the first corrupt block otherwise. */
 int orc_decode_stream(int nChan, int BlockSize, const uint8_t *in, int slotBytes, int nBlocks, float *pcm, int32_t *bitsRead);
+int orc_decode_stream_seeded(int nChan, int BlockSize, const uint8_t *in, int slotBytes, int nBlocks, float *pcm, int32_t *bitsRead, uint32_t *seed);
 int orc_decode_stream_coefs(int nChan, int BlockSize, const uint8_t *in, int slotBytes, int nBlocks, float *pcm, int32_t *bitsRead, float *coefs);
+
+/* bench.py's cpu_baseline worker loop (orc_bench.c): nThreads POSIX threads over S seeded streams for `seconds` of wall clock */
+int orc_bench_threads(int nThreads, int mode, int legs, int RateHz, int nChan, int BS, const float *pcm, const uint8_t *enc, int S, int nBlocks,
+                      int slot, float p0, double seconds, double *elapsed, long long *streamsDone);
 
 #ifdef __cplusplus
 }

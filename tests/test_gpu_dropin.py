@@ -121,7 +121,7 @@ def test_batched_front_end_matches_the_reference_tools_file_for_file(arg, fmt, t
 
 
 @pytest.mark.skipif(not os.path.exists(TOOL), reason="ulc-codec_amd/ulcx-tool not built")
-@pytest.mark.parametrize("ndev", [2, 3])
+@pytest.mark.parametrize("ndev", [2, 3, 8])
 def test_batched_front_end_devices_option_does_not_change_the_files(ndev, tmp_path):
     """SURVEY.md §8(e) below bench.py: `ulcx-tool -devices:N` deals the inputs round-robin over N groups, each with its own
     encoder / decoder and its own host thread (group g on device g % visible: on the 1-GPU box the groups share device 0).
@@ -273,3 +273,53 @@ def test_state_fields_the_reference_updates_are_mirrored_back():
                 if not pat: break
             assert d.LastSubBlockSize == last, f"call {k}: LastSubBlockSize {d.LastSubBlockSize}, expected {last} for WindowCtrl {e.WindowCtrl:#x}"
         lib.ULC_EncoderState_Destroy(C.byref(e)); lib.ULC_DecoderState_Destroy(C.byref(d))
+
+
+def test_two_files_decoded_by_one_process_share_the_noise_chain():
+    """The reference's noise generator is a function-static word (ulcDecoder.c:75-81): ONE xorshift32 chain per process,
+    not re-seeded by ULC_DecoderState_Init.  A process that decodes a second file through the drop-in therefore continues
+    the first file's chain.  Expected = the oracle run the same way (state handed from one decode to the next); the file
+    has noise fill (VBR -50 codes it), so a fresh seed for the second file would differ."""
+    import ctypes as C
+    import subprocess
+    import textwrap
+    code = textwrap.dedent(r"""
+        import ctypes as C, os, sys
+        import numpy as np
+        sys.path.insert(0, os.path.join(%r, "tests"))
+        from ulc_testlib import synth_pcm, oracle_encode_stream, oracle, ptr, u8p, f32p, i32p
+        lib = C.CDLL(os.path.join(%r, "ulc-codec_amd", "libulc_amd.so"))
+        class Dec(C.Structure):
+            _fields_ = [("nChan", C.c_int), ("BlockSize", C.c_int), ("LastSubBlockSize", C.c_int), ("BufferData", C.c_void_p),
+                        ("TransformBuffer", C.c_void_p), ("TransformTemp", C.c_void_p), ("TransformInvLap", C.c_void_p)]
+        lib.ULC_DecodeBlock.argtypes = [C.POINTER(Dec), C.POINTER(C.c_float), C.c_void_p]
+        orc = oracle()
+        orc.orc_decode_stream_seeded.argtypes = [C.c_int, C.c_int, u8p, C.c_int, C.c_int, f32p, i32p, C.POINTER(C.c_uint32)]
+        seed = C.c_uint32(1234567)
+        fresh_differs = 0
+        for f, (ch, bs, nblk) in enumerate(((2, 2048, 6), (1, 1024, 8), (2, 2048, 5))):
+            pcm = synth_pcm(20 + f, nblk * bs, ch, 44100, transient=True, seed=f)
+            out, bits, wc, cplx = oracle_encode_stream(pcm, bs, 44100, quality=50.0)
+            out = np.ascontiguousarray(out)
+            before = seed.value
+            ref = np.zeros((nblk * bs, ch), np.float32); rb = np.zeros(nblk, np.int32)
+            assert orc.orc_decode_stream_seeded(ch, bs, ptr(out, u8p), out.shape[1], nblk, ptr(ref, f32p), ptr(rb, i32p), C.byref(seed)) == 0
+            if f > 0:
+                fr = np.zeros_like(ref); s2 = C.c_uint32(1234567)
+                orc.orc_decode_stream_seeded(ch, bs, ptr(out, u8p), out.shape[1], nblk, ptr(fr, f32p), ptr(rb, i32p), C.byref(s2))
+                fresh_differs += int(not np.array_equal(fr.view(np.uint32), ref.view(np.uint32)))
+                assert before != 1234567, "the earlier file drew no noise: the test input is wrong"
+            st = Dec(); st.nChan = ch; st.BlockSize = bs
+            assert lib.ULC_DecoderState_Init(C.byref(st)) == 1
+            got = np.zeros((nblk, bs * ch), np.float32)
+            for k in range(nblk):
+                blk = out[k].tobytes() + bytes(16)
+                assert lib.ULC_DecodeBlock(C.byref(st), got[k].ctypes.data_as(C.POINTER(C.c_float)), blk) == rb[k]
+            lib.ULC_DecoderState_Destroy(C.byref(st))
+            assert np.array_equal(got.reshape(nblk * bs, ch).view(np.uint32), ref.view(np.uint32)), f"file {f}: PCM differs from the oracle's process-wide chain"
+        assert fresh_differs == 2, "a fresh seed per file gives the same PCM: the test does not discriminate"
+        print("ok")
+    """) % (ROOT, ROOT)
+    # a fresh interpreter: the process-wide word must start at 1234567, whatever other tests of this session decoded before
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr

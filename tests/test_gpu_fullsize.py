@@ -16,19 +16,26 @@ from ulc_testlib import oracle_encode_debug, oracle_decode_stream
 pytestmark = pytest.mark.gpu
 
 
-def _torch_pcm(B, n, rate, seed, transient_rate=4.0):
+def _torch_pcm(B, n, seed, config):
+    """The input bench.py feeds the named configuration: same generator, same rate, same burst rate and spread
+    (bench.CONFIGS) - what is benched is what is tested."""
     import torch
     sys.path.insert(0, ROOT)
     import bench
-    bench.RATE = rate
-    return bench.make_pcm(torch, B, n, torch.device("cuda", 0), seed)
+    cfg = bench.CONFIGS[config]
+    bench.RATE = cfg["rate"]
+    return bench.make_pcm(torch, B, n, torch.device("cuda", 0), seed, bursts_per_s=cfg["bursts"], decades=cfg["decades"])
 
 
-def _run(B, K, bs, ch, rate, mode, p0, calls=1, seed=1):
+def _run(B, K, bs, ch, rate, mode, p0, calls=1, seed=1, config="vbr50"):
     import torch
     import ulc_amd as amd
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = bench.CONFIGS[config]
+    assert (cfg["bs"], cfg["rate"]) == (bs, rate) and cfg["p0"] == p0 and (0 if cfg["mode"] == "vbr" else 1) == mode, "test geometry != bench configuration"
     dev = torch.device("cuda", 0)
-    pcm = _torch_pcm(B, K * bs, rate, seed)
+    pcm = _torch_pcm(B, K * bs, seed, config)
     if ch == 1:
         pcm = pcm[:, :, :1].contiguous()
     enc = amd.BatchEncoder(B, ch, bs, rate, K)
@@ -112,7 +119,7 @@ def test_config4_cbr64_48k_never_over_budget():
     """configs[3] shape: CBR 64 kbps, 48 kHz M/S stereo, BlockSize=2048 (one GPU's share: 4096 streams)."""
     import torch
     B, K, bs, ch, rate, kbps = 4096, 4, 2048, 2, 48000, 64.0
-    a = _run(B, K, bs, ch, rate, 1, kbps, seed=4)
+    a = _run(B, K, bs, ch, rate, 1, kbps, seed=4, config="cbr64_48k")
     budget = int((bs * kbps) * 1000.0 / rate)
     bits = a["bits"]
     assert int(bits.max()) <= budget + 7, (int(bits.max()), budget)
@@ -130,7 +137,7 @@ def test_config4_cbr64_48k_never_over_budget():
 def test_config5_window_switch_stress_bs4096():
     """configs[4] shape: transient-heavy input, BlockSize=4096 (one GPU's share: 2048 streams)."""
     B, K, bs, ch, rate = 2048, 8, 4096, 2, 44100
-    a = _run(B, K, bs, ch, rate, 0, 50.0, seed=5)
+    a = _run(B, K, bs, ch, rate, 0, 50.0, seed=5, config="wswitch_4096")
     codes = np.unique(a["wc"].cpu().numpy())
     dec_codes = sorted({int(c) >> 4 for c in codes if c >= 0x80})
     assert len(dec_codes) >= 6, f"decimation positions seen: {dec_codes}"     # 1/8-decimation positions 8..15

@@ -142,6 +142,30 @@ def test_exact_path_at_scale_in_stereo(mode, p0, every):
     enc.close()
 
 
+@pytest.mark.parametrize("mode,p0", [(0, 50.0), (1, 64.0)])
+def test_exact_path_over_several_groups_of_rank_slots(mode, p0):
+    """the resident rank slots are sized by what the device has free (and halved until the allocation succeeds),
+    so a call may hold fewer slots than blocks on the exact path: the launch then walks the slots group by group.  With
+    ULCX_RANK_SLOTS=96 and every block of a 640-block call forced onto that path (7 groups), same bytes as the oracle."""
+    amd = _amd()
+    bs, ch, rate, B, K = 2048, 2, 44100, 40, 16
+    pcm = _streams(B, K, bs, ch, rate, True, seed=616)
+    old = os.environ.get("ULCX_RANK_SLOTS")
+    os.environ["ULCX_RANK_SLOTS"] = "96"
+    try:
+        enc = amd.BatchEncoder(B, ch, bs, rate, K)
+    finally:
+        if old is None: os.environ.pop("ULCX_RANK_SLOTS", None)
+        else: os.environ["ULCX_RANK_SLOTS"] = old
+    enc.force_exact(1)
+    res = enc.encode(pcm, mode, p0)
+    assert enc.last_fallbacks() > 5 * 96
+    for s in range(B):
+        ref = oracle_encode_debug(pcm[s], bs, rate, mode, p0, slot=enc.slot)
+        _compare_encode(res, ref, s, 0, K, None, "exact path, 96 rank slots")
+    enc.close()
+
+
 def test_encode_many_blocks_bit_exact():
     """A few thousand blocks of the bench shape, every byte compared with the oracle."""
     amd = _amd()

@@ -159,14 +159,22 @@ done:
     { long bytes = (n + 1) >> 1; return bytes < maxBytes ? (int)bytes : maxBytes; }
 }
 
+/* The noise generator of the reference is a function-static word (ulcDecoder.c:75-81, `static uint32_t Seed = 1234567`):
+ * one chain per process, shared by all decoder states and not reset by ULC_DecoderState_Init.  Same here: the word lives in
+ * this shim and travels through every ULC_DecodeBlock call.  (As in the reference, two threads decoding at once interleave
+ * their draws in an unspecified order; the accesses themselves are atomic here.) */
+static unsigned int g_decode_rng = 1234567u;
+
 /* ulcDecoder.c:198-302.  The reference reads SrcBuffer only as far as the block extends (ulcDecoder.h:54), and so does this:
  * the block's extent is found on the host first, exactly those bytes are staged (the rest of the staging slot is zero). */
 int ULC_DecodeBlock(struct ULC_DecoderState_t *State, float *DstData, const void *SrcBuffer) {
     struct dec_priv *p = (struct dec_priv *)State->BufferData;
     int32_t bits = 0, lastSub = State->LastSubBlockSize;
     const int ext = ulcx_block_extent_bytes(SrcBuffer, State->nChan, State->BlockSize, p->slot);
-    int rc = ulcx_decode_block1(p->dec, (const unsigned char *)SrcBuffer, ext, DstData, &bits, &lastSub);
+    uint32_t rng = __atomic_load_n(&g_decode_rng, __ATOMIC_RELAXED);
+    int rc = ulcx_decode_block1_rng(p->dec, (const unsigned char *)SrcBuffer, ext, DstData, &bits, &lastSub, &rng);
     if (rc != ULCX_OK) { fprintf(stderr, "libulc_amd: decode failed: %s\n", ulcx_last_error()); return 0; }
+    __atomic_store_n(&g_decode_rng, rng, __ATOMIC_RELAXED);
     State->LastSubBlockSize = lastSub;                       /* ulcDecoder.c:300 */
     return bits;
 }

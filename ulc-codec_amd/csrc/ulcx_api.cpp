@@ -48,6 +48,7 @@ struct ulcx_decoder {
     // single-block path (ulcx_decode_block1)
     hipStream_t b1Stream; hipGraph_t b1Graph; hipGraphExec_t b1Exec; bool b1Init, b1Graphed, b1NoGraph; int b1Slot;
     uint8_t *pinIn; float *pinPcm; int32_t *pinMeta;
+    uint32_t b1Seed;                                              // the stream's RNG state between single-block calls
 };
 
 extern "C" int ulcx_device_count(void) {
@@ -239,14 +240,27 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.isFb, NB, true);
     DA(c.ownSlot, NB, true);
     {
+        // Rank slots of the exact path (one full ranking per tie-straddle block).  One slot per block while that stays
+        // within 8 GiB (a rate-search call over 524 288 blocks with 1 GiB of slots enqueued the exact path's fifteen passes
+        // for eight groups of slots, seven of them always empty) AND within a quarter of what the device has free right
+        // now: several encoders may share one GPU (`ulcx-tool -devices:N` above the visible count, two host threads, eight
+        // test ranks).  ULCX_RANK_SLOTS=n overrides (tests).  If the allocation fails all the same, halve down to 64 slots
+        // rather than fail the create: the launch walks groups of slots whatever their number (ulcx_enc_launch).
         size_t slots = NB;
-        // at most 8 GiB of resident rankings (a 288 GB device; 1 GiB until round 4: a rate-search call over 524 288 blocks
-        // then enqueued the exact path's fifteen passes for eight groups of slots, seven of them always empty)
         size_t maxSlots = ((size_t)8 << 30) / (cb * 4);
-        if (maxSlots < 1) maxSlots = 1;
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB / 4 / (cb * 4) < maxSlots) maxSlots = freeB / 4 / (cb * 4);
+        if (maxSlots < 64) maxSlots = 64;
         if (slots > maxSlots) slots = maxSlots;
+        if (const char *ev = getenv("ULCX_RANK_SLOTS")) { long n = atol(ev); if (n >= 1 && (size_t)n < slots) slots = (size_t)n; }
+        for (;;) {
+            int rc_ = dalloc(e->allocs, &c.rankBuf, slots * cb, false);
+            if (rc_ == ULCX_OK) break;
+            if (rc_ != ULCX_ERR_NOMEM || slots <= 64) { cleanup(e); return rc_; }
+            (void)hipGetLastError();
+            slots = (slots + 1) / 2; if (slots < 64) slots = 64;
+        }
         c.rankSlots = (int)slots;
-        DA(c.rankBuf, slots * cb, false);
     }
     rc = enc_reset_state(e);
     if (rc) { cleanup(e); return rc; }
@@ -481,6 +495,7 @@ static int dec_reset_state(ulcx_decoder *e) {
     CKR(hipMemset(c.packOff, 0, sizeof(int) * (size_t)e->B));
     std::vector<uint32_t> seed((size_t)e->B, 1234567u);                                // ulcDecoder.c:76, one RNG per stream
     CKR(hipMemcpy(c.seed, seed.data(), sizeof(uint32_t) * seed.size(), hipMemcpyHostToDevice));
+    e->b1Seed = 1234567u;
     return ULCX_OK;
 }
 
@@ -664,6 +679,12 @@ extern "C" int ulcx_decode_host(ulcx_decoder *e, const uint8_t *h_in, int slotBy
     return ULCX_OK;
 }
 extern "C" int ulcx_decode_block1(ulcx_decoder *e, const uint8_t *h_in, int nBytes, float *h_pcm, int32_t *bits, int32_t *lastSubBlockSize) {
+    return ulcx_decode_block1_rng(e, h_in, nBytes, h_pcm, bits, lastSubBlockSize, nullptr);
+}
+// rngState: the noise generator's state (ulcDecoder.c:75-81) before the block in, after it out.  The reference keeps it in a
+// function-static word, i.e. ONE state per process that every decoder object draws from; a caller that wants that behaviour
+// (the drop-in of section 1 does) owns the word and hands it through here.  NULL: the state stays with this decoder object.
+extern "C" int ulcx_decode_block1_rng(ulcx_decoder *e, const uint8_t *h_in, int nBytes, float *h_pcm, int32_t *bits, int32_t *lastSubBlockSize, uint32_t *rngState) {
     if (!e || !h_in || !h_pcm || nBytes < 1 || e->B != 1 || e->maxK != 1) { ulcx_set_error("ulcx_decode_block1: needs a decoder of one stream, one block per call"); return ULCX_ERR_ARG; }
     CKR(hipSetDevice(e->device));
     const size_t cb = (size_t)e->C * e->BS;
@@ -676,14 +697,16 @@ extern "C" int ulcx_decode_block1(ulcx_decoder *e, const uint8_t *h_in, int nByt
         if (!e->b1Stream) CKR(hipStreamCreateWithFlags(&e->b1Stream, hipStreamNonBlocking));
         if (!e->pinIn) CKR(hipHostMalloc((void **)&e->pinIn, (size_t)slot, hipHostMallocDefault));
         if (!e->pinPcm) CKR(hipHostMalloc((void **)&e->pinPcm, sizeof(float) * cb, hipHostMallocDefault));
-        if (!e->pinMeta) CKR(hipHostMalloc((void **)&e->pinMeta, 2 * sizeof(int32_t), hipHostMallocDefault));
+        if (!e->pinMeta) CKR(hipHostMalloc((void **)&e->pinMeta, 4 * sizeof(int32_t), hipHostMallocDefault));
         e->b1Init = true; e->b1Slot = slot;
         e->timing = false;
     }
     auto enqueue = [&]() -> int {
         CKR(hipMemcpyAsync(e->d_in, e->pinIn, (size_t)slot, hipMemcpyHostToDevice, e->b1Stream));
+        CKR(hipMemcpyAsync(e->ctx.seed, &e->pinMeta[2], sizeof(uint32_t), hipMemcpyHostToDevice, e->b1Stream));
         int rc = ulcx_decode_dev(e, e->d_in, slot, 1, e->d_pcm, e->d_bits, e->b1Stream);
         if (rc) return rc;
+        CKR(hipMemcpyAsync(&e->pinMeta[3], e->ctx.seed, sizeof(uint32_t), hipMemcpyDeviceToHost, e->b1Stream));
         CKR(hipMemcpyAsync(e->pinPcm, e->d_pcm, sizeof(float) * cb, hipMemcpyDeviceToHost, e->b1Stream));
         CKR(hipMemcpyAsync(&e->pinMeta[0], e->d_bits, sizeof(int32_t), hipMemcpyDeviceToHost, e->b1Stream));
         CKR(hipMemcpyAsync(&e->pinMeta[1], e->ctx.lastSub, sizeof(int32_t), hipMemcpyDeviceToHost, e->b1Stream));
@@ -691,6 +714,7 @@ extern "C" int ulcx_decode_block1(ulcx_decoder *e, const uint8_t *h_in, int nByt
     };
     memcpy(e->pinIn, h_in, (size_t)nBytes);
     memset(e->pinIn + nBytes, 0, (size_t)(slot - nBytes));         // (only the block's own bytes are the caller's: the rest of the slot reads as zero)
+    e->pinMeta[2] = (int32_t)(rngState ? *rngState : e->b1Seed);
     if (!e->b1Graphed && !e->b1NoGraph) {
         bool ok = hipStreamBeginCapture(e->b1Stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
         if (ok) {
@@ -710,6 +734,8 @@ extern "C" int ulcx_decode_block1(ulcx_decoder *e, const uint8_t *h_in, int nByt
     memcpy(h_pcm, e->pinPcm, sizeof(float) * cb);
     if (bits) *bits = e->pinMeta[0];
     if (lastSubBlockSize) *lastSubBlockSize = e->pinMeta[1];
+    e->b1Seed = (uint32_t)e->pinMeta[3];
+    if (rngState) *rngState = e->b1Seed;
     return ULCX_OK;
 }
 
