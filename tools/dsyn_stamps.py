@@ -5,7 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ulc-codec_amd")); sys.path.insert(0, ROOT)
 import ulc_amd, bench
 dev = torch.device("cuda", 0)
-B, K = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 16
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+NS = 20
 pcm = bench.make_pcm(torch, B, K * 2048, dev, seed=1)
 enc = ulc_amd.BatchEncoder(B, 2, 2048, 44100, K); dec = ulc_amd.BatchDecoder(B, 2, 2048, K)
 slot = enc.slot
@@ -18,10 +20,10 @@ for it in range(3):
 print("stage ms", dec.stage_ms())
 wc = d_wc.cpu().numpy()
 print("decimated blocks: %.1f %%" % (100.0 * np.mean((wc & 8) != 0)))
-out = np.zeros((B, 24), np.uint64)
+out = np.zeros((B, 2 * NS), np.uint64)
 l = ulc_amd.lib(); l.ulcx_decoder_debug_scratch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
-rc = l.ulcx_decoder_debug_scratch(dec.h, out.ctypes.data, 4 * 2048 * 4, 192, B)
-names = ["hdr", "zero+seed", "synth-tail", "fft", "barrierA", "post", "barrierB", "dec-time", "decode-rounds", "noise-setup", "noise-draws", "pretw"]
+rc = l.ulcx_decoder_debug_scratch(dec.h, out.ctypes.data, 4 * 2048 * 4, 2 * NS * 8, B)
+names = ["hdr", "unit-seed", "synth-tail", "fft", "barrierA", "post", "barrierB", "dec-time", "scatter", "noise-setup", "noise-draws", "pretw", "zero-fill", "wait-records"] + ["s%d" % i for i in range(14, NS)]
 tot = out.astype(np.float64).mean(axis=0)
 for w in range(2):
-    print("wave", w, "  ".join("%s %.0f" % (names[i], tot[w * 12 + i] / K) for i in range(12)), " sum/blk %.0f cycles" % (tot[w * 12: w * 12 + 12].sum() / K))
+    print("wave", w, "  ".join("%s %.0f" % (names[i], tot[w * NS + i] / K) for i in range(NS) if tot[w * NS + i] > 0), " sum/blk %.0f cycles" % (tot[w * NS: w * NS + NS].sum() / K))

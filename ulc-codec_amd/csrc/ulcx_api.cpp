@@ -582,7 +582,7 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     c.fastOK = (nChan == 2 && BlockSize <= 4096) ? 1 : 0;
     if (const char *ev = getenv("ULCX_DEC_FAST")) c.fastOK = c.fastOK && (ev[0] != '0');
     // stereo synthesis kernel: lapping state in global memory; BlockSize <= 2048: FFT twiddles in LDS (mode 2), above: from the tables
-    c.twInLds = c.fastOK ? ((BlockSize <= 2048) ? 2 : 0) : 0;
+    c.twInLds = c.fastOK ? ((BlockSize <= 2048 && ULCX_DSYN_TWL) ? 2 : 0) : 0;
     rc = ulcx_tables_build(&c.T, &e->tables, BlockSize, 44100, false);
     if (rc) { cleanup(e); return rc; }
     size_t B = nStreams, NB = B * maxBlocksPerCall;

@@ -23,6 +23,10 @@
 #ifndef DSYN_C2048
 #define DSYN_C2048 1
 #endif
+#define DSYN_TWL ULCX_DSYN_TWL
+#ifndef DSYN_EPI2
+#define DSYN_EPI2 1  // headline geometry: the epilogue's global operands fetched one trip ahead (0: the generic loop)
+#endif
 #ifndef DPS
 #define DPS 4        // FFT array padding (ulcx_fft.h): one complex after every 16 (3: after every 8 - conflict-free passes, 1 KB more LDS)
 #endif
@@ -35,22 +39,28 @@ __host__ __device__ constexpr uint32_t xorshift32(uint32_t s) {    // ulcDecoder
     s ^= s << 13; s ^= s >> 17; s ^= s << 5;
     return s;
 }
-// The decoder only looks at the top bit of a draw, and xorshift32 is linear over GF(2): the top bit of the i-th draw from
-// state s is the parity of s & m[i-1], with m fixed (row 31 of T^i).  Computed at compile time.
-struct XsTopMasks { uint32_t m[32]; };
-constexpr XsTopMasks xs_top_masks() {
-    XsTopMasks k = {};
-    for (int i = 0; i < 32; i++) {
-        uint32_t m = 0;
-        for (int b = 0; b < 32; b++) {
-            uint32_t t = 1u << b;
-            for (int d = 0; d <= i; d++) t = xorshift32(t);
-            if (t >> 31) m |= 1u << b;
-        }
-        k.m[i] = m;
+// The 32 sign-parity bits a lane contributes to a unit's stream P (synth_noise) are a LINEAR function of the state sj it
+// starts from: bit i of the word = parity of the top bits of draws 1..i+1 from sj.  As eight 16-entry tables indexed by
+// the state's nybbles (512 bytes, staged in LDS by the kernels): word = XOR over k of t[16 k + nybble k of sj] - 8 LDS
+// reads and 7 XORs instead of 32 x (and, popcount, shift, or) and a five-step prefix XOR (round 5).
+struct XsParityTab { uint32_t t[128]; };
+constexpr XsParityTab xs_parity_tab() {
+    XsParityTab r = {};
+    uint32_t col[32] = {};
+    for (int b = 0; b < 32; b++) {
+        uint32_t st = 1u << b, x = 0, par = 0;
+        for (int i = 0; i < 32; i++) { st = xorshift32(st); par ^= st >> 31; x |= par << i; }
+        col[b] = x;
     }
-    return k;
+    for (int k = 0; k < 8; k++)
+        for (int v = 0; v < 16; v++) {
+            uint32_t t = 0;
+            for (int j = 0; j < 4; j++) if ((v >> j) & 1) t ^= col[4 * k + j];
+            r.t[16 * k + v] = t;
+        }
+    return r;
 }
+__device__ const XsParityTab kXsParityTab = xs_parity_tab();
 
 // ---------------------------------------------------------------------------
 // One whole code of the block syntax (FormatSpecs.md:57-141, ulcDecoder.c:99-197) decoded from a
@@ -483,15 +493,19 @@ __device__ __forceinline__ int padf(int f) { return f + ((f >> (DPS + 1)) << 1);
 //   x = first coefficient | count << 16 (count - 1 for a tail, which may span the whole unit) | tail << 31
 //   y = draws made in the unit before the run | level << 16 | quantizer index << 21
 #ifdef ULCX_DSYN_STAMPS
-struct DsynStamps { unsigned long long t[12], t0; };
+#define DSYN_NSTAMP 20
+struct DsynStamps { unsigned long long t[DSYN_NSTAMP], t0; };
+#define SWAITALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")      // diagnostic: the stamp behind it sees the wait for everything in flight
 #define SSTAMP(sw, i) do { if ((sw).stp) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); (sw).stp->t[i] += t_ - (sw).stp->t0; (sw).stp->t0 = t_; } } while (0)
 #else
 #define SSTAMP(sw, i) do {} while (0)
+#define SWAITALL() do {} while (0)
 #endif
 struct SynWave {                 // one wave's working set while it synthesises one (channel, subblock) unit
     float *A;                    // the unit's coefficients = the FFT's input array (LDS, padded)
     int   *pre;                  // 64 prefix counts (LDS)
     uint32_t *seedTab;           // the unit's sign-parity stream P (LDS, synth_noise)
+    const uint32_t *ptab;        // kXsParityTab in LDS
     int lane;
 #ifdef ULCX_DSYN_STAMPS
     DsynStamps *stp;
@@ -514,21 +528,19 @@ __device__ __forceinline__ uint32_t rng_jump_digit(const uint32_t *__restrict__ 
 //   2. one lane per (run, 32-coefficient chunk) piece: 32 sign bits are a window of P (xor the parity at the run's
 //      start), the level is the run's constant or the tail's chain value at the chunk (k_dscan) decaying from there.
 // No sequential generator in step 2, no jumps, and every coefficient is written exactly once.
-__device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &sw, const uint2 *__restrict__ list, int nE, uint32_t sj, int unitDraws,
+__device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &sw, const uint2 *__restrict__ list, int nE, const uint2 ent0, uint32_t sj, int unitDraws,
                                             float tailRR, const float *tailMag) {
     const int lane = sw.lane;
     uint32_t *P = sw.seedTab;                                 // the unit's whole stream: max(64, BS/32) words + a zero word
-    const uint2 ent0 = (lane < nE) ? list[lane] : make_uint2(0u, 0u);     // round 0 of the run list: in flight behind the draws
+    // (ent0: round 0 of the run list, fetched by the caller with the unit's first records)
     // ---- 1. sign-parity stream, 2048 draws per pass (one pass unless the unit has more than 2048 noise coefficients)
     uint32_t passPar = 0;                                     // parity of the top bits of all earlier passes
     for (int dbase = 0; dbase < unitDraws; dbase += 2048) {
-        constexpr XsTopMasks K = xs_top_masks();
-        uint32_t W = 0;
-#pragma unroll
-        for (int i = 0; i < 32; i++) W |= (uint32_t)(__popc(sj & K.m[i]) & 1) << i;                     // bit i = top bit of draw dbase+32*lane+i+1
-        uint32_t x = W;
-        x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16;                                 // bit i = parity of bits 0..i
-        const unsigned long long odd = __ballot((__popc(W) & 1) != 0);
+        // bit i of x = parity of the top bits of draws dbase+32*lane+1 .. +i+1 (bit 31: of all 32): eight nybble look-ups (kXsParityTab)
+        const uint32_t *T = sw.ptab;
+        const uint32_t x = T[sj & 15u] ^ T[16 + ((sj >> 4) & 15u)] ^ T[32 + ((sj >> 8) & 15u)] ^ T[48 + ((sj >> 12) & 15u)]
+                         ^ T[64 + ((sj >> 16) & 15u)] ^ T[80 + ((sj >> 20) & 15u)] ^ T[96 + ((sj >> 24) & 15u)] ^ T[112 + (sj >> 28)];
+        const unsigned long long odd = __ballot((int)x < 0);
         const uint32_t carry = ((uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(odd >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)odd, 0)) + passPar) & 1u;
         P[(dbase >> 5) + lane] = carry ? ~x : x;
         passPar ^= (uint32_t)__popcll(odd) & 1u;
@@ -607,18 +619,25 @@ __device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &
 __device__ __forceinline__ void synth_unit(const UlcxDecCtx &c, const SynWave &sw, int S, const uint2 *__restrict__ prec, const uint2 *__restrict__ nrec,
                                            int4 ur, uint32_t unitSeed, int unitDraws, float tailRR, const float *tailMag, int zeroFloat2 = 0) {
     const int lane = sw.lane;
-    // seedTab[l] = RNG state after 32*l draws of the unit = unitSeed through T^(32 l): two table-driven steps per lane
-    // (hex digits 1 and 2 of 32*l), their loads in flight behind the coefficient scatter
+    // the lane's RNG state after 32*lane draws of the unit = unitSeed through T^(32 lane): two table-driven steps per lane
+    // (hex digits 1 and 2 of 32*lane); the first one's look-ups travel behind the zero fill
     uint32_t sj = rng_jump_digit(c.jumpT, unitSeed, 1, (uint32_t)(lane & 7) << 1);
     const uint2 *pr = prec + ur.x;
     // rounds 0..2 of the plain-run records: in flight behind the zero fill (one round trip to memory, not one per round)
     const uint2 recFirst = (lane < ur.y) ? pr[lane] : make_uint2(0u, 0u);
     const uint2 rec1 = (lane + 64 < ur.y) ? pr[lane + 64] : make_uint2(0u, 0u), rec2 = (lane + 128 < ur.y) ? pr[lane + 128] : make_uint2(0u, 0u);
+    const uint2 ent0 = (lane < ur.w) ? nrec[ur.z + lane] : make_uint2(0u, 0u);       // round 0 of the noise runs: one round trip for all of the unit's lists
     if (zeroFloat2) {                                            // (the caller's array: cleared here, behind the loads above)
         float2 *Az = (float2 *)sw.A;
         for (int i = lane; i < zeroFloat2; i += 64) Az[i] = make_float2(0.0f, 0.0f);
         WAVE_SYNC();
     }
+    SSTAMP(sw, 12);
+    SWAITALL();
+    SSTAMP(sw, 13);
+    // second step of the lanes' jump: its table look-ups travel behind the whole scatter (round 5; it used to follow the
+    // scatter's first round, and the noise synthesis then waited for it: 2-3 k cycles per unit)
+    sj = rng_jump_digit(c.jumpT, sj, 2, (uint32_t)lane >> 3);
     for (int r0 = 0; r0 < ur.y; r0 += 64) {
         const int r = r0 + lane;
         if (r < ur.y) {
@@ -635,12 +654,10 @@ __device__ __forceinline__ void synth_unit(const UlcxDecCtx &c, const SynWave &s
                 if (i < m && pos + i < S) dst[i + (i >= gap ? 2 : 0)] = (float)sv * quant;
             }
         }
-        if (r0 == 0) sj = rng_jump_digit(c.jumpT, sj, 2, (uint32_t)lane >> 3);
     }
-    if (ur.y <= 0) sj = rng_jump_digit(c.jumpT, sj, 2, (uint32_t)lane >> 3);
     SSTAMP(sw, 8);
     if (ur.w > 0) {
-        synth_noise(c, sw, nrec + ur.z, ur.w, sj, unitDraws, tailRR, tailMag);
+        synth_noise(c, sw, nrec + ur.z, ur.w, ent0, sj, unitDraws, tailRR, tailMag);
     }
     SSTAMP(sw, 10);
     WAVE_SYNC();
@@ -755,7 +772,7 @@ template <> __device__ __forceinline__ int16_t *out_base<int16_t>(const UlcxDecC
 //   per wave: noise runs, prefix counts, seed table | 128 block / unit seeds.  General kernel (k_dgen): z [1 array] | per-wave lists.
 #define DSYN_PWORDS(BS) (((BS) / 32 > 64 ? (BS) / 32 : 64) + 2)
 #define DSYN_CHUNK 32            // blocks of a stream whose RNG states and headers the stereo kernel stages at once (<= 64)
-struct DsynLds { int zFloats, lapFloats, twFloats, listFloats; };
+struct DsynLds { int zFloats, lapFloats, twFloats, listFloats, ptabOff; };
 __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int twInLds) {
     DsynLds l;
     l.zFloats = (fast ? 2 : 1) * 2 * FFT_PADDEDS(BS / 2, DPS);
@@ -764,6 +781,8 @@ __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int 
     l.twFloats = (fast && BS <= 2048 && twInLds != 0) ? BS / 2 : 0;               // (likewise the FFT twiddles: read from the tables in global memory, L1/L2-hot, a fourth workgroup per CU)
     l.listFloats = 2 * (64 + DSYN_PWORDS(BS)) + 128;             // per wave: prefix counts, sign-parity stream; per workgroup: 128 block / channel RNG states
     if (fast) l.listFloats += 2 * DSYN_CHUNK * 8;                // stereo kernel: the headers of a chunk of blocks, per channel
+    l.ptabOff = l.zFloats + l.lapFloats + l.twFloats + l.listFloats;
+    l.listFloats += 128;                                         // the sign-parity nybble tables (kXsParityTab)
     (void)C;
     return l;
 }
@@ -801,13 +820,15 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
     // [wave][block of the chunk][8]: {window code, the first unit's four record fields, its draws (un-decimated block), its tail decay, -}
     int *hdr = (int *)(bseed + 128) + wv * (DSYN_CHUNK * 8);
     sw.lane = lane;
+    sw.ptab = (const uint32_t *)(lds + L.ptabOff);
+    ((uint32_t *)(lds + L.ptabOff))[tid] = kXsParityTab.t[tid];      // (WG = 128 = the table's words)
     if (TWL) for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
     bool twFull = true;
     const int M0 = BS >> 1, Mp0 = FFT_PADDEDS(M0, DPS);
     float2 *zc = z + wv * Mp0;                                       // this wave's channel
 #ifdef ULCX_DSYN_STAMPS
     // diagnostic build only: shader cycles per phase, summed over the workgroup's blocks
-    DsynStamps stq; for (int i = 0; i < 12; i++) stq.t[i] = 0; stq.t0 = __builtin_amdgcn_s_memtime();
+    DsynStamps stq; for (int i = 0; i < DSYN_NSTAMP; i++) stq.t[i] = 0; stq.t0 = __builtin_amdgcn_s_memtime();
     sw.stp = &stq;
 #define STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stq.t[i] += t_ - stq.t0; stq.t0 = t_; } while (0)
 #else
@@ -1001,11 +1022,75 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
         if (whole) {
             // ---- un-decimated block (the common case), both channels together: post-twiddle fused with the windowed
             //      overlap-add (oracle/orc_fourier.c orc_imdct), inverse M/S in registers, interleaved stores
-            __syncthreads();
-            STAMP(4);
             int ov = BS;                                             // ulcDecoder.c:234-239
             if (pat0 & 8) ov >>= (wc & 7);
             if (ov > lastSub) ov = lastSub;
+            if constexpr (BSC == 2048 && DSYN_EPI2) {
+                // Headline geometry (round 5): a two-deep pipeline over the thread's four trips.  What a trip reads from global
+                // memory (two post-twiddles, the pending halves of both channels, the window pair: 12 registers) is asked for one
+                // trip ahead - the first trip's BEFORE the barrier, where the transform's registers are free and the other
+                // wave may still be transforming.  (All four at once spill: 1.70 -> 1.89 ms.)  Window pair: p1 = p0 - 1 is even
+                // and so are a and ov: aligned 8-byte loads; below the ramp the index is clamped, the value unused.
+                constexpr int S = BSC, M = BSC / 2, NT = M / 2 / WG;
+                const float2 *pre = c.T.pre[0];
+                const float2 *z0 = z, *z1 = z + Mp0;
+                const int a = (S - ov) >> 1;
+                const float *fall = c.T.winFall + ov, *rise = c.T.winRise + ov;
+                float *L0 = lapW, *L1 = lapW + H2;
+                struct Ops { float2 P1, P2, Am, As, F, R; };
+                auto fetch = [&](int t) {
+                    Ops o;
+                    const int k1 = tid + WG * t, k2 = M - 1 - k1;
+                    o.P1 = pre[k1]; o.P2 = pre[k2];
+                    o.Am = make_float2(0.0f, 0.0f); o.As = o.Am; o.F = o.Am; o.R = o.Am;
+                    if (!warm) {
+                        o.Am = *(const float2 *)(lapR + 2 * k1); o.As = *(const float2 *)(lapR + H2 + 2 * k1);
+                        int wi = M - 2 - 2 * k1 - a; wi = wi < 0 ? 0 : wi;
+                        o.F = *(const float2 *)(fall + wi); o.R = *(const float2 *)(rise + wi);
+                    }
+                    return o;
+                };
+                Ops nxt = fetch(0);
+                __syncthreads();
+                STAMP(4);
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const Ops cur = nxt;
+                    if (t + 1 < NT) nxt = fetch(t + 1);
+                    const int k1 = tid + WG * t, k2 = M - 1 - k1;
+                    int r1 = (int)(__brev((unsigned)k1) >> 22), r2 = (int)(__brev((unsigned)k2) >> 22);
+                    r1 = FFT_PADS(r1, DPS); r2 = FFT_PADS(r2, DPS);
+                    const float2 ya1 = cmulc_post(z0[r1], cur.P1), ya2 = cmulc_post(z0[r2], cur.P2);     // channel 0 (M): (Re y, -Im y)
+                    const float2 yb1 = cmulc_post(z1[r1], cur.P1), yb2 = cmulc_post(z1[r2], cur.P2);     // channel 1 (S)
+                    if (!warm) {
+                        const float Bm[2] = { ya1.y, ya2.x }, Bs[2] = { yb1.y, yb2.x };
+                        const float Am[2] = { cur.Am.x, cur.Am.y }, As[2] = { cur.As.x, cur.As.y };
+                        const float Fw[2] = { cur.F.y, cur.F.x }, Rw[2] = { cur.R.y, cur.R.x };        // (the pair is {p1, p0})
+                        const int   pv[2] = { M - 1 - 2 * k1, M - 2 - 2 * k1 };
+                        float2 lo2[2], hi2[2];
+#pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            float mLo, mHi, sLo, sHi;
+                            if (pv[q] < a) { mLo = Am[q]; mHi = Bm[q]; sLo = As[q]; sHi = Bs[q]; }
+                            else {
+                                const float cw = Fw[q], sn = Rw[q];
+                                const float m1 = sn * Bm[q], m3 = cw * Bm[q];
+                                mLo = __builtin_fmaf(cw, Am[q], -m1); mHi = __builtin_fmaf(sn, Am[q], m3);
+                                const float s1 = sn * Bs[q], s3 = cw * Bs[q];
+                                sLo = __builtin_fmaf(cw, As[q], -s1); sHi = __builtin_fmaf(sn, As[q], s3);
+                            }
+                            lo2[q] = make_float2(mLo + sLo, mLo - sLo);
+                            hi2[q] = make_float2(mHi + sHi, mHi - sHi);
+                        }
+                        st4(outp + 2 * pv[1], lo2[1].x, lo2[1].y, lo2[0].x, lo2[0].y);
+                        st4(outp + 2 * (S - 1 - pv[0]), hi2[0].x, hi2[0].y, hi2[1].x, hi2[1].y);
+                    }
+                    *(float2 *)(L0 + 2 * k1) = make_float2(ya1.x, ya2.y);
+                    *(float2 *)(L1 + 2 * k1) = make_float2(yb1.x, yb2.y);
+                }
+            } else {
+            __syncthreads();
+            STAMP(4);
             if (!(ULCX_DBG(c) & 4)) {
                 const int S = BS, M = M0;
                 const float2 *pre = c.T.pre[0];
@@ -1055,6 +1140,7 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                     L1[2 * k1] = yb1.x; L1[2 * k1 + 1] = yb2.y;
                 }
             }
+            }
             STAMP(5);
             __syncthreads();
             STAMP(6);
@@ -1094,7 +1180,7 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
         if (lastOfStream && tid == 0) { c.lastSubO[s] = lastSub; c.seedO[s] = seed; c.deadO[s] = dead; }
     }
 #ifdef ULCX_DSYN_STAMPS
-    if (lane == 0) for (int i = 0; i < 12; i++) ((unsigned long long *)(c.scratch + (size_t)s * 4 * BS))[wv * 12 + i] = stq.t[i];
+    if (lane == 0) for (int i = 0; i < DSYN_NSTAMP; i++) ((unsigned long long *)(c.scratch + (size_t)s * 4 * BS))[wv * DSYN_NSTAMP + i] = stq.t[i];
 #endif
     if (!LAPG && sCur >= 0) { __syncthreads(); float *go = c.lapO + (size_t)sCur * C * H2; for (int i = tid; i < 2 * H2; i += WG) go[i] = ldsLap[i]; }
 }
@@ -1116,6 +1202,9 @@ __global__ __launch_bounds__(WG) void k_dgen(UlcxDecCtx c) {
     sw.pre  = (int *)(lds + L.zFloats) + wv * (64 + DSYN_PWORDS(BS));
     sw.seedTab = (uint32_t *)(sw.pre + 64);
     sw.lane = lane;
+    sw.ptab = (const uint32_t *)(lds + L.ptabOff);
+    ((uint32_t *)(lds + L.ptabOff))[tid] = kXsParityTab.t[tid];      // (WG = 128 = the table's words)
+    __syncthreads();
 #ifdef ULCX_DSYN_STAMPS
     sw.stp = nullptr;
 #endif
@@ -1261,10 +1350,18 @@ size_t ulcx_dec_lds_bytes(int BS, int C, int fast, int twInLds) {
 
 // resident workgroups of the stereo synthesis kernel this context runs (float output; the PCM16 instantiation has the same
 // resources): what an even cut of the batch is sized for
+// the instantiation launch_syn() starts for this context (the one whose occupancy and dynamic-LDS attribute count)
+template <typename OUT>
+static const void *syn_fn(const UlcxDecCtx &cc, bool split) {
+    const bool small = cc.BS <= 2048;
+    if (!cc.fastOK) return (const void *)k_dgen<OUT>;
+    if (cc.BS == 2048 && DSYN_C2048) return split ? (const void *)k_dsyn<OUT, 16, DSYN_TWL != 0, true, 2048> : (const void *)k_dsyn<OUT, 16, DSYN_TWL != 0, false, 2048>;
+    if (small) return split ? (const void *)k_dsyn<OUT, 16, DSYN_TWL != 0, true> : (const void *)k_dsyn<OUT, 16, DSYN_TWL != 0, false>;
+    return split ? (const void *)k_dsyn<OUT, 32, false, true> : (const void *)k_dsyn<OUT, 32, false, false>;
+}
 int ulcx_dec_syn_slots(const UlcxDecCtx &c) {
     if (!c.fastOK) return 0;
-    const bool small = c.BS <= 2048;
-    const void *fn = small ? (const void *)k_dsyn<float, 16, true> : (const void *)k_dsyn<float, 32, false>;
+    const void *fn = syn_fn<float>(c, true);                       // (what an even cut would launch; the PCM16 instantiation has the same resources)
     const size_t lds = ulcx_dec_lds_bytes(c.BS, c.C, c.fastOK, c.twInLds);
     if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
     int dev = 0, cus = 0, per = 0;
@@ -1280,8 +1377,8 @@ template <typename OUT>
 static void launch_syn(const UlcxDecCtx &cc, unsigned g, size_t lds, hipStream_t s2, bool split) {
     const bool small = cc.BS <= 2048;
     if (!cc.fastOK) hipLaunchKernelGGL(k_dgen<OUT>, dim3(g), dim3(WG), lds, s2, cc);
-    else if (cc.BS == 2048 && DSYN_C2048) { if (split) hipLaunchKernelGGL((k_dsyn<OUT, 16, true, true, 2048>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<OUT, 16, true, false, 2048>), dim3(g), dim3(WG), lds, s2, cc); }
-    else if (small) { if (split) hipLaunchKernelGGL((k_dsyn<OUT, 16, true, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<OUT, 16, true, false>), dim3(g), dim3(WG), lds, s2, cc); }
+    else if (cc.BS == 2048 && DSYN_C2048) { if (split) hipLaunchKernelGGL((k_dsyn<OUT, 16, DSYN_TWL != 0, true, 2048>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<OUT, 16, DSYN_TWL != 0, false, 2048>), dim3(g), dim3(WG), lds, s2, cc); }
+    else if (small) { if (split) hipLaunchKernelGGL((k_dsyn<OUT, 16, DSYN_TWL != 0, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<OUT, 16, DSYN_TWL != 0, false>), dim3(g), dim3(WG), lds, s2, cc); }
     else { if (split) hipLaunchKernelGGL((k_dsyn<OUT, 32, false, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<OUT, 32, false, false>), dim3(g), dim3(WG), lds, s2, cc); }
 }
 int ulcx_dec_launch(const UlcxDecCtx &cIn, hipStream_t st, hipEvent_t *ev, const UlcxDecAux &aux) {
@@ -1290,17 +1387,10 @@ int ulcx_dec_launch(const UlcxDecCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     UlcxDecCtx c = cIn;
     c.s0 = 0; c.s1 = c.B; c.k0 = 0; c.k1 = c.K;
     const size_t lds = ulcx_dec_lds_bytes(c.BS, c.C, c.fastOK, c.twInLds);
-    const bool small = c.BS <= 2048;
     if (lds > 48 * 1024) {
-        const void *fn = !c.fastOK ? (c.pcm16 ? (const void *)k_dgen<int16_t> : (const void *)k_dgen<float>)
-                       : small ? (c.pcm16 ? (const void *)k_dsyn<int16_t, 16, true> : (const void *)k_dsyn<float, 16, true>)
-                               : (c.pcm16 ? (const void *)k_dsyn<int16_t, 32, false> : (const void *)k_dsyn<float, 32, false>);
+        const bool split = c.fastOK && aux.synGrid > 0;
+        const void *fn = c.pcm16 ? syn_fn<int16_t>(c, split) : syn_fn<float>(c, split);
         CK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (c.fastOK && aux.synGrid > 0) {
-            const void *fs = small ? (c.pcm16 ? (const void *)k_dsyn<int16_t, 16, true, true> : (const void *)k_dsyn<float, 16, true, true>)
-                                   : (c.pcm16 ? (const void *)k_dsyn<int16_t, 32, false, true> : (const void *)k_dsyn<float, 32, false, true>);
-            CK(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
     }
     if (c.packed) hipLaunchKernelGGL(k_dscan_packed, dim3((c.B + 63) / 64), dim3(64), 0, st, c);
     else hipLaunchKernelGGL(k_dscan, dim3((c.B * c.K + 63) / 64), dim3(64), 0, st, c);

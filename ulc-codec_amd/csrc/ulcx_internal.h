@@ -5,6 +5,9 @@
 #include <stdint.h>
 #include "../../include/ulc_amd.h"
 
+#ifndef ULCX_DSYN_TWL
+#define ULCX_DSYN_TWL 1                  // stereo synthesis, BlockSize <= 2048: FFT twiddles in LDS (0: from the tables in global memory; A/B builds)
+#endif
 #define ULCX_NBARK 25
 #define ULCX_MAX_SUB 4
 #define ULCX_BARK_EVENTS 52              // 25 lower edges + 25 upper edges + end of subblock (+ pad)
