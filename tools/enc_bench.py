@@ -22,4 +22,6 @@ for it in range(8):
     if it >= 3:
         tot += e0.elapsed_time(e1) / 5
         for k, v in enc.stage_ms().items(): acc[k] = acc.get(k, 0) + v / 5
-print(tag, "enc %.3f |" % tot, " ".join("%s %.2f" % (k[2:], v) for k, v in acc.items() if v > 0.05), "| mean bytes %.1f" % (d_bits.float().mean().item() / 8))
+import hashlib
+md5 = hashlib.md5(d_out.cpu().numpy().tobytes() + d_bits.cpu().numpy().tobytes()).hexdigest()[:8]
+print(tag, "enc %.3f |" % tot, " ".join("%s %.2f" % (k[2:], v) for k, v in acc.items() if v > 0.05), "| mean bytes %.1f" % (d_bits.float().mean().item() / 8), md5)

@@ -524,6 +524,26 @@ static void build_rng_tables(std::vector<uint32_t> &jumpT) {
         gf2_matmul(Md, P, Md);                            // P^16 = the next position's unit
         memcpy(P, Md, sizeof(P));
     }
+    // parT[k][v][l] (round 5), appended: what lane l of the synthesis contributes to a unit's sign-parity stream, straight from
+    // the unit's start state.  Bit i of the word = parity of the top bits of draws 32 l + 1 .. 32 l + i + 1 - linear in the
+    // state, so it is (parity map) x T^(32 l), kept as four byte tables.  The start state is the same for all lanes of the wave:
+    // with the LANE as the fastest index a look-up is one coalesced 256-byte row, not a gather.
+    auto par_word = [&](uint32_t st) { uint32_t x = 0, par = 0; for (int i = 0; i < 32; i++) { st = step(st); par ^= st >> 31; x |= par << i; } return x; };
+    uint32_t A[32], Ml[32];                               // A = T^32, Ml = A^l
+    for (int b = 0; b < 32; b++) { uint32_t v = 1u << b; for (int i = 0; i < 32; i++) v = step(v); A[b] = v; Ml[b] = 1u << b; }
+    const size_t base = jumpT.size();
+    jumpT.resize(base + (size_t)4 * 256 * 64);
+    for (int l = 0; l < 64; l++) {
+        uint32_t col[32];
+        for (int b = 0; b < 32; b++) col[b] = par_word(Ml[b]);
+        for (int k = 0; k < 4; k++)
+            for (int v = 0; v < 256; v++) {
+                uint32_t r = 0;
+                for (int t = 0; t < 8; t++) if (v >> t & 1) r ^= col[8 * k + t];
+                jumpT[base + ((size_t)(k * 256 + v) << 6) + l] = r;
+            }
+        gf2_matmul(Ml, A, Ml);
+    }
 }
 
 // One decode launch.  When the batch does not fill the machine in whole rounds of one workgroup per stream - 4096 streams on
@@ -626,6 +646,7 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
         DA(dj, jt.size(), false);
         if (hipMemcpy(dj, jt.data(), sizeof(uint32_t) * jt.size(), hipMemcpyHostToDevice) != hipSuccess) { ulcx_set_error("hipMemcpy(rng tables)"); cleanup(e); return ULCX_ERR_HIP; }
         c.jumpT = dj;
+        c.parT = dj + (size_t)8 * 16 * 4 * 256;
     }
     for (auto &v : e->ev) { if (hipEventCreate(&v) != hipSuccess) { ulcx_set_error("hipEventCreate failed"); cleanup(e); return ULCX_ERR_HIP; } }
     e->evOk = true;

@@ -39,29 +39,6 @@ __host__ __device__ constexpr uint32_t xorshift32(uint32_t s) {    // ulcDecoder
     s ^= s << 13; s ^= s >> 17; s ^= s << 5;
     return s;
 }
-// The 32 sign-parity bits a lane contributes to a unit's stream P (synth_noise) are a LINEAR function of the state sj it
-// starts from: bit i of the word = parity of the top bits of draws 1..i+1 from sj.  As eight 16-entry tables indexed by
-// the state's nybbles (512 bytes, staged in LDS by the kernels): word = XOR over k of t[16 k + nybble k of sj] - 8 LDS
-// reads and 7 XORs instead of 32 x (and, popcount, shift, or) and a five-step prefix XOR (round 5).
-struct XsParityTab { uint32_t t[128]; };
-constexpr XsParityTab xs_parity_tab() {
-    XsParityTab r = {};
-    uint32_t col[32] = {};
-    for (int b = 0; b < 32; b++) {
-        uint32_t st = 1u << b, x = 0, par = 0;
-        for (int i = 0; i < 32; i++) { st = xorshift32(st); par ^= st >> 31; x |= par << i; }
-        col[b] = x;
-    }
-    for (int k = 0; k < 8; k++)
-        for (int v = 0; v < 16; v++) {
-            uint32_t t = 0;
-            for (int j = 0; j < 4; j++) if ((v >> j) & 1) t ^= col[4 * k + j];
-            r.t[16 * k + v] = t;
-        }
-    return r;
-}
-__device__ const XsParityTab kXsParityTab = xs_parity_tab();
-
 // ---------------------------------------------------------------------------
 // One whole code of the block syntax (FormatSpecs.md:57-141, ulcDecoder.c:99-197) decoded from a
 // 32-bit window (>= 7 nybbles, low nybble first), with selects instead of a branch cascade:
@@ -505,7 +482,6 @@ struct SynWave {                 // one wave's working set while it synthesises 
     float *A;                    // the unit's coefficients = the FFT's input array (LDS, padded)
     int   *pre;                  // 64 prefix counts (LDS)
     uint32_t *seedTab;           // the unit's sign-parity stream P (LDS, synth_noise)
-    const uint32_t *ptab;        // kXsParityTab in LDS
     int lane;
 #ifdef ULCX_DSYN_STAMPS
     DsynStamps *stp;
@@ -513,45 +489,35 @@ struct SynWave {                 // one wave's working set while it synthesises 
 };
 #define SEEDTAB_DRAWS 2048       // draws of a unit the table covers; pieces beyond it jump on their own
 
-// one table-driven step of a jump: s through T^(dgt * 16^i)
-__device__ __forceinline__ uint32_t rng_jump_digit(const uint32_t *__restrict__ jt, uint32_t s, int i, uint32_t dgt) {
-    const uint32_t *J = jt + ((size_t)(i * 16 + (dgt ? dgt : 1u)) << 10);
-    const uint32_t r = J[s & 255u] ^ J[256 + ((s >> 8) & 255u)] ^ J[512 + ((s >> 16) & 255u)] ^ J[768 + (s >> 24)];
-    return dgt ? r : s;
-}
-
 // Noise synthesis (ulcDecoder.c:146-160, :166-186).  The decoder draws one xorshift value per noise coefficient and
 // only ever looks at its top bit: the sign of the run's level flips, cumulatively, on every draw with the top bit set.
-//   1. the unit's draws, densely: lane l makes draws 32l+1 .. 32l+32 from the state its jump gave it (sj = T^(32l) * unit
-//      seed) and keeps their top bits; a prefix XOR inside the word and a parity carry across the lanes turn them into
-//      P: bit n of the stream = parity of the top bits of draws 1 .. n+1.  P goes to LDS (2048 bits per pass).
+//   1. the unit's draws, densely: lane l owns draws 32l+1 .. 32l+32; its word of P (bit n of the stream = parity of the top
+//      bits of draws 1 .. n+1) is the parity prefix of those 32 top bits - a linear function of the unit's start state, read
+//      from tables (par_word) - completed by a parity carry across the lanes.  P goes to LDS (2048 bits per pass).
 //   2. one lane per (run, 32-coefficient chunk) piece: 32 sign bits are a window of P (xor the parity at the run's
 //      start), the level is the run's constant or the tail's chain value at the chunk (k_dscan) decaying from there.
 // No sequential generator in step 2, no jumps, and every coefficient is written exactly once.
-__device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &sw, const uint2 *__restrict__ list, int nE, const uint2 ent0, uint32_t sj, int unitDraws,
+// A lane's word of a unit's sign-parity stream P, from the state the (pass of the) unit starts from: bit i = parity of the top
+// bits of draws 32 lane + 1 .. 32 lane + i + 1.  Linear in the state: four byte tables per lane (host: build_rng_tables), and
+// since the state is the same in all lanes, each look-up is ONE coalesced row of 64 words (c.parT [4][256][lane]).
+__device__ __forceinline__ uint32_t par_word(const uint32_t *__restrict__ parT, uint32_t st, int lane) {
+    const uint32_t *J = parT + lane;
+    return J[(st & 255u) << 6] ^ J[(256u + ((st >> 8) & 255u)) << 6] ^ J[(512u + ((st >> 16) & 255u)) << 6] ^ J[(768u + (st >> 24)) << 6];
+}
+__device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &sw, const uint2 *__restrict__ list, int nE, const uint2 ent0, uint32_t x0, uint32_t unitSeed, int unitDraws,
                                             float tailRR, const float *tailMag) {
     const int lane = sw.lane;
     uint32_t *P = sw.seedTab;                                 // the unit's whole stream: max(64, BS/32) words + a zero word
-    // (ent0: round 0 of the run list, fetched by the caller with the unit's first records)
+    // (ent0: round 0 of the run list, x0: the lane's word of the first pass - both fetched by the caller with the unit's first records)
     // ---- 1. sign-parity stream, 2048 draws per pass (one pass unless the unit has more than 2048 noise coefficients)
     uint32_t passPar = 0;                                     // parity of the top bits of all earlier passes
     for (int dbase = 0; dbase < unitDraws; dbase += 2048) {
-        // bit i of x = parity of the top bits of draws dbase+32*lane+1 .. +i+1 (bit 31: of all 32): eight nybble look-ups (kXsParityTab)
-        const uint32_t *T = sw.ptab;
-        const uint32_t x = T[sj & 15u] ^ T[16 + ((sj >> 4) & 15u)] ^ T[32 + ((sj >> 8) & 15u)] ^ T[48 + ((sj >> 12) & 15u)]
-                         ^ T[64 + ((sj >> 16) & 15u)] ^ T[80 + ((sj >> 20) & 15u)] ^ T[96 + ((sj >> 24) & 15u)] ^ T[112 + (sj >> 28)];
+        // bit i of x = parity of the top bits of draws dbase+32*lane+1 .. +i+1 (bit 31: of all 32)
+        const uint32_t x = (dbase == 0) ? x0 : par_word(c.parT, rng_jump(c.jumpT, unitSeed, (uint32_t)dbase), lane);
         const unsigned long long odd = __ballot((int)x < 0);
         const uint32_t carry = ((uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(odd >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)odd, 0)) + passPar) & 1u;
         P[(dbase >> 5) + lane] = carry ? ~x : x;
         passPar ^= (uint32_t)__popcll(odd) & 1u;
-        if (dbase + 2048 < unitDraws) {
-            // next pass: lane l needs the state 2048 + 32 l draws on = T^(32 l) of lane 63's end state
-            uint32_t seed = sj;
-#pragma unroll
-            for (int i = 0; i < 32; i++) seed = xorshift32(seed);
-            const uint32_t endState = (uint32_t)__builtin_amdgcn_readlane((int)seed, 63);
-            sj = rng_jump(c.jumpT, endState, (uint32_t)lane << 5);
-        }
     }
     if (lane == 0) P[((unitDraws + 2047) >> 11) << 6] = 0u;   // the word behind the last pass: windows at the very end read it
     WAVE_SYNC();
@@ -619,9 +585,10 @@ __device__ __forceinline__ void synth_noise(const UlcxDecCtx &c, const SynWave &
 __device__ __forceinline__ void synth_unit(const UlcxDecCtx &c, const SynWave &sw, int S, const uint2 *__restrict__ prec, const uint2 *__restrict__ nrec,
                                            int4 ur, uint32_t unitSeed, int unitDraws, float tailRR, const float *tailMag, int zeroFloat2 = 0) {
     const int lane = sw.lane;
-    // the lane's RNG state after 32*lane draws of the unit = unitSeed through T^(32 lane): two table-driven steps per lane
-    // (hex digits 1 and 2 of 32*lane); the first one's look-ups travel behind the zero fill
-    uint32_t sj = rng_jump_digit(c.jumpT, unitSeed, 1, (uint32_t)(lane & 7) << 1);
+    // the lane's word of the unit's sign-parity stream (synth_noise): four coalesced table rows from the unit's start state, in
+    // flight behind the zero fill and the scatter (round 5; a two-step jump to the lane's own state - eight 64-address gathers -
+    // and 32 draws before: the noise synthesis waited 2-3 k cycles for them)
+    const uint32_t x0 = par_word(c.parT, unitSeed, lane);
     const uint2 *pr = prec + ur.x;
     // rounds 0..2 of the plain-run records: in flight behind the zero fill (one round trip to memory, not one per round)
     const uint2 recFirst = (lane < ur.y) ? pr[lane] : make_uint2(0u, 0u);
@@ -635,9 +602,6 @@ __device__ __forceinline__ void synth_unit(const UlcxDecCtx &c, const SynWave &s
     SSTAMP(sw, 12);
     SWAITALL();
     SSTAMP(sw, 13);
-    // second step of the lanes' jump: its table look-ups travel behind the whole scatter (round 5; it used to follow the
-    // scatter's first round, and the noise synthesis then waited for it: 2-3 k cycles per unit)
-    sj = rng_jump_digit(c.jumpT, sj, 2, (uint32_t)lane >> 3);
     for (int r0 = 0; r0 < ur.y; r0 += 64) {
         const int r = r0 + lane;
         if (r < ur.y) {
@@ -657,7 +621,7 @@ __device__ __forceinline__ void synth_unit(const UlcxDecCtx &c, const SynWave &s
     }
     SSTAMP(sw, 8);
     if (ur.w > 0) {
-        synth_noise(c, sw, nrec + ur.z, ur.w, ent0, sj, unitDraws, tailRR, tailMag);
+        synth_noise(c, sw, nrec + ur.z, ur.w, ent0, x0, unitSeed, unitDraws, tailRR, tailMag);
     }
     SSTAMP(sw, 10);
     WAVE_SYNC();
@@ -772,7 +736,7 @@ template <> __device__ __forceinline__ int16_t *out_base<int16_t>(const UlcxDecC
 //   per wave: noise runs, prefix counts, seed table | 128 block / unit seeds.  General kernel (k_dgen): z [1 array] | per-wave lists.
 #define DSYN_PWORDS(BS) (((BS) / 32 > 64 ? (BS) / 32 : 64) + 2)
 #define DSYN_CHUNK 32            // blocks of a stream whose RNG states and headers the stereo kernel stages at once (<= 64)
-struct DsynLds { int zFloats, lapFloats, twFloats, listFloats, ptabOff; };
+struct DsynLds { int zFloats, lapFloats, twFloats, listFloats; };
 __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int twInLds) {
     DsynLds l;
     l.zFloats = (fast ? 2 : 1) * 2 * FFT_PADDEDS(BS / 2, DPS);
@@ -781,8 +745,6 @@ __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int 
     l.twFloats = (fast && BS <= 2048 && twInLds != 0) ? BS / 2 : 0;               // (likewise the FFT twiddles: read from the tables in global memory, L1/L2-hot, a fourth workgroup per CU)
     l.listFloats = 2 * (64 + DSYN_PWORDS(BS)) + 128;             // per wave: prefix counts, sign-parity stream; per workgroup: 128 block / channel RNG states
     if (fast) l.listFloats += 2 * DSYN_CHUNK * 8;                // stereo kernel: the headers of a chunk of blocks, per channel
-    l.ptabOff = l.zFloats + l.lapFloats + l.twFloats + l.listFloats;
-    l.listFloats += 128;                                         // the sign-parity nybble tables (kXsParityTab)
     (void)C;
     return l;
 }
@@ -820,8 +782,6 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
     // [wave][block of the chunk][8]: {window code, the first unit's four record fields, its draws (un-decimated block), its tail decay, -}
     int *hdr = (int *)(bseed + 128) + wv * (DSYN_CHUNK * 8);
     sw.lane = lane;
-    sw.ptab = (const uint32_t *)(lds + L.ptabOff);
-    ((uint32_t *)(lds + L.ptabOff))[tid] = kXsParityTab.t[tid];      // (WG = 128 = the table's words)
     if (TWL) for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
     bool twFull = true;
     const int M0 = BS >> 1, Mp0 = FFT_PADDEDS(M0, DPS);
@@ -1202,9 +1162,6 @@ __global__ __launch_bounds__(WG) void k_dgen(UlcxDecCtx c) {
     sw.pre  = (int *)(lds + L.zFloats) + wv * (64 + DSYN_PWORDS(BS));
     sw.seedTab = (uint32_t *)(sw.pre + 64);
     sw.lane = lane;
-    sw.ptab = (const uint32_t *)(lds + L.ptabOff);
-    ((uint32_t *)(lds + L.ptabOff))[tid] = kXsParityTab.t[tid];      // (WG = 128 = the table's words)
-    __syncthreads();
 #ifdef ULCX_DSYN_STAMPS
     sw.stp = nullptr;
 #endif

@@ -143,6 +143,7 @@ struct UlcxDecCtx {
     int    tailStride;                   // BS/32
     float *scratch;                      // [B][4*BS] general-path staging of time samples (decimated / non-stereo blocks)
     const uint32_t *jumpT;               // [8][16][4][256] byte tables of T^(d*16^i), T = one xorshift32 step
+    const uint32_t *parT;                // [4][256][64] byte tables, lane fastest: a lane's word of a unit's sign-parity stream from the unit's start state
     int    fastOK, twInLds;              // stereo fast path / FFT twiddles resident in LDS
     // packed-stream mode (.ulc payloads): blocks are located by parsing, not by slot
     int   packed;
