@@ -744,7 +744,7 @@ __host__ __device__ static inline DsynLds dsyn_lds(int BS, int C, int fast, int 
     l.lapFloats = (fast && BS <= 2048 && twInLds == 1) ? 2 * (BS / 2) : 0;      // (above 2048 the stereo kernel keeps the lapping state in global memory: a third workgroup per CU)
     l.twFloats = (fast && BS <= 2048 && twInLds != 0) ? BS / 2 : 0;               // (likewise the FFT twiddles: read from the tables in global memory, L1/L2-hot, a fourth workgroup per CU)
     l.listFloats = 2 * (64 + DSYN_PWORDS(BS)) + 128;             // per wave: prefix counts, sign-parity stream; per workgroup: 128 block / channel RNG states
-    if (fast) l.listFloats += 2 * DSYN_CHUNK * 8;                // stereo kernel: the headers of a chunk of blocks, per channel
+    if (fast) l.listFloats += 2 * (DSYN_CHUNK + 4) * 8;          // stereo kernel: the headers of a chunk of blocks + of a decimated block's four units, per channel
     (void)C;
     return l;
 }
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
     sw.seedTab = (uint32_t *)(sw.pre + 64);
     uint32_t *bseed = (uint32_t *)(lds + L.zFloats + L.lapFloats + L.twFloats + 2 * (64 + DSYN_PWORDS(BS)));   // [0,64): RNG state at each block's start, [64,128): at its second channel
     // [wave][block of the chunk][8]: {window code, the first unit's four record fields, its draws (un-decimated block), its tail decay, -}
-    int *hdr = (int *)(bseed + 128) + wv * (DSYN_CHUNK * 8);
+    int *hdr = (int *)(bseed + 128) + wv * ((DSYN_CHUNK + 4) * 8);
     sw.lane = lane;
     if (TWL) for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
     bool twFull = true;
@@ -909,7 +909,6 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
         const bool whole = (BS >> (pat0 & 7)) == BS;                 // one subblock per channel (ulcDecoder.c:242-245)
         int nsub = 1;
         if (!whole) { nsub = 0; unsigned q = pat0; do nsub++; while (q >>= 4); }
-        auto unit_draws = [&](int ch, int j) { return ((j + 1 < nsub) ? udraw[ch * 4 + j + 1] : (ch + 1 < C) ? udraw[(ch + 1) * 4] : c.draws[blk]) - udraw[ch * 4 + j]; };
         if (TWL && whole != twFull) {
             // twiddle tables for this block's transform sizes: the full-size one, or those of N/2, N/4, N/8 back to back
             if (whole) for (int i = tid; i < BS / 4; i += WG) twl[i] = c.T.tw[0][i];
@@ -921,6 +920,22 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
             __syncthreads();
         }
         STAMP(0);
+        // Decimated block (round 5): what its 2..4 units need from the walk - record ranges, draws, tail decay - and their RNG start
+        // states (a table jump of up to four dependent look-ups each) are fetched for ALL units at once, unit j in lane j, and
+        // handed out by lane reads; a unit used to start with its own loads and its own jump, one after the other.
+        int *uh = hdr + DSYN_CHUNK * 8;                              // [4 units][8] of this wave, behind its chunk table
+        if (!whole) {
+            if (lane < nsub) {
+                const int dj = udraw[wv * 4 + lane];
+                const int dn = (lane + 1 < nsub) ? udraw[wv * 4 + lane + 1] : (wv + 1 < C) ? udraw[(wv + 1) * 4] : c.draws[blk];
+                const int4 urL = urec[wv * 4 + lane];
+                const float rrL = utail[wv * 4 + lane].y;
+                const uint32_t seedL = rng_jump(c.jumpT, bseed[kb], (uint32_t)dj);
+                int *u = uh + lane * 8;
+                u[0] = (int)seedL; u[1] = urL.x; u[2] = urL.y; u[3] = urL.z; u[4] = urL.w; u[5] = dn - dj; u[6] = __float_as_int(rrL);
+            }
+            WAVE_SYNC();
+        }
         // ---- coefficients -> spectra, this wave's channel, subblock by subblock (independent of each other)
         {
             unsigned pat = pat0; int off = 0;
@@ -928,12 +943,12 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                 const int d = pat & 7, S = BS >> d, M = S >> 1, Mp = FFT_PADDEDS(M, DPS);
                 float2 *zj = zc + FFT_PADS(off >> 1, DPS);
                 sw.A = (float *)zj;
-                const uint32_t unitSeed = (j == 0) ? bseed[wv * 64 + kb] : rng_jump(c.jumpT, bseed[kb], (uint32_t)udraw[wv * 4 + j]);
+                const int *uj = uh + j * 8;
+                const uint32_t unitSeed = whole ? bseed[wv * 64 + kb] : (uint32_t)uj[0];
                 STAMP(1);
-                const bool u0 = j == 0;
-                const int4 ur = u0 ? make_int4(hb[1], hb[2], hb[3], hb[4]) : urec[wv * 4 + j];
-                const int ud = (u0 && whole) ? hb[5] : unit_draws(wv, j);
-                const float urr = u0 ? __int_as_float(hb[6]) : utail[wv * 4 + j].y;
+                const int4 ur = whole ? make_int4(hb[1], hb[2], hb[3], hb[4]) : make_int4(uj[1], uj[2], uj[3], uj[4]);
+                const int ud = whole ? hb[5] : uj[5];
+                const float urr = __int_as_float(whole ? hb[6] : uj[6]);
                 if (!(ULCX_DBG(c) & 1)) synth_unit(c, sw, S, prec, nrec, ur, unitSeed, ud, urr, tmag + (size_t)(wv * 4 + j) * c.tailStride, Mp);
                 else for (int i = lane; i < Mp; i += 64) zj[i] = make_float2(0.0f, 0.0f);
                 STAMP(2);
