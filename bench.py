@@ -209,7 +209,8 @@ def main():
                     "(default: the config's: 32768 / 16384); a reduced total is a test run, never a result line for BASELINE's configuration")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pmc-summary", default="", help="tools/pmc_summary.py output of a rocprofv3 --pmc run of THIS command: fills roofline.traffic "
-                    "(default: null - a traffic figure is never taken from another run)")
+                    "(default: the committed profiles/r05_pmc_summary.json when its _meta.src_rev equals the library's ulcx_build_rev() "
+                    "and its workload is this one; null otherwise)")
     ap.add_argument("--pcm16", action="store_true", help="separate configuration (SURVEY.md 8f rank 4): PCM16 ingest and PCM16 output "
                     "fused into the first/last kernel instead of the C API's f32; NOT the headline line")
     args = ap.parse_args()
@@ -367,16 +368,25 @@ def main():
     # HBM bytes per launch of the roofline kernel: from the two PMC passes of THIS command (FETCH_SIZE / WRITE_SIZE cannot
     # be collected inside a timed run) - handed in with --pmc-summary (tools/gpu_r04.sh does the three runs on one box); null otherwise
     traffic, traffic_src = None, None
-    pmc_path = args.pmc_summary                              # only a summary of THIS command's own PMC passes, handed in explicitly
-    if pmc_path and os.path.exists(pmc_path):
+    # HBM bytes of the roofline kernel: the PMC counters cannot be collected inside a timed run, so the figure comes from the
+    # counter summary of the SAME command (tools/pmc_summary.py over separate FETCH_SIZE / WRITE_SIZE passes): the one handed in
+    # with --pmc-summary, else the committed profiles/r05_pmc_summary.json - and that one ONLY when it was taken on exactly the
+    # sources this library is built from (`_meta.src_rev` == ulcx_build_rev()) and on this workload.  Anything else: null.
+    lib_rev = ulc_amd.build_rev()
+    cands = [args.pmc_summary] if args.pmc_summary else [os.path.join(ROOT, "profiles", "r05_pmc_summary.json")]
+    for pmc_path in cands:
+        if not (pmc_path and os.path.exists(pmc_path)):
+            continue
         try:
             js = json.load(open(pmc_path))
             meta = js.get("_meta", {})
+            same_run = bool(args.pmc_summary)
+            same_src = meta.get("src_rev") == lib_rev and lib_rev != "unknown"
+            same_work = (meta.get("config") == args.config and meta.get("mode") == args.mode and meta.get("blocks") == K and meta.get("streams") == B and world == 1 and not args.pcm16)
             ent = js.get(kname, {})
-            traffic = ent.get("hbm_bytes_per_launch")
-            if traffic is not None:
-                traffic = traffic / launches
-                traffic_src = os.path.relpath(pmc_path, ROOT) + (" (git %s)" % meta["git"] if meta.get("git") else "")
+            if ent.get("hbm_bytes_per_launch") is not None and (same_run or (same_src and same_work)):
+                traffic = ent["hbm_bytes_per_launch"] / launches
+                traffic_src = os.path.relpath(pmc_path, ROOT) + " (src_rev %s%s)" % (meta.get("src_rev", "?"), ", git %s" % meta["git"] if meta.get("git") else "")
         except Exception:
             traffic, traffic_src = None, None
     launch_bytes = alg_bytes_block * B * K / launches
@@ -409,6 +419,7 @@ def main():
                        "streams_per_gpu": B, "blocks_per_stream_per_step": K, "block_size": bs, "channels": CH, "rate_hz": rate,
                        "parallelism": f"batch split over {world} GPU(s), no collective on the data path",
                        "per_rank_ms_per_step": [round(float(x), 4) for x in per_rank_ms]},
+            "library_src_rev": lib_rev,
             "roofline": {"bound": "hbm", "kernel": f"{kname} ({side})", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_block": alg_bytes_block, "blocks_per_launch": B * K / launches,

@@ -121,6 +121,7 @@ enum { ULCX_MODE_VBR = 0, ULCX_MODE_CBR = 1, ULCX_MODE_ABR = 2 };
 
 const char *ulcx_last_error(void);
 int  ulcx_device_count(void);                 /* <= 0 when no usable device */
+const char *ulcx_build_rev(void);             /* 12 hex digits: sha1 of the sources the library was built from (Makefile) */
 
 /* Encoder for nStreams independent streams (all same RateHz/nChan/BlockSize);
  * at most maxBlocksPerCall blocks per stream per call.  device = HIP ordinal. */

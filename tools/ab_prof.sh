@@ -1,5 +1,5 @@
-# usage: bash tools/_ab_prof.sh "<bench args>" "<kernel regex>"  -- per-kernel average durations under rocprofv3 for every ab/*.so
-cd /root/repo; export TMPDIR=/tmp
+# usage: bash tools/ab_prof.sh "<bench args>" "<kernel regex>"  -- per-kernel average durations under rocprofv3 for every ab/*.so
+cd "$(dirname "$0")/.."; export TMPDIR=/tmp
 ARGS=${1:---mode decode}; PAT=${2:-k_d}
 for f in ab/*.so; do
   n=$(basename $f .so); rm -rf /tmp/prof_$n

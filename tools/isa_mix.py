@@ -22,7 +22,38 @@ def cls(op):
     if b.startswith("global_") or b.startswith("buffer_") or b.startswith("flat_") or b.startswith("scratch_"): return "vmem"
     return "other"
 COST = {"vfull": 2.3, "vhalf": 4.2, "vpk": 5.6, "vtrans": 8.2}
+def all_kernels(paths):
+    """{demangled kernel name: {class: count}} for every kernel of the dumps (llvm-cxxfilt names, 'void ' and arguments stripped)."""
+    import subprocess
+    out = {}
+    for path in paths:
+        lines = open(path).read().split("\n")
+        name, cnt = None, None
+        for l in lines:
+            t = l.strip()
+            if re.match(r"^_Z[\w]+:", l) and "@" in l:
+                name = l.split(":")[0]; cnt = collections.Counter(); continue
+            if name is None: continue
+            if t.startswith(".Lfunc_end"):
+                out[name] = dict(cnt); name = None; continue
+            if not t or t.startswith(";") or t.startswith(".") or re.match(r"^\.?LBB", t): continue
+            cnt[cls(t.split()[0])] += 1
+    names = list(out)
+    dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
+    res = {}
+    for m, d in zip(names, dem):
+        short = d.replace("void ", "").split("(")[0]
+        c = out[m]
+        v = sum(c.get(k, 0) for k in COST)
+        if v == 0: continue
+        res[short] = dict(c, vector=v, cycles_per_vector=sum(c.get(k, 0) * COST[k] for k in COST) / v)
+    return res
 def main():
+    if sys.argv[1] == "--json":
+        import json
+        print(json.dumps({"_meta": {"cost_cycles": COST, "note": "static instruction mix per kernel (hipcc -S), priced with profiles/r05_valu_cost.md at >= 2 waves per SIMD"},
+                          **all_kernels(sys.argv[2:])}, indent=1))
+        return
     path, name = sys.argv[1], sys.argv[2]
     per_block = "--blocks" in sys.argv
     lines = open(path).read().split("\n")

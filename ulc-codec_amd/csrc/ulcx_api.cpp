@@ -51,6 +51,10 @@ struct ulcx_decoder {
     uint32_t b1Seed;                                              // the stream's RNG state between single-block calls
 };
 
+#ifndef ULCX_SRC_REV
+#define ULCX_SRC_REV "unknown"
+#endif
+extern "C" const char *ulcx_build_rev(void) { return ULCX_SRC_REV; }
 extern "C" int ulcx_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

@@ -21,7 +21,7 @@ EXPORTS = [
     "ulcx_encoder_slot_bytes", "ulcx_encode_dev", "ulcx_encode_dev_pcm16", "ulcx_encode_host", "ulcx_encoder_debug_fetch",
     "ulcx_decoder_create", "ulcx_decoder_destroy", "ulcx_decoder_reset", "ulcx_decode_dev", "ulcx_decode_dev_pcm16", "ulcx_decode_host",
     "ulcx_encoder_last_fallbacks", "ulcx_encoder_debug_force_exact", "ulcx_ulc_header_pack", "ulcx_ulc_header_parse", "ulcx_ulc_rate_kbps",
-    "ulcx_pack_streams_dev", "ulcx_decode_packed_dev", "ulcx_decode_packed_host", "ulcx_decoder_upload_payload", "ulcx_decode_resident_host", "ulcx_encoder_stage_ms", "ulcx_encoder_stage_name", "ulcx_encoder_last_xf_launches", "ulcx_decoder_stage_ms", "ulcx_decoder_stage_name", "ulcx_block_extent_bytes", "ulcx_encoder_set_timing", "ulcx_decoder_set_timing", "ulcx_encode_block1", "ulcx_decode_block1", "ulcx_decode_block1_rng", "ulcx_dec_split_plan",
+    "ulcx_pack_streams_dev", "ulcx_decode_packed_dev", "ulcx_decode_packed_host", "ulcx_decoder_upload_payload", "ulcx_decode_resident_host", "ulcx_encoder_stage_ms", "ulcx_encoder_stage_name", "ulcx_encoder_last_xf_launches", "ulcx_decoder_stage_ms", "ulcx_decoder_stage_name", "ulcx_block_extent_bytes", "ulcx_encoder_set_timing", "ulcx_decoder_set_timing", "ulcx_encode_block1", "ulcx_decode_block1", "ulcx_decode_block1_rng", "ulcx_build_rev", "ulcx_dec_split_plan",
 ]
 
 
@@ -42,6 +42,7 @@ def lib():
             raise RuntimeError(f"{LIB_PATH} not built: run `make -C ulc-codec_amd` (or __graft_entry__.build())")
         l = C.CDLL(LIB_PATH)
         l.ulcx_last_error.restype = C.c_char_p
+        l.ulcx_build_rev.restype = C.c_char_p
         l.ulcx_encoder_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         l.ulcx_encoder_destroy.argtypes = [C.c_void_p]
         l.ulcx_encoder_reset.argtypes = [C.c_void_p]
@@ -82,6 +83,11 @@ def lib():
 
 class UlcError(RuntimeError):
     pass
+
+
+def build_rev():
+    """Revision of the sources the loaded library was built from (sha1 prefix, ulc-codec_amd/Makefile)."""
+    return lib().ulcx_build_rev().decode()
 
 
 def _check(rc, what):
