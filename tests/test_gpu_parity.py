@@ -166,6 +166,55 @@ def test_exact_path_over_several_groups_of_rank_slots(mode, p0):
     enc.close()
 
 
+def _sparse_pcm(n, ch, rate, seed, floor):
+    """A few steady tones over a noise floor `floor` below them: at a low VBR quality a block keeps a handful of coefficients
+    and the gaps between them are hundreds to thousands of zeros - several noise runs per gap (a run code covers <= 527)."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / rate
+    x = np.zeros(n)
+    for f, a in zip(rng.uniform(200.0, 0.45 * rate, 3), rng.uniform(0.1, 0.3, 3)):
+        x += a * np.sin(2 * np.pi * f * t + rng.uniform(0, 6.28))
+    pcm = np.stack([x + floor * rng.standard_normal(n) for _ in range(ch)], axis=1)
+    if ch == 2:
+        pcm[:, 1] = 0.7 * pcm[:, 1] + 0.3 * pcm[:, 0]
+    return (np.clip(np.rint(pcm * 32768.0), -32768, 32767) / 32768.0).astype(np.float32)
+
+
+@pytest.mark.parametrize("wave", ["1", "0"])
+@pytest.mark.parametrize("bs,ch,q,floor", [(4096, 2, 25.0, 3e-3), (8192, 1, 20.0, 1e-2), (8192, 1, 30.0, 2e-4), (4096, 2, 35.0, 4e-5), (2048, 2, 15.0, 2e-3)])
+def test_long_zero_gaps_with_several_noise_runs(wave, bs, ch, q, floor):
+    """k_nsums speculates EVERY noise run of a gap (run r of the gap in front of kept coefficient i sits in component
+    r & 1 of gapSum[i - (r >> 1)]) and the writer chains through them as long as each run is coded as noise; nothing
+    targeted gaps of two or more runs (> 543 zeros) or three (> 1070).  Sparse spectra in large blocks: gaps of up to thousands
+    of zeros, noise floors from audible to below the quantiser (a run whose level quantises to 0 is coded as zeros and breaks
+    the chain).  Both writers (ULCX_WAVE=1 wave writer, 0 serial)."""
+    amd = _amd()
+    rate, B, K = 44100, 3, 6
+    pcm = np.stack([_sparse_pcm(K * bs, ch, rate, 900 + 7 * s, floor) for s in range(B)])
+    old = os.environ.get("ULCX_WAVE")
+    os.environ["ULCX_WAVE"] = wave
+    try:
+        enc = amd.BatchEncoder(B, ch, bs, rate, K)
+    finally:
+        if old is None: os.environ.pop("ULCX_WAVE", None)
+        else: os.environ["ULCX_WAVE"] = old
+    res = enc.encode(pcm, amd.MODE_VBR, q)
+    long2 = long3 = 0
+    for s in range(B):
+        ref = oracle_encode_debug(pcm[s], bs, rate, 0, q, slot=enc.slot)
+        _compare_encode(res, ref, s, 0, K, None, f"sparse bs={bs} q={q} floor={floor} wave={wave}")
+        for k in range(K):
+            keep = np.flatnonzero(ref["ranks"][k] < ref["nout"][k])
+            for c0 in range(ch):
+                kk = keep[(keep >= c0 * bs) & (keep < (c0 + 1) * bs)] - c0 * bs
+                gaps = np.diff(np.concatenate([[-1], kk, [bs]])) - 1
+                long2 += int((gaps > 543).sum()); long3 += int((gaps > 1070).sum())
+    assert long2 > 0, "no gap of more than 543 zeros: the input is not sparse enough for this test"
+    if bs >= 4096:
+        assert long3 > 0, "no gap of more than 1070 zeros"
+    enc.close()
+
+
 def test_encode_many_blocks_bit_exact():
     """A few thousand blocks of the bench shape, every byte compared with the oracle."""
     amd = _amd()

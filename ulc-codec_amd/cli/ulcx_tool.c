@@ -262,17 +262,46 @@ static int run_groups(struct group *proto, int nFiles, char **files, int nDev) {
     const int have = ulcx_device_count();
     if (have < 1) DIE("no HIP device: %s", ulcx_last_error());
     if (nDev <= 1) { proto->device = 0; proto->n = nFiles; proto->files = files; return proto->decode ? decode_group(proto) : encode_group(proto); }
+    /* what a single group checks per batch - every input of one call shares rate / channels (encode) or block size /
+     * channels / rate (decode) - is checked here ONCE over all files, before they are dealt out: a command line that a
+     * one-group run rejects must not be partly accepted with -devices:N */
+    {
+        uint32_t ref[3] = { 0, 0, 0 };
+        for (int i = 0; i < nFiles; i++) {
+            uint32_t cur[3] = { 0, 0, 0 };
+            if (!proto->decode) {
+                struct wav w;
+                const int e = wav_open(&w, files[i]);
+                if (e) DIE("cannot read '%s' (error %d: RIFF PCM16 / float32 only)", files[i], e);
+                cur[0] = w.rate; cur[1] = (uint32_t)w.chan; fclose(w.f);
+            } else {
+                uint8_t hb[24]; ulcx_file_header h;
+                FILE *f = fopen(files[i], "rb");
+                if (!f) DIE("cannot open '%s'", files[i]);
+                const size_t got = fread(hb, 1, sizeof(hb), f); fclose(f);
+                if (got != sizeof(hb) || ulcx_ulc_header_parse(&h, hb, sizeof(hb))) DIE("'%s' is not a ULC2 container", files[i]);
+                cur[0] = h.RateHz; cur[1] = h.nChan; cur[2] = h.BlockSize;
+            }
+            if (i == 0) memcpy(ref, cur, sizeof(ref));
+            else if (memcmp(ref, cur, sizeof(ref))) DIE("'%s': all inputs of one call must share %s", files[i], proto->decode ? "block size, channels and rate" : "rate and channel count");
+        }
+    }
     struct group *gs = (struct group *)calloc((size_t)nDev, sizeof(*gs));
     char **deal = (char **)calloc((size_t)nFiles, sizeof(char *));
     pthread_t *th = (pthread_t *)calloc((size_t)nDev, sizeof(pthread_t));
-    int at = 0, rc = 0;
+    if (!gs || !deal || !th) { free(gs); free(deal); free(th); DIE("out of memory"); }
+    int at = 0, rc = 0, started = 0;
     for (int g = 0; g < nDev; g++) {
         gs[g] = *proto; gs[g].device = g % have; gs[g].files = deal + at; gs[g].n = 0; gs[g].rc = 0;
         for (int i = g; i < nFiles; i += nDev) deal[at + gs[g].n++] = files[i];
         at += gs[g].n;
     }
-    for (int g = 0; g < nDev; g++) if (pthread_create(&th[g], NULL, group_main, &gs[g])) DIE("cannot start a host thread for group %d", g);
-    for (int g = 0; g < nDev; g++) { pthread_join(th[g], NULL); if (gs[g].rc > rc) rc = gs[g].rc; }
+    for (int g = 0; g < nDev; g++) {
+        if (pthread_create(&th[g], NULL, group_main, &gs[g])) { fprintf(stderr, "ulcx-tool: cannot start a host thread for group %d\n", g); rc = 2; break; }
+        started++;
+    }
+    /* (a failed start: the groups already running work on gs / deal - they are joined before anything is freed) */
+    for (int g = 0; g < started; g++) { pthread_join(th[g], NULL); if (gs[g].rc > rc) rc = gs[g].rc; }
     free(gs); free(deal); free(th);
     return rc;
 }
@@ -285,6 +314,7 @@ static int do_encode(int argc, char **argv) {
     int a = 4, nDev = 1;
     g.bs = 2048;
     for (; a < argc && argv[a][0] == '-'; a++) {
+        if (!strcmp(argv[a], "--")) { a++; break; }          /* end of options: input names may start with '-' behind it */
         if (!strncmp(argv[a], "-blocksize:", 11)) g.bs = atoi(argv[a] + 11);
         else if (!strncmp(argv[a], "-devices:", 9)) nDev = atoi(argv[a] + 9);
         else DIE("unknown option '%s'", argv[a]);
@@ -299,6 +329,7 @@ static int do_decode(int argc, char **argv) {
     g.decode = 1; g.outdir = argv[2];
     int a = 3, nDev = 1;
     for (; a < argc && argv[a][0] == '-'; a++) {
+        if (!strcmp(argv[a], "--")) { a++; break; }
         if (!strncmp(argv[a], "-format:", 8)) {
             const char *f = argv[a] + 8;
             if (!strcmp(f, "FLOAT32") || !strcmp(f, "float32")) g.isFloat = 1;
@@ -318,6 +349,7 @@ int main(int argc, char **argv) {
             "  ulcx-tool encode OUTDIR RATE[,AvgComplexity] [-blocksize:N] [-devices:N] IN1.wav IN2.wav ...\n"
             "      RATE < 0: VBR quality; RATE > 0: CBR kbps; RATE,AvgComplexity: ABR  (as ulcencodetool)\n"
             "  ulcx-tool decode OUTDIR [-format:PCM16|FLOAT32] [-devices:N] IN1.ulc IN2.ulc ...\n"
+            "  --          end of options (input names that start with '-')\n"
             "  -devices:N  inputs dealt round-robin over N groups, one host thread + one codec object each (device g %% visible)\n");
     return 1;
 }

@@ -2087,9 +2087,13 @@ __global__ __launch_bounds__(WG) void k_keep_ranks(UlcxEncCtx c, int finalPass) 
 // workgroup forms its block's {w, w*log} pairs from the 100 Bark levels per channel straight into LDS (noise_pair), lists
 // the gaps and sums them.  k_tails: the units' tail chains, 64 units per workgroup (a workgroup of k_nsums that also ran
 // its block's two 700-step chains lived 18 us for them).  A gap
-// longer than one noise run (16 + 511 coefficients) gets its SECOND run speculated too - where that one starts follows from
-// the gap's length alone as long as the first run is coded as noise: on the bench batch 0.30 runs per block, against 0.02
-// that need a third or sit elsewhere; those the writer sums itself, forming the pairs it needs (pair_demand).
+// longer than one noise run (16 + 511 coefficients) gets EVERY further run speculated too: where run r starts follows from the
+// gap's length alone as long as all runs before it are coded as noise, and its sums go to component r & 1 of
+// gapSum[i - (r >> 1)] (i = the kept coefficient behind the gap; those positions lie inside the gap).  On the bench batch: 0.30
+// second runs and 0.02 third runs per block.  The writer chains through them (gap_codes, write_zone) exactly as far as the
+// lister listed them - a next run exists iff >= 16 zeros are left behind an all-noise prefix - and sums a run that sits
+// elsewhere (a run before it fell back to zeros: ~0.0007 per block) itself, forming the pairs it needs (pair_demand).
+// (tests/test_gpu_parity.py::test_long_zero_gaps_with_several_noise_runs: gaps of thousands of zeros, both writers.)
 // ---------------------------------------------------------------------------
 #define E_GAPCAP(N) ((N) / 16)      // gaps >= 16 per block: at most N/17 of them
 #define WAVE_SYNC_E() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
