@@ -8,10 +8,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # The geometry-uniform Bark-sum kernel is the default from 256 blocks per call up (what bench.py runs); the parity tests
-    # use small batches, so they force it on; the lane-per-subblock path for every block (small batches, ULCX_BARK_UNIFORM=0)
-    # is one of the cases of test_runtime_switches_keep_parity.
-    os.environ.setdefault("ULCX_BARK_UNIFORM", "1")
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -171,8 +171,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
         }
         int ring = 4;
         while (ring < most) ring *= 2;
-        const char *bu = getenv("ULCX_BARK_UNIFORM");                    // =0: k_nbark for every block (the round-1 path)
-        c.barkRing = (ring <= 8 && N % 32 == 0 && !(bu && bu[0] == '0')) ? ring : 0;
+        c.barkRing = (ring <= 8 && N % 32 == 0) ? ring : 0;               // (0: k_nbark / k_pbark for every block - geometries whose band edges need a deeper ring)
         // (round 3: also for a few blocks per call - the drop-in's one: the four-wave kernel walks a row's 1024 lines in a
         //  quarter of the time the lane-per-subblock kernels take, which is what a single stream waits for)
     }
@@ -193,12 +192,10 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
     DA(c.cplx, NB, true);
     DA(c.nout, NB, true);
     DA(c.slow, 3 * NB + 2, true);                      // flags [NB], retry-queue counters [2], retry queues [2][NB]
-    c.useWave = 1;        // wave-per-unit encode pass fed by k_gapsums; ULCX_WAVE=0 selects the serial lane-per-unit kernel
+    c.useWave = 1;        // wave-per-unit encode pass fed by k_nsums / k_tails; the serial lane-per-unit kernel takes what its capacities cannot hold
     c.useGapSums = (cb <= 16384 && nChan <= 16) ? 1 : 0;          // (k_nsums: a block's pairs in LDS, two bits per channel in a word)
-    if (const char *ev = getenv("ULCX_GAPSUMS")) c.useGapSums = (ev[0] != '0');
     DA(c.gapSum, NB * cb, false);
     DA(c.tailSum, NB * nChan * 4 * 8, true);
-    if (const char *ev = getenv("ULCX_WAVE")) c.useWave = (ev[0] != '0');
     c.directPack = 1;
     if (const char *ev = getenv("ULCX_DIRECT_PACK")) c.directPack = (ev[0] != '0');
     c.dbgSkip = 0;
@@ -237,7 +234,7 @@ extern "C" int ulcx_encoder_create(ulcx_encoder **out, int device, int nStreams,
         e->wcPipe = e->sideOk ? 4 : 1;                         // transform chunks per call: 1 block, then thirds (4 vs 5 chunks: 9.50 vs 9.56 ms per bench step)
         if (const char *pv = getenv("ULCX_WC_PIPE")) { int n = atoi(pv); if (n >= 1 && n <= ULCX_XF_MAXCH && n != 2 && (n == 1 || e->sideOk)) e->wcPipe = n; }
         e->wcSteps = -1; if (const char *sv = getenv("ULCX_WC_STEPS")) e->wcSteps = atoi(sv);      // -1: default; 0: the transform's chunks
-        { const char *v = getenv("ULCX_WC_FUSE"); e->wcFuse = (v && v[0] == '0') ? 0 : 1; }
+        e->wcFuse = 1;                                           // (stereo: k_wc_ef; every other channel count: k_wc_energy + k_wc_forward)
     }
     e->nsSlots = c.useGapSums ? ulcx_enc_nsums_slots(BlockSize, nChan) : 0;
     if (e->nsSlots <= 0) e->nsSlots = 1024;

@@ -184,7 +184,7 @@ struct UlcxEncAux {
     hipEvent_t *evXf;                    // [2*ULCX_XF_MAXCH] timing pairs around each transform launch (used when ev != NULL)
     int wcPipe;                          // chunks of blocks pipelined between window control and transform; 1 = off
     int wcSteps;                         // fine steps of the window-control kernels per call (ULCX_WC_STEPS)
-    int wcFuse;                          // ULCX_WC_FUSE, read once when the encoder is created
+    int wcFuse;                          // stereo: envelope + forward recurrence in one kernel (k_wc_ef)
     int nsSlots;                         // workgroups of k_nsums the device holds at once (its persistent grid)
     int *nXf;                            // out: transform launches this call
 };
