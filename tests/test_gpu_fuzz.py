@@ -18,3 +18,12 @@ def test_randomised_parity_sweep(seed):
     import fuzz_parity
     n, nblk = fuzz_parity.run(budget=30.0, seed=seed)
     assert n >= 10 and nblk >= 200, f"the sweep covered too little in its time budget: {n} configurations, {nblk} blocks"
+
+
+def test_randomised_rate_search_sweep():
+    """The rate-search corner on its own (third seed): CBR / ABR at 150-700 kbps, three to five calls per encoder (the search
+    window and the keys of a block are carried from probe to probe and from pass to pass), half of the signals beyond full
+    scale.  Round 4's randomised sweep found two faults of the rate-search window exactly here."""
+    import fuzz_parity
+    n, nblk = fuzz_parity.run(budget=40.0, seed=3, rate_search=True)
+    assert n >= 8 and nblk >= 100, f"the sweep covered too little in its time budget: {n} configurations, {nblk} blocks"

@@ -8,7 +8,9 @@ sys.path.insert(0, os.path.join(ROOT, "ulc-codec_amd")); sys.path.insert(0, os.p
 import ulc_amd
 from ulc_testlib import synth_pcm, oracle_encode_debug, oracle_decode_stream
 
-def run(budget=120.0, seed=1, max_bs=8192, sizes=None, chans=None):
+def run(budget=120.0, seed=1, max_bs=8192, sizes=None, chans=None, rate_search=False):
+  """rate_search: only CBR / ABR at high rates over >= 3 calls, half of the signals beyond full scale - the corner where the two
+  faults of the rate-search window (round 4, e9a701a) lived."""
   rng = np.random.default_rng(seed)
   t0 = time.time(); n = 0; nblk = 0
   while time.time() - t0 < budget:
@@ -19,12 +21,15 @@ def run(budget=120.0, seed=1, max_bs=8192, sizes=None, chans=None):
       if K > 8: B = min(B, 3)                                         # (long calls exercise the chunked window-control pipeline)
       mode = int(rng.choice([0, 0, 1, 2]))
       p0 = float(rng.uniform(1, 100)) if mode == 0 else float(rng.choice([rng.uniform(1, 16), rng.uniform(16, 192), rng.uniform(192, 700)]))
+      if rate_search:
+          mode = int(rng.choice([1, 1, 2])); p0 = float(rng.uniform(150, 700)); calls = int(rng.integers(3, 6)); K = int(rng.choice([1, 2, 3, 5, 8])); B = min(B, 4)
       p1 = float(rng.uniform(0.2, 0.9)) if mode == 2 else 0.0
       transient = bool(rng.integers(0, 2))
       amp = float(rng.choice([1.0, 1.0, 0.05, 1e-4, 0.0]))           # loud, quiet, near-silent, digital silence
       seed = int(rng.integers(0, 1 << 30))
       pcm = np.stack([synth_pcm(s, calls * K * bs, ch, rate, transient=transient, seed=seed) for s in range(B)]) * np.float32(amp)
       kind = int(rng.integers(0, 8))                                 # other signal shapes on top of the synthetic mix
+      if rate_search: kind = int(rng.choice([0, 1, 6, 6, 6, 7]))
       nT = calls * K * bs
       if kind == 1:   pcm = (rng.random(pcm.shape, dtype=np.float32) * 2 - 1) * np.float32(amp if amp else 1.0)          # white noise
       elif kind == 2: pcm = pcm + np.float32(0.25)                                                                       # DC offset
