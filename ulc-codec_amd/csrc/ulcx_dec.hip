@@ -23,6 +23,9 @@
 #ifndef DSYN_C2048
 #define DSYN_C2048 1
 #endif
+#ifndef DSYN_C4096
+#define DSYN_C4096 1   // BlockSize 4096 with the size as a compile-time constant too (the pipelined epilogue; round 5)
+#endif
 #define DSYN_TWL ULCX_DSYN_TWL
 #ifndef DSYN_EPI2
 #define DSYN_EPI2 1  // headline geometry: the epilogue's global operands fetched one trip ahead (0: the generic loop)
@@ -1000,8 +1003,8 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
             int ov = BS;                                             // ulcDecoder.c:234-239
             if (pat0 & 8) ov >>= (wc & 7);
             if (ov > lastSub) ov = lastSub;
-            if constexpr (BSC == 2048 && DSYN_EPI2) {
-                // Headline geometry (round 5): a two-deep pipeline over the thread's four trips.  What a trip reads from global
+            if constexpr ((BSC == 2048 || BSC == 4096) && DSYN_EPI2) {
+                // Headline geometry and BlockSize 4096 (round 5): a two-deep pipeline over the thread's four (eight) trips.  What a trip reads from global
                 // memory (two post-twiddles, the pending halves of both channels, the window pair: 12 registers) is asked for one
                 // trip ahead - the first trip's BEFORE the barrier, where the transform's registers are free and the other
                 // wave may still be transforming.  (All four at once spill: 1.70 -> 1.89 ms.)  Window pair: p1 = p0 - 1 is even
@@ -1033,7 +1036,8 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                     const Ops cur = nxt;
                     if (t + 1 < NT) nxt = fetch(t + 1);
                     const int k1 = tid + WG * t, k2 = M - 1 - k1;
-                    int r1 = (int)(__brev((unsigned)k1) >> 22), r2 = (int)(__brev((unsigned)k2) >> 22);
+                    constexpr int LGM = BSC == 4096 ? 11 : 10;
+                    int r1 = (int)(__brev((unsigned)k1) >> (32 - LGM)), r2 = (int)(__brev((unsigned)k2) >> (32 - LGM));
                     r1 = FFT_PADS(r1, DPS); r2 = FFT_PADS(r2, DPS);
                     const float2 ya1 = cmulc_post(z0[r1], cur.P1), ya2 = cmulc_post(z0[r2], cur.P2);     // channel 0 (M): (Re y, -Im y)
                     const float2 yb1 = cmulc_post(z1[r1], cur.P1), yb2 = cmulc_post(z1[r2], cur.P2);     // channel 1 (S)
@@ -1329,6 +1333,7 @@ static const void *syn_fn(const UlcxDecCtx &cc, bool split) {
     if (!cc.fastOK) return (const void *)k_dgen<OUT>;
     if (cc.BS == 2048 && DSYN_C2048) return split ? (const void *)k_dsyn<OUT, 16, DSYN_TWL != 0, true, 2048> : (const void *)k_dsyn<OUT, 16, DSYN_TWL != 0, false, 2048>;
     if (small) return split ? (const void *)k_dsyn<OUT, 16, DSYN_TWL != 0, true> : (const void *)k_dsyn<OUT, 16, DSYN_TWL != 0, false>;
+    if (cc.BS == 4096 && DSYN_C4096) return split ? (const void *)k_dsyn<OUT, 32, false, true, 4096> : (const void *)k_dsyn<OUT, 32, false, false, 4096>;
     return split ? (const void *)k_dsyn<OUT, 32, false, true> : (const void *)k_dsyn<OUT, 32, false, false>;
 }
 int ulcx_dec_syn_slots(const UlcxDecCtx &c) {
@@ -1351,6 +1356,7 @@ static void launch_syn(const UlcxDecCtx &cc, unsigned g, size_t lds, hipStream_t
     if (!cc.fastOK) hipLaunchKernelGGL(k_dgen<OUT>, dim3(g), dim3(WG), lds, s2, cc);
     else if (cc.BS == 2048 && DSYN_C2048) { if (split) hipLaunchKernelGGL((k_dsyn<OUT, 16, DSYN_TWL != 0, true, 2048>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<OUT, 16, DSYN_TWL != 0, false, 2048>), dim3(g), dim3(WG), lds, s2, cc); }
     else if (small) { if (split) hipLaunchKernelGGL((k_dsyn<OUT, 16, DSYN_TWL != 0, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<OUT, 16, DSYN_TWL != 0, false>), dim3(g), dim3(WG), lds, s2, cc); }
+    else if (cc.BS == 4096 && DSYN_C4096) { if (split) hipLaunchKernelGGL((k_dsyn<OUT, 32, false, true, 4096>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<OUT, 32, false, false, 4096>), dim3(g), dim3(WG), lds, s2, cc); }
     else { if (split) hipLaunchKernelGGL((k_dsyn<OUT, 32, false, true>), dim3(g), dim3(WG), lds, s2, cc); else hipLaunchKernelGGL((k_dsyn<OUT, 32, false, false>), dim3(g), dim3(WG), lds, s2, cc); }
 }
 int ulcx_dec_launch(const UlcxDecCtx &cIn, hipStream_t st, hipEvent_t *ev, const UlcxDecAux &aux) {
