@@ -227,11 +227,8 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         launch_state_update(c, side3);
         CK(hipEventRecord(evState, side3));
     } else { hipLaunchKernelGGL(k_cplx, dim3((NB + 63) / 64), dim3(64), 0, st, c, 0, c.K);                 MARK(); }
-    // the noise chain right behind the transform (it only needs nsum), beside the masking sums; NOISE_ORDER (experiments): 1 = behind
-    // the masking sums' geometry-uniform kernel, 2 = behind k_pbark (beside the selection)
-    static const int noiseOrder = getenv("ULCX_NOISE_ORDER") ? atoi(getenv("ULCX_NOISE_ORDER")) : 0;
-    const bool noiseEarly = noiseAside && noiseOrder != 2;
-    if (noiseEarly && noiseOrder == 0) {
+    const bool noiseEarly = noiseAside;                        // the noise chain right behind the transform (it only needs nsum), beside the masking sums
+    if (noiseEarly) {
         CK(hipStreamWaitEvent(side2, evN0, 0));
         int rcn = launch_noise(side2, false); if (rcn) return rcn;
         CK(hipEventRecord(evNoise, side2));
@@ -240,12 +237,6 @@ int ulcx_enc_launch(const UlcxEncCtx &cIn, hipStream_t st, hipEvent_t *ev, const
         const bool uniP = c.barkRing != 0;                  // masking sums of the un-decimated blocks on the geometry-uniform kernel too
         if (uniP) {
             hipLaunchKernelGGL(k_bark_uniform<false>, dim3((NB + 63) / 64), dim3(256), barkLds, st, c);
-            if (noiseEarly && noiseOrder == 1) {
-                CK(hipEventRecord(evTail0, st));
-                CK(hipStreamWaitEvent(side2, evTail0, 0));
-                int rcn = launch_noise(side2, false); if (rcn) return rcn;
-                CK(hipEventRecord(evNoise, side2));
-            }
             hipLaunchKernelGGL(k_bark_levels<false>, dim3((unsigned)(((size_t)NB * 32 + WG - 1) / WG)), dim3(WG), 0, st, c);
         }
         hipLaunchKernelGGL(k_pbark, dim3((NB * 4 + 63) / 64), dim3(64), 0, st, c, uniP ? 1 : 0);          MARK();
