@@ -34,8 +34,8 @@ def main():
                   "launches_per_step": fc.get(k, 0) / steps_f,
                   "note": "per bench step (all launches of the kernel in one step summed); FETCH_SIZE doubled per MI355X_MICROARCH.md"}
     # stage-name aliases used by bench.py
-    for alias, real in (("k_select", "k_select_wave<64>"), ("k_encode_wave", "k_encode_wave<true>"), ("k_xf", "k_xf<true, float>"),
-                        ("k_wc_energy", "k_wc_energy<float>"), ("k_state_update", "k_state_update<float>"), ("k_dsyn", "k_dsyn<float, 16, false>"), ("k_wc_forward", "k_wc_ef<9, float>")):
+    for alias, real in (("k_select", "k_select_wave<64, 11, 0>"), ("k_encode_wave", "k_encode_wave<true>"), ("k_xf", "k_xf<true, float>"),
+                        ("k_wc_energy", "k_wc_energy<float>"), ("k_state_update", "k_state_update<float>"), ("k_dsyn", "k_dsyn<float, 16, true, false, 2048>"), ("k_wc_forward", "k_wc_ef<9, float>")):
         if real in res: res[alias] = res[real]
     if meta: res["_meta"] = meta
     json.dump(res, open(out, "w"), indent=1)
