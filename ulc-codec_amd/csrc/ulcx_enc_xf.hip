@@ -197,7 +197,13 @@ __device__ __forceinline__ void xf_block(const UlcxEncCtx &c, float *lds, int s,
     __syncthreads();
 
     // the steady state of the headline geometry (and of BlockSize 4096) takes the all-constants path (xf_fast)
-    const bool fastBlk = ST && (BS == 2048 || BS == 4096) && xf_is_fast<IN>(c, s, k);
+    // (the test xf_is_fast() makes, on the window codes and overlaps formed above - not a second round of loads and pattern look-ups)
+#ifdef XF_NO_FAST
+    const bool fastBlk = false;
+#else
+    const bool fastBlk = ST && (BS == 2048 || BS == 4096) && (k >= 2 || std::is_same<IN, float>::value) && (ulcx_pattern(wc) >> 4) == 0
+                         && ovFirst == BS && nextOv >= BS;
+#endif
     if (fastBlk) nnz = (BS == 2048) ? xf_fast<IN, 2048>(c, lds, s, k, blk, tid) : xf_fast<IN, 4096>(c, lds, s, k, blk, tid);
     else
     for (int ch0 = 0; ch0 < C; ch0 += 2) {             // one M/S pair (or a trailing single channel) at a time
