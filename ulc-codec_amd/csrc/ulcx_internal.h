@@ -155,12 +155,13 @@ struct UlcxDecCtx {
 
 // ulcHelper.h:24-46
 __host__ __device__ static inline unsigned ulcx_pattern(int wc) {
-    switch ((wc >> 4) & 15) {
-        case 0: return 0x0000; case 1: return 0x0008; case 2: return 0x0019; case 3: return 0x0091;
-        case 4: return 0x012A; case 5: return 0x01A2; case 6: return 0x02A1; case 7: return 0x0A21;
-        case 8: return 0x123B; case 9: return 0x12B3; case 10: return 0x13B2; case 11: return 0x1B32;
-        case 12: return 0x23B1; case 13: return 0x2B31; case 14: return 0x3B21; default: return 0xB321;
-    }
+    // (ulcHelper.h:24-46, the sixteen patterns packed four to a 64-bit constant and picked by selects and a shift: as a switch
+    //  this became a table in constant memory - a scalar load with its wait at the top of every workgroup of the transform,
+    //  a 64-address gather in the lane-per-block kernels)
+    const unsigned i = ((unsigned)wc >> 4) & 15u;
+    const unsigned long long t0 = 0x0091001900080000ull, t1 = 0x0A2102A101A2012Aull, t2 = 0x1B3213B212B3123Bull, t3 = 0xB3213B212B3123B1ull;
+    const unsigned long long t = (i & 8u) ? ((i & 4u) ? t3 : t2) : ((i & 4u) ? t1 : t0);
+    return (unsigned)(t >> (16u * (i & 3u))) & 0xFFFFu;
 }
 
 // host side (ulcx_tables.cpp)
