@@ -100,6 +100,11 @@ int  ulcx_block_extent_bytes(const void *SrcBuffer, int nChan, int BlockSize, in
  * synthesis kernel (1536 on an MI355X for stereo BlockSize 2048), or 0 = one workgroup per stream.  No reference counterpart
  * (the reference decodes one block per call, ulcDecoder.c:200-302). */
 int  ulcx_dec_split_plan(int nStreams, int nBlocks, int residentWG);
+/* Round 5: a batch of more streams than the device holds workgroups runs in rounds of one workgroup per stream; when the last
+ * round is partly empty (4096 streams on 1536 resident workgroups) only ITS streams are cut, over the returned number of
+ * workgroups at the end of the grid (0: no cut); *full receives the number of leading workgroups that take one whole stream
+ * each.  Host arithmetic, exported for inspection and the tests.  No reference counterpart. */
+int  ulcx_dec_tail_plan(int nStreams, int nBlocks, int residentWG, int *full);
 
 /* ------------------------------------------------------------------------- */
 /* 2. Batched layer                                                           */
@@ -172,6 +177,10 @@ int  ulcx_encoder_debug_fetch(ulcx_encoder *enc, int nBlocks, float *h_coef, flo
 /* Number of blocks of the last call (final pass) whose threshold tie group straddled the
  * cut and went through the exact heapsort emulation (BlockTransform.c:20-77).  Test hook. */
 int  ulcx_encoder_last_fallbacks(ulcx_encoder *enc);
+/* Test hook: how the last decode call's synthesis was launched - workgroups (0: one per stream), how many of them took one
+ * whole stream each (ulcx_dec_tail_plan; 0 for an even cut, ulcx_dec_split_plan), and the workgroups of the synthesis kernel
+ * the device holds at once (0: this geometry runs the general kernel, never cut). */
+int  ulcx_decoder_last_cut(ulcx_decoder *dec, int *workgroups, int *wholeStreams, int *residentWG);
 /* Test hook: from the next call on every `every`-th block of a call (block index % every == 0) is handed to the exact
  * heapsort path whether or not its threshold tie group straddles the cut (0 = off, the default).  The results must not
  * change: the full ranking decides the same kept set.  Exercises that path at a scale natural ties never reach. */

@@ -153,6 +153,27 @@ def test_decoder_split_plan_arithmetic(lib):
     assert f(0, 4, 16) == 0 and f(4, 0, 16) == 0 and f(4, 4, 0) == 0
 
 
+def test_decoder_tail_plan_arithmetic(lib):
+    """ulcx_dec_tail_plan (host arithmetic, round 5): a batch that runs in rounds of one workgroup per stream keeps its whole
+    rounds and cuts only the streams of the partly empty last round, into pieces of 8 blocks (a quarter of a longer call)."""
+    f = lib.ulcx_dec_tail_plan
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]; f.restype = C.c_int
+    full = C.c_int(-1)
+    assert f(4096, 32, 1536, C.byref(full)) == 1024 * 32 // 8 and full.value == 3072     # the bench batch: the last 1024 streams in 4 pieces each
+    assert f(2048, 32, 1536, C.byref(full)) == 512 * 4 and full.value == 1536
+    assert f(1024, 32, 1536, C.byref(full)) == 1024 * 4 and full.value == 0              # one partly empty round: every stream is in it
+    assert f(4096, 256, 1536, C.byref(full)) == 1024 * 4 and full.value == 3072          # a long call: four pieces of 64 blocks
+    assert f(4096, 16, 1536, C.byref(full)) == 0 and full.value == 0                     # two pieces per stream do not pay
+    assert f(3072, 32, 1536, C.byref(full)) == 0                                         # whole rounds only
+    assert f(1536 + 1300, 32, 1536, C.byref(full)) == 0                                  # the last round is more than four fifths full
+    assert f(1, 1, 1536, C.byref(full)) == 0 and f(6, 1, 1536, C.byref(full)) == 0      # the drop-in's shape
+    assert f(0, 32, 16, None) == 0 and f(4, 0, 16, None) == 0 and f(4, 32, 0, None) == 0
+    assert f(100, 33, 64, None) == 36 * 33 // 8
+    for (b, k, r) in [(5, 70, 64), (1000, 29, 100), (70, 24, 8), (1 << 20, 40, 1536)]:
+        n = f(b, k, r, C.byref(full))
+        assert n == 0 or (0 <= full.value < b and full.value % r == 0 and 0 < n <= 4 * r)
+
+
 def test_block_extent_walk_matches_the_decoder_and_never_overreads(lib):
     """ulcx_block_extent_bytes (host code, what ULC_DecodeBlock stages): the byte count equals what the oracle decoder
     consumed, on hand-assembled streams with every code of the syntax and on encoder output - with every block placed

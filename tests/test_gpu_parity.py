@@ -286,6 +286,68 @@ def test_decode_few_long_streams_cut_evenly(bs, rate):
         assert np.array_equal(got[:n * bs], ref_pcm[:n * bs]), f"stream {s}: decoded PCM differs"
 
 
+def test_decode_last_round_cut_into_pieces():
+    """Round 5: a batch of more streams than the device holds synthesis workgroups keeps one workgroup per stream for its whole
+    rounds and cuts the streams of the partly empty last round into pieces of 8 blocks (ulcx_dec_tail_plan).  2536 stereo
+    streams of 26 blocks per call (1536 resident workgroups on an MI355X: 1000 streams in 3250 pieces whose boundaries fall
+    anywhere; with fewer streams in the last round the even cut of the whole batch takes over), two calls (the state arrays swap), a corrupt block inside a cut stream; against the same decoder with the cut
+    switched off (every sample of every stream) and against the oracle on streams of both kinds."""
+    import torch
+    amd = _amd()
+    sys.path.insert(0, ROOT)
+    import bench
+    B, calls, K, ch, bs, rate = 2536, 2, 26, 2, 2048, 44100
+    dev = torch.device("cuda", 0)
+    bench.RATE = rate
+    pcm = bench.make_pcm(torch, B, calls * K * bs, dev, 4242, bursts_per_s=6.0, decades=3.0)
+    enc = amd.BatchEncoder(B, ch, bs, rate, K)
+    slot = enc.slot
+    out = torch.zeros(B, calls * K, slot, dtype=torch.uint8, device=dev)
+    for c in range(calls):
+        o = torch.zeros(B, K, slot, dtype=torch.uint8, device=dev); b = torch.zeros(B, K, dtype=torch.int32, device=dev)
+        enc.encode_dev(pcm[:, c * K * bs:(c + 1) * K * bs].contiguous().data_ptr(), K, o.data_ptr(), b.data_ptr(), 0, 0, mode=0, p0=50.0)
+        torch.cuda.synchronize()
+        out[:, c * K:(c + 1) * K] = o
+    enc.close()
+    dead_s, dead_k = 2100, K + 5
+    out[dead_s, dead_k, 2:40] = 0x11                                  # a stream of the cut part dies in the second call
+    outs = {}
+    cut_seen = False
+    for tail in ("1", "0"):
+        old = os.environ.get("ULCX_DSYN_TAIL")
+        os.environ["ULCX_DSYN_TAIL"] = tail
+        try:
+            dec = amd.BatchDecoder(B, ch, bs, K)
+            dp = torch.zeros(B, calls * K * bs, ch, dtype=torch.float32, device=dev); db = torch.zeros(B, calls * K, dtype=torch.int32, device=dev)
+            for c in range(calls):
+                p = torch.zeros(B, K * bs, ch, dtype=torch.float32, device=dev); b = torch.zeros(B, K, dtype=torch.int32, device=dev)
+                dec.decode_dev(out[:, c * K:(c + 1) * K].contiguous().data_ptr(), slot, K, p.data_ptr(), b.data_ptr())
+                torch.cuda.synchronize()
+                dp[:, c * K * bs:(c + 1) * K * bs] = p; db[:, c * K:(c + 1) * K] = b
+            outs[tail] = (dp, db)
+            grid, whole, resident = dec.last_cut()
+            if tail == "0": assert grid == 0
+            elif 0 < B % resident <= resident * 4 // 5:                # (an MI355X: 1536 resident, 1000 streams in the last round)
+                assert whole == B - B % resident and grid == whole + (B % resident) * K // 8, (grid, whole, resident)
+                cut_seen = True
+            dec.close()
+        finally:
+            if old is None: os.environ.pop("ULCX_DSYN_TAIL", None)
+            else: os.environ["ULCX_DSYN_TAIL"] = old
+    assert cut_seen, "this batch shape is meant to take the cut on an MI355X"
+    assert torch.equal(outs["1"][1], outs["0"][1]), "bits consumed: cut and uncut last round disagree"
+    assert torch.equal(outs["1"][0].view(torch.int32), outs["0"][0].view(torch.int32)), "decoded PCM: cut and uncut last round disagree"
+    for s in (0, 1535, 1536, 1537, 2000, dead_s, dead_s + 1, B - 1):
+        rc, ref_pcm, ref_bits = oracle_decode_stream(out[s].cpu().numpy(), ch, bs)
+        got = outs["1"][0][s].cpu().numpy(); gb = outs["1"][1][s].cpu().numpy()
+        n = calls * K
+        if s == dead_s:
+            assert (gb[dead_k:] == 0).all() and not got[dead_k * bs:].any(), "a dead stream must stay silent"
+            n = dead_k
+        assert np.array_equal(gb[:n], ref_bits[:n]), f"stream {s}: bits consumed differ"
+        assert np.array_equal(got[:n * bs].view(np.uint32), ref_pcm[:n * bs].view(np.uint32)), f"stream {s}: decoded PCM differs"
+
+
 @pytest.mark.parametrize("bs,ch,rate,q", [(2048, 2, 44100, 50.0), (512, 1, 48000, 70.0)])
 def test_decode_block_filling_its_slot_exactly(bs, ch, rate, q):
     """slotBytes = the byte count of the call's largest block (what a caller sizing slots to the container's MaxBlockSize

@@ -15,6 +15,8 @@ while time.time() - t0 < budget:
     bs = int(rng.choice([256, 512, 1024, 2048, 4096]))
     ch = int(rng.choice([1, 2, 2, 3]))
     B = int(rng.integers(1, 12)); K = int(rng.integers(1, 6)); calls = int(rng.integers(1, 4))
+    if rng.random() < 0.25:                       # calls long enough for the synthesis to cut streams into pieces (round 5: ulcx_dec_tail_plan)
+        B = int(rng.integers(1, 6)); K = int(rng.integers(24, 41)); calls = int(rng.integers(1, 3))
     slot = 2 * ch * bs + 16
     streams = [synth_block_stream(int(rng.integers(0, 1 << 30)), calls * K, ch, bs, slot)[0] for _ in range(B)]
     blocks = np.stack(streams)

@@ -44,7 +44,7 @@ struct ulcx_decoder {
     uint8_t *d_pay; int32_t *d_payBytes; long long payStride;     // resident packed payloads (ulcx_decoder_upload_payload)
     // k_dsyn over an even cut of the call's (stream, block) pairs: the second set of state arrays, the resident
     // workgroups of the kernel on this device, ULCX_DSYN_SPLIT=0 switches it off
-    float *lap2; int *lastSub2; uint32_t *seed2; int *dead2; int synSlots; bool splitOK;
+    float *lap2; int *lastSub2; uint32_t *seed2; int *dead2; int synSlots, scratchRows, lastGrid, lastFull; bool splitOK, tailCut;
     // single-block path (ulcx_decode_block1)
     hipStream_t b1Stream; hipGraph_t b1Graph; hipGraphExec_t b1Exec; bool b1Init, b1Graphed, b1NoGraph; int b1Slot;
     uint8_t *pinIn; float *pinPcm; int32_t *pinMeta;
@@ -562,17 +562,51 @@ extern "C" int ulcx_dec_split_plan(int nStreams, int nBlocks, int residentWG) {
     const long long costStream = (((long long)nStreams + residentWG - 1) / residentWG) * nBlocks;
     return (grid >= 1 && grid != nStreams && (per + 1) * 3 < costStream * 2) ? (int)grid : 0;
 }
+// Round 5: a batch runs in rounds of one workgroup per stream, and its last round is partly empty (4096 streams on 1536
+// resident workgroups: 2.67 rounds).  The whole rounds stay as they are - the hardware hands a free slot the next stream,
+// which evens out workgroups of different speed -; only the streams of the last round are cut, into pieces of
+// ULCX_DSYN_TAIL_LEN blocks (a quarter of a longer call's) at the end of the grid, each of which runs one block in front of
+// its range for the lapping state.  What the cut buys is a short end of the launch, what it costs is the extra block per
+// piece.  Measured (profiles/NOTES_r05.md), synthesis of 32 blocks of 4096 / 2048 / 1024 / 5000 streams: 1.50 -> 1.44, 0.89
+// -> 0.75, 0.485 -> 0.45, 1.81 -> 1.76 ms; ONE piece per slot (the even cut of the last round) 1.51, pieces of 4 blocks
+// 1.47-1.49, every stream cut 1.53-1.59; calls of 16 blocks (two pieces per stream) -1 % / +1.5 %: not cut.
+// Returns the number of pieces (0: no cut), *full = the leading workgroups that take one whole stream each.  The cut is
+// taken when the last round is at most four fifths full and a stream has at least three pieces.
+#define ULCX_DSYN_TAIL_LEN 8
+extern "C" int ulcx_dec_tail_plan(int nStreams, int nBlocks, int residentWG, int *full) {
+    if (full) *full = 0;
+    if (nStreams < 1 || nBlocks < 3 * ULCX_DSYN_TAIL_LEN || residentWG < 1) return 0;
+    const int rem = nStreams % residentWG;
+    if (rem == 0 || (long long)rem * 5 > (long long)residentWG * 4) return 0;
+    const int len = nBlocks / 4 > ULCX_DSYN_TAIL_LEN ? nBlocks / 4 : ULCX_DSYN_TAIL_LEN;     // (a long call: four pieces per stream)
+    const long long n = (long long)rem * nBlocks / len;                                      // < 4 residentWG
+    if (full) *full = nStreams - rem;
+    return (int)n;
+}
+extern "C" int ulcx_decoder_last_cut(ulcx_decoder *e, int *workgroups, int *wholeStreams, int *residentWG) {
+    if (!e) return ULCX_ERR_ARG;
+    if (workgroups) *workgroups = e->lastGrid;
+    if (wholeStreams) *wholeStreams = e->lastFull;
+    if (residentWG) *residentWG = e->synSlots;
+    return ULCX_OK;
+}
 static int dec_launch(ulcx_decoder *e, UlcxDecCtx &c, hipStream_t st) {
     UlcxDecAux a;
-    a.synGrid = 0;
+    a.synGrid = 0; a.synFull = 0;
     c.lapO = c.lap; c.lastSubO = c.lastSub; c.seedO = c.seed; c.deadO = c.dead;
     if (e->splitOK && e->synSlots > 0) {
         a.synGrid = ulcx_dec_split_plan(e->B, c.K, e->synSlots);
+        if (!a.synGrid) {
+            int full = 0;
+            const int tail = ulcx_dec_tail_plan(e->B, c.K, e->synSlots, &full);
+            if (tail > 0 && tail <= e->scratchRows && e->tailCut) { a.synGrid = full + tail; a.synFull = full; }
+        }
         if (a.synGrid) {
-            if (getenv("ULCX_DEBUG_PRINT")) fprintf(stderr, "[ulcx] synthesis: %lld (stream, block) pairs over %d workgroups (%d resident)\n", (long long)e->B * c.K, a.synGrid, e->synSlots);
+            if (getenv("ULCX_DEBUG_PRINT")) fprintf(stderr, "[ulcx] synthesis: %lld (stream, block) pairs over %d workgroups (%d of them one stream each; %d resident)\n", (long long)e->B * c.K, a.synGrid, a.synFull, e->synSlots);
             c.lapO = e->lap2; c.lastSubO = e->lastSub2; c.seedO = e->seed2; c.deadO = e->dead2;
         }
     }
+    e->lastGrid = a.synGrid; e->lastFull = a.synFull;
     const int rc = ulcx_dec_launch(c, st, e->timing ? e->ev : nullptr, a);
     if (rc == ULCX_OK && a.synGrid) {
         std::swap(e->ctx.lap, e->lap2); std::swap(e->ctx.lastSub, e->lastSub2); std::swap(e->ctx.seed, e->seed2); std::swap(e->ctx.dead, e->dead2);
@@ -590,7 +624,7 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     e->device = device; e->B = nStreams; e->C = nChan; e->BS = BlockSize; e->maxK = maxBlocksPerCall;
     e->tables = nullptr; e->evOk = false; e->evRecorded = false; e->timing = true;
     e->d_in = nullptr; e->d_in_bytes = 0; e->d_pcm = nullptr; e->d_bits = nullptr; e->d_pay = nullptr; e->d_payBytes = nullptr; e->payStride = 0;
-    e->lap2 = nullptr; e->lastSub2 = nullptr; e->seed2 = nullptr; e->dead2 = nullptr; e->synSlots = 0; e->splitOK = false;
+    e->lap2 = nullptr; e->lastSub2 = nullptr; e->seed2 = nullptr; e->dead2 = nullptr; e->synSlots = 0; e->scratchRows = 0; e->lastGrid = 0; e->lastFull = 0; e->splitOK = false; e->tailCut = true;
     e->b1Init = e->b1Graphed = e->b1NoGraph = false; e->b1Stream = nullptr; e->pinIn = nullptr; e->pinPcm = nullptr; e->pinMeta = nullptr; e->b1Slot = 0;
     UlcxDecCtx &c = e->ctx;
     memset(&c, 0, sizeof(c));
@@ -615,13 +649,15 @@ extern "C" int ulcx_decoder_create(ulcx_decoder **out, int device, int nStreams,
     if (c.fastOK) {                                                       // the kernel keeps the lapping state in global memory: any grid
         bool want = true;
         if (const char *ev = getenv("ULCX_DSYN_SPLIT")) want = ev[0] != '0';
+        if (const char *ev = getenv("ULCX_DSYN_TAIL")) e->tailCut = ev[0] != '0';          // (A/B: the last round uncut)
         e->synSlots = want ? ulcx_dec_syn_slots(c) : 0;
         if (e->synSlots > 0) {
             DA(e->lap2, B * nChan * (BlockSize / 2), true);
             DA(e->lastSub2, B, true);
             DA(e->seed2, B, true);
             DA(e->dead2, B, true);
-            DA(c.lapScratch, (size_t)e->synSlots * nChan * (BlockSize / 2), true);
+            e->scratchRows = 4 * e->synSlots;                              // (an even cut: <= synSlots workgroups; a cut of the last round: < synSlots streams in <= 4 pieces each)
+            DA(c.lapScratch, (size_t)e->scratchRows * nChan * (BlockSize / 2), true);
             e->splitOK = true;
         }
     }

@@ -776,7 +776,9 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
     // ones; the barriers between the two kinds of block order the rest.
     float  *ldsLap = lds + L.zFloats;
     // (one workgroup per stream - grid = streams -: the stream's own rows serve, nothing else touches them during the launch)
-    float  *scr = !LAPG ? ldsLap : !SPLIT ? c.lapO + (size_t)(c.s0 + blockIdx.x) * C * H2 : c.lapScratch + (size_t)blockIdx.x * C * H2;
+    // (a cut launch: the leading workgroups still take one whole stream each and use its rows; the others their own scratch rows)
+    const bool ownStream = !SPLIT || (int)blockIdx.x < c.synFull;
+    float  *scr = !LAPG ? ldsLap : ownStream ? c.lapO + (size_t)(c.s0 + blockIdx.x) * C * H2 : c.lapScratch + (size_t)((int)blockIdx.x - c.synFull) * C * H2;
     float2 *twl  = (float2 *)(lds + L.zFloats + L.lapFloats);        // FFT twiddles: the full-size table, or the three of a decimated block's sizes
     SynWave sw;
     sw.pre  = (int *)(lds + L.zFloats + L.lapFloats + L.twFloats) + wv * (64 + DSYN_PWORDS(BS));
@@ -808,7 +810,12 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
     // the last one a third full), and a few long streams fill the machine too.
     const int Kc = c.k1 - c.k0;
     const long long T = (long long)(c.s1 - c.s0) * Kc;
-    const long long f0 = SPLIT ? T * blockIdx.x / gridDim.x : (long long)blockIdx.x * Kc, f1 = SPLIT ? T * (blockIdx.x + 1) / gridDim.x : f0 + Kc;
+    long long f0 = (long long)blockIdx.x * Kc, f1 = f0 + Kc;
+    if (!ownStream) {
+        const long long base = (long long)c.synFull * Kc, Tr = T - base;
+        const int j = (int)blockIdx.x - c.synFull, n = (int)gridDim.x - c.synFull;
+        f0 = base + Tr * j / n; f1 = base + Tr * (j + 1) / n;
+    }
     if (f0 >= f1) return;
     bool warm = SPLIT && (f0 % Kc) != 0;
     int nTrip = (int)(f1 - f0) + (warm ? 1 : 0);
@@ -1376,6 +1383,7 @@ int ulcx_dec_launch(const UlcxDecCtx &cIn, hipStream_t st, hipEvent_t *ev, const
     if (!(ULCX_DBG(c) & 8)) {
         const bool split = c.fastOK && aux.synGrid > 0;
         const unsigned g = split ? (unsigned)aux.synGrid : (unsigned)c.B;
+        c.synFull = split ? aux.synFull : 0;
         if (c.pcm16) launch_syn<int16_t>(c, g, lds, st, split); else launch_syn<float>(c, g, lds, st, split);
     }
     if (ev) CK(hipEventRecord(ev[stage++], st));

@@ -129,7 +129,8 @@ struct UlcxDecCtx {
     // workgroup that enters a stream in the middle reads the state in front of the launch while the one that finishes the
     // stream writes the new one); the host swaps the two sets afterwards.  Without a split both sets are the same arrays.
     float *lapO; int *lastSubO; uint32_t *seedO; int *deadO;
-    float *lapScratch;                   // [grid][C][BS/2] a workgroup's own lapping state between its blocks
+    float *lapScratch;                   // [cut workgroups][C][BS/2] a workgroup's own lapping state between its blocks
+    int    synFull;                      // cut launches: the first synFull workgroups take one whole stream each, the rest an even cut of the remaining streams
     int    k0, k1;                       // blocks [k0, k1) of every stream this synthesis launch works on
     // per-call scratch: what the scan leaves for the synthesis (ulcx_dec.hip)
     int   *wcScan;                       // [NB] WindowCtrl as the scan saw it (0 = corrupt)
@@ -191,7 +192,8 @@ struct UlcxEncAux {
 };
 int ulcx_enc_launch(const UlcxEncCtx &c, hipStream_t st, hipEvent_t *ev /* ULCX_ENC_STAGES+1 or NULL */, const UlcxEncAux &aux);
 struct UlcxDecAux {
-    int synGrid;                         // > 0: workgroups of the synthesis over an even cut of the (stream, block) pairs; 0: one per stream
+    int synGrid;                         // > 0: workgroups of the synthesis over a cut of the (stream, block) pairs; 0: one per stream
+    int synFull;                         // of those, the leading ones that take one whole stream each (0: an even cut of everything)
 };
 int ulcx_dec_launch(const UlcxDecCtx &c, hipStream_t st, hipEvent_t *ev, const UlcxDecAux &aux);
 size_t ulcx_dec_lds_bytes(int BS, int C, int fast, int twInLds);

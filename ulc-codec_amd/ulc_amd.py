@@ -21,7 +21,7 @@ EXPORTS = [
     "ulcx_encoder_slot_bytes", "ulcx_encode_dev", "ulcx_encode_dev_pcm16", "ulcx_encode_host", "ulcx_encoder_debug_fetch",
     "ulcx_decoder_create", "ulcx_decoder_destroy", "ulcx_decoder_reset", "ulcx_decode_dev", "ulcx_decode_dev_pcm16", "ulcx_decode_host",
     "ulcx_encoder_last_fallbacks", "ulcx_encoder_debug_force_exact", "ulcx_ulc_header_pack", "ulcx_ulc_header_parse", "ulcx_ulc_rate_kbps",
-    "ulcx_pack_streams_dev", "ulcx_decode_packed_dev", "ulcx_decode_packed_host", "ulcx_decoder_upload_payload", "ulcx_decode_resident_host", "ulcx_encoder_stage_ms", "ulcx_encoder_stage_name", "ulcx_encoder_last_xf_launches", "ulcx_decoder_stage_ms", "ulcx_decoder_stage_name", "ulcx_block_extent_bytes", "ulcx_encoder_set_timing", "ulcx_decoder_set_timing", "ulcx_encode_block1", "ulcx_decode_block1", "ulcx_decode_block1_rng", "ulcx_build_rev", "ulcx_dec_split_plan",
+    "ulcx_pack_streams_dev", "ulcx_decode_packed_dev", "ulcx_decode_packed_host", "ulcx_decoder_upload_payload", "ulcx_decode_resident_host", "ulcx_encoder_stage_ms", "ulcx_encoder_stage_name", "ulcx_encoder_last_xf_launches", "ulcx_decoder_stage_ms", "ulcx_decoder_stage_name", "ulcx_block_extent_bytes", "ulcx_encoder_set_timing", "ulcx_decoder_set_timing", "ulcx_encode_block1", "ulcx_decode_block1", "ulcx_decode_block1_rng", "ulcx_build_rev", "ulcx_dec_split_plan", "ulcx_dec_tail_plan", "ulcx_decoder_last_cut",
 ]
 
 
@@ -59,6 +59,8 @@ def lib():
         l.ulcx_decode_dev_pcm16.argtypes = l.ulcx_decode_dev.argtypes
         l.ulcx_decode_host.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, _f32p, _i32p]
         l.ulcx_encoder_last_fallbacks.argtypes = [C.c_void_p]
+        l.ulcx_decoder_last_cut.argtypes = [C.c_void_p, _i32p, _i32p, _i32p]
+        l.ulcx_dec_tail_plan.argtypes = [C.c_int, C.c_int, C.c_int, _i32p]
         l.ulcx_encoder_debug_force_exact.argtypes = [C.c_void_p, C.c_int]
         l.ulcx_decode_packed_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         l.ulcx_decode_packed_host.argtypes = [C.c_void_p, _u8p, C.c_longlong, _i32p, C.c_int, _f32p, _i32p]
@@ -197,6 +199,12 @@ class BatchDecoder:
             self.close()
         except Exception:
             pass
+
+    def last_cut(self):
+        """(workgroups of the last call's synthesis or 0 = one per stream, leading whole-stream workgroups, resident workgroups)"""
+        g, f, r = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        _check(lib().ulcx_decoder_last_cut(self.h, C.byref(g), C.byref(f), C.byref(r)), "ulcx_decoder_last_cut")
+        return g.value, f.value, r.value
 
     def reset(self):
         _check(lib().ulcx_decoder_reset(self.h), "ulcx_decoder_reset")
