@@ -421,11 +421,15 @@ __host__ __device__ static inline size_t nsums_lds_bytes(int N, int C) {
 // what still does not fit goes to the serial kernel.
 struct WaveCaps { int k, z, nyb; };
 
+#ifndef WAVE_SK
 #define WAVE_SK 512
-
+#endif
+#ifndef WAVE_SZ
 #define WAVE_SZ 128
-
-#define WAVE_SN 2048
+#endif
+#ifndef WAVE_SN
+#define WAVE_SN 1280                                       // (round 5: 2048 -> 1280, 7 360 -> 6 592 bytes per wave: six workgroups per CU)
+#endif
 
 __host__ __device__ static inline int wavecaps_lds(const WaveCaps &w) { return w.k * 4 + w.z * 8 + w.k * 4 + w.z + w.nyb + 64; }
 
@@ -520,8 +524,15 @@ __global__ void k_keep_ranks(UlcxEncCtx c, int finalPass);
 __global__ void k_nsums(UlcxEncCtx c, int finalPass);
 __global__ void k_tails(UlcxEncCtx c, int finalPass);
 __global__ void k_encode_units(UlcxEncCtx c, int finalPass);
+// (the bound has to be on THIS declaration: on the definition alone it is dropped without a word, and the kernel ran at
+//  88 registers = five waves per SIMD.  Six - 80 registers, 12 bytes of spills, and a workgroup's LDS down from 29.4 to 26.4 KB
+//  so that six fit a CU - take the small-capacity launch from 1.30 to 1.15 ms; seven and eight are no faster.  The
+//  full-capacity retry holds a CU's whole LDS: one workgroup per CU, no bound.)
+#ifndef EW_LB
+#define EW_LB 6
+#endif
 template <bool SMALL>
-__global__ void k_encode_wave(UlcxEncCtx c, int finalPass, WaveCaps caps, int phase);
+__global__ __launch_bounds__(256, SMALL ? EW_LB : 1) void k_encode_wave(UlcxEncCtx c, int finalPass, WaveCaps caps, int phase);
 extern template __global__ void k_encode_wave<false>(UlcxEncCtx, int, WaveCaps, int);
 extern template __global__ void k_encode_wave<true>(UlcxEncCtx, int, WaveCaps, int);
 __global__ void k_rate_step(UlcxEncCtx c);

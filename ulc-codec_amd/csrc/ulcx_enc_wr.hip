@@ -926,7 +926,7 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
 // 4 waves per workgroup (single-wave workgroups are dispatch-rate bound: ~12 ns each on MI355X),
 // one wave per (block, channel), looping over that channel's subblocks.
 template <bool SMALL>
-__global__ __launch_bounds__(256) void k_encode_wave(UlcxEncCtx c, int finalPass, WaveCaps caps, int phase) {
+__global__ __launch_bounds__(256, SMALL ? EW_LB : 1) void k_encode_wave(UlcxEncCtx c, int finalPass, WaveCaps caps, int phase) {
     if (probes_over(c, finalPass)) return;
     extern __shared__ float e2all[];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wv: wave-uniform, so is all unit geometry
