@@ -9,7 +9,7 @@ dev = torch.device("cuda", 0)
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 B = 4096
-pcm = bench.make_pcm(torch, B, K * 2048, dev, seed=1234)
+pcm = bench.make_pcm(torch, B, K * 2048, dev, seed=1234, bursts_per_s=float(os.environ.get('ENC_BENCH_BURSTS', '4.0')))      # (ENC_BENCH_BURSTS=0: one burst per stream - nearly every block in the steady state)
 enc = ulc_amd.BatchEncoder(B, 2, 2048, 44100, K)
 slot = enc.slot
 d_out = torch.zeros(B * K * slot, dtype=torch.uint8, device=dev); d_bits = torch.zeros(B * K, dtype=torch.int32, device=dev)

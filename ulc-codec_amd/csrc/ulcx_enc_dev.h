@@ -455,25 +455,25 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
 
 // ---- kernels (defined in the unit named in ulcx_enc.hip's header comment)
 template <typename IN>
-__global__ void k_wc_energy(UlcxEncCtx c, int k0, int k1);
+__global__ __launch_bounds__(WG) void k_wc_energy(UlcxEncCtx c, int k0, int k1);
 extern template __global__ void k_wc_energy<float>(UlcxEncCtx, int, int);
 extern template __global__ void k_wc_energy<int16_t>(UlcxEncCtx, int, int);
 __global__ void k_wc_forward(UlcxEncCtx c, int k0, int k1);
 template <int NW, typename IN>
-__global__ void k_wc_ef(UlcxEncCtx c, int k0, int k1);
+__global__ __launch_bounds__(NW * 64) void k_wc_ef(UlcxEncCtx c, int k0, int k1);
 extern template __global__ void k_wc_ef<EF_NW, float>(UlcxEncCtx, int, int);
 extern template __global__ void k_wc_ef<EF_NW, int16_t>(UlcxEncCtx, int, int);
 __global__ void k_wc_backward(UlcxEncCtx c, int k0, int k1);
 __global__ void k_wc_integrate(UlcxEncCtx c, int k0, int k1);
 __global__ void k_wc_decide(UlcxEncCtx c, int k0, int k1);
 template <bool ST, typename IN>
-__global__ void k_xf(UlcxEncCtx c, int k0, int k1);
+__global__ __launch_bounds__(WG, 4) void k_xf(UlcxEncCtx c, int k0, int k1);
 extern template __global__ void k_xf<false, float>(UlcxEncCtx, int, int);
 extern template __global__ void k_xf<false, int16_t>(UlcxEncCtx, int, int);
 extern template __global__ void k_xf<true, float>(UlcxEncCtx, int, int);
 extern template __global__ void k_xf<true, int16_t>(UlcxEncCtx, int, int);
 template <typename IN>
-__global__ void k_xf_big(UlcxEncCtx c, int k0, int k1);
+__global__ __launch_bounds__(WG) void k_xf_big(UlcxEncCtx c, int k0, int k1);
 extern template __global__ void k_xf_big<float>(UlcxEncCtx, int, int);
 extern template __global__ void k_xf_big<int16_t>(UlcxEncCtx, int, int);
 __global__ void k_cplx(UlcxEncCtx c, int k0, int k1);
@@ -481,17 +481,22 @@ __global__ void k_nbark(UlcxEncCtx c, int useList);
 __global__ void k_nline(UlcxEncCtx c);
 __global__ void k_pbark(UlcxEncCtx c, int useList);
 template <bool NOISE>
-__global__ void k_bark_uniform(UlcxEncCtx c);
+__global__ __launch_bounds__(256) void k_bark_uniform(UlcxEncCtx c);
 extern template __global__ void k_bark_uniform<false>(UlcxEncCtx);
 extern template __global__ void k_bark_uniform<true>(UlcxEncCtx);
 template <bool NOISE>
-__global__ void k_bark_levels(UlcxEncCtx c);
+__global__ __launch_bounds__(WG) void k_bark_levels(UlcxEncCtx c);
 extern template __global__ void k_bark_levels<false>(UlcxEncCtx);
 extern template __global__ void k_bark_levels<true>(UlcxEncCtx);
 __global__ void k_keys_finalize(UlcxEncCtx c);
 __global__ void k_select(UlcxEncCtx c, int finalPass);
+// A kernel TEMPLATE's __launch_bounds__ must stand on the declaration its explicit instantiations see: written on the
+// definition alone they are dropped without a word and the kernel is compiled for 1024-thread workgroups - 128 registers at
+// most (round 5 found k_select_wave<128, ...> spilling 340 bytes under that cap after the split into translation units).
+// The selection keeps its keys in registers: R = 64 takes 78 (the headline instantiation: six waves per SIMD) to 96, R = 128 140-160.
+#define SEL_MINW(R, LGBS, PASS) ((R) >= 128 ? 2 : ((R) == 64 && !((LGBS) == 11 && (PASS) == 0)) ? 5 : 6)
 template <int R, int LGBS = 0, int PASS = 0>
-__global__ void k_select_wave(UlcxEncCtx c, int finalPass);
+__global__ __launch_bounds__(256, SEL_MINW(R, LGBS, PASS)) void k_select_wave(UlcxEncCtx c, int finalPass);
 extern template __global__ void k_select_wave<128, 0, 0>(UlcxEncCtx, int);
 extern template __global__ void k_select_wave<128, 0, 1>(UlcxEncCtx, int);
 extern template __global__ void k_select_wave<128, 0, 2>(UlcxEncCtx, int);
@@ -514,7 +519,7 @@ extern template __global__ void k_select_wave<8, 0, 0>(UlcxEncCtx, int);
 extern template __global__ void k_select_wave<8, 0, 1>(UlcxEncCtx, int);
 extern template __global__ void k_select_wave<8, 0, 2>(UlcxEncCtx, int);
 template <int R, int LGBS = 0, int PASS = 0>
-__global__ void k_select_pair(UlcxEncCtx c, int finalPass);
+__global__ __launch_bounds__(128) void k_select_pair(UlcxEncCtx c, int finalPass);
 extern template __global__ void k_select_pair<64, 12, 0>(UlcxEncCtx, int);
 extern template __global__ void k_select_pair<64, 12, 1>(UlcxEncCtx, int);
 extern template __global__ void k_select_pair<64, 12, 2>(UlcxEncCtx, int);
@@ -538,6 +543,6 @@ extern template __global__ void k_encode_wave<true>(UlcxEncCtx, int, WaveCaps, i
 __global__ void k_rate_step(UlcxEncCtx c);
 __global__ void k_pack(UlcxEncCtx c, int finalPass);
 template <typename IN>
-__global__ void k_state_update(UlcxEncCtx c);
+__global__ __launch_bounds__(WG) void k_state_update(UlcxEncCtx c);
 extern template __global__ void k_state_update<float>(UlcxEncCtx);
 extern template __global__ void k_state_update<int16_t>(UlcxEncCtx);

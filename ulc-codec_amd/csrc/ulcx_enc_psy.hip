@@ -598,7 +598,7 @@ __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, 
 
 // One WAVE per block, four blocks per workgroup
 template <int R, int LGBS, int PASS>
-__global__ __launch_bounds__(256) void k_select_wave(UlcxEncCtx c, int finalPass) {
+__global__ __launch_bounds__(256, SEL_MINW(R, LGBS, PASS)) void k_select_wave(UlcxEncCtx c, int finalPass) {
     if (probes_over(c, finalPass)) return;
     extern __shared__ float sel_lds[];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
