@@ -335,6 +335,17 @@ def test_decode_last_round_cut_into_pieces():
             if old is None: os.environ.pop("ULCX_DSYN_TAIL", None)
             else: os.environ["ULCX_DSYN_TAIL"] = old
     assert cut_seen, "this batch shape is meant to take the cut on an MI355X"
+    # the PCM16-output instantiation of the cut kernel: lrintf(clamp(y * 2^15)) of the float path's output (tools/WavIO_Helper.c:56-63)
+    dec = amd.BatchDecoder(B, ch, bs, K)
+    for c in range(calls):
+        p16 = torch.zeros(B, K * bs, ch, dtype=torch.int16, device=dev); b = torch.zeros(B, K, dtype=torch.int32, device=dev)
+        dec.decode_dev_pcm16(out[:, c * K:(c + 1) * K].contiguous().data_ptr(), slot, K, p16.data_ptr(), b.data_ptr())
+        torch.cuda.synchronize()
+        yf = outs["1"][0][:, c * K * bs:(c + 1) * K * bs]
+        want16 = torch.clamp(torch.round(yf * 32768.0), -32768, 32767).to(torch.int16)
+        assert torch.equal(p16, want16), f"call {c}: PCM16 output of the cut launch differs from lrintf(clamp(y*2^15))"
+    assert dec.last_cut()[0] > 0
+    dec.close()
     assert torch.equal(outs["1"][1], outs["0"][1]), "bits consumed: cut and uncut last round disagree"
     assert torch.equal(outs["1"][0].view(torch.int32), outs["0"][0].view(torch.int32)), "decoded PCM: cut and uncut last round disagree"
     for s in (0, 1535, 1536, 1537, 2000, dead_s, dead_s + 1, B - 1):
