@@ -156,6 +156,55 @@ def cpu_baseline(sample_pcm, n_blocks, cfg, legs, target_seconds=8.0):
                       f"without contraction is bit-identical and within a few per cent: DESIGN.md §8)"}
 
 
+def run_secondary(torch, ulc_amd, dev, name, B, K, steps=3):
+    """One short run of another BASELINE configuration at one GPU's share (outside the headline's timed region): so that a
+    regression in the rate search (cbr64_48k) or in the BlockSize-4096 / window-switching kernels (wswitch_4096) shows in the
+    driver's line.  A step = encode K blocks of B streams, then decode them; wall clock around `steps` steps after one warm-up,
+    the legs from the library's own hipEvents of one more step."""
+    global RATE
+    cfg = CONFIGS[name]
+    bs, rate = cfg["bs"], cfg["rate"]
+    keep_rate, RATE = RATE, rate
+    try:
+        pcm = make_pcm(torch, B, K * bs, dev, seed=4321, bursts_per_s=cfg["bursts"], decades=cfg["decades"])
+    finally:
+        RATE = keep_rate
+    enc = ulc_amd.BatchEncoder(B, CH, bs, rate, K, device=dev.index)
+    dec = ulc_amd.BatchDecoder(B, CH, bs, K, device=dev.index)
+    slot = enc.slot
+    d_out = torch.zeros(B * K * slot, dtype=torch.uint8, device=dev); d_bits = torch.zeros(B * K, dtype=torch.int32, device=dev)
+    d_dec = torch.zeros(B * K * bs * CH, dtype=torch.float32, device=dev); d_dbits = torch.zeros(B * K, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    emode = ulc_amd.MODE_VBR if cfg["mode"] == "vbr" else ulc_amd.MODE_CBR
+
+    def step():
+        enc.encode_dev(pcm.data_ptr(), K, d_out.data_ptr(), d_bits.data_ptr(), mode=emode, p0=cfg["p0"], stream=stream)
+        dec.decode_dev(d_out.data_ptr(), slot, K, d_dec.data_ptr(), d_dbits.data_ptr(), stream=stream)
+
+    enc.set_timing(False); dec.set_timing(False)
+    step(); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    enc.set_timing(True); dec.set_timing(True)
+    step(); torch.cuda.synchronize(dev)
+    enc_ms = sum(enc.stage_ms().values()); dec_ms = sum(dec.stage_ms().values())
+    bits_h = d_bits.cpu().numpy(); dbits_h = d_dbits.cpu().numpy()
+    ok = bool((dbits_h > 0).all() and (dbits_h <= bits_h).all())
+    res = {"workload": f"{name} ({cfg['ref']}) at one GPU's share: {B} streams x {K} blocks, BlockSize={bs}, "
+                       + ("VBR -%g" % cfg["p0"] if cfg["mode"] == "vbr" else "CBR %g kbps" % cfg["p0"]) + f", {rate / 1000:g} kHz stereo",
+           "steps": steps, "ms_per_step": ms, "encode_ms": enc_ms, "decode_ms": dec_ms, "decode_ok": ok,
+           "Msamples_s": B * K * bs * CH / (ms * 1e-3) / 1e6, "mean_block_bytes": float(bits_h.mean()) / 8.0}
+    if cfg["mode"] != "vbr":
+        budget = int((bs * cfg["p0"]) * 1000.0 / rate)
+        res["cbr_budget_bits"] = budget
+        res["cbr_max_block_bits"] = int(bits_h.max())
+    enc.close(); dec.close()
+    return res
+
+
 def self_launch(n):
     """Start n ranks of this script (one per GPU) and wait for them.  The launcher process initialises no GPU runtime (a
     process that has must not be replaced or forked); rank r gets LOCAL_RANK = r and talks to the others over 127.0.0.1."""
@@ -208,8 +257,10 @@ def main():
     ap.add_argument("--total-streams", type=int, default=0, help="fixed-total (strong-scaling) configurations: the total split over the GPUs "
                     "(default: the config's: 32768 / 16384); a reduced total is a test run, never a result line for BASELINE's configuration")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other two configurations that the default "
+                    "1-GPU headline run appends as `secondary` (outside the timed region)")
     ap.add_argument("--pmc-summary", default="", help="tools/pmc_summary.py output of a rocprofv3 --pmc run of THIS command: fills roofline.traffic "
-                    "(default: the committed profiles/r05_pmc_summary.json when its _meta.src_rev equals the library's ulcx_build_rev() "
+                    "(default: the committed profiles/r06_pmc_summary.json when its _meta.src_rev equals the library's ulcx_build_rev() "
                     "and its workload is this one; null otherwise)")
     ap.add_argument("--pcm16", action="store_true", help="separate configuration (SURVEY.md 8f rank 4): PCM16 ingest and PCM16 output "
                     "fused into the first/last kernel instead of the C API's f32; NOT the headline line")
@@ -370,10 +421,10 @@ def main():
     traffic, traffic_src = None, None
     # HBM bytes of the roofline kernel: the PMC counters cannot be collected inside a timed run, so the figure comes from the
     # counter summary of the SAME command (tools/pmc_summary.py over separate FETCH_SIZE / WRITE_SIZE passes): the one handed in
-    # with --pmc-summary, else the committed profiles/r05_pmc_summary.json - and that one ONLY when it was taken on exactly the
+    # with --pmc-summary, else the committed profiles/r06_pmc_summary.json (or r05's) - and that one ONLY when it was taken on exactly the
     # sources this library is built from (`_meta.src_rev` == ulcx_build_rev()) and on this workload.  Anything else: null.
     lib_rev = ulc_amd.build_rev()
-    cands = [args.pmc_summary] if args.pmc_summary else [os.path.join(ROOT, "profiles", "r05_pmc_summary.json")]
+    cands = [args.pmc_summary] if args.pmc_summary else [os.path.join(ROOT, "profiles", f) for f in ("r06_pmc_summary.json", "r05_pmc_summary.json")]
     for pmc_path in cands:
         if not (pmc_path and os.path.exists(pmc_path)):
             continue
@@ -384,7 +435,7 @@ def main():
             same_src = meta.get("src_rev") == lib_rev and lib_rev != "unknown"
             same_work = (meta.get("config") == args.config and meta.get("mode") == args.mode and meta.get("blocks") == K and meta.get("streams") == B and world == 1 and not args.pcm16)
             ent = js.get(kname, {})
-            if ent.get("hbm_bytes_per_launch") is not None and (same_run or (same_src and same_work)):
+            if traffic is None and ent.get("hbm_bytes_per_launch") is not None and (same_run or (same_src and same_work)):
                 traffic = ent["hbm_bytes_per_launch"] / launches
                 traffic_src = os.path.relpath(pmc_path, ROOT) + " (src_rev %s%s)" % (meta.get("src_rev", "?"), ", git %s" % meta["git"] if meta.get("git") else "")
         except Exception:
@@ -402,6 +453,18 @@ def main():
         S = 8
         sample = pcm[:S].cpu().numpy()
         cpu = cpu_baseline(sample, K, cfg, legs)
+
+    # the other two configurations, short and outside the timed region: only on the driver's shape of run (headline config,
+    # both legs, one GPU, the C API's f32)
+    secondary = None
+    if (rank == 0 and world == 1 and args.config == "vbr50" and args.mode == "both" and not args.pcm16 and not args.no_secondary
+            and not args.streams and not args.blocks):
+        secondary = {}
+        for nm, (sb, sk) in {"cbr64_48k": (CONFIGS["cbr64_48k"]["total"] // 8, 16), "wswitch_4096": (CONFIGS["wswitch_4096"]["total"] // 8, 16)}.items():
+            try:
+                secondary[nm] = run_secondary(torch, ulc_amd, dev, nm, sb, sk)
+            except Exception as e:                           # (never loses the headline line)
+                secondary[nm] = {"error": repr(e)}
 
     if rank == 0:
         what = {"both": "encode+decode", "encode": "encode", "decode": "decode"}[args.mode]
@@ -434,6 +497,8 @@ def main():
                                "mean_block_bytes": mean_bytes, "decode_ok": ok},
             "kernels_ms": {**{f"enc.{k_}": round(v, 4) for k_, v in acc_enc.items()}, **{f"dec.{k_}": round(v, 4) for k_, v in acc_dec.items()}},
         }
+        if secondary is not None:
+            line["secondary"] = secondary
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line))

@@ -16,6 +16,109 @@
 static inline float absf(float x) { return x < 0 ? -x : x; }
 
 /* ========================================================================== */
+/* The five call sites of the functions the real reference can supply          */
+/* ========================================================================== */
+/* BlockTransform.c:115,286,329 and Encode.c:153,284 call ULCi_GetWindowCtrl, ULCi_CalculateNoiseLogSpectrum,
+ * ULCi_CalculatePsychoacoustics, ULCi_GetNoiseQ and ULCi_GetHFExtParams - the functions of the three reference sources that
+ * compile from their own text (oracle/Makefile).  Built with -DORC_REFLOOP (oracle/_ref/liboracle_refloop.so, only where
+ * /root/reference is mounted) the restatement below calls the REAL functions at those sites - same pointers, same aliasing
+ * (MaskingNp over SampleBuffer, BufferAmp2 in the upper half of TransformTemp), same Band / N conventions - instead of its
+ * own orc_* versions; everything else (transforms, sort, writer, rate control) stays the restatement.  Either build folds
+ * what goes into and comes out of every call into a digest per site (FNV-1a, 64 bit; orc_site_*), so that "the restatement
+ * equals the real function on every input the configurations feed it, in situ" is a comparison of ten numbers, and - through
+ * the committed digests of the refloop build (tests/golden/refloop_digests.json) - also runs where the reference is absent. */
+#ifdef ORC_REFLOOP
+struct ULC_TransientData_t;
+extern int  ULCi_GetWindowCtrl(const float *BlockData, struct ULC_TransientData_t *TransientBuffer, float *TransientFilter,
+                               float *TmpBuffer, int BlockSize, int nChan, int RateHz);          /* ulcEncoder_Internals.h:37 */
+extern void ULCi_CalculatePsychoacoustics(float *MaskingNp, float *BufferAmp2, void *BufferTemp, int BlockSize, int RateHz,
+                                          uint32_t WindowCtrl);                                  /* ulcEncoder_Internals.h:59 */
+extern void ULCi_CalculateNoiseLogSpectrum(float *Data, void *Temp, int N, int RateHz);          /* ulcEncoder_Internals.h:76 */
+extern int  ULCi_GetNoiseQ(const float *Data, int Band, int N, float q);                         /* ulcEncoder_Internals.h:79 */
+extern void ULCi_GetHFExtParams(const float *Data, int Band, int N, float q, int *NoiseQ, int *NoiseDecay);   /* :82 */
+#define SITE_IMPL_WC(a, b, c, d, e, f, g) ULCi_GetWindowCtrl(a, (struct ULC_TransientData_t *)(b), c, d, e, f, g)
+#define SITE_IMPL_NLS   ULCi_CalculateNoiseLogSpectrum
+#define SITE_IMPL_PSY   ULCi_CalculatePsychoacoustics
+#define SITE_IMPL_NQ    ULCi_GetNoiseQ
+#define SITE_IMPL_HF    ULCi_GetHFExtParams
+int orc_site_is_refloop(void) { return 1; }
+#else
+#define SITE_IMPL_WC    orc_get_window_ctrl
+#define SITE_IMPL_NLS   orc_calc_noise_log_spectrum
+#define SITE_IMPL_PSY   orc_calc_psychoacoustics
+#define SITE_IMPL_NQ    orc_get_noise_q
+#define SITE_IMPL_HF    orc_get_hfext_params
+int orc_site_is_refloop(void) { return 0; }
+#endif
+
+enum { SITE_WC, SITE_NLS, SITE_PSY, SITE_NQ, SITE_HF, SITE_N };
+static __thread int      site_on;
+static __thread uint64_t site_dig[SITE_N];
+static __thread int64_t  site_cnt[SITE_N];
+static void site_fold(int s, const void *p, size_t n) {
+    const uint8_t *b = (const uint8_t *)p;
+    uint64_t h = site_dig[s];
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001B3ull; }
+    site_dig[s] = h;
+}
+static void site_fold_i(int s, int32_t v) { site_fold(s, &v, 4); }
+/* digests of the calling thread; on = 0 (default) costs one test per call */
+void orc_site_reset(int on) {
+    site_on = on;
+    for (int s = 0; s < SITE_N; s++) { site_dig[s] = 0xCBF29CE484222325ull; site_cnt[s] = 0; }
+}
+void orc_site_digests(uint64_t dig[5], int64_t cnt[5]) {
+    for (int s = 0; s < SITE_N; s++) { dig[s] = site_dig[s]; cnt[s] = site_cnt[s]; }
+}
+
+static int site_get_window_ctrl(const float *BlockData, orc_transient_t *TransientBuffer, float *TransientFilter,
+                                float *TmpBuffer, int BlockSize, int nChan, int RateHz) {
+    if (site_on) {
+        site_fold(SITE_WC, BlockData, sizeof(float) * 2 * (size_t)nChan * BlockSize);
+        site_fold(SITE_WC, TransientBuffer, sizeof(orc_transient_t) * ORC_MAX_DECIMATION * 2);
+        site_fold(SITE_WC, TransientFilter, sizeof(float) * 3);
+        site_fold_i(SITE_WC, BlockSize); site_fold_i(SITE_WC, nChan); site_fold_i(SITE_WC, RateHz);
+    }
+    int r = SITE_IMPL_WC(BlockData, TransientBuffer, TransientFilter, TmpBuffer, BlockSize, nChan, RateHz);
+    if (site_on) {
+        site_fold_i(SITE_WC, r);
+        site_fold(SITE_WC, TransientBuffer, sizeof(orc_transient_t) * ORC_MAX_DECIMATION * 2);
+        site_fold(SITE_WC, TransientFilter, sizeof(float) * 3);
+        site_cnt[SITE_WC]++;
+    }
+    return r;
+}
+static void site_calc_noise_log_spectrum(float *Data, void *Temp, int N, int RateHz) {
+    if (site_on) { site_fold(SITE_NLS, Data, sizeof(float) * (size_t)(N / 2)); site_fold_i(SITE_NLS, N); site_fold_i(SITE_NLS, RateHz); }
+    SITE_IMPL_NLS(Data, Temp, N, RateHz);
+    if (site_on) { site_fold(SITE_NLS, Data, sizeof(float) * (size_t)N); site_cnt[SITE_NLS]++; }
+}
+static void site_calc_psychoacoustics(float *MaskingNp, float *BufferAmp2, void *BufferTemp, int BlockSize, int RateHz, uint32_t WindowCtrl) {
+    if (site_on) {
+        site_fold(SITE_PSY, BufferAmp2, sizeof(float) * (size_t)(BlockSize / 2));
+        site_fold_i(SITE_PSY, BlockSize); site_fold_i(SITE_PSY, RateHz); site_fold_i(SITE_PSY, (int32_t)WindowCtrl);
+    }
+    SITE_IMPL_PSY(MaskingNp, BufferAmp2, BufferTemp, BlockSize, RateHz, WindowCtrl);
+    if (site_on) { site_fold(SITE_PSY, MaskingNp, sizeof(float) * (size_t)(BlockSize / 2)); site_cnt[SITE_PSY]++; }
+}
+/* what the two noise-fill functions read: the pairs from Band / 2 * 2 on, (N + (Band & 1) + 1) / 2 of them (NoiseFill.c:17-18, 68-69) */
+static void site_fold_pairs(int s, const float *Data, int Band, int N, float q) {
+    site_fold(s, Data + Band / 2 * 2, sizeof(float) * 2 * (size_t)((N + (Band & 1) + 1) / 2));
+    site_fold_i(s, Band); site_fold_i(s, N); site_fold(s, &q, 4);
+}
+static int site_get_noise_q(const float *Data, int Band, int N, float q) {
+    if (site_on) site_fold_pairs(SITE_NQ, Data, Band, N, q);
+    int r = SITE_IMPL_NQ(Data, Band, N, q);
+    if (site_on) { site_fold_i(SITE_NQ, r); site_cnt[SITE_NQ]++; }
+    return r;
+}
+static void site_get_hfext_params(const float *Data, int Band, int N, float q, int *NoiseQ, int *NoiseDecay) {
+    if (site_on) site_fold_pairs(SITE_HF, Data, Band, N, q);
+    SITE_IMPL_HF(Data, Band, N, q, NoiseQ, NoiseDecay);
+    if (site_on) { site_fold_i(SITE_HF, *NoiseQ); site_fold_i(SITE_HF, *NoiseDecay); site_cnt[SITE_HF]++; }
+}
+
+/* ========================================================================== */
 /* Shared inline math: /root/reference/libulc/ulcHelper.h                      */
 /* ========================================================================== */
 
@@ -395,7 +498,7 @@ static int write_zone(int cur, int end, float quant, const float *coef, const fl
             if (zr >= 16) {
                 v = zr - 16; if (v > 0x1FF) v = 0x1FF;
                 n = v + 16;
-                nq = orc_get_noise_q(noise, nextCoded, n, quant);
+                nq = site_get_noise_q(noise, nextCoded, n, quant);
             }
             if (nq) {                                                        /* :155-160 */
                 put_nybble(0x8, dst, size);
@@ -455,7 +558,7 @@ static void write_subblock(int idx, int S, const float *coef, const float *noise
         if (prevQ != -1) put_nybble(0xF, dst, size);
         int nq = 0, nd = 0;
         if (prevQ != -1 && n >= 16)
-            orc_get_hfext_params(noise, nextCoded, n, (float)(1u << prevQ), &nq, &nd);
+            site_get_hfext_params(noise, nextCoded, n, (float)(1u << prevQ), &nq, &nd);
         if (nq) {
             put_nybble(0xF, dst, size);
             put_nybble((unsigned)(nq - 1), dst, size);
@@ -578,7 +681,7 @@ int orc_transform_block(orc_encoder *st, const float *Data) {
     }
 
     int wc = st->WindowCtrl = st->NextWindowCtrl;                             /* :114-123 */
-    int nwc = st->NextWindowCtrl = orc_get_window_ctrl(st->SampleBuffer, st->TransientBuffer, st->TransientFilter,
+    int nwc = st->NextWindowCtrl = site_get_window_ctrl(st->SampleBuffer, st->TransientBuffer, st->TransientFilter,
                                                        st->TransformTemp, BS, C, st->RateHz);
     int nextOverlap;                                                          /* :124-128 */
     {
@@ -648,7 +751,7 @@ int orc_transform_block(orc_encoder *st, const float *Data) {
                 cplx  += re2;
                 cplxW += are;
             }
-            orc_calc_noise_log_spectrum(noise, tmp, S, st->RateHz);           /* :286 */
+            site_calc_noise_log_spectrum(noise, tmp, S, st->RateHz);          /* :286 */
 
             smp += S; mdct += S; key += S; amp2 += S / 2; noise += S; mdstOut += S;
         } while (pat);
@@ -666,7 +769,7 @@ int orc_transform_block(orc_encoder *st, const float *Data) {
     st->BlockComplexity = cplx;
 
     float *mask = st->SampleBuffer;                                           /* :148, :329 */
-    orc_calc_psychoacoustics(mask, amp2, tmp, BS, st->RateHz, (uint32_t)wc);
+    site_calc_psychoacoustics(mask, amp2, tmp, BS, st->RateHz, (uint32_t)wc);
     memcpy(st->Masking, mask, sizeof(float) * (BS / 2));
     for (int ch = 0; ch < C; ch++) {                                          /* :337-345 */
         for (int n = 0; n < BS; n++) {

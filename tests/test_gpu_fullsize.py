@@ -152,3 +152,64 @@ def test_config5_window_switch_stress_bs4096():
         for k in range(K):
             nb = bits_h[s, k] // 8
             assert np.array_equal(out_h[s, k, :nb], ref["out"][k, :nb]), (s, k)
+
+
+def test_bench_launch_4096x32_sampled_against_the_oracle():
+    """What is benched is what is tested: ONE call of 4096 streams x 32 blocks - bench.py's `vbr50` step, its input (same
+    generator and seed as rank 0), fresh encoder and decoder, the pointers bench.py passes (no WindowCtrl / BlockComplexity
+    taps: a second fresh encoder supplies those) - and 8 seeded streams of it, at least two from the decoder's cut last round
+    (streams >= 3072 on an MI355X: ulcx_dec_tail_plan), byte-equal to the oracle's encode (sizes, WindowCtrl, BlockComplexity,
+    bytes) and bit-equal to the oracle's decode.  BASELINE configs[1] / configs[2]; ulcEncoder.c:140-158, ulcDecoder.c:198-302."""
+    import torch
+    import ulc_amd as amd
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = bench.CONFIGS["vbr50"]
+    B, K, bs, ch, rate = cfg["per_gpu"], cfg["blocks"], cfg["bs"], bench.CH, cfg["rate"]
+    assert (B, K, bs, ch) == (4096, 32, 2048, 2)
+    dev = torch.device("cuda", 0)
+    bench.RATE = rate
+    pcm = bench.make_pcm(torch, B, K * bs, dev, seed=1234, bursts_per_s=cfg["bursts"], decades=cfg["decades"])
+    enc = amd.BatchEncoder(B, ch, bs, rate, K); dec = amd.BatchDecoder(B, ch, bs, K)
+    enc.set_timing(False); dec.set_timing(False)                     # as in bench.py's timed region
+    slot = enc.slot
+    out = torch.zeros(B, K, slot, dtype=torch.uint8, device=dev); bits = torch.zeros(B, K, dtype=torch.int32, device=dev)
+    dpcm = torch.zeros(B, K * bs, ch, dtype=torch.float32, device=dev); dbits = torch.zeros(B, K, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    enc.encode_dev(pcm.data_ptr(), K, out.data_ptr(), bits.data_ptr(), mode=amd.MODE_VBR, p0=cfg["p0"], stream=stream)
+    dec.decode_dev(out.data_ptr(), slot, K, dpcm.data_ptr(), dbits.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    grid, whole, resident = dec.last_cut()
+    enc.close()
+    # the taps, from a second fresh encoder (the same call with the two optional outputs)
+    enc2 = amd.BatchEncoder(B, ch, bs, rate, K)
+    out2 = torch.zeros_like(out); bits2 = torch.zeros_like(bits)
+    wc = torch.zeros(B, K, dtype=torch.int32, device=dev); cplx = torch.zeros(B, K, dtype=torch.float32, device=dev)
+    enc2.encode_dev(pcm.data_ptr(), K, out2.data_ptr(), bits2.data_ptr(), wc.data_ptr(), cplx.data_ptr(), mode=amd.MODE_VBR, p0=cfg["p0"], stream=stream)
+    torch.cuda.synchronize()
+    assert torch.equal(bits, bits2) and torch.equal(out, out2), "the optional taps changed the stream"
+    enc2.close(); del out2, bits2
+    assert bool((dbits > 0).all()) and bool((bits - dbits < 8).all())
+    # the sample: 8 seeded streams, two of them from the last round of the synthesis launch (cut into pieces when the plan says so)
+    first_cut = whole if grid else (B - B % resident if resident else 3 * B // 4)
+    first_cut = min(first_cut, B - 2)
+    rng = np.random.default_rng(6)
+    sample = sorted(set(rng.choice(first_cut, 6, replace=False).tolist()) | set((first_cut + rng.choice(B - first_cut, 2, replace=False)).tolist()))
+    assert len(sample) == 8 and sum(s >= first_cut for s in sample) >= 2
+    if resident == 1536:                                              # MI355X, stereo BlockSize 2048: the bench's launch cuts streams 3072..4095
+        assert grid > 0 and whole == 3072, (grid, whole, resident)
+    idx = torch.tensor(sample, device=dev)
+    pcm_h = pcm[idx].cpu().numpy(); out_h = out[idx].cpu().numpy(); bits_h = bits[idx].cpu().numpy()
+    wc_h = wc[idx].cpu().numpy(); cplx_h = cplx[idx].cpu().numpy(); dp_h = dpcm[idx].cpu().numpy(); db_h = dbits[idx].cpu().numpy()
+    for i, s in enumerate(sample):
+        ref = oracle_encode_debug(pcm_h[i], bs, rate, 0, cfg["p0"], slot=slot)
+        assert np.array_equal(bits_h[i], ref["bits"]), s
+        assert np.array_equal(wc_h[i], ref["wc"]), s
+        assert np.array_equal(cplx_h[i].view(np.uint32), ref["cplx"].view(np.uint32)), s
+        for k in range(K):
+            nb = bits_h[i, k] // 8
+            assert np.array_equal(out_h[i, k, :nb], ref["out"][k, :nb]), (s, k)
+        rc, ref_pcm, ref_bits = oracle_decode_stream(out_h[i], ch, bs)
+        assert rc == 0 and np.array_equal(db_h[i], ref_bits), s
+        assert np.array_equal(dp_h[i].view(np.uint32), ref_pcm.view(np.uint32)), f"stream {s}: decoded PCM differs from the oracle's"
+    dec.close()

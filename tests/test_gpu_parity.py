@@ -288,15 +288,28 @@ def test_decode_few_long_streams_cut_evenly(bs, rate):
 
 def test_decode_last_round_cut_into_pieces():
     """Round 5: a batch of more streams than the device holds synthesis workgroups keeps one workgroup per stream for its whole
-    rounds and cuts the streams of the partly empty last round into pieces of 8 blocks (ulcx_dec_tail_plan).  2536 stereo
-    streams of 26 blocks per call (1536 resident workgroups on an MI355X: 1000 streams in 3250 pieces whose boundaries fall
-    anywhere; with fewer streams in the last round the even cut of the whole batch takes over), two calls (the state arrays swap), a corrupt block inside a cut stream; against the same decoder with the cut
+    rounds and cuts the streams of the partly empty last round into pieces of 8 blocks (ulcx_dec_tail_plan).  Whole rounds plus
+    a last round two thirds full of stereo streams, 26 blocks per call (1536 resident workgroups on an MI355X: 2560 streams, 1024
+    of them in 3328 pieces whose boundaries fall anywhere; the expected launch is what the exported plans say for the residency
+    the decoder reports), two calls (the state arrays swap), a corrupt block inside a cut stream; against the same decoder with the cut
     switched off (every sample of every stream) and against the oracle on streams of both kinds."""
     import torch
     amd = _amd()
     sys.path.insert(0, ROOT)
     import bench
-    B, calls, K, ch, bs, rate = 2536, 2, 26, 2, 2048, 44100
+    calls, K, ch, bs, rate = 2, 26, 2, 2048, 44100
+    # the batch shape follows from the device: whole rounds + a last round two thirds full, so that the tail plan is the one
+    # taken whatever the residency of the synthesis kernel's instantiations is (1536 on an MI355X: B = 2560)
+    import ctypes as C
+    probe = amd.BatchDecoder(8, ch, bs, K)
+    resident = probe.last_cut()[2]
+    probe.close()
+    assert resident > 0, "stereo BlockSize 2048 runs the two-wave synthesis kernel"
+    B = resident + (resident * 2 // 3)
+    L = amd.lib()
+    want_full = C.c_int32(0)
+    want_tail = L.ulcx_dec_tail_plan(B, K, resident, C.byref(want_full))
+    assert L.ulcx_dec_split_plan(B, K, resident) == 0 and want_tail > 0 and want_full.value == resident, (B, resident, want_tail)
     dev = torch.device("cuda", 0)
     bench.RATE = rate
     pcm = bench.make_pcm(torch, B, calls * K * bs, dev, 4242, bursts_per_s=6.0, decades=3.0)
@@ -309,7 +322,7 @@ def test_decode_last_round_cut_into_pieces():
         torch.cuda.synchronize()
         out[:, c * K:(c + 1) * K] = o
     enc.close()
-    dead_s, dead_k = 2100, K + 5
+    dead_s, dead_k = resident + (B - resident) // 2, K + 5
     out[dead_s, dead_k, 2:40] = 0x11                                  # a stream of the cut part dies in the second call
     outs = {}
     cut_seen = False
@@ -325,16 +338,17 @@ def test_decode_last_round_cut_into_pieces():
                 torch.cuda.synchronize()
                 dp[:, c * K * bs:(c + 1) * K * bs] = p; db[:, c * K:(c + 1) * K] = b
             outs[tail] = (dp, db)
-            grid, whole, resident = dec.last_cut()
+            grid, whole, res2 = dec.last_cut()
+            assert res2 == resident
             if tail == "0": assert grid == 0
-            elif 0 < B % resident <= resident * 4 // 5:                # (an MI355X: 1536 resident, 1000 streams in the last round)
-                assert whole == B - B % resident and grid == whole + (B % resident) * K // 8, (grid, whole, resident)
+            else:                                                      # what the exported plan says for this device
+                assert whole == want_full.value and grid == want_full.value + want_tail, (grid, whole, resident, want_tail)
                 cut_seen = True
             dec.close()
         finally:
             if old is None: os.environ.pop("ULCX_DSYN_TAIL", None)
             else: os.environ["ULCX_DSYN_TAIL"] = old
-    assert cut_seen, "this batch shape is meant to take the cut on an MI355X"
+    assert cut_seen
     # the PCM16-output instantiation of the cut kernel: lrintf(clamp(y * 2^15)) of the float path's output (tools/WavIO_Helper.c:56-63)
     dec = amd.BatchDecoder(B, ch, bs, K)
     for c in range(calls):
@@ -348,7 +362,7 @@ def test_decode_last_round_cut_into_pieces():
     dec.close()
     assert torch.equal(outs["1"][1], outs["0"][1]), "bits consumed: cut and uncut last round disagree"
     assert torch.equal(outs["1"][0].view(torch.int32), outs["0"][0].view(torch.int32)), "decoded PCM: cut and uncut last round disagree"
-    for s in (0, 1535, 1536, 1537, 2000, dead_s, dead_s + 1, B - 1):
+    for s in (0, resident - 1, resident, resident + 1, resident + (B - resident) // 3, dead_s, dead_s + 1, B - 1):
         rc, ref_pcm, ref_bits = oracle_decode_stream(out[s].cpu().numpy(), ch, bs)
         got = outs["1"][0][s].cpu().numpy(); gb = outs["1"][1][s].cpu().numpy()
         n = calls * K
@@ -764,3 +778,34 @@ def test_timing_events_can_be_switched_off():
         assert rc == 0 and np.array_equal(got[0], ref_pcm) and np.array_equal(gbits[0], ref_bits)
         assert bool(enc.stage_ms()) == timing and bool(dec.stage_ms()) == timing
         enc.close(); dec.close()
+
+
+def test_single_block_and_batched_calls_mixed_on_one_decoder_keep_the_noise_chain():
+    """ulcx_decode_block1 uploads its host copy of the noise generator's state in front of every block; a batched call on
+    the same one-stream decoder advances only the device word.  Mixed use must still draw ONE chain (ulcDecoder.c:75-81):
+    blocks decoded alternately through ulcx_decode_host and ulcx_decode_block1 equal the oracle's continuous decode."""
+    import ctypes as C
+    import ulc_amd as amd
+    bs, ch, rate, nblk = 2048, 2, 44100, 12
+    pcm = synth_pcm(31, nblk * bs, ch, rate, transient=True, seed=77)
+    slot = 2 * ch * bs + 16
+    ref = oracle_encode_debug(pcm, bs, rate, 0, 30.0, slot=slot)           # low quality: long noise-filled gaps, many draws
+    rc, want, want_bits = oracle_decode_stream(ref["out"], ch, bs)
+    assert rc == 0
+    dec = amd.BatchDecoder(1, ch, bs, 1)
+    L = amd.lib()
+    L.ulcx_decode_block1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    got = np.zeros((nblk, bs, ch), np.float32)
+    for k in range(nblk):
+        blk = np.ascontiguousarray(ref["out"][k])
+        if (k // 3) % 2 == 0:                                              # three blocks through the batched entry ...
+            p, b = dec.decode(blk[None, None, :])
+            got[k] = p[0]; bits = int(b[0, 0])
+        else:                                                              # ... three through the single-block one
+            o = np.zeros((bs, ch), np.float32); b = C.c_int32(0); ls = C.c_int32(0)
+            r = L.ulcx_decode_block1(dec.h, blk.ctypes.data, int(slot), o.ctypes.data, C.byref(b), C.byref(ls))
+            assert r == 0, amd.lib().ulcx_last_error()
+            got[k] = o; bits = b.value
+        assert bits == want_bits[k], k
+    assert np.array_equal(got.reshape(-1, ch).view(np.uint32), want.view(np.uint32)), "the noise chain was rewound or forked"
+    dec.close()

@@ -49,6 +49,10 @@ struct ulcx_decoder {
     hipStream_t b1Stream; hipGraph_t b1Graph; hipGraphExec_t b1Exec; bool b1Init, b1Graphed, b1NoGraph; int b1Slot;
     uint8_t *pinIn; float *pinPcm; int32_t *pinMeta;
     uint32_t b1Seed;                                              // the stream's RNG state between single-block calls
+    // The device word (ctx.seed) is the authoritative state of the object's own noise chain; b1Seed is its host copy, which the
+    // single-block path uploads in front of every block.  Any OTHER decode call on this object advances the device word only:
+    // it marks the copy stale, and the next single-block call without a caller-owned state reads the device word back first.
+    bool b1SeedStale, inBlock1;
 };
 
 #ifndef ULCX_SRC_REV
@@ -496,7 +500,7 @@ static int dec_reset_state(ulcx_decoder *e) {
     CKR(hipMemset(c.packOff, 0, sizeof(int) * (size_t)e->B));
     std::vector<uint32_t> seed((size_t)e->B, 1234567u);                                // ulcDecoder.c:76, one RNG per stream
     CKR(hipMemcpy(c.seed, seed.data(), sizeof(uint32_t) * seed.size(), hipMemcpyHostToDevice));
-    e->b1Seed = 1234567u;
+    e->b1Seed = 1234567u; e->b1SeedStale = false; e->inBlock1 = false;
     return ULCX_OK;
 }
 
@@ -591,6 +595,7 @@ extern "C" int ulcx_decoder_last_cut(ulcx_decoder *e, int *workgroups, int *whol
     return ULCX_OK;
 }
 static int dec_launch(ulcx_decoder *e, UlcxDecCtx &c, hipStream_t st) {
+    if (!e->inBlock1) e->b1SeedStale = true;                      // (a batched / packed call on a one-stream decoder: see b1Seed)
     UlcxDecAux a;
     a.synGrid = 0; a.synFull = 0;
     c.lapO = c.lap; c.lastSubO = c.lastSub; c.seedO = c.seed; c.deadO = c.dead;
@@ -772,7 +777,13 @@ extern "C" int ulcx_decode_block1_rng(ulcx_decoder *e, const uint8_t *h_in, int 
     };
     memcpy(e->pinIn, h_in, (size_t)nBytes);
     memset(e->pinIn + nBytes, 0, (size_t)(slot - nBytes));         // (only the block's own bytes are the caller's: the rest of the slot reads as zero)
+    if (!rngState && e->b1SeedStale) {                            // mixed use: ulcx_decode_dev / _host / _packed ran on this object since
+        CKR(hipDeviceSynchronize());
+        CKR(hipMemcpy(&e->b1Seed, e->ctx.seed, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    e->b1SeedStale = false;
     e->pinMeta[2] = (int32_t)(rngState ? *rngState : e->b1Seed);
+    struct InB1 { ulcx_decoder *d; InB1(ulcx_decoder *x) : d(x) { d->inBlock1 = true; } ~InB1() { d->inBlock1 = false; } } inB1(e);
     if (!e->b1Graphed && !e->b1NoGraph) {
         bool ok = hipStreamBeginCapture(e->b1Stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
         if (ok) {

@@ -1035,9 +1035,13 @@ __global__ __launch_bounds__(WG, 3) void k_dsyn(UlcxDecCtx c) {
                     }
                     return o;
                 };
+                // The 8-byte window loads want a, ov and p1 even: ov = BS >> (0..7) capped by lastSub >= BS / 8, both multiples of 4
+                // for every BlockSize this branch is compiled for (>= 2048), so a = (S - ov) / 2 is even too.
+                static_assert(BSC >= 2048 && (BSC >> 7) % 4 == 0 && (BSC >> 3) % 4 == 0, "k_dsyn: the pipelined epilogue loads window pairs as float2");
                 Ops nxt = fetch(0);
                 __syncthreads();
                 STAMP(4);
+                if (!(ULCX_DBG(c) & 4))                             // (ablation builds only: the epilogue skipped, as in the generic loop below)
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
                     const Ops cur = nxt;
@@ -1345,12 +1349,17 @@ static const void *syn_fn(const UlcxDecCtx &cc, bool split) {
 }
 int ulcx_dec_syn_slots(const UlcxDecCtx &c) {
     if (!c.fastOK) return 0;
-    const void *fn = syn_fn<float>(c, true);                       // (what an even cut would launch; the PCM16 instantiation has the same resources)
+    // what a cut would launch: the float and the PCM16 instantiation are both asked, the smaller residency sizes the cut
+    const void *fns[2] = { syn_fn<float>(c, true), syn_fn<int16_t>(c, true) };
     const size_t lds = ulcx_dec_lds_bytes(c.BS, c.C, c.fastOK, c.twInLds);
-    if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
     int dev = 0, cus = 0, per = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, WG, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    for (const void *fn : fns) {
+        int p1 = 0;
+        if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p1, fn, WG, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        per = (fn == fns[0] || p1 < per) ? p1 : per;
+    }
     return cus * per;
 }
 
