@@ -45,8 +45,13 @@ static int get_quantizer(nyb_reader *r) {
     if (q == 0xE + 0xF) return ESC_STOP;
     return q;
 }
-/* ulcDecoder.c:96-98 */
-static float expand_quantizer(int q) { return 0x1.0p-31f * ((1u << (31 - 5)) >> q); }
+/* ulcDecoder.c:96-98.  q is -2 when a unit OPENS with Fh (get_quantizer's ESC_STOP_NOISE reaches here unchecked,
+ * ulcDecoder.c:103-112; no encoder writes that and FormatSpecs.md allocates no such code): the reference then shifts by a
+ * negative count - undefined in C, and on x86-64 `shr` takes the count modulo 32, i.e. 30, which leaves 0: the unit's quantizer
+ * is exactly 0.0 until a change code.  That is the behaviour of the reference BINARY on x86, not a rule of the format; it is
+ * written out here (count & 31) instead of being inherited from the compiler, and the device decoder does the same explicitly
+ * (csrc/ulcx_dec.hip: index 30).  tests/test_oracle_codec.py::test_opening_Fh_quantizer_is_x86_shift_behaviour. */
+static float expand_quantizer(int q) { return 0x1.0p-31f * ((1u << (31 - 5)) >> ((unsigned)q & 31u)); }
 
 /* ulcDecoder.c:99-197 */
 static int decode_subblock(orc_decoder *st, float *dst, int N, nyb_reader *r) {

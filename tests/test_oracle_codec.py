@@ -110,6 +110,22 @@ def test_decoder_syntax_codes():
     assert np.array_equal(coef, exp)
 
 
+def test_opening_Fh_quantizer_is_x86_shift_behaviour():
+    """A unit that OPENS with Fh (no encoder writes it, FormatSpecs.md allocates no such code) reaches the reference's
+    quantizer expansion with index -2 (ulcDecoder.c:89-98,103-112): a shift by a negative count - undefined in C, 30 on
+    x86-64's `shr`, which leaves 0.  So the unit's quantizer is exactly 0.0 until a change code: the behaviour of the
+    reference binary on x86, not a format rule; the oracle (count & 31) and the device decoder (index 30) write it out."""
+    bs = 256
+    # header 0h; opening Fh; coefs +2, -7, +5 (all scaled by 0.0: signed zeros); change Fh,2h -> 2^-(5+2); coef +3; stop Fh,Eh,Fh
+    nyb = [0x0, 0xF, 0x2, 0x9, 0x5, 0xF, 0x2, 0x3, 0xF, 0xE, 0xF]
+    bits, coef, out = _decode_coefs(nyb, bs)
+    assert bits == 4 * len(nyb)
+    assert not coef[:3].any(), "quantizer -2 must expand to exactly 0.0"
+    assert np.signbit(coef[1]) and not np.signbit(coef[0]), "the coefficients are v * 0.0: the zero keeps the sign of v"
+    assert coef[3] == np.float32(9 * 2.0 ** -7) and not coef[4:].any()
+    assert np.isfinite(out).all()
+
+
 def test_decoder_noise_fill_and_tail():
     bs = 256
     # quantizer 0 (2^-5); noise run 8h,Z=0,Y=2,X=5 -> n = (0<<5|2<<1|1)+16 = 21, level ((5>>1)+1)^2 * Q/4 = 9Q/4
