@@ -156,7 +156,9 @@ __device__ __forceinline__ size_t envq_idx(const UlcxEncCtx &c, int s, int q) { 
 
 #define EF_SPW 8                                          // streams per workgroup
 
+#ifndef EF_NW
 #define EF_NW 9                                           // waves per workgroup: the chain + one producer per stream
+#endif
 
 #define EF_TILE_FLOATS (EF_SPW * 2 * EF_TS)
 
