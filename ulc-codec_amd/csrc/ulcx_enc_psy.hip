@@ -385,6 +385,10 @@ __device__ __forceinline__ void sel_gather_keep(const uint32_t (&u)[R], uint32_t
 // workgroup: every count, minimum and decision of the search is formed over both waves through two words of LDS and a
 // workgroup barrier (the two waves take every branch together).  BlockSize 4096 stereo: 128 keys per lane in one wave are
 // 200 registers, two waves per SIMD.
+#ifndef SEL_BRK_DLO
+#define SEL_BRK_DLO 2.5f          // the sample bracket: ranks q - DLO and q + DHI of the 128 sample keys (q = kSel * 128 / N)
+#define SEL_BRK_DHI 3.5f
+#endif
 template <int R, int LGBS, int PASS, bool PAIR>          // LGBS: log2(BlockSize) as a compile-time constant (0: read from the context)
 __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, int blk, int wv, int lane, int half, volatile uint32_t *xch, float *sel_lds) {
     // sums / minima / maxima over the pair's two waves (wave-uniform values; the exchanges alternate between two slots, so
@@ -510,8 +514,106 @@ __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, 
             for (int j = 0; j < SEL_CAP; j++) { const uint32_t v = cd[j] ? cd[j] : 0xFFFFFFFFu; mn = v < mn ? v : mn; mx = cd[j] > mx ? cd[j] : mx; }
         }
         mn = pair_min(wave_min_u32(mn)); mx = pair_max(wave_max_u32(mx));
+        // Round 6 - a sample bracket in front of the search (one-pass calls, one wave per block of 4096 keys).  The bit-by-bit
+        // search below needs ~14 full probes (64 compares, 128 scalar instructions each) before the window that holds T is down
+        // to SEL_CAND keys: log-domain keys spend their first probes on empty value space between an outlier and the bulk.
+        // Instead: (i) 128 sample keys - lane group g = lane / 4 takes registers 4 g + 1 and 4 g + 3: sixteen runs of four
+        // lines spread over both channels' spectra; (ii) ONE bit descent on the sample (2 compares a probe) to the value of
+        // sample rank q + 3.5, q = kSel * 128 / N, keeping the smallest value it met whose sample count is below rank q - 2.5;
+        // (iii) those two values are the first full probes: they bracket T in nine blocks of ten, and whatever they say the
+        // window [lo, hiX] stays valid (count(u >= lo) >= kSel > count(u > hiX)); (iv) further full probes at the value where a
+        // linear count between the ends crosses kSel (Illinois weights: an end that stays put counts half) until the window holds
+        // <= SEL_CAP * 64 keys; (v) those go DENSELY to the candidate registers and the search below finishes on them, exactly
+        // as it does for a rate search's window.  2.2 full probes + 16 sample probes on the bench's blocks instead of 13.6
+        // (sized offline on the oracle's keys: tools/sel_probe_sim.py); k_select_wave<64, 11, 0> 1.07 -> 0.90 ms.  T is the same
+        // number: any probe value keeps the invariant.
+        bool solved = false;
+        if constexpr (SEL_COMPACT && PASS == 0 && !PAIR && R == 64) {
+            if (mn != mx && !(ULCX_DBG(c) & 0x1000)) {
+                uint32_t s0 = 0u, s1 = 0u;
+                __builtin_amdgcn_sched_barrier(0);           // (picked here, not while the keys are formed: that is where the registers are tightest)
+#pragma unroll
+                for (int g = 0; g < 16; g++) { const bool in = (lane >> 2) == g; s0 = in ? u[4 * g + 1] : s0; s1 = in ? u[4 * g + 3] : s1; }
+                __builtin_amdgcn_sched_barrier(0);
+                const float q = (float)kSel * (128.0f / (float)N);
+                int kkLo = (int)ceilf(q + SEL_BRK_DHI); kkLo = (kkLo > 127 ? 127 : kkLo) + 1;
+                int kkHi = (int)floorf(q - SEL_BRK_DLO); kkHi = (kkHi < 0 ? 0 : kkHi) + 1;
+                uint32_t tLoS, tHiS = 0u; bool haveHi = false;
+                {
+                    int b = 31 - __clz(mn ^ mx);
+                    uint32_t Ts = mx & ~((2u << b) - 1u);
+                    for (; b >= 0; b--) {
+                        const uint32_t t = Ts | (1u << b);
+                        const int cS = __popcll(__ballot(s0 >= t)) + __popcll(__ballot(s1 >= t));
+                        Ts = (cS >= kkLo) ? t : Ts;
+                        if (cS < kkHi && (!haveHi || t < tHiS)) { tHiS = t; haveHi = true; }
+                        if (cS == kkLo) break;
+                    }
+                    tLoS = Ts;
+                }
+                uint32_t lo = mn, hiX = mx; int cLo = N, cHi = 0;
+                int last = 0, shLo = 0, shHi = 0;                 // Illinois weights as shifts: an end that stayed put counts half (all wave-uniform integers: scalar registers)
+                int iter = 0, stage = 0;                          // stage 0 / 1: the sample's two values, then interpolation
+                bool want = false;
+                for (;;) {
+                    if (lo == hiX) { T = lo; cntT = cLo; solved = true; break; }
+                    uint32_t t;
+                    if (stage == 0) { stage = 1; t = tLoS; if (!(t > lo && t <= hiX)) continue; }
+                    else if (stage == 1) { stage = 2; t = tHiS; last = 0; shLo = shHi = 0; if (!(haveHi && t > lo && t <= hiX)) continue; }
+                    else {
+                        if (cLo - cHi <= SEL_CAP * 64) { want = true; break; }  // few enough for the candidate registers
+                        if (cLo == kSel) {                    // exactly kSel keys from lo up: T is the smallest of them
+                            uint32_t m2 = 0xFFFFFFFFu;
+#pragma unroll
+                            for (int r = 0; r < R; r++) { const uint32_t v = (u[r] >= lo) ? u[r] : 0xFFFFFFFFu; m2 = v < m2 ? v : m2; }
+                            T = wave_min_u32(m2); cntT = kSel; solved = true;
+                            break;
+                        }
+                        const int aI = (cLo - kSel) >> shLo, bI = (kSel - cHi) >> shHi;
+                        const float frac = (++iter > 12 || aI + bI == 0) ? 0.5f : (float)aI / (float)(aI + bI);      // (a window that will not close by interpolation - heavy ties - is halved)
+                        uint32_t off = (uint32_t)(frac * (float)(hiX - lo));
+                        off = off < 1u ? 1u : off; off = off > hiX - lo ? hiX - lo : off;
+                        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lo + off));
+                    }
+                    // one full probe at t (lo < t <= hiX)
+                    int cnt = 0;
+#pragma unroll
+                    for (int r = 0; r < R; r++) cnt += __popcll(__ballot(u[r] >= t));
+                    if (cnt >= kSel) { lo = t; cLo = cnt; shHi = (last == 1) ? (shHi < 20 ? shHi + 1 : shHi) : 0; shLo = 0; last = 1; }
+                    else { hiX = t - 1u; cHi = cnt; shLo = (last == -1) ? (shLo < 20 ? shLo + 1 : shLo) : 0; shHi = 0; last = -1; }
+                }
+                if (want) {
+                    // the keys of [lo, hiX] to the candidate registers, DENSELY: key number n of the window (register-major, lane-minor)
+                    // goes to slot n of a list in LDS (lane mask of the compare -> mbcnt), lane l then takes slots l, 64 + l, ...: up to
+                    // SEL_CAP * 64 = 512 candidates whatever their spread over the lanes (a lane's own list overflows at SEL_CAP:
+                    // the search below stops at SEL_CAND = 128 for that reason and needs two more full probes to get there)
+                    uint32_t *cl = (uint32_t *)(sel_lds + wv * selStride);
+                    const uint32_t span = hiX - lo;
+                    int base = 0;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const bool act = (u[r] - lo) <= span;
+                        const unsigned long long m = __ballot(act);
+                        const int idx = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (act) cl[idx] = u[r];
+                        base += (int)__popcll(m);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int j = 0; j < SEL_CAP; j++) cd[j] = (j * 64 + lane < base) ? cl[j * 64 + lane] : 0u;       // (base = cLo - cHi)
+                    compacted = true; tried = true; cntLo = cLo; cntHi = cHi;
+                }
+                if (compacted) {
+                    mn = 0xFFFFFFFFu; mx = 0u;
+#pragma unroll
+                    for (int j = 0; j < SEL_CAP; j++) { const uint32_t v = cd[j] ? cd[j] : 0xFFFFFFFFu; mn = v < mn ? v : mn; mx = cd[j] > mx ? cd[j] : mx; }
+                    mn = wave_min_u32(mn); mx = wave_max_u32(mx);
+                }
+            }
+        }
         const uint32_t dif = mn ^ mx;
-        if (ULCX_DBG(c) & 0x1000) T = mn;                  // (ablation build only: no search, everything is kept)
+        if (solved) { }
+        else if (ULCX_DBG(c) & 0x1000) T = mn;             // (ablation build only: no search, everything is kept)
         else if (same) { T = c.selWin[blk].y; cntT = kSel; }
         else if (dif == 0) { T = mn; cntT = cntLo; }
         else {
