@@ -528,15 +528,28 @@ __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, 
         // (sized offline on the oracle's keys: tools/sel_probe_sim.py); k_select_wave<64, 11, 0> 1.07 -> 0.90 ms.  T is the same
         // number: any probe value keeps the invariant.
         bool solved = false;
-        if constexpr (SEL_COMPACT && PASS == 0 && !PAIR && R == 64) {
-            if (mn != mx && !(ULCX_DBG(c) & 0x1000)) {
-                uint32_t s0 = 0u, s1 = 0u;
+        // Every geometry with more than two candidate registers' worth of keys per lane, one-pass calls and the first probe of a
+        // rate search (its later probes already search a window: selWin).  R keys per lane: lane group g of 256 / R lanes takes
+        // registers 4 g + 1, 4 g + 3.  PAIR (a wave per channel): the two waves swap their 128 sample keys through LDS once and
+        // each runs the descent on all 256 - no exchange per sample probe; the full probes' counts are summed over the pair.
+        if constexpr (SEL_COMPACT && PASS != 2 && R % 4 == 0) {
+            if (mn != mx && !(ULCX_DBG(c) & 0x1000) && !compacted) {
+                constexpr int G = R / 4, LPG = 64 / G, STOT = PAIR ? 256 : 128;
+                uint32_t s0 = 0u, s1 = 0u, s2 = 0u, s3 = 0u;
                 __builtin_amdgcn_sched_barrier(0);           // (picked here, not while the keys are formed: that is where the registers are tightest)
 #pragma unroll
-                for (int g = 0; g < 16; g++) { const bool in = (lane >> 2) == g; s0 = in ? u[4 * g + 1] : s0; s1 = in ? u[4 * g + 3] : s1; }
+                for (int g = 0; g < G; g++) { const bool in = (lane / LPG) == g; s0 = in ? u[4 * g + 1] : s0; s1 = in ? u[4 * g + 3] : s1; }
                 __builtin_amdgcn_sched_barrier(0);
-                const float q = (float)kSel * (128.0f / (float)N);
-                int kkLo = (int)ceilf(q + SEL_BRK_DHI); kkLo = (kkLo > 127 ? 127 : kkLo) + 1;
+                if constexpr (PAIR) {
+                    __syncthreads();                                               // (the masking levels are used up - by both waves)
+                    uint32_t *sx = (uint32_t *)(sel_lds + wv * selStride);
+                    sx[half * 128 + lane] = s0; sx[half * 128 + 64 + lane] = s1;
+                    __syncthreads();
+                    s2 = sx[(1 - half) * 128 + lane]; s3 = sx[(1 - half) * 128 + 64 + lane];
+                    __syncthreads();                                               // (the region is the candidates' next)
+                }
+                const float q = (float)kSel * ((float)STOT / (float)N);
+                int kkLo = (int)ceilf(q + SEL_BRK_DHI); kkLo = (kkLo > STOT - 1 ? STOT - 1 : kkLo) + 1;
                 int kkHi = (int)floorf(q - SEL_BRK_DLO); kkHi = (kkHi < 0 ? 0 : kkHi) + 1;
                 uint32_t tLoS, tHiS = 0u; bool haveHi = false;
                 {
@@ -544,7 +557,8 @@ __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, 
                     uint32_t Ts = mx & ~((2u << b) - 1u);
                     for (; b >= 0; b--) {
                         const uint32_t t = Ts | (1u << b);
-                        const int cS = __popcll(__ballot(s0 >= t)) + __popcll(__ballot(s1 >= t));
+                        int cS = __popcll(__ballot(s0 >= t)) + __popcll(__ballot(s1 >= t));
+                        if constexpr (PAIR) cS += __popcll(__ballot(s2 >= t)) + __popcll(__ballot(s3 >= t));
                         Ts = (cS >= kkLo) ? t : Ts;
                         if (cS < kkHi && (!haveHi || t < tHiS)) { tHiS = t; haveHi = true; }
                         if (cS == kkLo) break;
@@ -566,7 +580,7 @@ __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, 
                             uint32_t m2 = 0xFFFFFFFFu;
 #pragma unroll
                             for (int r = 0; r < R; r++) { const uint32_t v = (u[r] >= lo) ? u[r] : 0xFFFFFFFFu; m2 = v < m2 ? v : m2; }
-                            T = wave_min_u32(m2); cntT = kSel; solved = true;
+                            T = pair_min(wave_min_u32(m2)); cntT = kSel; solved = true;
                             break;
                         }
                         const int aI = (cLo - kSel) >> shLo, bI = (kSel - cHi) >> shHi;
@@ -579,6 +593,7 @@ __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, 
                     int cnt = 0;
 #pragma unroll
                     for (int r = 0; r < R; r++) cnt += __popcll(__ballot(u[r] >= t));
+                    cnt = pair_sum(cnt);
                     if (cnt >= kSel) { lo = t; cLo = cnt; shHi = (last == 1) ? (shHi < 20 ? shHi + 1 : shHi) : 0; shLo = 0; last = 1; }
                     else { hiX = t - 1u; cHi = cnt; shLo = (last == -1) ? (shLo < 20 ? shLo + 1 : shLo) : 0; shHi = 0; last = -1; }
                 }
@@ -587,7 +602,7 @@ __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, 
                     // goes to slot n of a list in LDS (lane mask of the compare -> mbcnt), lane l then takes slots l, 64 + l, ...: up to
                     // SEL_CAP * 64 = 512 candidates whatever their spread over the lanes (a lane's own list overflows at SEL_CAP:
                     // the search below stops at SEL_CAND = 128 for that reason and needs two more full probes to get there)
-                    uint32_t *cl = (uint32_t *)(sel_lds + wv * selStride);
+                    uint32_t *cl = (uint32_t *)(sel_lds + wv * selStride) + half * (SEL_CAP * 64);
                     const uint32_t span = hiX - lo;
                     int base = 0;
 #pragma unroll
@@ -600,14 +615,14 @@ __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, 
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-                    for (int j = 0; j < SEL_CAP; j++) cd[j] = (j * 64 + lane < base) ? cl[j * 64 + lane] : 0u;       // (base = cLo - cHi)
+                    for (int j = 0; j < SEL_CAP; j++) cd[j] = (j * 64 + lane < base) ? cl[j * 64 + lane] : 0u;       // (base = this wave's share of the cLo - cHi)
                     compacted = true; tried = true; cntLo = cLo; cntHi = cHi;
                 }
                 if (compacted) {
                     mn = 0xFFFFFFFFu; mx = 0u;
 #pragma unroll
                     for (int j = 0; j < SEL_CAP; j++) { const uint32_t v = cd[j] ? cd[j] : 0xFFFFFFFFu; mn = v < mn ? v : mn; mx = cd[j] > mx ? cd[j] : mx; }
-                    mn = wave_min_u32(mn); mx = wave_max_u32(mx);
+                    mn = pair_min(wave_min_u32(mn)); mx = pair_max(wave_max_u32(mx));
                 }
             }
         }
