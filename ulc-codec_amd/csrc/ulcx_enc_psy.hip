@@ -505,15 +505,18 @@ __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, 
                 }
             }
         }
+        constexpr bool BRK = SEL_COMPACT && PASS != 2 && R % 4 == 0;       // the sample bracket below: needs no minimum / maximum of all the keys
         uint32_t mn = 0xFFFFFFFFu, mx = 0u;
         if (!compacted) {
+            if (!BRK || (ULCX_DBG(c) & 0x1000)) {
 #pragma unroll
-            for (int r = 0; r < R; r++) { mn = u[r] < mn ? u[r] : mn; mx = u[r] > mx ? u[r] : mx; }
+                for (int r = 0; r < R; r++) { mn = u[r] < mn ? u[r] : mn; mx = u[r] > mx ? u[r] : mx; }
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < SEL_CAP; j++) { const uint32_t v = cd[j] ? cd[j] : 0xFFFFFFFFu; mn = v < mn ? v : mn; mx = cd[j] > mx ? cd[j] : mx; }
         }
-        mn = pair_min(wave_min_u32(mn)); mx = pair_max(wave_max_u32(mx));
+        if (!BRK || compacted || (ULCX_DBG(c) & 0x1000)) { mn = pair_min(wave_min_u32(mn)); mx = pair_max(wave_max_u32(mx)); }
         // Round 6 - a sample bracket in front of the search (one-pass calls, one wave per block of 4096 keys).  The bit-by-bit
         // search below needs ~14 full probes (64 compares, 128 scalar instructions each) before the window that holds T is down
         // to SEL_CAND keys: log-domain keys spend their first probes on empty value space between an outlier and the bulk.
@@ -532,8 +535,8 @@ __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, 
         // rate search (its later probes already search a window: selWin).  R keys per lane: lane group g of 256 / R lanes takes
         // registers 4 g + 1, 4 g + 3.  PAIR (a wave per channel): the two waves swap their 128 sample keys through LDS once and
         // each runs the descent on all 256 - no exchange per sample probe; the full probes' counts are summed over the pair.
-        if constexpr (SEL_COMPACT && PASS != 2 && R % 4 == 0) {
-            if (mn != mx && !(ULCX_DBG(c) & 0x1000) && !compacted) {
+        if constexpr (BRK) {
+            if (!(ULCX_DBG(c) & 0x1000) && !compacted) {
                 constexpr int G = R / 4, LPG = 64 / G, STOT = PAIR ? 256 : 128;
                 uint32_t s0 = 0u, s1 = 0u, s2 = 0u, s3 = 0u;
                 __builtin_amdgcn_sched_barrier(0);           // (picked here, not while the keys are formed: that is where the registers are tightest)
@@ -552,9 +555,15 @@ __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, 
                 int kkLo = (int)ceilf(q + SEL_BRK_DHI); kkLo = (kkLo > STOT - 1 ? STOT - 1 : kkLo) + 1;
                 int kkHi = (int)floorf(q - SEL_BRK_DLO); kkHi = (kkHi < 0 ? 0 : kkHi) + 1;
                 uint32_t tLoS, tHiS = 0u; bool haveHi = false;
-                {
-                    int b = 31 - __clz(mn ^ mx);
-                    uint32_t Ts = mx & ~((2u << b) - 1u);
+                // (the window starts as [0, 2^32 - 1]: count(u >= 0) = N, nothing above the top - no pass over the keys for their minimum and
+                //  maximum; the descent's prefix comes from the sample's own)
+                uint32_t smn = s0 < s1 ? s0 : s1, smx = s0 > s1 ? s0 : s1;
+                if constexpr (PAIR) { const uint32_t a2 = s2 < s3 ? s2 : s3, b2 = s2 > s3 ? s2 : s3; smn = a2 < smn ? a2 : smn; smx = b2 > smx ? b2 : smx; }
+                smn = wave_min_u32(smn); smx = wave_max_u32(smx);
+                if (smn == smx) tLoS = smn;                  // (a sample of equal keys: that value is the one probe it can offer)
+                else {
+                    int b = 31 - __clz(smn ^ smx);
+                    uint32_t Ts = smx & ~((2u << b) - 1u);
                     for (; b >= 0; b--) {
                         const uint32_t t = Ts | (1u << b);
                         int cS = __popcll(__ballot(s0 >= t)) + __popcll(__ballot(s1 >= t));
@@ -565,7 +574,7 @@ __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, 
                     }
                     tLoS = Ts;
                 }
-                uint32_t lo = mn, hiX = mx; int cLo = N, cHi = 0;
+                uint32_t lo = 0u, hiX = 0xFFFFFFFFu; int cLo = N, cHi = 0;
                 int last = 0, shLo = 0, shHi = 0;                 // Illinois weights as shifts: an end that stayed put counts half (all wave-uniform integers: scalar registers)
                 int iter = 0, stage = 0;                          // stage 0 / 1: the sample's two values, then interpolation
                 bool want = false;
@@ -584,7 +593,7 @@ __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, 
                             break;
                         }
                         const int aI = (cLo - kSel) >> shLo, bI = (kSel - cHi) >> shHi;
-                        const float frac = (++iter > 12 || aI + bI == 0) ? 0.5f : (float)aI / (float)(aI + bI);      // (a window that will not close by interpolation - heavy ties - is halved)
+                        const float frac = (++iter > 40 || aI + bI == 0) ? 0.5f : (float)aI / (float)(aI + bI);      // (a window that will not close by interpolation - heavy ties - is halved)
                         uint32_t off = (uint32_t)(frac * (float)(hiX - lo));
                         off = off < 1u ? 1u : off; off = off > hiX - lo ? hiX - lo : off;
                         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lo + off));
