@@ -809,3 +809,35 @@ def test_single_block_and_batched_calls_mixed_on_one_decoder_keep_the_noise_chai
         assert bits == want_bits[k], k
     assert np.array_equal(got.reshape(-1, ch).view(np.uint32), want.view(np.uint32)), "the noise chain was rewound or forked"
     dec.close()
+
+
+@pytest.mark.parametrize("bs,ch,rate", [(2048, 2, 44100), (4096, 2, 44100), (2048, 1, 48000), (1024, 2, 32000), (8192, 1, 44100)])
+def test_selection_bracket_on_degenerate_key_distributions(bs, ch, rate):
+    """Round 6: the selection brackets its threshold from 128 sampled keys before it searches (k_select_wave / k_select_pair,
+    BlockTransform.c:20-77 decides the same set by a full sort).  Key distributions that starve or mislead the sample: a silent
+    channel (half the keys -inf), two pure tones (a handful of large keys over a floor of ties), one impulse per block (flat
+    spectrum: every key close to the next), near-silence, clipping square wave, white noise at quality 100 / 1 (nearly all / nearly
+    none kept) - kept sets, keys and bytes must equal the oracle's, VBR and the first probe of a rate search."""
+    amd = _amd()
+    K = 4
+    n = K * bs
+    rng = np.random.default_rng(bs + ch)
+    t = np.arange(n) / rate
+    sig = []
+    x = synth_pcm(1, n, ch, rate, transient=True, seed=5).copy(); x[:, -1] = 0.0; sig.append(x)                       # a silent channel
+    x = np.zeros((n, ch), np.float32); x[:, 0] = 0.4 * np.sin(2 * np.pi * 1000 * t) + 0.3 * np.sin(2 * np.pi * 5000 * t); x[:, -1] = x[:, 0]; sig.append(x)
+    x = np.zeros((n, ch), np.float32); x[bs // 3::bs, :] = 0.9; sig.append(x)                                           # an impulse per block
+    sig.append((synth_pcm(2, n, ch, rate, transient=False, seed=6) * np.float32(2.0 ** -14)).astype(np.float32))        # near silence
+    x = np.sign(np.sin(2 * np.pi * 440 * t)).astype(np.float32)[:, None].repeat(ch, 1) * np.float32(1.5); sig.append(x)  # beyond full scale, clipped shape
+    sig.append(rng.uniform(-1, 1, (n, ch)).astype(np.float32))                                                          # white noise
+    sig = [np.ascontiguousarray(np.round(s * 32768.0) / 32768.0, dtype=np.float32) for s in sig]
+    pcm = np.stack(sig)
+    B = len(sig)
+    for mode, p0 in ((amd.MODE_VBR, 100.0), (amd.MODE_VBR, 50.0), (amd.MODE_VBR, 1.0), (amd.MODE_CBR, 96.0)):
+        enc = amd.BatchEncoder(B, ch, bs, rate, K)
+        res = enc.encode(pcm, mode, p0)
+        dbg = enc.debug_fetch(K)
+        for s in range(B):
+            ref = oracle_encode_debug(pcm[s], bs, rate, mode, p0, slot=enc.slot)
+            _compare_encode(res, ref, s, 0, K, dbg if mode == amd.MODE_VBR else None, what=f"mode {mode} p0 {p0} signal {s}")
+        enc.close()
