@@ -23,6 +23,16 @@ CASES = {
     "cfg3_abr64_48k":  (2048, 2, 48000, 16, 103, 4, ABR, 64.0, 0.35),        # the third rate-control driver (ulcEncoder.c:118-138)
     "cfg4_wswitch":    (4096, 2, 44100, 16, 104, 5, VBR, 50.0, 0.0),         # transient-heavy, BlockSize 4096
     "abr96_1024s":     (1024, 2, 32000, 24, 105, 6, ABR, 96.0, 0.6),
+    # the rest of the geometry range the reference accepts (ulcEncoder.c:32-34): every BlockSize, odd and large channel counts
+    "vbr60_256s":      (256, 2, 22050, 48, 106, 7, VBR, 60.0, 0.0),
+    "cbr48_512m":      (512, 1, 32000, 40, 107, 8, CBR, 48.0, 0.0),
+    "vbr40_1024t":     (1024, 3, 48000, 20, 108, 9, VBR, 40.0, 0.0),           # unpaired last channel (no M/S partner)
+    "vbr50_8192m":     (8192, 1, 44100, 8, 109, 10, VBR, 50.0, 0.0),
+    "cbr128_8192s":    (8192, 2, 48000, 6, 110, 11, CBR, 128.0, 0.0),
+    "vbr50_16384s":    (16384, 2, 96000, 5, 111, 12, VBR, 50.0, 0.0),
+    "vbr30_32768m":    (32768, 1, 48000, 4, 112, 13, VBR, 30.0, 0.0),
+    "vbr70_2048x6":    (2048, 6, 48000, 8, 113, 14, VBR, 70.0, 0.0),           # 5.1: three M/S pairs
+    "abr192_4096s":    (4096, 2, 96000, 10, 114, 15, ABR, 192.0, 0.5),
 }
 
 
