@@ -426,6 +426,14 @@ __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, 
         // being read from an array another kernel wrote
         float *msk = sel_lds + wv * selStride;
         float *sbarkw = msk + c.BS / 2;
+        // (round 6: the first SEL_PRE coefficients of a lane are asked for here, in front of the masking levels - the registers are
+        //  free until the keys pile up, and the block's first trip to HBM runs beside the levels instead of behind them)
+        constexpr int SEL_PRE = (PASS != 2 && R >= 16) ? 16 : 0;
+        float cpre[SEL_PRE ? SEL_PRE : 1];
+        if constexpr (SEL_PRE > 0) {
+#pragma unroll
+            for (int q = 0; q < SEL_PRE; q++) cpre[q] = ldnt(coef + q * 64 + lane);
+        }
         if constexpr (PASS != 2) {
             for (int i = lane; i < 4 * ULCX_NBARK; i += 64) sbarkw[i] = c.barkP[(size_t)blk * 4 * ULCX_NBARK + i];
             const int wcB = c.wcArr[(size_t)(blk / c.K) * (c.maxK + 2) + (blk % c.K) + 1];
@@ -452,7 +460,7 @@ __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, 
         for (int r0 = 0; r0 < R; r0 += 8) {
             float cv[8], mv[8];
 #pragma unroll
-            for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; cv[q] = ldnt(coef + i); mv[q] = msk[(i & (bsK - 1)) >> 1]; }
+            for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; cv[q] = (r0 + q < SEL_PRE) ? cpre[r0 + q < SEL_PRE ? r0 + q : 0] : ldnt(coef + i); mv[q] = msk[(i & (bsK - 1)) >> 1]; }
 #pragma unroll
             for (int q = 0; q < 8 && r0 + q < R; q++) { int i = (r0 + q) * 64 + lane; u[r0 + q] = sel_key(cv[q], mv[q], PAIR ? half : (i >> lgK)); }
             if constexpr (PASS == 1) {
