@@ -239,12 +239,9 @@ __device__ __forceinline__ float2 noise_pair(const UlcxEncCtx &c, const float *b
     int off = 0, d = 0, S = c.BS, j = 0;
     for (;; j++) { d = pat & 7; S = c.BS >> d; if (2 * jp < off + S) break; off += S; pat >>= 4; }
     const int line = jp - off / 2;
-    const int bi = c.T.bandIdx[d][line];
-    const float fr = c.T.bandFrac[d][line];
+    const float4 t = c.T.bandW[d][line];                   // {left index, right index (clamped), 1 - frac, frac}
     const float *bark = bark4 + j * ULCX_NBARK;
-    const float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
-    const float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
-    const float noise = L * (1.0f - fr) + R * fr;
+    const float noise = bark[__float_as_int(t.x)] * t.z + bark[__float_as_int(t.y)] * t.w;
     const float w = SEXP ? ulcx_expf_t(0.5f * noise, sexp) : ulcx_expf(0.5f * noise);
     return make_float2(w, w * (noise + 0x1.62E430p-1f));
 }

@@ -276,11 +276,8 @@ __device__ __forceinline__ float mask_level(const UlcxEncCtx &c, const float *ba
     for (;; j++) { d = pat & 7; S = c.BS >> d; if (2 * jp < off + S) break; off += S; pat >>= 4; }
     const int line = jp - off / 2;
     const float *bark = bark4 + j * ULCX_NBARK;
-    const int bi = c.T.bandIdx[d][line];
-    const float fr = c.T.bandFrac[d][line];
-    const float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
-    const float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
-    return L * (1.0f - fr) + R * fr;
+    const float4 t = c.T.bandW[d][line];                   // {left index, right index (clamped), 1 - frac, frac}
+    return bark[__float_as_int(t.x)] * t.z + bark[__float_as_int(t.y)] * t.w;
 }
 
 // key of coefficient i of block blk, from the stored coefficient and the masking level of its line; once
@@ -444,7 +441,7 @@ __device__ __forceinline__ void select_body(const UlcxEncCtx &c, int finalPass, 
                 // clamps them - and its weights come ready from one 16-byte table entry (round 6: 9 instead of ~30 instructions a line)
 #pragma unroll 4
                 for (int jp = lane + (PAIR ? 64 * half : 0); jp < c.BS / 2; jp += (PAIR ? 128 : 64)) {
-                    const float4 t = c.T.bandW0[jp];
+                    const float4 t = c.T.bandW[0][jp];
                     const float L = sbarkw[__float_as_int(t.x)], Rv = sbarkw[__float_as_int(t.y)];
                     msk[jp] = L * t.z + Rv * t.w;
                 }

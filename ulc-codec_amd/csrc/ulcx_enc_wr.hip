@@ -136,19 +136,15 @@ __device__ void nsums_block(const UlcxEncCtx &c, int blk, const NsPre &pre) {
         int off = 0, dd = 0, S = c.BS, j = 0;
         for (;; j++) { dd = pat & 7; S = c.BS >> dd; if (2 * jp < off + S) break; off += S; pat >>= 4; }
         const int line = jp - off / 2;                     // (subblocks are multiples of 32 lines: both pairs lie in the same one)
-        const int2 bi2 = *(const int2 *)(c.T.bandIdx[dd] + line);
-        const float2 fr2 = *(const float2 *)(c.T.bandFrac[dd] + line);
+        const float4 t0 = c.T.bandW[dd][line], t1 = c.T.bandW[dd][line + 1];      // per line {left level index, right one (clamped), 1 - frac, frac}
         for (int ch = 0; ch < c.C; ch++) {
             if (!((want >> (2 * ch)) & 3u)) continue;
             const float *bark = sbark + (ch * 4 + j) * ULCX_NBARK;
             float o[4];
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-                const int bi = q ? bi2.y : bi2.x;
-                const float fr = q ? fr2.y : fr2.x;
-                const float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
-                const float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
-                const float noise = L * (1.0f - fr) + R * fr;
+                const float4 t = q ? t1 : t0;
+                const float noise = bark[__float_as_int(t.x)] * t.z + bark[__float_as_int(t.y)] * t.w;
                 const float w = ulcx_expf_t(0.5f * noise, sexp);
                 o[2 * q] = w; o[2 * q + 1] = w * (noise + 0x1.62E430p-1f);
             }
@@ -248,8 +244,7 @@ __global__ __launch_bounds__(WG) void k_tails(UlcxEncCtx c, int finalPass) {
         // ---- forming: this thread's unit and its two pairs of every tile
         const int fu = lane, fe = wv;                        // unit, first pair of the tile (the second: fe + 4)
         const int fnp = uNp[fu], fline0 = uLine0[fu];
-        const int *bandIdx = c.T.bandIdx[uD[fu]];
-        const float *bandFrac = c.T.bandFrac[uD[fu]];
+        const float4 *bandW = c.T.bandW[uD[fu]];             // per line {left level index, right one (clamped), 1 - frac, frac}
         const float *bark = sbark[fu];
         auto form = [&](int T) {
 #pragma unroll
@@ -258,11 +253,8 @@ __global__ __launch_bounds__(WG) void k_tails(UlcxEncCtx c, int finalPass) {
                 float w = 0.0f, wy = 0.0f;
                 if (q < fnp) {
                     const int line = fline0 + q;
-                    const int bi = bandIdx[line];
-                    const float fr = bandFrac[line];
-                    const float L = (bi < ULCX_NBARK) ? bark[bi] : bark[ULCX_NBARK - 1];
-                    const float R = (bi + 1 < ULCX_NBARK) ? bark[bi + 1] : L;
-                    const float noise = L * (1.0f - fr) + R * fr;
+                    const float4 t = bandW[line];
+                    const float noise = bark[__float_as_int(t.x)] * t.z + bark[__float_as_int(t.y)] * t.w;
                     w = ulcx_expf_t(0.5f * noise, sexp);
                     wy = w * (noise + 0x1.62E430p-1f);
                 }

@@ -34,8 +34,8 @@ struct UlcxTables {
     const float  *winRise;
     const int    *bandIdx[ULCX_MAX_SUB]; // per line < S/2: (int)Bark(line)         Psyopt.c:141-143,237-239
     const float  *bandFrac[ULCX_MAX_SUB];//               Bark(line) - (int)Bark(line)
-    const float4 *bandW0;                // the same for the un-decimated block, ready to use (round 6): per line {index of the left Bark level,
-                                         // of the right one - both clamped as Psyopt.c:143-147 clamps them, as int bits -, 1 - frac, frac}
+    const float4 *bandW[ULCX_MAX_SUB];   // the two above ready to use (round 6): per line {index of the left Bark level, of the right one - both
+                                         // clamped as Psyopt.c:143-147 / :240-244 clamp them, as int bits -, 1 - frac, frac}
     const uint32_t *barkSched;           // [2][ULCX_MAX_SUB][ULCX_BARK_EVENTS] band edges in line order (k_bark_uniform)
     // Bark band edges per subblock size (lines of the S/2-line pseudo-DFT)
     short nBeg[ULCX_MAX_SUB][ULCX_NBARK], nEnd[ULCX_MAX_SUB][ULCX_NBARK];   // noise:  [b, b+2)        Psyopt.c:198-205

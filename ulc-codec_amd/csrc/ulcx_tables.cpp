@@ -50,7 +50,7 @@ int ulcx_tables_build(UlcxTables *T, void **devBlob, int BS, int rateHz, bool fo
     memset(T, 0, sizeof(*T));
     std::vector<unsigned char> blob;
     auto reserve = [&](size_t bytes) { size_t off = (blob.size() + 255) & ~(size_t)255; blob.resize(off + bytes); return off; };
-    size_t offPre[ULCX_MAX_SUB], offTw[ULCX_MAX_SUB], offIdx[ULCX_MAX_SUB], offFrac[ULCX_MAX_SUB], offW0 = 0;
+    size_t offPre[ULCX_MAX_SUB], offTw[ULCX_MAX_SUB], offIdx[ULCX_MAX_SUB], offFrac[ULCX_MAX_SUB], offW[ULCX_MAX_SUB] = {0};
     float nyq = (float)rateHz * 0.5f;
     for (int d = 0; d < ULCX_MAX_SUB; d++) {
         int S = BS >> d, M = S / 2;
@@ -78,9 +78,9 @@ int ulcx_tables_build(UlcxTables *T, void **devBlob, int BS, int rateHz, bool fo
                 bi[line] = i;
                 fr[line] = bb - (float)i;
             }
-            if (d == 0) {
-                offW0 = reserve(sizeof(float) * 4 * nLines);
-                float *w0 = (float *)(blob.data() + offW0);
+            {
+                offW[d] = reserve(sizeof(float) * 4 * nLines);
+                float *w0 = (float *)(blob.data() + offW[d]);
                 bi = (int *)(blob.data() + offIdx[d]); fr = (float *)(blob.data() + offFrac[d]);      // (reserve() may have moved the blob)
                 for (int line = 0; line < nLines; line++) {
                     const int iL = bi[line] < ULCX_NBARK ? bi[line] : ULCX_NBARK - 1;                   // Psyopt.c:143-147
@@ -140,10 +140,10 @@ int ulcx_tables_build(UlcxTables *T, void **devBlob, int BS, int rateHz, bool fo
         if (forEncoder) {
             T->bandIdx[d]  = (const int *)(base + offIdx[d]);
             T->bandFrac[d] = (const float *)(base + offFrac[d]);
+            T->bandW[d]    = (const float4 *)(base + offW[d]);
         }
     }
     T->barkSched = (const uint32_t *)(base + offSched);
-    T->bandW0 = forEncoder ? (const float4 *)(base + offW0) : nullptr;
     T->winFall = (const float *)(base + offFall);
     T->winRise = (const float *)(base + offRise);
     *devBlob = dev;
