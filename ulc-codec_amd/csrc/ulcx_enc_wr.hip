@@ -573,7 +573,7 @@ __device__ __forceinline__ void gap_codes(int nc, int zr, float quant, const flo
 
 template <bool SMALL>
 __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, int ch, int j, int wc, int lane, float *e2, const WaveCaps caps, int failBit,
-                                 unsigned long long *xch = nullptr, int seq = 0) {
+                                 unsigned long long *xch = nullptr, int seq = 0, uint32_t kwPre = 0u, bool havePre = false) {
     // SMALL: the ordinary-block capacities as compile-time constants (constant LDS offsets); else the launch's
     const int E2_KCAP = SMALL ? WAVE_SK : caps.k, E2_ZCAP = SMALL ? WAVE_SZ : caps.z, E2_NYBCAP = SMALL ? WAVE_SN : caps.nyb;
     int gid = (blk * c.C + ch) * 4 + j;
@@ -608,7 +608,9 @@ __device__ void encode_unit_wave(const UlcxEncCtx &c, int finalPass, int blk, in
     const float4 tsA = *(const float4 *)(c.tailSum + (size_t)gid * 8);
     const float2 tsB = *(const float2 *)(c.tailSum + (size_t)gid * 8 + 4);
     for (int wb = 0; wb < nWords; wb += 64) {
-        const uint32_t kw = (wb + lane < nWords) ? keepU[wb + lane] : 0u;      // words past the unit read as "nothing kept"
+        // (round 6: a channel's first unit starts at the channel's first keep word whatever the window code says, so its first 64 words
+        //  were asked for beside the window code - k_encode_wave - instead of behind it: one trip to memory less in front of the search)
+        const uint32_t kw = (wb + lane < nWords) ? ((havePre && wb == 0) ? kwPre : keepU[wb + lane]) : 0u;      // words past the unit read as "nothing kept"
         const int pc = __popc(kw);
         int incl = pc;
 #define STEP(ctl, rmask) incl += __builtin_amdgcn_update_dpp(0, incl, ctl, rmask, 0xf, false);
@@ -946,10 +948,13 @@ __global__ __launch_bounds__(256, SMALL ? EW_LB : 1) void k_encode_wave(UlcxEncC
             if (skip_block(c, blk, finalPass)) continue;
         }
         int s = blk / c.K, k = blk % c.K;
+        // (the first keep words of the channel: where they are does not depend on the window code)
+        const int nW0 = c.BS >> 5;
+        const uint32_t kwPre = (lane < nW0) ? c.keep[(size_t)blk * (c.C * c.BS / 32) + (size_t)ch * nW0 + lane] : 0u;
         int wc = c.wcArr[(size_t)s * (c.maxK + 2) + k + 1];
         const bool whole = (c.BS >> (ulcx_pattern(wc) & 7)) == c.BS;          // one unit per channel
         for (int j = 0; j < 4; j++) {
-            encode_unit_wave<SMALL>(c, finalPass, blk, ch, j, wc, lane, e2, caps, phase ? 2 : 1, (directOK && whole && j == 0) ? xchAll + (wv >> 1) : nullptr, seq);
+            encode_unit_wave<SMALL>(c, finalPass, blk, ch, j, wc, lane, e2, caps, phase ? 2 : 1, (directOK && whole && j == 0) ? xchAll + (wv >> 1) : nullptr, seq, kwPre, j == 0);
             WAVE_SYNC();
         }
     }
