@@ -8,7 +8,7 @@ import ulc_amd, bench
 dev = torch.device("cuda", 0)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 16
-pcm = bench.make_pcm(torch, B, K * 2048, dev, seed=1234)
+pcm = bench.make_pcm(torch, B, K * 2048, dev, seed=1234, bursts_per_s=float(os.environ.get('DEC_BENCH_BURSTS', '4.0')))      # (DEC_BENCH_BURSTS=0: one burst per stream - nearly no decimated blocks)
 enc = ulc_amd.BatchEncoder(B, 2, 2048, 44100, K); dec = ulc_amd.BatchDecoder(B, 2, 2048, K)
 slot = enc.slot
 d_out = torch.zeros(B * K * slot, dtype=torch.uint8, device=dev); d_bits = torch.zeros(B * K, dtype=torch.int32, device=dev)
